@@ -1,0 +1,266 @@
+/*
+ * nsp_hip.h -- C ABI of libnsp_hip.so: the MI355X (gfx950) kernels behind the
+ * neural_sp Speech2Text training hot path.
+ *
+ * The reference (hirofumi0810/neural_sp) has no FFI of its own: the hot path is
+ * plain torch ops plus three un-vendored loss libraries.  Every entry point
+ * below names the reference call site(s) it replaces (paths relative to the
+ * reference root).  The Python host side (neural_sp_amd/ops.py) binds these with
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a hipError_t (>0) on a HIP failure,
+ *     or a negative NSP_E* code for invalid arguments;
+ *   - pointers are device pointers unless a comment says "host";
+ *   - `stream` is a hipStream_t passed as void*; nothing here synchronises,
+ *     allocates or frees: workspaces are passed in by the caller;
+ *   - tensors are dense fp32 row-major unless stated; lengths are int32;
+ *   - `mode`: NSP_COMPUTE_BF16 = bf16 MFMA operands / fp32 accumulate,
+ *             NSP_COMPUTE_F32  = exact fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ */
+#ifndef NSP_HIP_H
+#define NSP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSP_OK 0
+#define NSP_EINVAL (-1)
+#define NSP_EUNSUPPORTED (-2)
+
+#define NSP_COMPUTE_BF16 0
+#define NSP_COMPUTE_F32 1
+
+/* activations understood by the GEMM epilogue and the elementwise kernels */
+#define NSP_ACT_NONE 0
+#define NSP_ACT_RELU 1
+#define NSP_ACT_SWISH 2
+#define NSP_ACT_TANH 3
+#define NSP_ACT_GELU 4 /* 0.5x(1+erf(x/sqrt2)), reference modules/gelu.py gelu_accurate=tanh form is 5 */
+#define NSP_ACT_GELU_TANH 5
+
+int nsp_version(void);
+
+/* ------------------------------------------------------------------------ *
+ * Batched strided GEMM with fused epilogue.                                *
+ * Replaces every nn.Linear / 1x1 Conv1d / einsum contraction on the path:  *
+ *   positionwise_feed_forward.py:89, relative_multihead_attention.py:169-  *
+ *   193,215,217, multihead_attention.py:124-153, conformer_convolution.py: *
+ *   108,127, conv.py:192-193 (bridge), ctc.py:124, rnn_transducer.py:272-  *
+ *   275, and their autograd backward (dgrad / wgrad).                      *
+ *                                                                          *
+ *   C[z][m][n] = epi( sum_k A[z](m,k) * B[z](k,n) )                        *
+ *   A(m,k) at A + z1*a_b1 + z2*a_b2 + m*a_rs + k*a_cs                       *
+ *   B(k,n) at B + z1*b_b1 + z2*b_b2 + k*b_ks + n*b_ns                       *
+ *   C(m,n) at C + z1*c_b1 + z2*c_b2 + m*ldc + n                             *
+ *   epi(v): v += bias[n]; if(pre_out) pre_out(m,n)=v; v = act(v);          *
+ *           if(dact_src) v *= act'(dact_src(m,n)) (dact selects act');     *
+ *           v *= alpha; if(res) v += res(m,n);                             *
+ *           if(mask_keep) v *= mask(m,n) (0 or 1/(1-p) dropout scale)      *
+ *   splitk>1: partial sums are atomically added into C (caller zeroes C;   *
+ *             only alpha is applied).                                      *
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  int M, N, K;
+  const float* A; long long a_rs, a_cs;
+  const float* B; long long b_ks, b_ns;
+  float* C; long long ldc;
+  int batch1, batch2;
+  long long a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
+  const float* bias;      /* [N] or NULL */
+  int act;                /* NSP_ACT_* applied after bias */
+  float* pre_out;         /* optional: value before activation, layout of C */
+  const float* dact_src;  /* optional: multiply by act'(dact_src), layout of C */
+  int dact;               /* NSP_ACT_* of the derivative */
+  const float* res;       /* optional residual, layout of C (may alias C) */
+  float alpha;
+  int splitk;             /* >=1 */
+  int mode;               /* NSP_COMPUTE_* */
+  float dropout_p;        /* 0 => off; else philox-style keep mask regenerated from seed */
+  unsigned long long seed, offset;
+} nsp_gemm_params;
+
+int nsp_gemm(const nsp_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * LayerNorm over the last dim (eps inside sqrt, biased variance).          *
+ * Replaces nn.LayerNorm at conformer_block.py:132,140,160,177,180,         *
+ * transformer_block.py:109,132, transformer.py:600,                        *
+ * conformer_convolution.py:64,119.                                         *
+ *   y = (x-mean)*rstd*gamma + beta ; optional fused activation on y.       *
+ *   mean/rstd [rows] are saved for backward.                               *
+ * ------------------------------------------------------------------------ */
+int nsp_layernorm_fwd(const float* x, const float* gamma, const float* beta,
+                      float* y, float* mean, float* rstd,
+                      int rows, int d, float eps, int act, float* y_pre,
+                      void* stream);
+/* dx (may alias dy), dgamma/dbeta accumulated via atomics into zeroed buffers.
+ * If act != NONE, y_pre is the pre-activation LN output saved by fwd. */
+int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
+                      const float* mean, const float* rstd, const float* y_pre,
+                      float* dx, float* dgamma, float* dbeta,
+                      int rows, int d, int act, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Elementwise helpers (vectorised, grid-stride).                           *
+ * ------------------------------------------------------------------------ */
+/* y = alpha*x + beta*z (z may be NULL) */
+int nsp_axpby(const float* x, const float* z, float* y, float alpha, float beta,
+              long long n, void* stream);
+/* y = act(x) ; out = alpha * dy * act'(pre) */
+int nsp_act_fwd(const float* x, float* y, int act, long long n, void* stream);
+int nsp_dact_mul(const float* dy, const float* pre, float* out, int act, float alpha,
+                 long long n, void* stream);
+/* column sum: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
+int nsp_colsum(const float* x, float* out, int rows, int cols, long long ld,
+               int accumulate, void* stream);
+/* GLU over the channel dim of [rows, 2C] -> [rows, C]: a*sigmoid(b)
+ * (conformer_convolution.py:109, F.glu(dim=1) on [B,2C,T]) */
+int nsp_glu_fwd(const float* x, float* y, long long rows, int C, void* stream);
+int nsp_glu_bwd(const float* x, const float* dy, float* dx, long long rows, int C,
+                void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Attention score softmax with relative-position term and in-kernel masks. *
+ * Replaces relative_multihead_attention.py:112-144 (_rel_shift gather),    *
+ * :196-206 (scale, masked_fill(NEG_INF=fp32 min), softmax) and             *
+ * multihead_attention.py:137-142; mask semantics of transformer.py:633-686 *
+ * (make_san_mask / causal / make_chunkwise_san_mask) are evaluated from    *
+ * klens instead of reading a [B,T,T] mask tensor.                          *
+ *   S  [B,H,Tq,Tk] content scores (AC), overwritten in place by softmax    *
+ *   QP [B,Tq,H,R]  q . pos table (BD before shift), NULL for plain MHA     *
+ *   e(i,j) = (S + QP[i, min(|i-j|,clamp) ]) * scale                        *
+ *   key j is visible to query i iff j < klens[b]                           *
+ *        and (!causal || j <= i + lookahead)                               *
+ *        and (chunk_nc==0 || (j >= max(0,c0-chunk_nl) && j < c0+chunk_nc)  *
+ *                             with c0 = (i/chunk_nc)*chunk_nc)             *
+ *   masked scores are set to -FLT_MAX (not -inf), exactly as the reference.*
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  int B, H, Tq, Tk, R;     /* R = rows of the position table (clamp+1 or Tk) */
+  int clamp;               /* <=0: no clamp */
+  float scale;             /* 1/sqrt(d_k) */
+  const int* klens;        /* [B] device int32 or NULL (no padding mask) */
+  int causal, lookahead;
+  int chunk_nl, chunk_nc;
+  float dropout_p; unsigned long long seed, offset;
+} nsp_attn_mask_params;
+
+/* Pdrop: optional second output = dropout(P) (required iff dropout_p > 0);
+ * S always receives the un-dropped probabilities needed by backward. */
+int nsp_attn_softmax_fwd(float* S, const float* QP, float* Pdrop,
+                         const nsp_attn_mask_params* p, void* stream);
+/* dS (in place over dP) = P*(dP - sum_j P*dP) * scale; dQP[b,i,h,r] = sum of
+ * dS(i,j) with rel(i,j)==r (before the scale folded into e). */
+int nsp_attn_softmax_bwd(const float* P, float* dP, float* dQP,
+                         const nsp_attn_mask_params* p, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Conformer convolution module core: depthwise Conv1d over time on         *
+ * channels-last [B,T,C] (conformer_convolution.py:111-113; groups=C,       *
+ * padding (k-1)/2, or causal: left pad k-1).                               *
+ * ------------------------------------------------------------------------ */
+int nsp_dwconv1d_fwd(const float* x, const float* w /*[C,k]*/, const float* bias,
+                     float* y, int B, int T, int C, int k, int causal, void* stream);
+int nsp_dwconv1d_bwd(const float* x, const float* w, const float* dy,
+                     float* dx, float* dw, float* dbias,
+                     int B, int T, int C, int k, int causal, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * VGG-style Conv2d frontend on channels-last [B,T,F,C] (conv.py:289-396).  *
+ * 3x3, padding 1, stride 1, fused bias + ReLU; MaxPool2d(ceil_mode).       *
+ * ------------------------------------------------------------------------ */
+int nsp_conv2d3x3_fwd(const float* x, const float* w /*[Co,3,3,Ci]*/, const float* bias,
+                      float* y, int B, int T, int F, int Ci, int Co, int relu,
+                      int mode, void* stream);
+/* dy must already be masked by ReLU (nsp_relu_mask). dx may be NULL (first layer). */
+int nsp_conv2d3x3_bwd(const float* x, const float* w, const float* dy,
+                      float* dx, float* dw, float* dbias,
+                      int B, int T, int F, int Ci, int Co, int mode, void* stream);
+int nsp_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);
+/* MaxPool2d(kernel=stride=(pt,pf), ceil_mode=True) on [B,T,F,C]; if
+ * to_btcf != 0 the output is written as [B,T',C,F'] (= the reference's
+ * transpose(2,1).view(B,T',C*F'), conv.py:189) */
+int nsp_maxpool2d_fwd(const float* x, float* y, int* argmax, int B, int T, int F, int C,
+                      int pt, int pf, int to_btcf, void* stream);
+int nsp_maxpool2d_bwd(const float* dy, const int* argmax, float* dx, int B, int T, int F,
+                      int C, int pt, int pf, int from_btcf, void* stream);
+/* MaxPool1d(k=s=factor, ceil_mode=True) over time of [B,T,C]
+ * (subsampling.py:188-209) */
+int nsp_maxpool1d_fwd(const float* x, float* y, int* argmax, int B, int T, int C, int factor,
+                      void* stream);
+int nsp_maxpool1d_bwd(const float* dy, const int* argmax, float* dx, int B, int T, int C,
+                      int factor, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * CTC: fused log-softmax + alpha/beta lattice + gradient w.r.t. logits.    *
+ * Replaces ctc.py:139-150 (nn.CTCLoss(reduction='sum', zero_infinity=True) *
+ * on logits.log_softmax(2)) and criterion.py:110-127 (kldiv_lsm_ctc).      *
+ *   logits [B,T,V]; labels [B,Lmax] int32 (padded); elens/ylens [B] int32  *
+ *   nll[b] = -log p(y_b | x_b) (0 if infinite); grad [B,T,V] = d sum_b     *
+ *   nll_b / d logits (zero for t >= elens[b]).                             *
+ *   workspace: alpha/beta fp32 [B,T,2*Lmax+1] each + lse [B,T].            *
+ * ------------------------------------------------------------------------ */
+long long nsp_ctc_workspace_bytes(int B, int T, int Lmax);
+int nsp_ctc_loss_fwd_bwd(const float* logits, const int* labels, const int* elens,
+                         const int* ylens, float* nll, float* grad, void* workspace,
+                         int B, int T, int V, int Lmax, int blank, void* stream);
+/* label-smoothing KL term and its gradient (criterion.py:110-127):
+ * kl_sum[0] += sum_{b,t<elens_b,v} p (log p - log(1/(V-1))); grad (+)= gscale * d kl_sum */
+int nsp_ctc_kldiv_fwd_bwd(const float* logits, const int* elens, float* kl_sum,
+                          float* grad, float gscale, int accumulate,
+                          int B, int T, int V, void* stream);
+/* CTC forced alignment (ctc.py:628-753): trigger_points [B,Lmax+1] int32 */
+long long nsp_ctc_align_workspace_bytes(int B, int T, int Lmax);
+int nsp_ctc_forced_align(const float* logits, const int* labels, const int* elens,
+                         const int* ylens, int* trigger_points, void* workspace,
+                         int B, int T, int V, int Lmax, int blank, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * RNN-T: joint log-softmax gather + alpha/beta lattice loss + gradients.   *
+ * Replaces rnn_transducer.py:242-256 (log_softmax over [B,T,U+1,V] +       *
+ * warp_rnnt.rnnt_loss(average_frames=False, reduction='mean',gather=False) *
+ * / warprnnt_pytorch.RNNTLoss()).                                          *
+ *   nsp_rnnt_logsoftmax_gather: logits [B,T,U1,V] -> lse [B,T,U1],         *
+ *        lp_blank, lp_label [B,T,U1] (label of (t,u) is labels[b,u])       *
+ *   nsp_rnnt_lattice: alpha/beta recursions, nll[b], lattice occupancies   *
+ *        g_blank/g_label [B,T,U1] = d nll_b / d lp_*                       *
+ *   nsp_rnnt_grad_logits: in place logits <- d(sum_b w_b nll_b)/d logits   *
+ * ------------------------------------------------------------------------ */
+int nsp_rnnt_logsoftmax_gather(const float* logits, const int* labels, float* lse,
+                               float* lp_blank, float* lp_label,
+                               int B, int T, int U1, int V, int blank, void* stream);
+int nsp_rnnt_lattice(const float* lp_blank, const float* lp_label, const int* elens,
+                     const int* ylens, float* alpha, float* beta, float* nll,
+                     float* g_blank, float* g_label, int B, int T, int U1, void* stream);
+int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* labels,
+                         const float* g_blank, const float* g_label, const int* elens,
+                         const int* ylens, float wscale,
+                         int B, int T, int U1, int V, int blank, void* stream);
+/* joint pre-activation: h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:]) and its backward
+ * reductions (rnn_transducer.py:272-274) */
+int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h,
+                            int B, int T, int U1, int J, void* stream);
+int nsp_rnnt_joint_tanh_bwd(const float* h, const float* dh, float* de, float* dg,
+                            int B, int T, int U1, int J, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * SpecAugment band zeroing in place on [B,T,F] (spec_augment.py:112-140).  *
+ * bands are host arrays of [start,end) pairs (drawn by the host with the   *
+ * reference's np.random stream).                                           *
+ * ------------------------------------------------------------------------ */
+int nsp_specaug_apply(float* x, int B, int T, int F,
+                      const int* freq_bands /*host*/, int n_freq,
+                      const int* time_bands /*host*/, int n_time, void* stream);
+
+/* pad a ragged batch: src is one packed device buffer of sum(T_b)*F floats
+ * (torch_utils.py:56 pad_list + speech2text.py:397) */
+int nsp_pad_batch(const float* packed, const long long* offsets /*device [B]*/,
+                  const int* lens /*device [B]*/, float* out, int B, int Tmax, int F,
+                  float pad_value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSP_HIP_H */

@@ -1,0 +1,131 @@
+"""Build + load libnsp_hip.so (the gfx950 kernels) and expose its C ABI via ctypes.
+
+The library is built in-tree (neural_sp_amd/lib/libnsp_hip.so) with
+``hipcc --offload-arch=gfx950``; hipcc cross-compiles without a GPU.  There is
+no CPU fallback: if the library is missing and cannot be built, importing the
+ops fails loudly.
+"""
+import ctypes
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIBDIR = os.path.join(_HERE, 'lib')
+LIBPATH = os.path.join(LIBDIR, 'libnsp_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+CFLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-munsafe-fp-atomics',
+          '-Wno-unused-result']
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def _src_digest():
+    h = hashlib.sha1()
+    for f in _sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + \
+            [os.path.join(_HERE, '..', 'include', 'nsp_hip.h')]:
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(CFLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    """Compile every csrc/*.hip for gfx950 and link libnsp_hip.so (incremental)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, 'build.stamp')
+    digest = _src_digest()
+    if not force and os.path.exists(LIBPATH) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == digest:
+                return LIBPATH
+    if not os.path.exists(HIPCC):
+        raise RuntimeError('hipcc not found at %s and %s is stale/missing' % (HIPCC, LIBPATH))
+    objs, procs = [], []
+    hdr_mtime = max(os.path.getmtime(f) for f in
+                    glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(_HERE, '..', 'include', 'nsp_hip.h')])
+    for src in _sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src).replace('.hip', '.o'))
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > hdr_mtime):
+            continue
+        cmd = [HIPCC] + CFLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
+    cmd = [HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIBPATH] + objs
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError('link failed:\n%s' % res.stdout.decode(errors='replace'))
+    with open(stamp, 'w') as fh:
+        fh.write(digest)
+    return LIBPATH
+
+
+class GemmParams(ctypes.Structure):
+    """Mirror of nsp_gemm_params (include/nsp_hip.h)."""
+    _fields_ = [
+        ('M', ctypes.c_int), ('N', ctypes.c_int), ('K', ctypes.c_int),
+        ('A', ctypes.c_void_p), ('a_rs', ctypes.c_longlong), ('a_cs', ctypes.c_longlong),
+        ('B', ctypes.c_void_p), ('b_ks', ctypes.c_longlong), ('b_ns', ctypes.c_longlong),
+        ('C', ctypes.c_void_p), ('ldc', ctypes.c_longlong),
+        ('batch1', ctypes.c_int), ('batch2', ctypes.c_int),
+        ('a_b1', ctypes.c_longlong), ('a_b2', ctypes.c_longlong),
+        ('b_b1', ctypes.c_longlong), ('b_b2', ctypes.c_longlong),
+        ('c_b1', ctypes.c_longlong), ('c_b2', ctypes.c_longlong),
+        ('bias', ctypes.c_void_p), ('act', ctypes.c_int),
+        ('pre_out', ctypes.c_void_p), ('dact_src', ctypes.c_void_p), ('dact', ctypes.c_int),
+        ('res', ctypes.c_void_p), ('alpha', ctypes.c_float),
+        ('splitk', ctypes.c_int), ('mode', ctypes.c_int),
+        ('dropout_p', ctypes.c_float),
+        ('seed', ctypes.c_ulonglong), ('offset', ctypes.c_ulonglong),
+    ]
+
+
+class AttnMaskParams(ctypes.Structure):
+    """Mirror of nsp_attn_mask_params."""
+    _fields_ = [
+        ('B', ctypes.c_int), ('H', ctypes.c_int), ('Tq', ctypes.c_int), ('Tk', ctypes.c_int),
+        ('R', ctypes.c_int), ('clamp', ctypes.c_int), ('scale', ctypes.c_float),
+        ('klens', ctypes.c_void_p), ('causal', ctypes.c_int), ('lookahead', ctypes.c_int),
+        ('chunk_nl', ctypes.c_int), ('chunk_nc', ctypes.c_int),
+        ('dropout_p', ctypes.c_float), ('seed', ctypes.c_ulonglong), ('offset', ctypes.c_ulonglong),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Return the loaded shared library (builds it first if sources changed)."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  -- loads the process-wide HIP runtime (libamdhip64.so.7) first
+        path = LIBPATH
+        if os.path.exists(HIPCC):
+            path = build()
+        elif not os.path.exists(path):
+            raise RuntimeError('libnsp_hip.so missing and no hipcc to build it: the HIP path is '
+                               'mandatory, there is no CPU fallback')
+        _lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        _lib.nsp_version.restype = ctypes.c_int
+    return _lib
+
+
+def exported_symbols():
+    """Symbols declared in include/nsp_hip.h (for the ABI-completeness test)."""
+    import re
+    hdr = open(os.path.join(_HERE, '..', 'include', 'nsp_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return sorted(set(re.findall(r'\b(nsp_[a-z0-9_]+)\s*\(', hdr)))

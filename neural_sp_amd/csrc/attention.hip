@@ -1,0 +1,179 @@
+// attention.hip -- masked softmax over attention scores with the relative-
+// position (BD) term folded in, forward and backward.  One wave64 per score row
+// (b,h,i); the row is staged in LDS so HBM sees one read + one write per
+// element.  Mask predicates (padding / causal+lookahead / chunkwise) are
+// evaluated in-kernel from klens: the reference's [B,T,T] mask tensor and its
+// H-fold repeat (relative_multihead_attention.py:164-166) are never built.
+//
+// Reference semantics reproduced exactly:
+//   e(i,j) = (AC(i,j) + QP(i, min(|i-j|, clamp))) / sqrt(d_k)
+//   masked e := -FLT_MAX (finite!), softmax over ALL Tk keys; a fully masked
+//   row therefore becomes uniform 1/Tk, as in the reference.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bool key_visible(const nsp_attn_mask_params& p, int klen, int i, int j) {
+  bool ok = j < klen;
+  if (p.causal) ok = ok && (j <= i + p.lookahead);
+  if (p.chunk_nc > 0) {
+    int c0 = (i / p.chunk_nc) * p.chunk_nc;
+    int lo = c0 - p.chunk_nl;
+    if (lo < 0) lo = 0;
+    ok = ok && (j >= lo) && (j < c0 + p.chunk_nc);
+  }
+  return ok;
+}
+
+__device__ __forceinline__ int rel_index(int i, int j, int clamp) {
+  int r = i > j ? i - j : j - i;
+  if (clamp > 0 && r > clamp) r = clamp;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict__ S,
+                                                               const float* __restrict__ QP,
+                                                               float* __restrict__ Pdrop,
+                                                               const nsp_attn_mask_params p) {
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // [4][Tk]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long nrows = (long long)p.B * p.H * p.Tq;
+  float* buf = rowbuf + (long long)w * p.Tk;
+  for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
+    const int i = (int)(row % p.Tq);
+    const int h = (int)((row / p.Tq) % p.H);
+    const int b = (int)(row / ((long long)p.Tq * p.H));
+    const int klen = p.klens ? p.klens[b] : p.Tk;
+    float* s = S + row * p.Tk;
+    const float* qp = QP ? QP + (((long long)b * p.Tq + i) * p.H + h) * p.R : nullptr;
+    float mx = -FLT_MAX;
+    for (int j = lane; j < p.Tk; j += 64) {
+      float e = s[j];
+      if (qp) e += qp[rel_index(i, j, p.clamp)];
+      e *= p.scale;
+      if (!key_visible(p, klen, i, j)) e = -FLT_MAX;
+      buf[j] = e;
+      mx = fmaxf(mx, e);
+    }
+    mx = wave_reduce_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < p.Tk; j += 64) {
+      float ex = __expf(buf[j] - mx);
+      buf[j] = ex;
+      sum += ex;
+    }
+    sum = wave_reduce_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < p.Tk; j += 64) {
+      float pr = buf[j] * inv;
+      s[j] = pr;
+      if (Pdrop)
+        Pdrop[row * p.Tk + j] =
+            pr * nsp_keep_scale(p.seed, p.offset + (unsigned long long)(row * p.Tk + j), p.dropout_p);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ P,
+                                                               float* __restrict__ dP,
+                                                               float* __restrict__ dQP,
+                                                               const nsp_attn_mask_params p) {
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // [4][Tk]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long nrows = (long long)p.B * p.H * p.Tq;
+  float* buf = rowbuf + (long long)w * p.Tk;
+  for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
+    const int i = (int)(row % p.Tq);
+    const int h = (int)((row / p.Tq) % p.H);
+    const int b = (int)(row / ((long long)p.Tq * p.H));
+    const int klen = p.klens ? p.klens[b] : p.Tk;
+    const float* pr = P + row * p.Tk;
+    float* g = dP + row * p.Tk;
+    float t = 0.f;
+    for (int j = lane; j < p.Tk; j += 64) {
+      float gj = g[j];
+      if (p.dropout_p > 0.f)
+        gj *= nsp_keep_scale(p.seed, p.offset + (unsigned long long)(row * p.Tk + j), p.dropout_p);
+      buf[j] = gj;
+      t += pr[j] * gj;
+    }
+    t = wave_reduce_sum(t);
+    float far = 0.f;  // sum of dS over |i-j| >= clamp
+    for (int j = lane; j < p.Tk; j += 64) {
+      float ds = pr[j] * (buf[j] - t) * p.scale;
+      if (!key_visible(p, klen, i, j)) ds = 0.f;  // masked_fill_ blocks the gradient
+      buf[j] = ds;
+      g[j] = ds;
+      if (p.clamp > 0) {
+        int r = i > j ? i - j : j - i;
+        if (r >= p.clamp) far += ds;
+      }
+    }
+    if (dQP) {
+      float* dq = dQP + (((long long)b * p.Tq + i) * p.H + h) * p.R;
+      if (p.clamp > 0) {
+        far = wave_reduce_sum(far);
+        // make this wave's LDS writes visible to its own other lanes
+        __builtin_amdgcn_wave_barrier();
+        for (int r = lane; r < p.R; r += 64) {
+          float v;
+          if (r == p.clamp) {
+            v = far;
+          } else {
+            v = 0.f;
+            if (i - r >= 0) v += buf[i - r];
+            if (r > 0 && i + r < p.Tk) v += buf[i + r];
+          }
+          dq[r] = v;
+        }
+      } else {
+        __builtin_amdgcn_wave_barrier();
+        for (int r = lane; r < p.R; r += 64) {
+          float v = 0.f;
+          if (i - r >= 0 && i - r < p.Tk) v += buf[i - r];
+          if (r > 0 && i + r < p.Tk) v += buf[i + r];
+          dq[r] = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+
+extern "C" int nsp_attn_softmax_fwd(float* S, const float* QP, float* Pdrop,
+                                    const nsp_attn_mask_params* pp, void* stream) {
+  if (!pp || !S) return NSP_EINVAL;
+  nsp_attn_mask_params p = *pp;
+  if (QP && !(p.clamp > 0 ? p.R >= p.clamp + 1 : p.R >= p.Tk)) return NSP_EINVAL;
+  if (p.dropout_p > 0.f && !Pdrop) return NSP_EINVAL;
+  const size_t shmem = sizeof(float) * 4 * (size_t)p.Tk;
+  if (shmem > 150 * 1024) return NSP_EUNSUPPORTED;
+  long long nrows = (long long)p.B * p.H * p.Tq;
+  int grid = nsp_cdiv(nrows, 4);
+  if (grid > 256 * 32) grid = 256 * 32;
+  if (shmem > 64 * 1024)
+    hipFuncSetAttribute((const void*)attn_softmax_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, S, QP,
+                     p.dropout_p > 0.f ? Pdrop : nullptr, p);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_attn_softmax_bwd(const float* P, float* dP, float* dQP,
+                                    const nsp_attn_mask_params* pp, void* stream) {
+  if (!pp || !P || !dP) return NSP_EINVAL;
+  nsp_attn_mask_params p = *pp;
+  const size_t shmem = sizeof(float) * 4 * (size_t)p.Tk;
+  if (shmem > 150 * 1024) return NSP_EUNSUPPORTED;
+  long long nrows = (long long)p.B * p.H * p.Tq;
+  int grid = nsp_cdiv(nrows, 4);
+  if (grid > 256 * 32) grid = 256 * 32;
+  if (shmem > 64 * 1024)
+    hipFuncSetAttribute((const void*)attn_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, P, dP,
+                     dQP, p);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

@@ -1,0 +1,116 @@
+// common.h -- shared device helpers for libnsp_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include "../../include/nsp_hip.h"
+
+#define NSP_LAUNCH_CHECK()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+static inline int nsp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float nsp_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__device__ __forceinline__ float nsp_act(float v, int act) {
+  switch (act) {
+    case NSP_ACT_RELU: return v > 0.f ? v : 0.f;
+    case NSP_ACT_SWISH: return v * nsp_sigmoid(v);
+    case NSP_ACT_TANH: return tanhf(v);
+    case NSP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case NSP_ACT_GELU_TANH: {
+      float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      return 0.5f * v * (1.f + tanhf(u));
+    }
+    default: return v;
+  }
+}
+
+// derivative of act evaluated at the PRE-activation value x
+__device__ __forceinline__ float nsp_dact(float x, int act) {
+  switch (act) {
+    case NSP_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case NSP_ACT_SWISH: {
+      float s = nsp_sigmoid(x);
+      return s * (1.f + x * (1.f - s));
+    }
+    case NSP_ACT_TANH: {
+      float t = tanhf(x);
+      return 1.f - t * t;
+    }
+    case NSP_ACT_GELU: {
+      float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+      float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case NSP_ACT_GELU_TANH: {
+      float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      float t = tanhf(u);
+      float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
+      return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+    }
+    default: return 1.f;
+  }
+}
+
+// Counter-based RNG for dropout masks: a keep decision is a pure function of
+// (seed, offset + element index), so backward regenerates the forward mask.
+__device__ __forceinline__ uint32_t nsp_hash_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float nsp_keep_scale(unsigned long long seed, unsigned long long idx,
+                                                float p) {
+  // returns 0 (dropped) or 1/(1-p)
+  float u = (float)(nsp_hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.f / (1.f - p);
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide reductions for blockDim.x <= 1024 (multiple of 64); `sh` holds >= 16 floats
+__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_reduce_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* sh) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_reduce_max(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = -FLT_MAX;
+  for (int i = 0; i < nw; ++i) r = fmaxf(r, sh[i]);
+  return r;
+}
+
+__device__ __forceinline__ float nsp_logaddexp(float a, float b) {
+  float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + log1pf(__expf(-fabsf(a - b)));
+}

@@ -1,0 +1,239 @@
+// elementwise.hip -- HBM-bound helpers: axpby, activation fwd/bwd, column sums
+// (bias gradients), GLU, ReLU backward, SpecAugment band zeroing, batch padding.
+// All kernels are grid-stride with 16 B/lane accesses where alignment allows.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline int ew_grid(long long n_vec) {
+  long long g = (n_vec + EW_THREADS - 1) / EW_THREADS;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                             float* __restrict__ y, float alpha, float beta, long long n) {
+  long long n4 = n >> 2;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 a = reinterpret_cast<const float4*>(x)[i];
+    float4 r = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
+    if (z) {
+      float4 b = reinterpret_cast<const float4*>(z)[i];
+      r.x += beta * b.x; r.y += beta * b.y; r.z += beta * b.z; r.w += beta * b.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = r;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = alpha * x[i] + (z ? beta * z[i] : 0.f);
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int act,
+                               long long n) {
+  long long n4 = n >> 2;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 a = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<float4*>(y)[i] =
+        make_float4(nsp_act(a.x, act), nsp_act(a.y, act), nsp_act(a.z, act), nsp_act(a.w, act));
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = nsp_act(x[i], act);
+}
+
+__global__ void dact_mul_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                float* __restrict__ out, int act, float alpha, long long n) {
+  long long n4 = n >> 2;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 g = reinterpret_cast<const float4*>(dy)[i];
+    float4 p = reinterpret_cast<const float4*>(pre)[i];
+    reinterpret_cast<float4*>(out)[i] =
+        make_float4(alpha * g.x * nsp_dact(p.x, act), alpha * g.y * nsp_dact(p.y, act),
+                    alpha * g.z * nsp_dact(p.z, act), alpha * g.w * nsp_dact(p.w, act));
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = alpha * dy[i] * nsp_dact(pre[i], act);
+}
+
+// relu backward from the OUTPUT y (y > 0)
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                float* __restrict__ dx, long long n) {
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// column sums: each block reduces a slab of rows for 64 columns (one wave-width),
+// 4 waves stride over rows; partials are combined in LDS then atomically added.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x,
+                                                     float* __restrict__ out, int rows, int cols,
+                                                     long long ld, int rows_per_block) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + w; r < r1; r += 4) s += x[(long long)r * ld + c];
+  sh[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < cols) unsafeAtomicAdd(out + c, sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
+}
+
+// GLU on channels-last rows: x [rows, 2C] -> y [rows, C] = x[:, :C] * sigmoid(x[:, C:])
+__global__ void glu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows,
+                               int C) {
+  const int C4 = C >> 2;
+  long long total = rows * C4;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long r = i / C4;
+    int c = (int)(i % C4);
+    float4 a = reinterpret_cast<const float4*>(x + r * 2 * C)[c];
+    float4 b = reinterpret_cast<const float4*>(x + r * 2 * C + C)[c];
+    reinterpret_cast<float4*>(y + r * C)[c] =
+        make_float4(a.x * nsp_sigmoid(b.x), a.y * nsp_sigmoid(b.y), a.z * nsp_sigmoid(b.z),
+                    a.w * nsp_sigmoid(b.w));
+  }
+}
+
+__global__ void glu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                               float* __restrict__ dx, long long rows, int C) {
+  const int C4 = C >> 2;
+  long long total = rows * C4;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long r = i / C4;
+    int c = (int)(i % C4);
+    float4 a = reinterpret_cast<const float4*>(x + r * 2 * C)[c];
+    float4 b = reinterpret_cast<const float4*>(x + r * 2 * C + C)[c];
+    float4 g = reinterpret_cast<const float4*>(dy + r * C)[c];
+    float4 s = make_float4(nsp_sigmoid(b.x), nsp_sigmoid(b.y), nsp_sigmoid(b.z), nsp_sigmoid(b.w));
+    reinterpret_cast<float4*>(dx + r * 2 * C)[c] = make_float4(g.x * s.x, g.y * s.y, g.z * s.z, g.w * s.w);
+    reinterpret_cast<float4*>(dx + r * 2 * C + C)[c] =
+        make_float4(g.x * a.x * s.x * (1.f - s.x), g.y * a.y * s.y * (1.f - s.y),
+                    g.z * a.z * s.z * (1.f - s.z), g.w * a.w * s.w * (1.f - s.w));
+  }
+}
+
+__global__ void specaug_kernel(float* __restrict__ x, int B, int T, int F, const int* fb, int nf,
+                               const int* tb, int nt) {
+  // fb/tb are tiny device arrays of [start,end) pairs
+  long long total = (long long)B * T * F;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int f = (int)(i % F);
+    int t = (int)((i / F) % T);
+    bool z = false;
+    for (int k = 0; k < nf; ++k) z |= (f >= fb[2 * k] && f < fb[2 * k + 1]);
+    for (int k = 0; k < nt; ++k) z |= (t >= tb[2 * k] && t < tb[2 * k + 1]);
+    if (z) x[i] = 0.f;
+  }
+}
+
+__global__ void pad_batch_kernel(const float* __restrict__ packed, const long long* __restrict__ offs,
+                                 const int* __restrict__ lens, float* __restrict__ out, int B,
+                                 int Tmax, int F, float pad) {
+  long long total = (long long)B * Tmax * F;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int f = (int)(i % F);
+    int t = (int)((i / F) % Tmax);
+    int b = (int)(i / ((long long)F * Tmax));
+    out[i] = t < lens[b] ? packed[offs[b] + (long long)t * F + f] : pad;
+  }
+}
+
+}  // namespace
+
+extern "C" int nsp_axpby(const float* x, const float* z, float* y, float alpha, float beta,
+                         long long n, void* stream) {
+  if (n <= 0) return NSP_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     x, z, y, alpha, beta, n);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_act_fwd(const float* x, float* y, int act, long long n, void* stream) {
+  if (n <= 0) return NSP_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     x, y, act, n);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_dact_mul(const float* dy, const float* pre, float* out, int act, float alpha,
+                            long long n, void* stream) {
+  if (n <= 0) return NSP_OK;
+  hipLaunchKernelGGL(dact_mul_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, dy, pre, out, act, alpha, n);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* stream) {
+  if (n <= 0) return NSP_OK;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, y,
+                     dy, dx, n);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_colsum(const float* x, float* out, int rows, int cols, long long ld,
+                          int accumulate, void* stream) {
+  if (rows <= 0 || cols <= 0) return NSP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * cols, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  int gx = nsp_cdiv(cols, 64);
+  int gy = 2048 / gx;
+  if (gy < 1) gy = 1;
+  int rpb = nsp_cdiv(rows, gy);
+  if (rpb < 32) rpb = 32;
+  gy = nsp_cdiv(rows, rpb);
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, out, rows, cols, ld, rpb);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_glu_fwd(const float* x, float* y, long long rows, int C, void* stream) {
+  if (C % 4) return NSP_EUNSUPPORTED;
+  hipLaunchKernelGGL(glu_fwd_kernel, dim3(ew_grid(rows * (C / 4))), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, x, y, rows, C);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_glu_bwd(const float* x, const float* dy, float* dx, long long rows, int C,
+                           void* stream) {
+  if (C % 4) return NSP_EUNSUPPORTED;
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(ew_grid(rows * (C / 4))), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, x, dy, dx, rows, C);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_specaug_apply(float* x, int B, int T, int F, const int* freq_bands, int n_freq,
+                                 const int* time_bands, int n_time, void* stream) {
+  // bands arrive as DEVICE int32 arrays of [start,end) pairs (the host draws them)
+  if (n_freq + n_time == 0) return NSP_OK;
+  hipLaunchKernelGGL(specaug_kernel, dim3(ew_grid((long long)B * T * F)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, x, B, T, F, freq_bands, n_freq, time_bands, n_time);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_pad_batch(const float* packed, const long long* offsets, const int* lens,
+                             float* out, int B, int Tmax, int F, float pad_value, void* stream) {
+  hipLaunchKernelGGL(pad_batch_kernel, dim3(ew_grid((long long)B * Tmax * F)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, packed, offsets, lens, out, B, Tmax, F, pad_value);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

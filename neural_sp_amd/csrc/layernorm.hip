@@ -1,0 +1,189 @@
+// layernorm.hip -- row LayerNorm forward/backward, one wave64 per row, the row
+// held in registers (two-pass mean/variance in fp32, matching ATen's numerics
+// at eps=1e-12).  HBM-bound: forward reads x once and
+// writes y once; backward reads dy, x (+y_pre) once and writes dx once, with
+// dgamma/dbeta accumulated per wave in registers over a grid-stride loop of
+// rows and flushed with one atomic per column per block.
+#include "common.h"
+
+namespace {
+
+template <int VPL>  // float4 per lane; covers d <= VPL*256
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     float* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int rows, int d,
+                                                     float eps, int act, float* __restrict__ y_pre) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int d4 = d >> 2;
+  const float inv_d = 1.f / (float)d;
+  for (long long row = (long long)blockIdx.x * 4 + w; row < rows; row += (long long)gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      int c = lane + i * 64;
+      v[i] = c < d4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mu = wave_reduce_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      int c = lane + i * 64;
+      if (c < d4) {
+        float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
+        q += a * a + b * b + cc * cc + dd * dd;
+      }
+    }
+    const float var = wave_reduce_sum(q) * inv_d;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+    float4* yr = reinterpret_cast<float4*>(y + row * d);
+    float4* ypr = y_pre ? reinterpret_cast<float4*>(y_pre + row * d) : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      int c = lane + i * 64;
+      if (c < d4) {
+        float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        float4 b = reinterpret_cast<const float4*>(beta)[c];
+        float4 o = make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
+                               (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w);
+        if (ypr) ypr[c] = o;
+        if (act != NSP_ACT_NONE)
+          o = make_float4(nsp_act(o.x, act), nsp_act(o.y, act), nsp_act(o.z, act), nsp_act(o.w, act));
+        yr[c] = o;
+      }
+    }
+  }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ y_pre,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int d,
+    int act) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][4][d]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int d4 = d >> 2;
+  const float inv_d = 1.f / (float)d;
+  float4 dg[VPL], db[VPL], gm[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c = lane + i * 64;
+    gm[i] = c < d4 ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (long long row = (long long)blockIdx.x * 4 + w; row < rows; row += (long long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+    const float4* gr = reinterpret_cast<const float4*>(dy + row * d);
+    const float4* pr = (act != NSP_ACT_NONE) ? reinterpret_cast<const float4*>(y_pre + row * d) : nullptr;
+    float4 xh[VPL], g[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      int c = lane + i * 64;
+      if (c < d4) {
+        float4 xv = xr[c];
+        float4 gv = gr[c];
+        if (pr) {
+          float4 p = pr[c];
+          gv.x *= nsp_dact(p.x, act); gv.y *= nsp_dact(p.y, act);
+          gv.z *= nsp_dact(p.z, act); gv.w *= nsp_dact(p.w, act);
+        }
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        db[i].x += gv.x; db[i].y += gv.y; db[i].z += gv.z; db[i].w += gv.w;
+        dg[i].x += gv.x * xh[i].x; dg[i].y += gv.y * xh[i].y;
+        dg[i].z += gv.z * xh[i].z; dg[i].w += gv.w * xh[i].w;
+        g[i] = make_float4(gv.x * gm[i].x, gv.y * gm[i].y, gv.z * gm[i].z, gv.w * gm[i].w);
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+      } else {
+        xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    s1 = wave_reduce_sum(s1) * inv_d;
+    s2 = wave_reduce_sum(s2) * inv_d;
+    float4* dxr = reinterpret_cast<float4*>(dx + row * d);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      int c = lane + i * 64;
+      if (c < d4)
+        dxr[c] = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
+                             rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
+    }
+  }
+  // combine the 4 waves' partial dgamma/dbeta through LDS, one atomic per column
+  float4* shg = reinterpret_cast<float4*>(sh);            // [4][d4]
+  float4* shb = reinterpret_cast<float4*>(sh) + 4 * d4;   // [4][d4]
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    int c = lane + i * 64;
+    if (c < d4) {
+      shg[w * d4 + c] = dg[i];
+      shb[w * d4 + c] = db[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      a += sh[ww * d + c];
+      b += sh[4 * d + ww * d + c];
+    }
+    unsafeAtomicAdd(dgamma + c, a);
+    unsafeAtomicAdd(dbeta + c, b);
+  }
+}
+
+}  // namespace
+
+extern "C" int nsp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                                 float* mean, float* rstd, int rows, int d, float eps, int act,
+                                 float* y_pre, void* stream) {
+  if (d % 4 || d > 2048 || rows <= 0) return NSP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = nsp_cdiv(rows, 4);
+  if (grid > 4096) grid = 4096;
+  const int vpl = nsp_cdiv(d, 256);
+#define LN_FWD(V) hipLaunchKernelGGL((ln_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps, act, y_pre)
+  if (vpl <= 1) LN_FWD(1);
+  else if (vpl <= 2) LN_FWD(2);
+  else if (vpl <= 4) LN_FWD(4);
+  else LN_FWD(8);
+#undef LN_FWD
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
+                                 const float* mean, const float* rstd, const float* y_pre,
+                                 float* dx, float* dgamma, float* dbeta, int rows, int d, int act,
+                                 void* stream) {
+  if (d % 4 || d > 2048 || rows <= 0) return NSP_EUNSUPPORTED;
+  if (act != NSP_ACT_NONE && !y_pre) return NSP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = nsp_cdiv(rows, 4 * 8);  // >= 8 rows per wave to amortise the column atomics
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  const size_t shmem = sizeof(float) * 8 * d;
+  const int vpl = nsp_cdiv(d, 256);
+#define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), shmem, st, dy, x, gamma, mean, rstd, y_pre, dx, dgamma, dbeta, rows, d, act)
+  if (vpl <= 1) LN_BWD(1);
+  else if (vpl <= 2) LN_BWD(2);
+  else if (vpl <= 4) LN_BWD(4);
+  else LN_BWD(8);
+#undef LN_BWD
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

@@ -1,0 +1,174 @@
+"""GPU parity of the basic HIP kernels against plain torch fp32 ops on the same device."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize('mode,tol', [('f32', 2e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (300, 1000, 512), (77, 130, 68), (1024, 512, 2048)])
+def test_gemm_nt(mode, tol, M, N, K):
+    from neural_sp_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(M, K, device=_dev())
+    w = torch.randn(N, K, device=_dev()) / math.sqrt(K)
+    b = torch.randn(N, device=_dev())
+    r = torch.randn(M, N, device=_dev())
+    with ops.compute_mode(mode):
+        pre = torch.empty(M, N, device=_dev())
+        y = ops.linear_fwd(x, w, b, act=ops.ACT['swish'], res=r, alpha=0.5, pre_out=pre)
+    ref_pre = x @ w.t() + b
+    ref = r + 0.5 * ref_pre * torch.sigmoid(ref_pre)
+    assert _rel(pre, ref_pre) < tol, ('pre', _rel(pre, ref_pre))
+    assert _rel(y, ref) < tol, ('y', _rel(y, ref))
+
+
+def test_gemm_layout_asymmetric():
+    """A = I against an asymmetric B catches transposed fragments / outputs."""
+    from neural_sp_amd import ops
+    n = 128
+    eye = torch.eye(n, device=_dev())
+    w = torch.arange(n * n, device=_dev(), dtype=torch.float32).view(n, n) / (n * n)
+    for mode in ('f32', 'bf16'):
+        with ops.compute_mode(mode):
+            y = ops.linear_fwd(eye, w)  # = w^T
+        assert _rel(y, w.t()) < (1e-6 if mode == 'f32' else 5e-3), mode
+
+
+@pytest.mark.parametrize('mode,tol', [('f32', 2e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('M,N,K', [(256, 128, 96), (531, 1000, 512), (12800, 512, 2048)])
+def test_gemm_dgrad_wgrad(mode, tol, M, N, K):
+    from neural_sp_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(M, K, device=_dev())
+    w = torch.randn(N, K, device=_dev()) / math.sqrt(K)
+    dy = torch.randn(M, N, device=_dev())
+    with ops.compute_mode(mode):
+        dx = ops.linear_dgrad(dy, w)
+        dw = ops.linear_wgrad(dy, x)
+        db = ops.colsum(dy)
+    assert _rel(dx, dy @ w) < tol
+    assert _rel(dw, dy.t() @ x) < tol
+    assert _rel(db, dy.sum(0)) < 1e-4
+
+
+def test_gemm_batched_strided():
+    """q.k^T and P.v in the [B,T,H,dk] layout used by the attention path."""
+    from neural_sp_amd import ops
+    torch.manual_seed(2)
+    B, T, H, dk = 3, 70, 4, 64
+    d = H * dk
+    q = torch.randn(B, T, H, dk, device=_dev())
+    k = torch.randn(B, T, H, dk, device=_dev())
+    v = torch.randn(B, T, H, dk, device=_dev())
+    S = torch.empty(B, H, T, T, device=_dev())
+    with ops.compute_mode('f32'):
+        ops.gemm_raw(T, T, dk, q, d, 1, k, 1, d, S, T, batch=(B, H), a_b=(T * d, dk),
+                     b_b=(T * d, dk), c_b=(H * T * T, T * T))
+        ref = torch.einsum('bihd,bjhd->bhij', q, k)
+        assert _rel(S, ref) < 2e-5
+        P = torch.softmax(ref, -1).contiguous()
+        O = torch.empty(B, T, H, dk, device=_dev())
+        ops.gemm_raw(T, dk, T, P, T, 1, v, d, 1, O, d, batch=(B, H), a_b=(H * T * T, T * T),
+                     b_b=(T * d, dk), c_b=(T * d, dk))
+        assert _rel(O, torch.einsum('bhij,bjhd->bihd', P, v)) < 2e-5
+        # dV = P^T dO   (TN), reduction over queries
+        dO = torch.randn(B, T, H, dk, device=_dev())
+        dV = torch.empty(B, T, H, dk, device=_dev())
+        ops.gemm_raw(T, dk, T, P, 1, T, dO, d, 1, dV, d, batch=(B, H), a_b=(H * T * T, T * T),
+                     b_b=(T * d, dk), c_b=(T * d, dk))
+        assert _rel(dV, torch.einsum('bhij,bihd->bjhd', P, dO)) < 2e-5
+
+
+@pytest.mark.parametrize('rows,d', [(5, 256), (1000, 512), (33, 1024), (64, 144)])
+def test_layernorm(rows, d):
+    from neural_sp_amd import ops
+    torch.manual_seed(3)
+    x = (torch.randn(rows, d, device=_dev()) * 3 + 1).requires_grad_()
+    g = torch.randn(d, device=_dev()).requires_grad_()
+    b = torch.randn(d, device=_dev()).requires_grad_()
+    dy = torch.randn(rows, d, device=_dev())
+    for act in ('none', 'swish'):
+        y = ops.layer_norm(x, g, b, 1e-12, act)
+        ref = torch.nn.functional.layer_norm(x, (d,), g, b, 1e-12)
+        if act == 'swish':
+            ref = ref * torch.sigmoid(ref)
+        assert _rel(y, ref) < 1e-5
+        gx, gg, gb = torch.autograd.grad(y, (x, g, b), dy)
+        rx, rg, rb = torch.autograd.grad(ref, (x, g, b), dy)
+        assert _rel(gx, rx) < 1e-4 and _rel(gg, rg) < 1e-4 and _rel(gb, rb) < 1e-4
+
+
+def _ref_attn_probs(S, QP, klens, clamp, scale, causal, lookahead, nl, nc):
+    B, H, Tq, Tk = S.shape
+    i = torch.arange(Tq, device=S.device)[:, None]
+    j = torch.arange(Tk, device=S.device)[None, :]
+    e = S.clone()
+    if QP is not None:
+        rel = (i - j).abs()
+        if clamp > 0:
+            rel = rel.clamp(max=clamp)
+        bd = torch.gather(QP.permute(0, 2, 1, 3), 3, rel[None, None].expand(B, H, Tq, Tk))
+        e = e + bd
+    e = e * scale
+    vis = (j[None] < klens[:, None, None])
+    if causal:
+        vis = vis & (j <= i + lookahead)[None]
+    if nc > 0:
+        c0 = (i // nc) * nc
+        vis = vis & ((j >= (c0 - nl).clamp(min=0)) & (j < c0 + nc))[None]
+    e = e.masked_fill(~vis[:, None], torch.finfo(torch.float32).min)
+    return torch.softmax(e, -1), vis
+
+
+@pytest.mark.parametrize('clamp,causal,nc', [(10, False, 0), (-1, False, 0), (10, True, 0), (4, False, 8)])
+def test_attn_softmax(clamp, causal, nc):
+    from neural_sp_amd import ops
+    torch.manual_seed(4)
+    B, H, T = 3, 4, 45
+    R = clamp + 1 if clamp > 0 else T
+    S0 = torch.randn(B, H, T, T, device=_dev())
+    QP0 = torch.randn(B, T, H, R, device=_dev())
+    klens = torch.tensor([45, 30, 17], device=_dev(), dtype=torch.int32)
+    scale = 0.125
+    nl = 8 if nc else 0
+    S = S0.clone().requires_grad_()
+    QP = QP0.clone().requires_grad_()
+    Pref, vis = _ref_attn_probs(S, QP, klens, clamp, scale, causal, 1, nl, nc)
+    dP = torch.randn_like(Pref)
+    gS, gQP = torch.autograd.grad(Pref, (S, QP), dP)
+    mp = ops._mask_params(B, H, T, T, R, clamp, scale, klens, causal, 1, nl, nc)
+    P = S0.clone()
+    ops.attn_softmax_fwd_raw(P, QP0, mp)
+    assert _rel(P, Pref.detach()) < 1e-5
+    dS = dP.clone()
+    dQP = torch.empty_like(QP0)
+    ops.attn_softmax_bwd_raw(P, dS, dQP, mp)
+    assert _rel(dS, gS) < 1e-4
+    assert _rel(dQP, gQP) < 1e-4
+
+
+def test_elementwise():
+    from neural_sp_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(1000, 37, device=_dev())
+    z = torch.randn(1000, 37, device=_dev())
+    assert _rel(ops.axpby(x, z, 0.5, 2.0), 0.5 * x + 2 * z) < 1e-6
+    for name, f in [('relu', torch.relu), ('swish', lambda t: t * torch.sigmoid(t)), ('tanh', torch.tanh),
+                    ('gelu_accurate', lambda t: torch.nn.functional.gelu(t)),
+                    ('gelu', lambda t: torch.nn.functional.gelu(t, approximate='tanh'))]:
+        xr = x.clone().requires_grad_()
+        ref = f(xr)
+        assert _rel(ops.act_fwd(x, ops.ACT[name]), ref.detach()) < 1e-5, name
+        g, = torch.autograd.grad(ref, xr, z)
+        assert _rel(ops.dact_mul(z, x, ops.ACT[name]), g) < 1e-4, name
