@@ -161,11 +161,14 @@ int nsp_attn_softmax_bwd(const float* P, float* dP, float* dQP,
  * channels-last [B,T,C] (conformer_convolution.py:111-113; groups=C,       *
  * padding (k-1)/2, or causal: left pad k-1).                               *
  * ------------------------------------------------------------------------ */
-int nsp_dwconv1d_fwd(const float* x, const float* w /*[C,k]*/, const float* bias,
-                     float* y, int B, int T, int C, int k, int causal, void* stream);
-int nsp_dwconv1d_bwd(const float* x, const float* w, const float* dy,
-                     float* dx, float* dw, float* dbias,
-                     int B, int T, int C, int k, int causal, void* stream);
+/* y[b,t,c] = bias[c] + sum_j wt[jj][c] * x[b, t+j-pad, c], jj = flip ? k-1-j : j.
+ * wt is tap-major [k][C] (the host transposes the reference's [C,1,k] weight).
+ * The data gradient is the same kernel on dy with flip=1, pad = k-1-pad. */
+int nsp_dwconv1d_fwd(const float* x, const float* wt /*[k,C]*/, const float* bias,
+                     float* y, int B, int T, int C, int k, int pad, int flip, void* stream);
+/* dwt[k][C], dbias[C] are accumulated atomically into caller-zeroed buffers */
+int nsp_dwconv1d_wgrad(const float* x, const float* dy, float* dwt, float* dbias,
+                       int B, int T, int C, int k, int pad, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * VGG-style Conv2d frontend on channels-last [B,T,F,C] (conv.py:289-396).  *
@@ -174,10 +177,12 @@ int nsp_dwconv1d_bwd(const float* x, const float* w, const float* dy,
 int nsp_conv2d3x3_fwd(const float* x, const float* w /*[Co,3,3,Ci]*/, const float* bias,
                       float* y, int B, int T, int F, int Ci, int Co, int relu,
                       int mode, void* stream);
-/* dy must already be masked by ReLU (nsp_relu_mask). dx may be NULL (first layer). */
-int nsp_conv2d3x3_bwd(const float* x, const float* w, const float* dy,
-                      float* dx, float* dw, float* dbias,
-                      int B, int T, int F, int Ci, int Co, int mode, void* stream);
+/* dw [Co,3,3,Ci] and dbias [Co] accumulated atomically into caller-zeroed
+ * buffers; dy must already be masked by the ReLU (nsp_relu_bwd).  The data
+ * gradient is nsp_conv2d3x3_fwd on dy with the tap-flipped, channel-transposed
+ * filter bank (built by the host, 9K floats). */
+int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, float* dbias,
+                        int B, int T, int F, int Ci, int Co, void* stream);
 int nsp_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);
 /* MaxPool2d(kernel=stride=(pt,pf), ceil_mode=True) on [B,T,F,C]; if
  * to_btcf != 0 the output is written as [B,T',C,F'] (= the reference's
@@ -204,8 +209,9 @@ int nsp_maxpool1d_bwd(const float* dy, const int* argmax, float* dx, int B, int 
  * ------------------------------------------------------------------------ */
 long long nsp_ctc_workspace_bytes(int B, int T, int Lmax);
 int nsp_ctc_loss_fwd_bwd(const float* logits, const int* labels, const int* elens,
-                         const int* ylens, float* nll, float* grad, void* workspace,
-                         int B, int T, int V, int Lmax, int blank, void* stream);
+                         const int* ylens, float* nll, float* grad, float gscale,
+                         void* workspace, int B, int T, int V, int Lmax, int blank,
+                         void* stream);
 /* label-smoothing KL term and its gradient (criterion.py:110-127):
  * kl_sum[0] += sum_{b,t<elens_b,v} p (log p - log(1/(V-1))); grad (+)= gscale * d kl_sum */
 int nsp_ctc_kldiv_fwd_bwd(const float* logits, const int* elens, float* kl_sum,
@@ -228,8 +234,8 @@ int nsp_ctc_forced_align(const float* logits, const int* labels, const int* elen
  *        g_blank/g_label [B,T,U1] = d nll_b / d lp_*                       *
  *   nsp_rnnt_grad_logits: in place logits <- d(sum_b w_b nll_b)/d logits   *
  * ------------------------------------------------------------------------ */
-int nsp_rnnt_logsoftmax_gather(const float* logits, const int* labels, float* lse,
-                               float* lp_blank, float* lp_label,
+int nsp_rnnt_logsoftmax_gather(const float* logits, const int* labels, const int* elens,
+                               const int* ylens, float* lse, float* lp_blank, float* lp_label,
                                int B, int T, int U1, int V, int blank, void* stream);
 int nsp_rnnt_lattice(const float* lp_blank, const float* lp_label, const int* elens,
                      const int* ylens, float* alpha, float* beta, float* nll,
@@ -242,17 +248,18 @@ int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* labels,
  * reductions (rnn_transducer.py:272-274) */
 int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h,
                             int B, int T, int U1, int J, void* stream);
-int nsp_rnnt_joint_tanh_bwd(const float* h, const float* dh, float* de, float* dg,
+/* dh is overwritten with dz = dh*(1-h^2); de[b,t,:] = sum_u dz, dg[b,u,:] = sum_t dz */
+int nsp_rnnt_joint_tanh_bwd(const float* h, float* dh, float* de, float* dg,
                             int B, int T, int U1, int J, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * SpecAugment band zeroing in place on [B,T,F] (spec_augment.py:112-140).  *
- * bands are host arrays of [start,end) pairs (drawn by the host with the   *
- * reference's np.random stream).                                           *
+ * bands are small device arrays of [start,end) pairs (drawn on the host     *
+ * with the reference's np.random stream, then copied).                      *
  * ------------------------------------------------------------------------ */
 int nsp_specaug_apply(float* x, int B, int T, int F,
-                      const int* freq_bands /*host*/, int n_freq,
-                      const int* time_bands /*host*/, int n_time, void* stream);
+                      const int* freq_bands /*device [n_freq][2]*/, int n_freq,
+                      const int* time_bands /*device [n_time][2]*/, int n_time, void* stream);
 
 /* pad a ragged batch: src is one packed device buffer of sum(T_b)*F floats
  * (torch_utils.py:56 pad_list + speech2text.py:397) */

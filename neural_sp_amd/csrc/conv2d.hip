@@ -1,0 +1,419 @@
+// conv2d.hip -- VGG-style Conv2d frontend (reference conv.py:289-396) on
+// channels-last [B,T,F,C] activations.
+//
+//   * 3x3 / pad 1 / stride 1, C_in = C_out = 32: MFMA kernel.  A block owns an
+//     8(time) x 16(freq) output tile; its 10x18 input halo is staged ONCE in LDS
+//     (bf16 in NSP_COMPUTE_BF16, fp32 in NSP_COMPUTE_F32) and the 9 taps are read
+//     as shifted MFMA A-fragments straight out of that tile -- no im2col copy
+//     ever exists, HBM sees each input pixel ~1.4x.  The 32x288 filter bank
+//     lives in registers (bf16) or LDS (fp32).  The same kernel computes the
+//     data gradient with the tap-flipped, channel-transposed filter bank.
+//   * C_in = 1 (first layer): direct kernel, HBM-bound on the 32-channel write.
+//   * weight gradients: register-tiled SIMT kernels (persistent blocks, one
+//     atomic flush per block).
+//   * MaxPool2d(ceil_mode=True) with argmax for the backward gather; can emit the
+//     reference's [B,T',C*F'] feature order (conv.py:189) directly.
+// Filter layout everywhere: w[co][3][3][ci] (tap-major, ci innermost).
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 8, TF = 16, HT = TT + 2, HF = TF + 2, CH = 32;
+
+template <int MODE> struct ConvCfg;
+template <> struct ConvCfg<0> { static constexpr int PIX_PITCH = 80; };    // 32 bf16 + 16 B pad
+template <> struct ConvCfg<1> { static constexpr int PIX_PITCH = 144; };   // 32 fp32 + 16 B pad
+constexpr int W_PITCH = 292;  // floats per co row of the fp32 LDS filter bank (288 + 4 pad)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ y, int B, int T, int F,
+                                                          int relu) {
+  constexpr int PP = ConvCfg<MODE>::PIX_PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xs = smem;                                          // [HT*HF][PP]
+  float* ws = reinterpret_cast<float*>(smem + HT * HF * PP);          // MODE 1 only: [32][W_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f0 = blockIdx.x * TF, t0 = blockIdx.y * TT, b = blockIdx.z;
+  const int r = lane & 15, g = lane >> 4;
+
+  // ---- stage the halo tile: HT*HF pixels x 8 float4
+  for (int idx = tid; idx < HT * HF * 8; idx += 256) {
+    const int c4 = idx & 7, pix = idx >> 3;
+    const int ht = pix / HF, hf = pix % HF;
+    const int t = t0 + ht - 1, f = f0 + hf - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < T && f >= 0 && f < F)
+      v = reinterpret_cast<const float4*>(x + (((long long)b * T + t) * F + f) * CH)[c4];
+    if (MODE == 0) {
+      bf16x4 h;
+      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(xs + pix * PP + c4 * 8) = h;
+    } else {
+      *reinterpret_cast<float4*>(xs + pix * PP + c4 * 16) = v;
+    }
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) acc[a][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (MODE == 0) {
+    // filter bank -> registers: bfrag[tap][nb] = w[nb*16+r][tap][g*8 .. g*8+7]
+    bf16x8 bfrag[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float* wp = w + ((long long)(nb * 16 + r) * 9 + tap) * CH + g * 8;
+        const float4 lo = reinterpret_cast<const float4*>(wp)[0];
+        const float4 hi = reinterpret_cast<const float4*>(wp)[1];
+        bf16x8 h;
+        h[0] = (__bf16)lo.x; h[1] = (__bf16)lo.y; h[2] = (__bf16)lo.z; h[3] = (__bf16)lo.w;
+        h[4] = (__bf16)hi.x; h[5] = (__bf16)hi.y; h[6] = (__bf16)hi.z; h[7] = (__bf16)hi.w;
+        bfrag[tap][nb] = h;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dt = tap / 3, df = tap % 3;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int pix = (wave * 2 + a + dt) * HF + r + df;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(xs + pix * PP + g * 16);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[tap][nb], af, acc[a][nb], 0, 0, 0);
+      }
+    }
+  } else {
+    for (int idx = tid; idx < CH * 288 / 4; idx += 256) {
+      const int co = idx / 72, q = idx % 72;
+      *reinterpret_cast<float4*>(ws + co * W_PITCH + q * 4) =
+          reinterpret_cast<const float4*>(w + (long long)co * 288)[q];
+    }
+    __syncthreads();
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dt = tap / 3, df = tap % 3;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        float af[2], bf[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int pix = (wave * 2 + a + dt) * HF + r + df;
+          af[a] = *reinterpret_cast<const float*>(xs + pix * PP + (s * 4 + g) * 4);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) bf[nb] = ws[(nb * 16 + r) * W_PITCH + tap * CH + s * 4 + g];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nb], af[a], acc[a][nb], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: lane holds pixel (t0+2*wave+a, f0+r), co = nb*16 + g*4 .. +3
+  const int f = f0 + r;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int t = t0 + wave * 2 + a;
+    if (t >= T || f >= F) continue;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int co = nb * 16 + g * 4;
+      float4 v = make_float4(acc[a][nb][0], acc[a][nb][1], acc[a][nb][2], acc[a][nb][3]);
+      if (bias) {
+        const float4 bb = reinterpret_cast<const float4*>(bias + co)[0];
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(y + (((long long)b * T + t) * F + f) * CH + co) = v;
+    }
+  }
+}
+
+// ---- first layer: C_in = 1 -> 32, direct; thread = (pixel, co-quad)
+__global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ y, int B, int T, int F,
+                                                         int relu) {
+  __shared__ float wt[9][CH];  // tap-major copy of w[co][tap]
+  for (int i = threadIdx.x; i < 9 * CH; i += blockDim.x) wt[i % 9][i / 9] = w[i];
+  __syncthreads();
+  const long long total = (long long)B * T * F * 8;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int c4 = (int)(idx & 7);
+    const long long pix = idx >> 3;
+    const int f = (int)(pix % F);
+    const int t = (int)((pix / F) % T);
+    const long long b = pix / ((long long)F * T);
+    float4 acc = bias ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tt = t + tap / 3 - 1, ff = f + tap % 3 - 1;
+      if (tt < 0 || tt >= T || ff < 0 || ff >= F) continue;
+      const float xv = x[(b * T + tt) * F + ff];
+      const float4 wv = *reinterpret_cast<const float4*>(&wt[tap][c4 * 4]);
+      acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
+    }
+    if (relu) {
+      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    }
+    reinterpret_cast<float4*>(y)[idx] = acc;
+  }
+}
+
+// ---- weight gradient, C_in = 1: dw[co][tap] += sum_p dy[p][co] x[p+tap]; dbias[co] += sum dy
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ dy,
+                                                               float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int B, int T,
+                                                               int F, long long pix_per_block) {
+  __shared__ float sh[8][10][CH];
+  const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const long long npix = (long long)B * T * F;
+  const long long p0 = (long long)blockIdx.x * pix_per_block;
+  const long long p1 = min(npix, p0 + pix_per_block);
+  float acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+  for (long long p = p0 + pl; p < p1; p += 8) {
+    const int f = (int)(p % F);
+    const int t = (int)((p / F) % T);
+    const long long b = p / ((long long)F * T);
+    const float g = dy[p * CH + co];
+    acc[9] += g;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tt = t + tap / 3 - 1, ff = f + tap % 3 - 1;
+      if (tt >= 0 && tt < T && ff >= 0 && ff < F) acc[tap] += g * x[(b * T + tt) * F + ff];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) sh[pl][i][co] = acc[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 10 * CH; i += blockDim.x) {
+    const int tap = i / CH, c = i % CH;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += sh[q][tap][c];
+    if (tap < 9) unsafeAtomicAdd(dw + c * 9 + tap, s);
+    else if (dbias) unsafeAtomicAdd(dbias + c, s);
+  }
+}
+
+// ---- weight gradient, 32 -> 32: thread = (ci, 4 co), 9x4 accumulators, persistent over tiles
+__global__ __launch_bounds__(256) void conv3x3_c32_wgrad_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ dy,
+                                                                float* __restrict__ dw,
+                                                                float* __restrict__ dbias, int B, int T,
+                                                                int F, int tiles_f, int tiles_t) {
+  __shared__ __attribute__((aligned(16))) float xs[HT * HF][CH];
+  __shared__ __attribute__((aligned(16))) float ds[TT * TF][CH];
+  const int tid = threadIdx.x;
+  const int ci = tid & 31, cog = tid >> 5;
+  float acc[9][4];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  float accb[4] = {0.f, 0.f, 0.f, 0.f};
+  const long long ntiles = (long long)B * tiles_t * tiles_f;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tf = (int)(tile % tiles_f);
+    const int tt = (int)((tile / tiles_f) % tiles_t);
+    const long long b = tile / ((long long)tiles_f * tiles_t);
+    const int f0 = tf * TF, t0 = tt * TT;
+    __syncthreads();
+    for (int idx = tid; idx < HT * HF * 8; idx += 256) {
+      const int c4 = idx & 7, pix = idx >> 3;
+      const int t = t0 + pix / HF - 1, f = f0 + pix % HF - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < T && f >= 0 && f < F)
+        v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
+      *reinterpret_cast<float4*>(&xs[pix][c4 * 4]) = v;
+    }
+    for (int idx = tid; idx < TT * TF * 8; idx += 256) {
+      const int c4 = idx & 7, pix = idx >> 3;
+      const int t = t0 + pix / TF, f = f0 + pix % TF;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T && f < F) v = reinterpret_cast<const float4*>(dy + ((b * T + t) * F + f) * CH)[c4];
+      *reinterpret_cast<float4*>(&ds[pix][c4 * 4]) = v;
+    }
+    __syncthreads();
+    for (int p = 0; p < TT * TF; ++p) {
+      const int pt = p / TF, pf = p % TF;
+      const float4 g = *reinterpret_cast<const float4*>(&ds[p][cog * 4]);
+      if (ci == 0) { accb[0] += g.x; accb[1] += g.y; accb[2] += g.z; accb[3] += g.w; }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float xv = xs[(pt + tap / 3) * HF + pf + tap % 3][ci];
+        acc[tap][0] += g.x * xv; acc[tap][1] += g.y * xv;
+        acc[tap][2] += g.z * xv; acc[tap][3] += g.w * xv;
+      }
+    }
+  }
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      unsafeAtomicAdd(dw + ((long long)(cog * 4 + j) * 9 + tap) * CH + ci, acc[tap][j]);
+  if (ci == 0 && dbias)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dbias + cog * 4 + j, accb[j]);
+}
+
+// ---- MaxPool2d(kernel=stride=(pt,pf), ceil_mode) on [B,T,F,C]
+__global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                     int* __restrict__ argmax, int B, int T, int F, int C, int To,
+                                     int Fo, int pt, int pf, int to_btcf) {
+  const int C4 = C >> 2;
+  const long long total = (long long)B * To * Fo * C4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int c4 = (int)(idx % C4);
+    const int fo = (int)((idx / C4) % Fo);
+    const int to = (int)((idx / ((long long)C4 * Fo)) % To);
+    const long long b = idx / ((long long)C4 * Fo * To);
+    float best[4] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int bi[4] = {0, 0, 0, 0};
+    bool first = true;
+    for (int dt = 0; dt < pt; ++dt) {
+      const int t = to * pt + dt;
+      if (t >= T) break;
+      for (int df = 0; df < pf; ++df) {
+        const int f = fo * pf + df;
+        if (f >= F) break;
+        const float4 v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * C)[c4];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (first || vv[e] > best[e]) { best[e] = vv[e]; bi[e] = t * F + f; }
+        first = false;
+      }
+    }
+    if (to_btcf) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long o = ((b * To + to) * C + c4 * 4 + e) * Fo + fo;
+        y[o] = best[e];
+        argmax[o] = bi[e];
+      }
+    } else {
+      reinterpret_cast<float4*>(y)[idx] = make_float4(best[0], best[1], best[2], best[3]);
+      reinterpret_cast<int4*>(argmax)[idx] = make_int4(bi[0], bi[1], bi[2], bi[3]);
+    }
+  }
+}
+
+__global__ void maxpool2d_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ argmax,
+                                     float* __restrict__ dx, int B, int T, int F, int C, int To,
+                                     int Fo, int pt, int pf, int from_btcf) {
+  const int C4 = C >> 2;
+  const long long total = (long long)B * T * F * C4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int c4 = (int)(idx % C4);
+    const int f = (int)((idx / C4) % F);
+    const int t = (int)((idx / ((long long)C4 * F)) % T);
+    const long long b = idx / ((long long)C4 * F * T);
+    const int to = t / pt, fo = f / pf;
+    const int self = t * F + f;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long oi = from_btcf ? ((b * To + to) * C + c4 * 4 + e) * Fo + fo
+                                     : ((b * To + to) * Fo + fo) * C + c4 * 4 + e;
+      o[e] = argmax[oi] == self ? dy[oi] : 0.f;
+    }
+    reinterpret_cast<float4*>(dx)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+inline int ew_grid(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int nsp_conv2d3x3_fwd(const float* x, const float* w, const float* bias, float* y, int B,
+                                 int T, int F, int Ci, int Co, int relu, int mode, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (Co != CH) return NSP_EUNSUPPORTED;
+  if (Ci == 1) {
+    hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(ew_grid((long long)B * T * F * 8)), dim3(256), 0, st, x,
+                       w, bias, y, B, T, F, relu);
+  } else if (Ci == CH) {
+    dim3 grid(nsp_cdiv(F, TF), nsp_cdiv(T, TT), B);
+    if (grid.y > 65535 || grid.z > 65535) return NSP_EUNSUPPORTED;
+    if (mode == NSP_COMPUTE_BF16) {
+      const size_t sh = HT * HF * ConvCfg<0>::PIX_PITCH;
+      hipLaunchKernelGGL((conv3x3_c32_kernel<0>), grid, dim3(256), sh, st, x, w, bias, y, B, T, F, relu);
+    } else {
+      const size_t sh = HT * HF * ConvCfg<1>::PIX_PITCH + sizeof(float) * CH * W_PITCH;
+      hipFuncSetAttribute((const void*)conv3x3_c32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipLaunchKernelGGL((conv3x3_c32_kernel<1>), grid, dim3(256), sh, st, x, w, bias, y, B, T, F, relu);
+    }
+  } else {
+    return NSP_EUNSUPPORTED;
+  }
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+// dw / dbias must be zeroed by the caller (atomic accumulation)
+extern "C" int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B,
+                                   int T, int F, int Ci, int Co, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (Co != CH) return NSP_EUNSUPPORTED;
+  if (Ci == 1) {
+    const long long npix = (long long)B * T * F;
+    int blocks = 1024;
+    long long ppb = (npix + blocks - 1) / blocks;
+    if (ppb < 64) ppb = 64;
+    blocks = nsp_cdiv(npix, ppb);
+    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dy, dw, dbias, B, T,
+                       F, ppb);
+  } else if (Ci == CH) {
+    const int tiles_f = nsp_cdiv(F, TF), tiles_t = nsp_cdiv(T, TT);
+    long long ntiles = (long long)B * tiles_f * tiles_t;
+    int blocks = ntiles < 1024 ? (int)ntiles : 1024;
+    hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dy, dw, dbias, B, T,
+                       F, tiles_f, tiles_t);
+  } else {
+    return NSP_EUNSUPPORTED;
+  }
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_maxpool2d_fwd(const float* x, float* y, int* argmax, int B, int T, int F, int C,
+                                 int pt, int pf, int to_btcf, void* stream) {
+  if (C % 4) return NSP_EUNSUPPORTED;
+  const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
+  hipLaunchKernelGGL(maxpool2d_fwd_kernel, dim3(ew_grid((long long)B * To * Fo * (C / 4))), dim3(256),
+                     0, (hipStream_t)stream, x, y, argmax, B, T, F, C, To, Fo, pt, pf, to_btcf);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_maxpool2d_bwd(const float* dy, const int* argmax, float* dx, int B, int T, int F,
+                                 int C, int pt, int pf, int from_btcf, void* stream) {
+  if (C % 4) return NSP_EUNSUPPORTED;
+  const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
+  hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(ew_grid((long long)B * T * F * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, dy, argmax, dx, B, T, F, C, To, Fo, pt, pf, from_btcf);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

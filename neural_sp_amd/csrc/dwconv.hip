@@ -1,0 +1,208 @@
+// dwconv.hip -- depthwise Conv1d over time on channels-last [B,T,C]
+// (Conformer convolution module, reference conformer_convolution.py:47-53,
+// 111-113) and MaxPool1d time subsampling (subsampling.py:188-209).
+//
+// Channels-last keeps the [B,T,C] activation layout of the rest of the block:
+// the reference's two transposes [B,T,C]<->[B,C,T] (:106,:115) disappear.
+// Each lane owns 4 adjacent channels (16 B), a wave covers 256 channels, so
+// every global access is a fully coalesced 1 KiB row segment; the k-tap
+// re-reads of x hit L1/L2 (HBM sees x once).  HBM-bound.
+#include "common.h"
+
+namespace {
+
+// y[b,t,c] = bias[c] + sum_j w[jj][c] * x[b, t + j - pad, c],  jj = flip ? k-1-j : j
+// wt is tap-major: [k][C]
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ wt,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ y, int B, int T, int C,
+                                                         int k, int pad, int flip) {
+  const int C4 = C >> 2;
+  const long long total = (long long)B * T * C4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int c4 = (int)(idx % C4);
+    const int t = (int)((idx / C4) % T);
+    const int b = (int)(idx / ((long long)C4 * T));
+    float4 acc = bias ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xb = x + (long long)b * T * C;
+    for (int j = 0; j < k; ++j) {
+      const int ts = t + j - pad;
+      if (ts < 0 || ts >= T) continue;
+      const float4 xv = reinterpret_cast<const float4*>(xb + (long long)ts * C)[c4];
+      const float4 wv = reinterpret_cast<const float4*>(wt + (long long)(flip ? k - 1 - j : j) * C)[c4];
+      acc.x += wv.x * xv.x; acc.y += wv.y * xv.y; acc.z += wv.z * xv.z; acc.w += wv.w * xv.w;
+    }
+    reinterpret_cast<float4*>(y)[idx] = acc;
+  }
+}
+
+// dwt[j][c] += sum_{b,t} dy[b,t,c] * x[b, t + j - pad, c] ; dbias[c] += sum dy
+// grid: (ceil(C4/64), nchunks); block 256 = 4 waves striding over the rows of a chunk
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ dy,
+                                                           float* __restrict__ dwt,
+                                                           float* __restrict__ dbias, int B, int T,
+                                                           int C, int k, int pad, int rows_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float4 sh4[];  // [4 waves][(k+1)][64 lanes]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  const int c4 = blockIdx.x * 64 + lane;
+  const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+  const long long r1 = min((long long)B * T, r0 + rows_per_chunk);
+  const bool active = c4 < C4;
+  // accumulate taps in chunks of 8 to bound registers for large kernels
+  for (int j0 = 0; j0 < k; j0 += 8) {
+    float4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+      for (long long r = r0 + w; r < r1; r += 4) {
+        const int t = (int)(r % T);
+        const long long b = r / T;
+        const float4 g = reinterpret_cast<const float4*>(dy + r * C)[c4];
+        if (j0 == 0) { accb.x += g.x; accb.y += g.y; accb.z += g.z; accb.w += g.w; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ts = t + j0 + j - pad;
+          if (j0 + j < k && ts >= 0 && ts < T) {
+            const float4 xv = reinterpret_cast<const float4*>(x + (b * T + ts) * C)[c4];
+            acc[j].x += g.x * xv.x; acc[j].y += g.y * xv.y; acc[j].z += g.z * xv.z; acc[j].w += g.w * xv.w;
+          }
+        }
+      }
+    }
+    // combine the 4 waves
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh4[(w * 9 + j) * 64 + lane] = acc[j];
+    sh4[(w * 9 + 8) * 64 + lane] = accb;
+    __syncthreads();
+    if (w == 0 && active) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        float4 s = sh4[(0 * 9 + j) * 64 + lane];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+          float4 o = sh4[(ww * 9 + j) * 64 + lane];
+          s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        float* dst = nullptr;
+        if (j < 8) {
+          if (j0 + j < k) dst = dwt + (long long)(j0 + j) * C + c4 * 4;
+        } else if (j0 == 0 && dbias) {
+          dst = dbias + c4 * 4;
+        }
+        if (dst) {
+          unsafeAtomicAdd(dst + 0, s.x); unsafeAtomicAdd(dst + 1, s.y);
+          unsafeAtomicAdd(dst + 2, s.z); unsafeAtomicAdd(dst + 3, s.w);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// MaxPool1d(kernel=stride=factor, ceil_mode=True) over time; argmax saved as the
+// source time index for the backward scatter.
+__global__ void maxpool1d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                     int* __restrict__ argmax, int B, int T, int To, int C,
+                                     int factor) {
+  const int C4 = C >> 2;
+  const long long total = (long long)B * To * C4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int c4 = (int)(idx % C4);
+    const int to = (int)((idx / C4) % To);
+    const long long b = idx / ((long long)C4 * To);
+    float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    int4 bi = make_int4(to * factor, to * factor, to * factor, to * factor);
+    for (int f = 0; f < factor; ++f) {
+      const int t = to * factor + f;
+      if (t >= T) break;
+      const float4 v = reinterpret_cast<const float4*>(x + (b * T + t) * C)[c4];
+      if (v.x > best.x || f == 0) { if (v.x > best.x || f == 0) { best.x = v.x; bi.x = t; } }
+      if (v.y > best.y || f == 0) { best.y = v.y; bi.y = t; }
+      if (v.z > best.z || f == 0) { best.z = v.z; bi.z = t; }
+      if (v.w > best.w || f == 0) { best.w = v.w; bi.w = t; }
+    }
+    reinterpret_cast<float4*>(y)[idx] = best;
+    reinterpret_cast<int4*>(argmax)[idx] = bi;
+  }
+}
+
+__global__ void maxpool1d_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ argmax,
+                                     float* __restrict__ dx, int B, int T, int To, int C,
+                                     int factor) {
+  // one thread per INPUT element quad: gather from its pooling window's output
+  const int C4 = C >> 2;
+  const long long total = (long long)B * T * C4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int c4 = (int)(idx % C4);
+    const int t = (int)((idx / C4) % T);
+    const long long b = idx / ((long long)C4 * T);
+    const int to = t / factor;
+    const long long o = (b * To + to) * C4 + c4;
+    const float4 g = reinterpret_cast<const float4*>(dy)[o];
+    const int4 a = reinterpret_cast<const int4*>(argmax)[o];
+    reinterpret_cast<float4*>(dx)[idx] = make_float4(a.x == t ? g.x : 0.f, a.y == t ? g.y : 0.f,
+                                                     a.z == t ? g.z : 0.f, a.w == t ? g.w : 0.f);
+  }
+}
+
+inline int ew_grid(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int nsp_dwconv1d_fwd(const float* x, const float* wt, const float* bias, float* y, int B,
+                                int T, int C, int k, int pad, int flip, void* stream) {
+  if (C % 4 || k < 1) return NSP_EUNSUPPORTED;
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(ew_grid((long long)B * T * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, wt, bias, y, B, T, C, k, pad, flip);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_dwconv1d_wgrad(const float* x, const float* dy, float* dwt, float* dbias, int B,
+                                  int T, int C, int k, int pad, void* stream) {
+  if (C % 4 || k < 1) return NSP_EUNSUPPORTED;
+  const int gx = nsp_cdiv(C / 4, 64);
+  const long long rows = (long long)B * T;
+  int chunks = 1024 / gx;
+  if (chunks < 1) chunks = 1;
+  int rpc = nsp_cdiv(rows, chunks);
+  if (rpc < 64) rpc = 64;
+  chunks = nsp_cdiv(rows, rpc);
+  const size_t shmem = sizeof(float4) * 4 * 9 * 64;
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(gx, chunks), dim3(256), shmem, (hipStream_t)stream, x,
+                     dy, dwt, dbias, B, T, C, k, pad, rpc);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_maxpool1d_fwd(const float* x, float* y, int* argmax, int B, int T, int C,
+                                 int factor, void* stream) {
+  if (C % 4 || factor < 1) return NSP_EUNSUPPORTED;
+  const int To = (T + factor - 1) / factor;
+  hipLaunchKernelGGL(maxpool1d_fwd_kernel, dim3(ew_grid((long long)B * To * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, y, argmax, B, T, To, C, factor);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_maxpool1d_bwd(const float* dy, const int* argmax, float* dx, int B, int T, int C,
+                                 int factor, void* stream) {
+  if (C % 4 || factor < 1) return NSP_EUNSUPPORTED;
+  const int To = (T + factor - 1) / factor;
+  hipLaunchKernelGGL(maxpool1d_bwd_kernel, dim3(ew_grid((long long)B * T * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, dy, argmax, dx, B, T, To, C, factor);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

@@ -1,0 +1,296 @@
+// rnnt.hip -- RNN-Transducer loss on CDNA4.
+//
+// The reference (rnn_transducer.py:242-256) materialises log_softmax over the
+// joint tensor [B,T,U+1,V] and hands it to an external CUDA library
+// (warp_rnnt 0.3: rnnt_loss(average_frames=False, reduction='mean',
+// gather=False)).  That arithmetic is restated here from Graves (2012):
+//   alpha(0,0)=0
+//   alpha(t,u)=logaddexp(alpha(t-1,u)+lp_blank(t-1,u), alpha(t,u-1)+lp_label(t,u-1))
+//   nll = -(alpha(T-1,U) + lp_blank(T-1,U))
+// Only two numbers per lattice node matter, so the path is split in three:
+//   1. rnnt_logsoftmax_gather: ONE pass over the logits -> lse, lp_blank,
+//      lp_label per node (the dense log-prob tensor is never written);
+//   2. rnnt_lattice: alpha and beta anti-diagonal wavefronts, one workgroup
+//      per utterance (alpha on the first half, beta on the second half, the
+//      previous diagonal in LDS), then node occupancies
+//      g_blank/g_label = d nll / d lp_*;
+//   3. rnnt_grad_logits: in place, logits <- d loss / d logits
+//      = w * ( -(g_b+g_l) * softmax + g_b*[v=blank] + g_l*[v=label] ).
+// plus the joint tanh(e_t + g_u) forward and its two backward reductions.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void rnnt_lsm_gather_kernel(
+    const float* __restrict__ logits, const int* __restrict__ labels, const int* __restrict__ elens,
+    const int* __restrict__ ylens, float* __restrict__ lse, float* __restrict__ lp_blank,
+    float* __restrict__ lp_label, int B, int T, int U1, int V, int blank) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long nrows = (long long)B * T * U1;
+  const int U = U1 - 1;
+  for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
+    const int u = (int)(row % U1);
+    const int t = (int)((row / U1) % T);
+    const int b = (int)(row / ((long long)U1 * T));
+    if (t >= elens[b] || u > ylens[b]) {
+      if (lane == 0) { lse[row] = 0.f; lp_blank[row] = -INFINITY; lp_label[row] = -INFINITY; }
+      continue;
+    }
+    const float* xr = logits + row * V;
+    float mx = -FLT_MAX;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, xr[v]);
+    mx = wave_reduce_max(mx);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(xr[v] - mx);
+    s = wave_reduce_sum(s);
+    if (lane == 0) {
+      const float ls = mx + logf(s);
+      lse[row] = ls;
+      lp_blank[row] = xr[blank] - ls;
+      lp_label[row] = (u < ylens[b] && u < U) ? xr[labels[(long long)b * U + u]] - ls : -INFINITY;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void rnnt_lattice_kernel(
+    const float* __restrict__ lp_blank, const float* __restrict__ lp_label,
+    const int* __restrict__ elens, const int* __restrict__ ylens, float* __restrict__ alpha,
+    float* __restrict__ beta, float* __restrict__ nll, float* __restrict__ g_blank,
+    float* __restrict__ g_label, int B, int T, int U1) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // a[2][U1], b[2][U1]
+  float* abuf = sh;
+  float* bbuf = sh + 2 * U1;
+  const int b = blockIdx.x;
+  const int half = blockDim.x >> 1;
+  const bool is_beta = threadIdx.x >= half;
+  const int tid = is_beta ? threadIdx.x - half : threadIdx.x;
+  const int Tb = min(elens[b], T);
+  const int Ub = min(ylens[b], U1 - 1);  // number of labels
+  const long long base = (long long)b * T * U1;
+  const float* lb = lp_blank + base;
+  const float* ll = lp_label + base;
+  float* al = alpha + base;
+  float* be = beta + base;
+  if (Tb <= 0) {
+    if (threadIdx.x == 0) nll[b] = INFINITY;
+    return;
+  }
+  const int ndiag = Tb + Ub;  // diagonals d = t+u, 0 .. Tb-1+Ub
+  for (int d = 0; d < ndiag; ++d) {
+    const int cur = d & 1, prv = cur ^ 1;
+    if (!is_beta) {
+      for (int u = tid; u <= Ub; u += half) {
+        const int t = d - u;
+        if (t < 0 || t >= Tb) continue;
+        float a;
+        if (t == 0 && u == 0) {
+          a = 0.f;
+        } else {
+          float x = -INFINITY, y = -INFINITY;
+          if (t > 0) x = abuf[prv * U1 + u] + lb[(long long)(t - 1) * U1 + u];
+          if (u > 0) y = abuf[prv * U1 + u - 1] + ll[(long long)t * U1 + u - 1];
+          a = nsp_logaddexp(x, y);
+        }
+        abuf[cur * U1 + u] = a;
+        al[(long long)t * U1 + u] = a;
+      }
+    } else {
+      // mirrored diagonal: t = Tb-1 - (d - (Ub-u))
+      for (int u = tid; u <= Ub; u += half) {
+        const int t = Tb - 1 - (d - (Ub - u));
+        if (t < 0 || t >= Tb) continue;
+        float v;
+        if (t == Tb - 1 && u == Ub) {
+          v = lb[(long long)t * U1 + u];
+        } else {
+          float x = -INFINITY, y = -INFINITY;
+          if (t + 1 < Tb) x = bbuf[prv * U1 + u] + lb[(long long)t * U1 + u];
+          if (u < Ub) y = bbuf[prv * U1 + u + 1] + ll[(long long)t * U1 + u];
+          v = nsp_logaddexp(x, y);
+        }
+        bbuf[cur * U1 + u] = v;
+        be[(long long)t * U1 + u] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // beta(0,0) was produced on the last diagonal by the beta half
+  __shared__ float s_nll;
+  if (threadIdx.x == half) {
+    const float lpz = bbuf[((ndiag - 1) & 1) * U1 + 0];
+    s_nll = -lpz;
+    nll[b] = -lpz;
+  }
+  __syncthreads();
+  const float nl = s_nll;
+  const bool bad = isinf(nl) || isnan(nl);
+  // occupancies (visible through global memory after the barrier within this workgroup)
+  __threadfence_block();
+  for (int i = threadIdx.x; i < T * U1; i += blockDim.x) {
+    const int t = i / U1, u = i % U1;
+    float gb = 0.f, gl = 0.f;
+    if (!bad && t < Tb && u <= Ub) {
+      const float a = al[i];
+      if (t + 1 < Tb) gb = -expf(a + lb[i] + be[i + U1] + nl);
+      else if (u == Ub) gb = -expf(a + lb[i] + nl);
+      if (u < Ub) gl = -expf(a + ll[i] + be[i + 1] + nl);
+    }
+    g_blank[base + i] = gb;
+    g_label[base + i] = gl;
+  }
+}
+
+__global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
+    float* __restrict__ logits, const float* __restrict__ lse, const int* __restrict__ labels,
+    const float* __restrict__ g_blank, const float* __restrict__ g_label,
+    const int* __restrict__ elens, const int* __restrict__ ylens, float wscale, int B, int T, int U1,
+    int V, int blank) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long nrows = (long long)B * T * U1;
+  const int U = U1 - 1;
+  for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
+    const int u = (int)(row % U1);
+    const int t = (int)((row / U1) % T);
+    const int b = (int)(row / ((long long)U1 * T));
+    float* xr = logits + row * V;
+    if (t >= elens[b] || u > ylens[b]) {
+      for (int v = lane; v < V; v += 64) xr[v] = 0.f;
+      continue;
+    }
+    const float ls = lse[row];
+    const float gb = g_blank[row], gl = g_label[row];
+    const int lab = (u < ylens[b] && u < U) ? labels[(long long)b * U + u] : -1;
+    const float gsum = gb + gl;
+    for (int v = lane; v < V; v += 64) {
+      float g = -gsum * expf(xr[v] - ls);
+      if (v == blank) g += gb;
+      if (v == lab) g += gl;
+      xr[v] = wscale * g;
+    }
+  }
+}
+
+// h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:])
+__global__ __launch_bounds__(256) void joint_tanh_fwd_kernel(const float* __restrict__ e,
+                                                             const float* __restrict__ g,
+                                                             float* __restrict__ h, int B, int T,
+                                                             int U1, int J) {
+  const int J4 = J >> 2;
+  const long long total = (long long)B * T * U1 * J4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int j4 = (int)(idx % J4);
+    const int u = (int)((idx / J4) % U1);
+    const int t = (int)((idx / ((long long)J4 * U1)) % T);
+    const long long b = idx / ((long long)J4 * U1 * T);
+    const float4 ev = reinterpret_cast<const float4*>(e + (b * T + t) * J)[j4];
+    const float4 gv = reinterpret_cast<const float4*>(g + (b * U1 + u) * J)[j4];
+    reinterpret_cast<float4*>(h)[idx] =
+        make_float4(tanhf(ev.x + gv.x), tanhf(ev.y + gv.y), tanhf(ev.z + gv.z), tanhf(ev.w + gv.w));
+  }
+}
+
+// dz = dh * (1 - h^2) written in place over dh; de[b,t,:] = sum_u dz
+__global__ __launch_bounds__(256) void joint_tanh_bwd_de_kernel(const float* __restrict__ h,
+                                                                float* __restrict__ dh,
+                                                                float* __restrict__ de, int B, int T,
+                                                                int U1, int J) {
+  const int J4 = J >> 2;
+  const long long bt = blockIdx.x;  // one block per (b,t)
+  for (int j4 = threadIdx.x; j4 < J4; j4 += blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < U1; ++u) {
+      const long long o = (bt * U1 + u) * J4 + j4;
+      const float4 hv = reinterpret_cast<const float4*>(h)[o];
+      float4 dv = reinterpret_cast<float4*>(dh)[o];
+      dv.x *= (1.f - hv.x * hv.x); dv.y *= (1.f - hv.y * hv.y);
+      dv.z *= (1.f - hv.z * hv.z); dv.w *= (1.f - hv.w * hv.w);
+      reinterpret_cast<float4*>(dh)[o] = dv;
+      acc.x += dv.x; acc.y += dv.y; acc.z += dv.z; acc.w += dv.w;
+    }
+    reinterpret_cast<float4*>(de)[bt * J4 + j4] = acc;
+  }
+}
+
+// dg[b,u,:] = sum_t dz[b,t,u,:]
+__global__ __launch_bounds__(256) void joint_tanh_bwd_dg_kernel(const float* __restrict__ dz,
+                                                                float* __restrict__ dg, int B, int T,
+                                                                int U1, int J) {
+  const int J4 = J >> 2;
+  const long long bu = blockIdx.x;  // one block per (b,u)
+  const long long b = bu / U1;
+  const int u = (int)(bu % U1);
+  for (int j4 = threadIdx.x; j4 < J4; j4 += blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {
+      const float4 dv = reinterpret_cast<const float4*>(dz)[((b * T + t) * U1 + u) * J4 + j4];
+      acc.x += dv.x; acc.y += dv.y; acc.z += dv.z; acc.w += dv.w;
+    }
+    reinterpret_cast<float4*>(dg)[bu * J4 + j4] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int nsp_rnnt_logsoftmax_gather(const float* logits, const int* labels, const int* elens,
+                                          const int* ylens, float* lse, float* lp_blank,
+                                          float* lp_label, int B, int T, int U1, int V, int blank,
+                                          void* stream) {
+  if (B <= 0 || T <= 0 || U1 <= 0 || V <= 1) return NSP_EINVAL;
+  int grid = nsp_cdiv((long long)B * T * U1, 4);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(rnnt_lsm_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits,
+                     labels, elens, ylens, lse, lp_blank, lp_label, B, T, U1, V, blank);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_rnnt_lattice(const float* lp_blank, const float* lp_label, const int* elens,
+                                const int* ylens, float* alpha, float* beta, float* nll,
+                                float* g_blank, float* g_label, int B, int T, int U1, void* stream) {
+  if (B <= 0 || T <= 0 || U1 <= 0) return NSP_EINVAL;
+  const size_t sh = sizeof(float) * 4 * U1;
+  if (sh > 150 * 1024) return NSP_EUNSUPPORTED;
+  int half = ((U1 + 63) / 64) * 64;
+  if (half > 512) half = 512;
+  if (sh > 64 * 1024)
+    hipFuncSetAttribute((const void*)rnnt_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL(rnnt_lattice_kernel, dim3(B), dim3(2 * half), sh, (hipStream_t)stream, lp_blank,
+                     lp_label, elens, ylens, alpha, beta, nll, g_blank, g_label, B, T, U1);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* labels,
+                                    const float* g_blank, const float* g_label, const int* elens,
+                                    const int* ylens, float wscale, int B, int T, int U1, int V,
+                                    int blank, void* stream) {
+  int grid = nsp_cdiv((long long)B * T * U1, 4);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(rnnt_grad_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits,
+                     lse, labels, g_blank, g_label, elens, ylens, wscale, B, T, U1, V, blank);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h, int B, int T, int U1,
+                                       int J, void* stream) {
+  if (J % 4) return NSP_EUNSUPPORTED;
+  long long n = (long long)B * T * U1 * (J / 4);
+  long long gr = (n + 255) / 256;
+  if (gr > 256 * 32) gr = 256 * 32;
+  hipLaunchKernelGGL(joint_tanh_fwd_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, e, g, h,
+                     B, T, U1, J);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_rnnt_joint_tanh_bwd(const float* h, float* dh, float* de, float* dg, int B, int T,
+                                       int U1, int J, void* stream) {
+  if (J % 4) return NSP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(joint_tanh_bwd_de_kernel, dim3(B * T), dim3(128), 0, st, h, dh, de, B, T, U1, J);
+  hipLaunchKernelGGL(joint_tanh_bwd_dg_kernel, dim3(B * U1), dim3(128), 0, st, dh, dg, B, T, U1, J);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

@@ -294,3 +294,423 @@ def attn_softmax_fwd_raw(S, QP, mp, Pdrop=None):
 def attn_softmax_bwd_raw(P, dP, dQP, mp):
     _check(_lib.lib().nsp_attn_softmax_bwd(_p(P), _p(dP), _p(dQP), ctypes.byref(mp), _stream()),
            'nsp_attn_softmax_bwd')
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax((q_ac k^T + shift(q_bd pos^T)) / sqrt(dk), masks) v  on [B,T,H,dk] tensors.
+
+    Replaces relative_multihead_attention.py:179-215 and multihead_attention.py:124-153.
+    `pos` is the projected position table [R,H,dk] (None for plain MHA); masks are
+    evaluated in-kernel from `klens` (int32, device) + (causal, lookahead, chunk_nl, chunk_nc).
+    Returns the context [B,Tq,H*dk]; the probabilities are kept on ctx.aw for plotting.
+    """
+
+    @staticmethod
+    def forward(ctx, q_ac, q_bd, k, v, pos, klens, cfg):
+        B, Tq, H, dk = q_ac.shape
+        Tk = k.shape[1]
+        d = H * dk
+        dev = q_ac.device
+        q_ac, k, v = _f32c(q_ac), _f32c(k), _f32c(v)
+        q_bd = _f32c(q_bd) if q_bd is not None else q_ac
+        clamp = cfg.get('clamp', -1)
+        S = torch.empty((B, H, Tq, Tk), device=dev, dtype=torch.float32)
+        gemm_raw(Tq, Tk, dk, q_ac, d, 1, k, 1, d, S, Tk, batch=(B, H), a_b=(Tq * d, dk),
+                 b_b=(Tk * d, dk), c_b=(H * Tq * Tk, Tq * Tk))
+        QP, R = None, 0
+        if pos is not None:
+            pos = _f32c(pos)
+            R = pos.shape[0]
+            QP = torch.empty((B, Tq, H, R), device=dev, dtype=torch.float32)
+            gemm_raw(B * Tq, R, dk, q_bd, d, 1, pos, 1, d, QP, H * R, batch=(H, 1), a_b=(dk, 0),
+                     b_b=(dk, 0), c_b=(R, 0))
+        p_drop = cfg.get('dropout', 0.0) if cfg.get('training', False) else 0.0
+        seed, offset = next_dropout_seed() if p_drop > 0 else (0, 0)
+        mp = _mask_params(B, H, Tq, Tk, R, clamp, 1.0 / math.sqrt(dk), klens,
+                          cfg.get('causal', False), cfg.get('lookahead', 0),
+                          cfg.get('chunk_nl', 0), cfg.get('chunk_nc', 0), p_drop, seed, offset)
+        Pd = torch.empty_like(S) if p_drop > 0 else None
+        attn_softmax_fwd_raw(S, QP, mp, Pd)
+        P = S
+        Puse = Pd if Pd is not None else P
+        O = torch.empty((B, Tq, H, dk), device=dev, dtype=torch.float32)
+        gemm_raw(Tq, dk, Tk, Puse, Tk, 1, v, d, 1, O, d, batch=(B, H), a_b=(H * Tq * Tk, Tq * Tk),
+                 b_b=(Tk * d, dk), c_b=(Tq * d, dk))
+        ctx.save_for_backward(q_ac, q_bd, k, v, pos, P, Pd, klens)
+        ctx.mp_args = (B, H, Tq, Tk, R, clamp, 1.0 / math.sqrt(dk), cfg.get('causal', False),
+                       cfg.get('lookahead', 0), cfg.get('chunk_nl', 0), cfg.get('chunk_nc', 0),
+                       p_drop, seed, offset)
+        ctx.same_q = q_bd is q_ac
+        ctx.mark_non_differentiable(P)
+        return O.view(B, Tq, d), P
+
+    @staticmethod
+    def backward(ctx, dO, _dP_unused):
+        q_ac, q_bd, k, v, pos, P, Pd, klens = ctx.saved_tensors
+        (B, H, Tq, Tk, R, clamp, scale, causal, lookahead, nl, nc, p_drop, seed, offset) = ctx.mp_args
+        dk_ = q_ac.shape[-1]
+        d = H * dk_
+        dev = dO.device
+        dO = _f32c(dO).view(B, Tq, H, dk_)
+        Puse = Pd if Pd is not None else P
+        # dP = dO v^T
+        dP = torch.empty((B, H, Tq, Tk), device=dev, dtype=torch.float32)
+        gemm_raw(Tq, Tk, dk_, dO, d, 1, v, 1, d, dP, Tk, batch=(B, H), a_b=(Tq * d, dk_),
+                 b_b=(Tk * d, dk_), c_b=(H * Tq * Tk, Tq * Tk))
+        # dV = Puse^T dO
+        dV = torch.empty((B, Tk, H, dk_), device=dev, dtype=torch.float32)
+        gemm_raw(Tk, dk_, Tq, Puse, 1, Tk, dO, d, 1, dV, d, batch=(B, H),
+                 a_b=(H * Tq * Tk, Tq * Tk), b_b=(Tq * d, dk_), c_b=(Tk * d, dk_))
+        mp = _mask_params(B, H, Tq, Tk, R, clamp, scale, klens, causal, lookahead, nl, nc,
+                          p_drop, seed, offset)
+        dQP = torch.empty((B, Tq, H, R), device=dev, dtype=torch.float32) if pos is not None else None
+        attn_softmax_bwd_raw(P, dP, dQP, mp)
+        dS = dP
+        # dq_ac = dS k ; dk = dS^T q_ac
+        dQ = torch.empty((B, Tq, H, dk_), device=dev, dtype=torch.float32)
+        gemm_raw(Tq, dk_, Tk, dS, Tk, 1, k, d, 1, dQ, d, batch=(B, H), a_b=(H * Tq * Tk, Tq * Tk),
+                 b_b=(Tk * d, dk_), c_b=(Tq * d, dk_))
+        dK = torch.empty((B, Tk, H, dk_), device=dev, dtype=torch.float32)
+        gemm_raw(Tk, dk_, Tq, dS, 1, Tk, q_ac, d, 1, dK, d, batch=(B, H),
+                 a_b=(H * Tq * Tk, Tq * Tk), b_b=(Tq * d, dk_), c_b=(Tk * d, dk_))
+        dQbd = dpos = None
+        if pos is not None:
+            # d q_bd = dQP pos   (accumulated into dQ when q_bd is q_ac)
+            tgt = dQ if ctx.same_q else torch.empty_like(dQ)
+            gemm_raw(B * Tq, dk_, R, dQP, H * R, 1, pos, d, 1, tgt, d, batch=(H, 1), a_b=(R, 0),
+                     b_b=(dk_, 0), c_b=(dk_, 0), res=tgt if ctx.same_q else None)
+            if not ctx.same_q:
+                dQbd = tgt
+            if ctx.needs_input_grad[4]:
+                dpos = torch.zeros((R, H, dk_), device=dev, dtype=torch.float32)
+                sk = max(1, min(64, (B * Tq) // 256))
+                gemm_raw(R, dk_, B * Tq, dQP, 1, H * R, q_bd, d, 1, dpos, d, batch=(H, 1),
+                         a_b=(R, 0), b_b=(dk_, 0), c_b=(dk_, 0), splitk=sk)
+                if sk == 1:
+                    pass
+        return dQ, dQbd, dK, dV, dpos, None, None
+
+
+_DROPOUT_STATE = {'seed': 0x5EED, 'counter': 0}
+
+
+def manual_dropout_seed(seed):
+    _DROPOUT_STATE['seed'] = int(seed)
+    _DROPOUT_STATE['counter'] = 0
+
+
+def next_dropout_seed():
+    """(seed, offset) for one dropout site; offsets advance by 2^40 so sites never overlap."""
+    _DROPOUT_STATE['counter'] += 1
+    return _DROPOUT_STATE['seed'], _DROPOUT_STATE['counter'] << 40
+
+
+# --------------------------------------------------------------------------
+# GLU / depthwise conv / max-pool (Conformer conv module, subsampling)
+# --------------------------------------------------------------------------
+class GLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        C = x.shape[-1] // 2
+        rows = x.numel() // (2 * C)
+        y = torch.empty(x.shape[:-1] + (C,), device=x.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_glu_fwd(_p(x), _p(y), ctypes.c_longlong(rows), ctypes.c_int(C), _stream()),
+               'nsp_glu_fwd')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = _f32c(dy)
+        C = x.shape[-1] // 2
+        rows = x.numel() // (2 * C)
+        dx = torch.empty_like(x)
+        _check(_lib.lib().nsp_glu_bwd(_p(x), _p(dy), _p(dx), ctypes.c_longlong(rows), ctypes.c_int(C),
+                                      _stream()), 'nsp_glu_bwd')
+        return dx
+
+
+def glu(x):
+    return GLUFn.apply(x)
+
+
+def _dwconv_fwd(x, wt, bias, k, pad, flip):
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    _check(_lib.lib().nsp_dwconv1d_fwd(_p(x), _p(wt), _p(bias), _p(y), ctypes.c_int(B), ctypes.c_int(T),
+                                       ctypes.c_int(C), ctypes.c_int(k), ctypes.c_int(pad),
+                                       ctypes.c_int(flip), _stream()), 'nsp_dwconv1d_fwd')
+    return y
+
+
+class DepthwiseConv1dFn(torch.autograd.Function):
+    """x [B,T,C] channels-last; weight [C,1,k] (nn.Conv1d groups=C layout); causal pads left k-1."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, causal):
+        x = _f32c(x)
+        C, _, k = weight.shape
+        wt = weight.reshape(C, k).t().contiguous()  # tap-major [k, C]
+        pad = (k - 1) if causal else (k - 1) // 2
+        y = _dwconv_fwd(x, wt, bias, k, pad, 0)
+        ctx.save_for_backward(x, wt)
+        ctx.k, ctx.pad, ctx.has_bias = k, pad, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, T, C = x.shape
+        k, pad = ctx.k, ctx.pad
+        dx = _dwconv_fwd(dy, wt, None, k, k - 1 - pad, 1) if ctx.needs_input_grad[0] else None
+        buf = torch.zeros((k + 1, C), device=x.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_dwconv1d_wgrad(_p(x), _p(dy), ctypes.c_void_p(buf.data_ptr()),
+                                             ctypes.c_void_p(buf.data_ptr() + 4 * k * C),
+                                             ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(C),
+                                             ctypes.c_int(k), ctypes.c_int(pad), _stream()),
+               'nsp_dwconv1d_wgrad')
+        dw = buf[:k].t().contiguous().view(C, 1, k)
+        db = buf[k] if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+def depthwise_conv1d(x, weight, bias, causal=False):
+    return DepthwiseConv1dFn.apply(x, weight, bias, causal)
+
+
+class MaxPool1dFn(torch.autograd.Function):
+    """MaxPool1d(kernel=stride=factor, ceil_mode=True) over time of [B,T,C]."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        x = _f32c(x)
+        B, T, C = x.shape
+        To = (T + factor - 1) // factor
+        y = torch.empty((B, To, C), device=x.device, dtype=torch.float32)
+        am = torch.empty((B, To, C), device=x.device, dtype=torch.int32)
+        _check(_lib.lib().nsp_maxpool1d_fwd(_p(x), _p(y), _p(am), ctypes.c_int(B), ctypes.c_int(T),
+                                            ctypes.c_int(C), ctypes.c_int(factor), _stream()),
+               'nsp_maxpool1d_fwd')
+        ctx.save_for_backward(am)
+        ctx.dims = (B, T, C, factor)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        am, = ctx.saved_tensors
+        B, T, C, factor = ctx.dims
+        dy = _f32c(dy)
+        dx = torch.empty((B, T, C), device=dy.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_maxpool1d_bwd(_p(dy), _p(am), _p(dx), ctypes.c_int(B), ctypes.c_int(T),
+                                            ctypes.c_int(C), ctypes.c_int(factor), _stream()),
+               'nsp_maxpool1d_bwd')
+        return dx, None
+
+
+def maxpool1d_time(x, factor):
+    return MaxPool1dFn.apply(x, factor)
+
+
+# --------------------------------------------------------------------------
+# Conv2d frontend (channels-last)
+# --------------------------------------------------------------------------
+def _conv3x3_fwd(x, w_cl, bias, relu):
+    B, T, F, Ci = x.shape
+    Co = w_cl.shape[0]
+    y = torch.empty((B, T, F, Co), device=x.device, dtype=torch.float32)
+    _check(_lib.lib().nsp_conv2d3x3_fwd(_p(x), _p(w_cl), _p(bias), _p(y), ctypes.c_int(B),
+                                        ctypes.c_int(T), ctypes.c_int(F), ctypes.c_int(Ci),
+                                        ctypes.c_int(Co), ctypes.c_int(int(relu)),
+                                        ctypes.c_int(_COMPUTE_MODE['mode']), _stream()),
+           'nsp_conv2d3x3_fwd (only 3x3, pad 1, stride 1, C_in in {1,32}, C_out=32 are built)')
+    return y
+
+
+class Conv3x3ReLUFn(torch.autograd.Function):
+    """relu(conv2d(x, w, b, padding=1)) on channels-last x [B,T,F,Ci]; weight in the
+    reference's nn.Conv2d layout [Co,Ci,3,3] (conv.py:303-307,317-321)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _f32c(x)
+        w_cl = weight.permute(0, 2, 3, 1).contiguous()  # [Co,3,3,Ci]
+        y = _conv3x3_fwd(x, w_cl, bias, True)
+        ctx.save_for_backward(x, w_cl, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_cl, y = ctx.saved_tensors
+        B, T, F, Ci = x.shape
+        Co = w_cl.shape[0]
+        dy = _f32c(dy)
+        dz = torch.empty_like(dy)
+        _check(_lib.lib().nsp_relu_bwd(_p(y), _p(dy), _p(dz), ctypes.c_longlong(dy.numel()), _stream()),
+               'nsp_relu_bwd')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # data gradient = conv of dz with the tap-flipped, channel-transposed bank
+            w_t = w_cl.flip(1, 2).permute(3, 1, 2, 0).contiguous()  # [Ci,3,3,Co]
+            dx = _conv3x3_fwd(dz, w_t, None, False)
+        buf = torch.zeros((Co * 9 * Ci + Co,), device=x.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_conv2d3x3_wgrad(_p(x), _p(dz), ctypes.c_void_p(buf.data_ptr()),
+                                              ctypes.c_void_p(buf.data_ptr() + 4 * Co * 9 * Ci),
+                                              ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(F),
+                                              ctypes.c_int(Ci), ctypes.c_int(Co), _stream()),
+               'nsp_conv2d3x3_wgrad')
+        dw = buf[:Co * 9 * Ci].view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
+        db = buf[Co * 9 * Ci:]
+        return dx, dw, db
+
+
+def conv3x3_relu(x_cl, weight, bias):
+    return Conv3x3ReLUFn.apply(x_cl, weight, bias)
+
+
+class MaxPool2dFn(torch.autograd.Function):
+    """MaxPool2d(kernel=stride=(pt,pf), ceil_mode=True) on [B,T,F,C]; optionally emits
+    [B,T',C,F'] (flattened = the reference's [B,T',C*F'] feature order)."""
+
+    @staticmethod
+    def forward(ctx, x, pt, pf, to_btcf):
+        x = _f32c(x)
+        B, T, F, C = x.shape
+        To, Fo = (T + pt - 1) // pt, (F + pf - 1) // pf
+        shape = (B, To, C, Fo) if to_btcf else (B, To, Fo, C)
+        y = torch.empty(shape, device=x.device, dtype=torch.float32)
+        am = torch.empty(shape, device=x.device, dtype=torch.int32)
+        _check(_lib.lib().nsp_maxpool2d_fwd(_p(x), _p(y), _p(am), ctypes.c_int(B), ctypes.c_int(T),
+                                            ctypes.c_int(F), ctypes.c_int(C), ctypes.c_int(pt),
+                                            ctypes.c_int(pf), ctypes.c_int(int(to_btcf)), _stream()),
+               'nsp_maxpool2d_fwd')
+        ctx.save_for_backward(am)
+        ctx.dims = (B, T, F, C, pt, pf, to_btcf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        am, = ctx.saved_tensors
+        B, T, F, C, pt, pf, to_btcf = ctx.dims
+        dy = _f32c(dy)
+        dx = torch.empty((B, T, F, C), device=dy.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_maxpool2d_bwd(_p(dy), _p(am), _p(dx), ctypes.c_int(B), ctypes.c_int(T),
+                                            ctypes.c_int(F), ctypes.c_int(C), ctypes.c_int(pt),
+                                            ctypes.c_int(pf), ctypes.c_int(int(to_btcf)), _stream()),
+               'nsp_maxpool2d_bwd')
+        return dx, None, None, None
+
+
+def maxpool2d(x_cl, pt, pf, to_btcf=False):
+    return MaxPool2dFn.apply(x_cl, pt, pf, to_btcf)
+
+
+# --------------------------------------------------------------------------
+# CTC loss (+ label smoothing) and RNN-T loss
+# --------------------------------------------------------------------------
+class CTCLossFn(torch.autograd.Function):
+    """loss = (1-lsm) * sum_b nll_b / B + lsm * KL(p || uniform_{V-1}) / sum(elens)
+    (ctc.py:124-129,139-150; criterion.py:110-127).  The gradient w.r.t. the logits
+    is produced in the same pass and scaled by the incoming gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, elens, ylens, lsm_prob, sum_elens, blank):
+        logits = _f32c(logits)
+        B, T, V = logits.shape
+        Lmax = max(1, labels.shape[1])
+        dev = logits.device
+        L = _lib.lib()
+        L.nsp_ctc_workspace_bytes.restype = ctypes.c_longlong
+        ws_bytes = L.nsp_ctc_workspace_bytes(ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(Lmax))
+        ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32)
+        nll = torch.empty((B,), device=dev, dtype=torch.float32)
+        grad = torch.empty_like(logits)
+        _check(L.nsp_ctc_loss_fwd_bwd(_p(logits), _p(labels), _p(elens), _p(ylens), _p(nll), _p(grad),
+                                      ctypes.c_float((1.0 - lsm_prob) / B), _p(ws), ctypes.c_int(B),
+                                      ctypes.c_int(T), ctypes.c_int(V), ctypes.c_int(Lmax),
+                                      ctypes.c_int(blank), _stream()), 'nsp_ctc_loss_fwd_bwd')
+        nll = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll))  # zero_infinity
+        loss = nll.sum() / B
+        if lsm_prob > 0:
+            kl = torch.zeros((1,), device=dev, dtype=torch.float32)
+            _check(L.nsp_ctc_kldiv_fwd_bwd(_p(logits), _p(elens), _p(kl), _p(grad),
+                                           ctypes.c_float(lsm_prob / sum_elens), ctypes.c_int(1),
+                                           ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(V), _stream()),
+                   'nsp_ctc_kldiv_fwd_bwd')
+            loss = loss * (1 - lsm_prob) + kl[0] / sum_elens * lsm_prob
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(nll)
+        return loss.view(1), nll
+
+    @staticmethod
+    def backward(ctx, dloss, _dnll):
+        grad, = ctx.saved_tensors
+        return grad * dloss.view(1, 1, 1), None, None, None, None, None, None
+
+
+def ctc_loss(logits, labels, elens, ylens, lsm_prob=0.0, sum_elens=1, blank=0):
+    return CTCLossFn.apply(logits, labels, elens, ylens, float(lsm_prob), int(sum_elens), int(blank))
+
+
+class RNNTJointLossFn(torch.autograd.Function):
+    """mean_b -log P(y_b | x_b) of the RNN-Transducer from the joint inputs
+    (rnn_transducer.py:239-256,262-276):
+        h = tanh(enc_proj[B,T,1,J] + dec_proj[B,1,U+1,J]); logits = h W_out^T + b_out
+    The lattice works on (lse, lp_blank, lp_label) only; backward turns the saved
+    logits into d loss/d logits in place and contracts them with the MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blank):
+        enc_proj, dec_proj, w_out = _f32c(enc_proj), _f32c(dec_proj), _f32c(w_out)
+        B, T, J = enc_proj.shape
+        U1 = dec_proj.shape[1]
+        V = w_out.shape[0]
+        dev = enc_proj.device
+        L = _lib.lib()
+        h = torch.empty((B, T, U1, J), device=dev, dtype=torch.float32)
+        _check(L.nsp_rnnt_joint_tanh_fwd(_p(enc_proj), _p(dec_proj), _p(h), ctypes.c_int(B), ctypes.c_int(T),
+                                         ctypes.c_int(U1), ctypes.c_int(J), _stream()), 'nsp_rnnt_joint_tanh_fwd')
+        logits = linear_fwd(h.view(-1, J), w_out, b_out)  # [B*T*U1, V]
+        n = B * T * U1
+        aux = torch.empty((7, n), device=dev, dtype=torch.float32)  # lse, lpb, lpl, alpha, beta, gb, gl
+        nll = torch.empty((B,), device=dev, dtype=torch.float32)
+        _check(L.nsp_rnnt_logsoftmax_gather(_p(logits), _p(labels), _p(elens), _p(ylens), _p(aux[0]),
+                                            _p(aux[1]), _p(aux[2]), ctypes.c_int(B), ctypes.c_int(T),
+                                            ctypes.c_int(U1), ctypes.c_int(V), ctypes.c_int(blank), _stream()),
+               'nsp_rnnt_logsoftmax_gather')
+        _check(L.nsp_rnnt_lattice(_p(aux[1]), _p(aux[2]), _p(elens), _p(ylens), _p(aux[3]), _p(aux[4]),
+                                  _p(nll), _p(aux[5]), _p(aux[6]), ctypes.c_int(B), ctypes.c_int(T),
+                                  ctypes.c_int(U1), _stream()), 'nsp_rnnt_lattice')
+        ctx.save_for_backward(h, logits, aux, w_out, labels, elens, ylens)
+        ctx.dims = (B, T, U1, J, V, blank)
+        ctx.has_bias = b_out is not None
+        ctx.mark_non_differentiable(nll)
+        return nll.mean().view(1), nll
+
+    @staticmethod
+    def backward(ctx, dloss, _dnll):
+        h, logits, aux, w_out, labels, elens, ylens = ctx.saved_tensors
+        B, T, U1, J, V, blank = ctx.dims
+        L = _lib.lib()
+        # logits <- d loss / d logits (in place; the saved buffer is consumed)
+        wscale = float(dloss.item()) / B
+        _check(L.nsp_rnnt_grad_logits(_p(logits), _p(aux[0]), _p(labels), _p(aux[5]), _p(aux[6]),
+                                      _p(elens), _p(ylens), ctypes.c_float(wscale), ctypes.c_int(B),
+                                      ctypes.c_int(T), ctypes.c_int(U1), ctypes.c_int(V),
+                                      ctypes.c_int(blank), _stream()), 'nsp_rnnt_grad_logits')
+        dlogits = logits
+        h2d = h.view(-1, J)
+        dw = linear_wgrad(dlogits, h2d)
+        db = colsum(dlogits) if ctx.has_bias else None
+        dh = linear_dgrad(dlogits, w_out)  # [B*T*U1, J]
+        de = torch.empty((B, T, J), device=h.device, dtype=torch.float32)
+        dg = torch.empty((B, U1, J), device=h.device, dtype=torch.float32)
+        _check(L.nsp_rnnt_joint_tanh_bwd(_p(h), _p(dh), _p(de), _p(dg), ctypes.c_int(B), ctypes.c_int(T),
+                                         ctypes.c_int(U1), ctypes.c_int(J), _stream()), 'nsp_rnnt_joint_tanh_bwd')
+        return de, dg, dw, db, None, None, None, None
+
+
+def rnnt_joint_loss(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blank=0):
+    return RNNTJointLossFn.apply(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, int(blank))

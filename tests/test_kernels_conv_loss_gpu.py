@@ -1,0 +1,159 @@
+"""GPU parity of conv / pooling / CTC / RNN-T kernels against torch fp32 (same device) and
+the fp64 lattice oracle (oracle/)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def test_glu_dwconv_maxpool1d():
+    from neural_sp_amd import ops
+    torch.manual_seed(0)
+    B, T, C, k = 3, 53, 64, 15
+    x = torch.randn(B, T, 2 * C, device=_dev(), requires_grad=True)
+    y = ops.glu(x)
+    ref = F.glu(x, dim=-1)
+    g = torch.randn_like(ref)
+    assert _rel(y, ref) < 1e-5
+    assert _rel(torch.autograd.grad(y, x, g)[0], torch.autograd.grad(ref, x, g)[0]) < 1e-4
+    for causal in (False, True):
+        xc = torch.randn(B, T, C, device=_dev(), requires_grad=True)
+        w = torch.randn(C, 1, k, device=_dev(), requires_grad=True)
+        b = torch.randn(C, device=_dev(), requires_grad=True)
+        y = ops.depthwise_conv1d(xc, w, b, causal)
+        pad = k - 1 if causal else (k - 1) // 2
+        ref = F.conv1d(xc.transpose(1, 2), w, b, padding=pad, groups=C)
+        if causal:
+            ref = ref[:, :, :-pad]
+        ref = ref.transpose(1, 2)
+        g = torch.randn_like(ref)
+        assert _rel(y, ref) < 1e-5
+        for a, r in zip(torch.autograd.grad(y, (xc, w, b), g), torch.autograd.grad(ref, (xc, w, b), g)):
+            assert _rel(a, r) < 1e-4
+    for T2 in (53, 54):
+        xm = torch.randn(B, T2, C, device=_dev(), requires_grad=True)
+        y = ops.maxpool1d_time(xm, 2)
+        ref = F.max_pool1d(xm.transpose(1, 2), 2, 2, ceil_mode=True).transpose(1, 2)
+        g = torch.randn_like(ref)
+        assert _rel(y, ref) < 1e-6
+        assert _rel(torch.autograd.grad(y, xm, g)[0], torch.autograd.grad(ref, xm, g)[0]) < 1e-6
+
+
+@pytest.mark.parametrize('mode,tol', [('f32', 1e-4), ('bf16', 3e-2)])
+@pytest.mark.parametrize('Ci', [1, 32])
+def test_conv3x3(mode, tol, Ci):
+    from neural_sp_amd import ops
+    torch.manual_seed(1)
+    B, T, Fq, Co = 2, 37, 40, 32
+    x = torch.randn(B, Ci, T, Fq, device=_dev(), requires_grad=True)
+    w = (torch.randn(Co, Ci, 3, 3, device=_dev()) / math.sqrt(9 * Ci)).requires_grad_()
+    b = torch.randn(Co, device=_dev(), requires_grad=True)
+    ref = torch.relu(F.conv2d(x, w, b, padding=1))
+    g = torch.randn_like(ref)
+    rx, rw, rb = torch.autograd.grad(ref, (x, w, b), g)
+    xcl = x.detach().permute(0, 2, 3, 1).contiguous().requires_grad_()
+    with ops.compute_mode(mode):
+        y = ops.conv3x3_relu(xcl, w, b)
+        assert _rel(y.permute(0, 3, 1, 2), ref) < tol
+        gx, gw, gb = torch.autograd.grad(y, (xcl, w, b), g.permute(0, 2, 3, 1).contiguous())
+    assert _rel(gx.permute(0, 3, 1, 2), rx) < tol
+    assert _rel(gw, rw) < max(tol, 1e-3 if mode == 'f32' else tol)
+    assert _rel(gb, rb) < 1e-4
+
+
+def test_maxpool2d():
+    from neural_sp_amd import ops
+    torch.manual_seed(2)
+    B, T, Fq, C = 2, 37, 41, 32
+    for pt, pf in ((2, 2), (1, 1), (2, 1)):
+        x = torch.randn(B, C, T, Fq, device=_dev(), requires_grad=True)
+        ref = F.max_pool2d(x, (pt, pf), (pt, pf), ceil_mode=True) if pt * pf > 1 else x * 1
+        g = torch.randn_like(ref)
+        rx, = torch.autograd.grad(ref, x, g)
+        xcl = x.detach().permute(0, 2, 3, 1).contiguous().requires_grad_()
+        for btcf in (False, True):
+            y = ops.maxpool2d(xcl, pt, pf, btcf)
+            yr = y.permute(0, 2, 1, 3) if btcf else y.permute(0, 3, 1, 2)
+            assert _rel(yr, ref) < 1e-6
+            gg = g.permute(0, 2, 1, 3) if btcf else g.permute(0, 2, 3, 1)
+            gx, = torch.autograd.grad(y, xcl, gg.contiguous())
+            assert _rel(gx.permute(0, 3, 1, 2), rx) < 1e-6
+
+
+def _ctc_ref(logits, ys, elens, lsm):
+    B, T, V = logits.shape
+    ylens = torch.tensor([len(y) for y in ys], dtype=torch.int32)
+    ys_cat = torch.cat([torch.tensor(y, dtype=torch.int32) for y in ys])
+    lp = logits.transpose(0, 1).log_softmax(2)
+    loss = F.ctc_loss(lp, ys_cat, elens.cpu(), ylens, reduction='sum', zero_infinity=True) / B
+    if lsm > 0:
+        p = torch.softmax(logits, -1)
+        lpp = torch.log_softmax(logits, -1)
+        kl = p * (lpp - math.log(1 / (V - 1)))
+        kl = sum(kl[b, :elens[b]].sum() for b in range(B)) / elens.sum()
+        loss = loss * (1 - lsm) + kl * lsm
+    return loss
+
+
+@pytest.mark.parametrize('lsm', [0.0, 0.1])
+def test_ctc_loss(lsm):
+    from neural_sp_amd import ops
+    torch.manual_seed(3)
+    B, T, V = 4, 50, 37
+    logits = torch.randn(B, T, V, device=_dev()) * 2
+    elens = torch.tensor([50, 41, 30, 8], dtype=torch.int32)
+    # last utterance: labels longer than frames allow -> infinite NLL -> zero_infinity
+    ys = [[5, 5, 7, 9, 11], [4, 6, 6, 6, 8, 10, 12, 3], [20] * 3, list(range(4, 16))]
+    Lmax = max(len(y) for y in ys)
+    lab = torch.zeros(B, Lmax, dtype=torch.int32)
+    for b, y in enumerate(ys):
+        lab[b, :len(y)] = torch.tensor(y)
+    ylens = torch.tensor([len(y) for y in ys], dtype=torch.int32)
+    lg = logits.clone().requires_grad_()
+    loss, nll = ops.ctc_loss(lg, lab.to(_dev()), elens.to(_dev()), ylens.to(_dev()), lsm, int(elens.sum()), 0)
+    gl, = torch.autograd.grad(loss, lg)
+    lref = logits.detach().cpu().double().requires_grad_()
+    ref = _ctc_ref(lref, ys, elens, lsm)
+    gr, = torch.autograd.grad(ref, lref)
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-5, (loss.item(), ref.item())
+    assert _rel(gl.cpu().double(), gr) < 1e-4
+
+
+def test_rnnt_joint_loss():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from oracle.rnnt_ref import rnnt_loss_ref
+    from neural_sp_amd import ops
+    torch.manual_seed(4)
+    B, T, U, J, V = 3, 13, 6, 32, 29
+    e = torch.randn(B, T, J, device=_dev(), requires_grad=True)
+    gq = torch.randn(B, U + 1, J, device=_dev(), requires_grad=True)
+    w = (torch.randn(V, J, device=_dev()) * 0.3).requires_grad_()
+    bo = torch.randn(V, device=_dev(), requires_grad=True)
+    elens = torch.tensor([13, 9, 5], dtype=torch.int32)
+    ylens = torch.tensor([6, 3, 0], dtype=torch.int32)
+    lab = torch.randint(1, V, (B, U), dtype=torch.int32)
+    for b in range(B):
+        lab[b, ylens[b]:] = 0
+    with ops.compute_mode('f32'):
+        loss, nll = ops.rnnt_joint_loss(e, gq, w, bo, lab.to(_dev()), elens.to(_dev()), ylens.to(_dev()), 0)
+        grads = torch.autograd.grad(loss, (e, gq, w, bo))
+    # fp64 oracle on CPU
+    e64, g64, w64, b64 = [t.detach().cpu().double().requires_grad_() for t in (e, gq, w, bo)]
+    logits = torch.tanh(e64[:, :, None] + g64[:, None]) @ w64.t() + b64
+    ref = rnnt_loss_ref(torch.log_softmax(logits, -1), lab.long(), elens.long(), ylens.long(), blank=0).mean()
+    rg = torch.autograd.grad(ref, (e64, g64, w64, b64))
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-5, (loss.item(), ref.item())
+    for a, r in zip(grads, rg):
+        assert _rel(a.cpu().double(), r) < 2e-4
