@@ -112,6 +112,18 @@ int nsp_axpby(const float* x, const float* z, float* y, float alpha, float beta,
 int nsp_act_fwd(const float* x, float* y, int act, long long n, void* stream);
 int nsp_dact_mul(const float* dy, const float* pre, float* out, int act, float alpha,
                  long long n, void* stream);
+/* y[i] = alpha * x[i] * keep(seed, offset+i) / (1-p): dropout forward; applied to dy with
+ * the same (seed, offset) it is the backward.  Same counter-based mask as the GEMM /
+ * softmax epilogues (nn.Dropout sites: conformer_block.py:134,154,171,179 ...). */
+int nsp_dropout(const float* x, float* y, float p, float alpha, unsigned long long seed,
+                unsigned long long offset, long long n, void* stream);
+/* y[i] = alpha*x[i] + z[i % period]: additive sinusoidal encoding broadcast over the batch
+ * (positional_embedding.py:80-88) */
+int nsp_scale_add_bcast(const float* x, const float* z, float* y, float alpha,
+                        long long n, long long period, void* stream);
+/* relative position table out[L][d] = [sin(-(j+1)w_i), cos(-(j+1)w_i)]
+ * (positional_embedding.py:131-138) */
+int nsp_xl_pos_table(const float* inv_freq, float* out, int L, int d, void* stream);
 /* column sum: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
 int nsp_colsum(const float* x, float* out, int rows, int cols, long long ld,
                int accumulate, void* stream);

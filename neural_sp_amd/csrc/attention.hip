@@ -146,7 +146,8 @@ extern "C" int nsp_attn_softmax_fwd(float* S, const float* QP, float* Pdrop,
                                     const nsp_attn_mask_params* pp, void* stream) {
   if (!pp || !S) return NSP_EINVAL;
   nsp_attn_mask_params p = *pp;
-  if (QP && !(p.clamp > 0 ? p.R >= p.clamp + 1 : p.R >= p.Tk)) return NSP_EINVAL;
+  // the gather index min(|i-j|, clamp) never exceeds min(clamp, Tk-1)
+  if (QP && p.R < (p.clamp > 0 && p.clamp + 1 < p.Tk ? p.clamp + 1 : p.Tk)) return NSP_EINVAL;
   if (p.dropout_p > 0.f && !Pdrop) return NSP_EINVAL;
   const size_t shmem = sizeof(float) * 4 * (size_t)p.Tk;
   if (shmem > 150 * 1024) return NSP_EUNSUPPORTED;

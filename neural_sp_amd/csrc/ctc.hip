@@ -202,7 +202,134 @@ __global__ __launch_bounds__(256) void ctc_kldiv_kernel(const float* __restrict_
   if (lane == 0 && local != 0.f) atomicAdd(kl_sum, local);
 }
 
+// CTC forced alignment (reference ctc.py:657-753).  One workgroup per utterance:
+//   pass A: fb[t][s] = alpha_t(s)                      (emission at t included)
+//   pass B: fb[t][s] += btilde_t(s), btilde = beta without the emission at t
+//           -> fb = log posterior numerator alpha*beta/y, as accumulated by the
+//           reference's two `cum_log_prob +=` passes (:547-561, :685-699)
+//   pass C: greedy left-to-right walk: from the previously chosen lattice state s
+//           only {s, s+1, s+2 (if a different non-blank label)} are reachable
+//           (:708-725); take the arg-max of fb over them (lowest index on ties),
+//           then emit the leftmost frame of every label run (:727-748) and the
+//           last frame for <eos>.
+__global__ __launch_bounds__(256) void ctc_align_kernel(
+    const float* __restrict__ logits, const float* __restrict__ lse, const int* __restrict__ labels,
+    const int* __restrict__ elens, const int* __restrict__ ylens, float* __restrict__ fb,
+    int* __restrict__ best, int* __restrict__ trig, int B, int T, int V, int Lmax, int blank) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][Smax]
+  const int Smax = 2 * Lmax + 1;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Tb = min(elens[b], T);
+  const int Lb = min(ylens[b], Lmax);
+  const int Sb = 2 * Lb + 1;
+  const int* lab = labels + (long long)b * Lmax;
+  const float* lg = logits + (long long)b * T * V;
+  const float* ls = lse + (long long)b * T;
+  float* f = fb + (long long)b * T * Smax;
+  int* bp = best + (long long)b * T;
+  int* tp = trig + (long long)b * (Lmax + 1);
+  for (int i = tid; i < Lmax + 1; i += blockDim.x) tp[i] = 0;
+  if (Tb <= 0) return;
+  // pass A
+  for (int t = 0; t < Tb; ++t) {
+    const int cur = t & 1, prv = cur ^ 1;
+    for (int s = tid; s < Sb; s += blockDim.x) {
+      const int l = ctc_label(lab, s, blank);
+      const float lp = lg[(long long)t * V + l] - ls[t];
+      float a;
+      if (t == 0) {
+        a = (s <= 1) ? lp : -INFINITY;
+      } else {
+        a = sh[prv * Smax + s];
+        if (s >= 1) a = nsp_logaddexp(a, sh[prv * Smax + s - 1]);
+        if (s >= 2 && l != blank && l != ctc_label(lab, s - 2, blank))
+          a = nsp_logaddexp(a, sh[prv * Smax + s - 2]);
+        a += lp;
+      }
+      sh[cur * Smax + s] = a;
+      f[(long long)t * Smax + s] = a;
+    }
+    __syncthreads();
+  }
+  // pass B
+  for (int step = 0; step < Tb; ++step) {
+    const int t = Tb - 1 - step;
+    const int cur = step & 1, prv = cur ^ 1;
+    for (int s = tid; s < Sb; s += blockDim.x) {
+      const int l = ctc_label(lab, s, blank);
+      float bt;
+      if (step == 0) {
+        bt = (s >= Sb - 2) ? 0.f : -INFINITY;
+      } else {
+        bt = sh[prv * Smax + s];
+        if (s + 1 < Sb) bt = nsp_logaddexp(bt, sh[prv * Smax + s + 1]);
+        if (s + 2 < Sb && l != blank && l != ctc_label(lab, s + 2, blank))
+          bt = nsp_logaddexp(bt, sh[prv * Smax + s + 2]);
+      }
+      f[(long long)t * Smax + s] += bt;
+      sh[cur * Smax + s] = bt + (lg[(long long)t * V + l] - ls[t]);
+    }
+    __syncthreads();
+  }
+  // pass C (sequential)
+  if (tid == 0) {
+    int sprev = -1;  // virtual start: reachable {0, 1}
+    for (int t = 0; t < Tb; ++t) {
+      int lo = sprev < 0 ? 0 : sprev;
+      int hi = sprev < 0 ? 1 : sprev + 2;
+      int arg = lo;
+      float bestv = -INFINITY;
+      bool have = false;
+      for (int s = lo; s <= hi && s < Sb; ++s) {
+        if (sprev >= 0 && s == sprev + 2) {
+          const int l = ctc_label(lab, s, blank);
+          if (l == blank || l == ctc_label(lab, sprev, blank)) continue;
+        }
+        const float v = f[(long long)t * Smax + s];
+        if (!have || v > bestv) { bestv = v; arg = s; have = true; }
+      }
+      bp[t] = ctc_label(lab, arg, blank);
+      sprev = arg;
+    }
+    tp[Lb] = Tb - 1;  // <eos> boundary (:732)
+    int n = 0;
+    for (int t = 0; t < Tb; ++t) {
+      const int tok = bp[t];
+      if (tok == blank) continue;
+      if (t > 0 && tok == bp[t - 1]) continue;
+      if (n < Lmax + 1) tp[n] = t;
+      ++n;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" long long nsp_ctc_align_workspace_bytes(int B, int T, int Lmax) {
+  const long long Smax = 2LL * (Lmax < 1 ? 1 : Lmax) + 1;
+  return sizeof(float) * ((long long)B * T * Smax + (long long)B * T) + sizeof(int) * (long long)B * T;
+}
+
+extern "C" int nsp_ctc_forced_align(const float* logits, const int* labels, const int* elens,
+                                    const int* ylens, int* trigger_points, void* workspace, int B,
+                                    int T, int V, int Lmax, int blank, void* stream) {
+  if (B <= 0 || T <= 0 || V <= 1 || !workspace) return NSP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int Lm = Lmax < 1 ? 1 : Lmax;
+  const long long Smax = 2LL * Lm + 1;
+  float* fb = (float*)workspace;
+  float* lse = fb + (long long)B * T * Smax;
+  int* best = (int*)(lse + (long long)B * T);
+  int grid = nsp_cdiv((long long)B * T, 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(row_lse_kernel, dim3(grid), dim3(256), 0, st, logits, elens, lse, B, T, V);
+  const size_t sh = sizeof(float) * 2 * Smax;
+  if (sh > 150 * 1024) return NSP_EUNSUPPORTED;
+  hipLaunchKernelGGL(ctc_align_kernel, dim3(B), dim3(256), sh, st, logits, lse, labels, elens, ylens,
+                     fb, best, trigger_points, B, T, V, Lm, blank);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
 
 extern "C" long long nsp_ctc_workspace_bytes(int B, int T, int Lmax) {
   const long long Smax = 2LL * Lmax + 1;

@@ -58,6 +58,15 @@ __global__ void dact_mul_kernel(const float* __restrict__ dy, const float* __res
     out[i] = alpha * dy[i] * nsp_dact(pre[i], act);
 }
 
+// y = alpha * x * keep(seed, offset+i)/(1-p): forward dropout and, applied to dy, its backward
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, float p,
+                               float alpha, unsigned long long seed, unsigned long long offset,
+                               long long n) {
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = alpha * x[i] * nsp_keep_scale(seed, offset + (unsigned long long)i, p);
+}
+
 // relu backward from the OUTPUT y (y > 0)
 __global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                 float* __restrict__ dx, long long n) {
@@ -120,6 +129,31 @@ __global__ void glu_bwd_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
+// y[i] = alpha*x[i] + z[i % period]  (sinusoidal table broadcast over the batch,
+// positional_embedding.py:85-88)
+__global__ void scale_add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                       float* __restrict__ y, float alpha, long long n,
+                                       long long period) {
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = alpha * x[i] + z[i % period];
+}
+
+// Transformer-XL style table (positional_embedding.py:131-138):
+// out[j][i] = sin(-(j+1) * inv_freq[i]) for i < d/2, cos(...) for the second half
+__global__ void xl_pos_table_kernel(const float* __restrict__ inv_freq, float* __restrict__ out,
+                                    int L, int d) {
+  const int half = d >> 1;
+  const long long total = (long long)L * d;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % d);
+    const int j = (int)(i / d);
+    const float ang = -(float)(j + 1) * inv_freq[c < half ? c : c - half];
+    out[i] = c < half ? sinf(ang) : cosf(ang);
+  }
+}
+
 __global__ void specaug_kernel(float* __restrict__ x, int B, int T, int F, const int* fb, int nf,
                                const int* tb, int nt) {
   // fb/tb are tiny device arrays of [start,end) pairs
@@ -176,6 +210,16 @@ extern "C" int nsp_dact_mul(const float* dy, const float* pre, float* out, int a
   return NSP_OK;
 }
 
+extern "C" int nsp_dropout(const float* x, float* y, float p, float alpha, unsigned long long seed,
+                           unsigned long long offset, long long n, void* stream) {
+  if (n <= 0) return NSP_OK;
+  if (p < 0.f || p >= 1.f) return NSP_EINVAL;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y,
+                     p, alpha, seed, offset, n);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
 extern "C" int nsp_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* stream) {
   if (n <= 0) return NSP_OK;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, y,
@@ -216,6 +260,23 @@ extern "C" int nsp_glu_bwd(const float* x, const float* dy, float* dx, long long
   if (C % 4) return NSP_EUNSUPPORTED;
   hipLaunchKernelGGL(glu_bwd_kernel, dim3(ew_grid(rows * (C / 4))), dim3(EW_THREADS), 0,
                      (hipStream_t)stream, x, dy, dx, rows, C);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_scale_add_bcast(const float* x, const float* z, float* y, float alpha,
+                                   long long n, long long period, void* stream) {
+  if (n <= 0 || period <= 0) return NSP_EINVAL;
+  hipLaunchKernelGGL(scale_add_bcast_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, x, z, y, alpha, n, period);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_xl_pos_table(const float* inv_freq, float* out, int L, int d, void* stream) {
+  if (L <= 0 || d <= 0 || (d & 1)) return NSP_EINVAL;
+  hipLaunchKernelGGL(xl_pos_table_kernel, dim3(ew_grid((long long)L * d)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, inv_freq, out, L, d);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -1,0 +1,285 @@
+"""Training-side decoders of the Speech2Text hot path: CTC and RNN-Transducer losses.
+
+Mirrors neural_sp/models/seq2seq/decoders/ctc.py (CTC.__init__ :51-103, forward :105-137,
+loss_fn :139-150, CTCForcedAligner :628-753), rnn_transducer.py (RNNTransducer.__init__
+:60-132, forward :174-215, forward_transducer :217-260, joint :262-276, recurrency
+:278-311) and build.py.  Beam search / greedy decoding (ctc.py:219-531,
+rnn_transducer.py:330-819) is inference and out of scope.
+"""
+import logging
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from neural_sp_amd import ops
+from neural_sp_amd.torch_utils import np2tensor, pad_list, tensor2scalar, repeat
+
+logger = logging.getLogger(__name__)
+
+
+class DecoderBase(nn.Module):
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def device_id(self):
+        return torch.cuda.device_of(next(self.parameters())).idx
+
+    def reset_session(self):
+        pass
+
+    def trigger_scheduled_sampling(self):
+        pass
+
+    def trigger_quantity_loss(self):
+        pass
+
+    def trigger_latency_loss(self):
+        pass
+
+    def trigger_stableemit(self):
+        pass
+
+
+def _labels_to_device(ys, device, pad=0):
+    """list of label lists -> (labels int32 [B,Lmax] on device, ylens int32 on device, ylens list)."""
+    ylens = [len(y) for y in ys]
+    Lmax = max(1, max(ylens) if ylens else 1)
+    lab = np.full((len(ys), Lmax), pad, dtype=np.int32)
+    for b, y in enumerate(ys):
+        lab[b, :len(y)] = np.asarray(y, dtype=np.int32)
+    return (torch.from_numpy(lab).to(device), torch.tensor(ylens, dtype=torch.int32, device=device), ylens)
+
+
+class CTC(DecoderBase):
+    """ctc.py:35-150: output head (Linear or fc-stack) + CTC loss (+ label smoothing)."""
+
+    def __init__(self, eos, blank, enc_n_units, vocab, dropout=0., lsm_prob=0., fc_list=None,
+                 param_init=0.1, backward=False):
+        super().__init__()
+        self.eos = eos
+        self.blank = blank
+        self.vocab = vocab
+        self.lsm_prob = lsm_prob
+        self.bwd = backward
+        self.dropout_p = dropout
+        self.prob_dict = {}
+        self.data_dict = {}
+        if fc_list is not None and len(fc_list) > 0:
+            _fc_list = [int(fc) for fc in fc_list.split('_')]
+            fc_layers = OrderedDict()
+            for i in range(len(_fc_list)):
+                input_dim = enc_n_units if i == 0 else _fc_list[i - 1]
+                fc_layers['fc' + str(i)] = nn.Linear(input_dim, _fc_list[i])
+                fc_layers['dropout' + str(i)] = nn.Dropout(p=dropout)
+            fc_layers['fc' + str(len(_fc_list))] = nn.Linear(_fc_list[-1], vocab)
+            self.output = nn.Sequential(fc_layers)
+        else:
+            self.output = nn.Linear(enc_n_units, vocab)
+        self.forced_aligner = CTCForcedAligner(blank=blank)
+
+    def logits(self, eouts):
+        """self.output(eouts) of ctc.py:124 with the Dropout layers fused into the GEMM epilogues."""
+        if isinstance(self.output, nn.Linear):
+            return ops.linear(eouts, self.output.weight, self.output.bias)
+        xs = eouts
+        fcs = [m for m in self.output if isinstance(m, nn.Linear)]
+        for i, fc in enumerate(fcs):
+            last = i == len(fcs) - 1
+            xs = ops.linear(xs, fc.weight, fc.bias,
+                            dropout_p=0.0 if (last or not self.training) else self.dropout_p)
+        return xs
+
+    def forward(self, eouts, elens, ys, forced_align=False):
+        """eouts `[B,T,enc_n_units]`, elens IntTensor (CPU), ys list of label lists ->
+        (loss `[1]`, trigger_points IntTensor `[B,L+1]` or None)."""
+        ys_lab = [y[::-1] if self.bwd else y for y in ys]
+        lab, ylens_dev, _ = _labels_to_device(ys_lab, eouts.device, pad=0)
+        elens_dev = elens.to(device=eouts.device, dtype=torch.int32)
+        logits = self.logits(eouts)
+        loss, _ = ops.ctc_loss(logits, lab, elens_dev, ylens_dev, self.lsm_prob,
+                               int(elens.sum()), self.blank)
+        trigger_points = None
+        if forced_align:
+            trigger_points = self.forced_aligner(logits.detach(), elens, ys, None)
+        if not self.training:
+            self.data_dict['elens'] = elens.numpy()
+        return loss, trigger_points
+
+    def probs(self, eouts, temperature=1.):
+        return torch.softmax(self.logits(eouts) / temperature, dim=-1)
+
+    def scores(self, eouts, temperature=1.):
+        return torch.log_softmax(self.logits(eouts) / temperature, dim=-1)
+
+
+class CTCForcedAligner(object):
+    """ctc.py:628-753: leftmost frame of every label on the best path under the CTC
+    forward-backward posterior (+ last frame for <eos>)."""
+
+    def __init__(self, blank=0):
+        self.blank = blank
+
+    def __call__(self, logits, elens, ys, ylens=None):
+        lab, ylens_dev, _ = _labels_to_device(ys, logits.device, pad=0)
+        elens_dev = elens.to(device=logits.device, dtype=torch.int32)
+        return ops.ctc_forced_align(logits, lab, elens_dev, ylens_dev, self.blank)
+
+
+class RNNTransducer(DecoderBase):
+    """rnn_transducer.py:32-311 (training part).  The joint network, its log-softmax and
+    the lattice loss run as HIP kernels (ops.rnnt_joint_loss); the prediction network
+    (Embedding + LSTM stack) is a strictly sequential recurrence over U+1 <= ~200 label
+    steps and is left on torch.nn.LSTM (MIOpen) for now -- DESIGN.md lists it as the next
+    row to move."""
+
+    def __init__(self, special_symbols, enc_n_units, n_units, n_projs, n_layers, bottleneck_dim,
+                 emb_dim, vocab, dropout, dropout_emb, ctc_weight, ctc_lsm_prob, ctc_fc_list,
+                 external_lm, global_weight, mtl_per_batch, param_init):
+        super().__init__()
+        self.eos = special_symbols['eos']
+        self.unk = special_symbols['unk']
+        self.pad = special_symbols['pad']
+        self.blank = special_symbols['blank']
+        self.vocab = vocab
+        self.enc_n_units = enc_n_units
+        self.dec_n_units = n_units
+        self.n_projs = n_projs
+        self.n_layers = n_layers
+        self.rnnt_weight = global_weight - ctc_weight
+        self.ctc_weight = ctc_weight
+        self.mtl_per_batch = mtl_per_batch
+        if external_lm is not None:
+            raise NotImplementedError('prediction-network initialisation from an external LM')
+        if ctc_weight > 0:
+            self.ctc = CTC(eos=self.eos, blank=self.blank, enc_n_units=enc_n_units, vocab=vocab,
+                           dropout=dropout, lsm_prob=ctc_lsm_prob, fc_list=ctc_fc_list, param_init=0.1)
+        if self.rnnt_weight > 0:
+            self.rnn = nn.ModuleList()
+            dec_odim = emb_dim
+            self.proj = repeat(nn.Linear(n_units, n_projs), n_layers) if n_projs > 0 else None
+            self.dropout = nn.Dropout(p=dropout)
+            for _ in range(n_layers):
+                self.rnn += [nn.LSTM(dec_odim, n_units, 1, batch_first=True)]
+                dec_odim = n_projs if n_projs > 0 else n_units
+            self.embed = nn.Embedding(vocab, emb_dim, padding_idx=self.pad)
+            self.dropout_emb = nn.Dropout(p=dropout_emb)
+            self.w_enc = nn.Linear(enc_n_units, bottleneck_dim)
+            self.w_dec = nn.Linear(dec_odim, bottleneck_dim, bias=False)
+            self.output = nn.Linear(bottleneck_dim, vocab)
+        self.reset_parameters(param_init)
+
+    def reset_parameters(self, param_init):
+        """rnn_transducer.py:161-172"""
+        for n, p in self.named_parameters():
+            if p.dim() == 1:
+                nn.init.constant_(p, 0.)
+            elif p.dim() in [2, 4]:
+                nn.init.uniform_(p, a=-param_init, b=param_init)
+            else:
+                raise ValueError(n)
+
+    def forward(self, eouts, elens, ys, task='all', teacher_logits=None,
+                recog_params={}, idx2token=None, trigger_points=None):
+        observation = {'loss': None, 'loss_transducer': None, 'loss_ctc': None, 'loss_mbr': None}
+        loss = eouts.new_zeros((1,))
+        if self.ctc_weight > 0 and (task == 'all' or 'ctc' in task):
+            loss_ctc, _ = self.ctc(eouts, elens, ys)
+            observation['loss_ctc'] = tensor2scalar(loss_ctc)
+            loss = loss + (loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight)
+        if self.rnnt_weight > 0 and (task == 'all' or 'ctc' not in task):
+            loss_transducer = self.forward_transducer(eouts, elens, ys)
+            observation['loss_transducer'] = tensor2scalar(loss_transducer)
+            loss = loss + (loss_transducer if self.mtl_per_batch else loss_transducer * self.rnnt_weight)
+        observation['loss'] = tensor2scalar(loss)
+        return loss, observation
+
+    def forward_transducer(self, eouts, elens, ys):
+        dev = eouts.device
+        _ys = [np2tensor(np.fromiter(y, dtype=np.int64), dev) for y in ys]
+        eos = eouts.new_zeros((1,), dtype=torch.int64).fill_(self.eos)
+        ys_in = pad_list([torch.cat([eos, y], dim=0) for y in _ys], self.pad)  # `[B, L+1]`
+        lab, ylens_dev, _ = _labels_to_device(ys, dev, pad=self.blank)         # ys_out, blank-padded
+        elens_dev = elens.to(device=dev, dtype=torch.int32)
+        dout, _ = self.recurrency(self.embed_token_id(ys_in), None)
+        enc_proj = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias)       # `[B,T,J]`
+        dec_proj = ops.linear(dout, self.w_dec.weight, None)                    # `[B,L+1,J]`
+        loss, _ = ops.rnnt_joint_loss(enc_proj, dec_proj, self.output.weight, self.output.bias,
+                                      lab, elens_dev, ylens_dev, self.blank)
+        return loss
+
+    def embed_token_id(self, indices):
+        return self.dropout_emb(self.embed(indices))
+
+    def recurrency(self, ys_emb, dstate):
+        if dstate is None:
+            dstate = self.zero_state(ys_emb.size(0))
+        new_hxs, new_cxs = [], []
+        for lth in range(self.n_layers):
+            ys_emb, (h, c) = self.rnn[lth](ys_emb, hx=(dstate['hxs'][lth:lth + 1],
+                                                       dstate['cxs'][lth:lth + 1]))
+            new_hxs.append(h)
+            new_cxs.append(c)
+            ys_emb = self.dropout(ys_emb)
+            if self.proj is not None:
+                ys_emb = torch.relu(self.proj[lth](ys_emb))
+        return ys_emb, {'hxs': torch.cat(new_hxs, dim=0), 'cxs': torch.cat(new_cxs, dim=0)}
+
+    def zero_state(self, batch_size):
+        w = next(self.parameters())
+        return {'hxs': w.new_zeros(self.n_layers, batch_size, self.dec_n_units),
+                'cxs': w.new_zeros(self.n_layers, batch_size, self.dec_n_units)}
+
+
+class CTCOnlyDecoder(DecoderBase):
+    """The reference routes CTC-only models through RNNDecoder/TransformerDecoder with
+    ctc_weight == global_weight (las.py:438-505 / decoders/transformer.py:314-371); only
+    their CTC branch runs.  This shell exposes the same `.ctc` submodule name and the same
+    (loss, observation) contract for that case."""
+
+    def __init__(self, special_symbols, enc_n_units, vocab, dropout, ctc_weight, ctc_lsm_prob,
+                 ctc_fc_list, global_weight, mtl_per_batch):
+        super().__init__()
+        self.ctc_weight = ctc_weight
+        self.mtl_per_batch = mtl_per_batch
+        self.ctc = CTC(eos=special_symbols['eos'], blank=special_symbols['blank'],
+                       enc_n_units=enc_n_units, vocab=vocab, dropout=dropout,
+                       lsm_prob=ctc_lsm_prob, fc_list=ctc_fc_list, param_init=0.1)
+        for n, p in self.named_parameters():
+            if p.dim() == 1:
+                nn.init.constant_(p, 0.)
+            else:
+                nn.init.uniform_(p, a=-0.1, b=0.1)
+
+    def forward(self, eouts, elens, ys, task='all', teacher_logits=None, recog_params={},
+                idx2token=None, trigger_points=None):
+        observation = {'loss': None, 'loss_att': None, 'loss_ctc': None, 'loss_mbr': None,
+                       'acc_att': None, 'ppl_att': None}
+        loss_ctc, _ = self.ctc(eouts, elens, ys)
+        observation['loss_ctc'] = tensor2scalar(loss_ctc)
+        loss = loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight
+        observation['loss'] = tensor2scalar(loss)
+        return loss, observation
+
+
+def build_decoder(args, special_symbols, enc_n_units, vocab, ctc_weight, global_weight, external_lm=None):
+    """decoders/build.py:7-140 for the loss heads on the hot path."""
+    if args.dec_type in ['lstm_transducer', 'gru_transducer']:
+        if args.dec_type == 'gru_transducer':
+            raise NotImplementedError('gru_transducer')
+        return RNNTransducer(
+            special_symbols=special_symbols, enc_n_units=enc_n_units, n_units=args.dec_n_units,
+            n_projs=args.dec_n_projs, n_layers=args.dec_n_layers, bottleneck_dim=args.dec_bottleneck_dim,
+            emb_dim=args.emb_dim, vocab=vocab, dropout=args.dropout_dec, dropout_emb=args.dropout_emb,
+            ctc_weight=ctc_weight, ctc_lsm_prob=args.ctc_lsm_prob, ctc_fc_list=args.ctc_fc_list,
+            external_lm=external_lm if args.lm_init else None, global_weight=global_weight,
+            mtl_per_batch=args.mtl_per_batch, param_init=args.param_init)
+    if ctc_weight > 0 and abs(global_weight - ctc_weight) < 1e-12:
+        return CTCOnlyDecoder(special_symbols, enc_n_units, vocab, args.dropout_dec, ctc_weight,
+                              args.ctc_lsm_prob, args.ctc_fc_list, global_weight, args.mtl_per_batch)
+    raise NotImplementedError(
+        'dec_type=%s with an attention loss: the LAS / Transformer / MoChA decoders are "next" rows '
+        '(SURVEY.md section 8f), not yet built' % args.dec_type)

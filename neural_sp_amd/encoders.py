@@ -1,0 +1,699 @@
+"""Encoders of the Speech2Text hot path: CNN frontend + Transformer / Conformer stacks.
+
+Mirrors (class names, constructor signatures, parameter names, forward contract):
+  neural_sp/models/seq2seq/encoders/conv.py            ConvEncoder, Conv2dBlock
+  neural_sp/models/seq2seq/encoders/subsampling.py     MaxPoolSubsampler
+  neural_sp/models/seq2seq/encoders/transformer_block.py
+  neural_sp/models/seq2seq/encoders/conformer_block.py, conformer_block_v2.py
+  neural_sp/models/seq2seq/encoders/transformer.py     TransformerEncoder
+  neural_sp/models/seq2seq/encoders/conformer.py       ConformerEncoder
+  neural_sp/models/seq2seq/encoders/build.py           build_encoder
+Activations stay channels-last on the device; sequence lengths stay on the host
+(IntTensor on CPU, as in the reference) plus one int32 device copy per resolution for the
+in-kernel attention masks.  Streaming inference (caches) is out of scope.
+"""
+import copy
+import logging
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from neural_sp_amd import ops
+from neural_sp_amd.modules import (
+    AttnMask,
+    ConformerConvBlock,
+    MultiheadAttentionMechanism as MHA,
+    PositionalEncoding,
+    PositionwiseFeedForward as FFN,
+    RelativeMultiheadAttentionMechanism as RelMHA,
+    XLPositionalEmbedding,
+    init_with_lecun_normal,
+)
+
+random.seed(1)  # conformer_block.py:15 / transformer_block.py -- LayerDrop stream
+
+logger = logging.getLogger(__name__)
+
+
+class EncoderBase(nn.Module):
+    """encoder_base.py:20-51 (properties only; plotting is out of scope)."""
+
+    @property
+    def output_dim(self):
+        return self._odim
+
+    @property
+    def output_dim_sub1(self):
+        return getattr(self, '_odim_sub1', self._odim)
+
+    @property
+    def output_dim_sub2(self):
+        return getattr(self, '_odim_sub2', self._odim)
+
+    @property
+    def subsampling_factor(self):
+        return self._factor
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def reset_cache(self):
+        raise NotImplementedError
+
+    def _plot_attention(self, save_path=None, n_cols=2):
+        raise NotImplementedError('plotting is out of scope (SURVEY.md section 8)')
+
+
+# --------------------------------------------------------------------------- CNN frontend
+def parse_cnn_config(channels, kernel_sizes, strides, poolings):
+    """conv.py:480-505"""
+    _channels, _kernel_sizes, _strides, _poolings = [], [], [], []
+    is_1dconv = '(' not in kernel_sizes
+    if len(channels) > 0:
+        _channels = [int(c) for c in channels.split('_')]
+    if len(kernel_sizes) > 0:
+        if is_1dconv:
+            _kernel_sizes = [int(c) for c in kernel_sizes.split('_')]
+        else:
+            _kernel_sizes = [[int(c.split(',')[0].replace('(', '')),
+                              int(c.split(',')[1].replace(')', ''))] for c in kernel_sizes.split('_')]
+    if len(strides) > 0:
+        if is_1dconv:
+            _strides = [int(s) for s in strides.split('_')]
+        else:
+            _strides = [[int(s.split(',')[0].replace('(', '')),
+                         int(s.split(',')[1].replace(')', ''))] for s in strides.split('_')]
+    if len(poolings) > 0:
+        if is_1dconv:
+            _poolings = [int(p) for p in poolings.split('_')]
+        else:
+            _poolings = [[int(p.split(',')[0].replace('(', '')),
+                          int(p.split(',')[1].replace(')', ''))] for p in poolings.split('_')]
+    return (_channels, _kernel_sizes, _strides, _poolings), is_1dconv
+
+
+def _conv_len(seq_len, k, pad, stride):
+    """conv.py:471-477 (_update_2d, conv branch)"""
+    return int(math.floor((seq_len + 2 * pad - (k - 1) - 1) // stride + 1))
+
+
+def _pool_len_ceil(seq_len, k, stride):
+    """conv.py:471-474 (_update_2d, MaxPool ceil_mode branch)"""
+    return int(math.ceil((seq_len + 1 - (k - 1) - 1) // stride + 1))
+
+
+class Conv2dBlock(EncoderBase):
+    """conv.py:289-396: conv3x3 -> ReLU -> conv3x3 -> ReLU -> MaxPool2d(ceil), on
+    channels-last `[B,T,F,C]`.  Built: 3x3 kernels, stride (1,1), no normalisation, no
+    residual (the configuration of every *former recipe)."""
+
+    def __init__(self, input_dim, in_channel, out_channel, kernel_size, stride, pooling,
+                 dropout, normalization, residual):
+        super().__init__()
+        if tuple(kernel_size) != (3, 3) or tuple(stride) != (1, 1) or normalization or residual:
+            raise NotImplementedError('Conv2dBlock: only 3x3 / stride 1 / no norm / no residual is built')
+        self.dropout_p = dropout
+        self.time_axis = 0
+        self.conv1 = nn.Conv2d(in_channel, out_channel, kernel_size=tuple(kernel_size),
+                               stride=(1, 1), padding=(1, 1))
+        self._odim = _conv_len(input_dim, 3, 1, 1)
+        self.conv2 = nn.Conv2d(out_channel, out_channel, kernel_size=tuple(kernel_size),
+                               stride=tuple(stride), padding=(1, 1))
+        self._odim = _conv_len(self._odim, 3, 1, 1)
+        self.pool = None
+        self.pooling = (1, 1)
+        self._factor = 1
+        if len(pooling) > 0 and np.prod(pooling) > 1:
+            self.pooling = tuple(pooling)
+            self.pool = nn.MaxPool2d(kernel_size=tuple(pooling), stride=tuple(pooling),
+                                     padding=(0, 0), ceil_mode=True)
+            self._odim = _pool_len_ceil(self._odim, pooling[1], pooling[1])
+            if self._odim % 2 != 0:
+                self._odim = (self._odim // 2) * 2
+            self._factor *= pooling[0]
+
+    def forward(self, xs, xlens, lookback=False, lookahead=False, last=False):
+        """xs `[B,T,F,C_i]` -> `[B,T',F',C_o]` (or `[B,T',C_o,F']` if last)."""
+        if lookback or lookahead:
+            raise NotImplementedError('CNN lookback/lookahead belong to streaming inference')
+        xs = ops.conv3x3_relu(xs, self.conv1.weight, self.conv1.bias)
+        xs = ops.dropout(xs, self.dropout_p, self.training)
+        xlens = torch.IntTensor([_conv_len(int(x), 3, 1, 1) for x in xlens])
+        xs = ops.conv3x3_relu(xs, self.conv2.weight, self.conv2.bias)
+        xs = ops.dropout(xs, self.dropout_p, self.training)
+        xlens = torch.IntTensor([_conv_len(int(x), 3, 1, 1) for x in xlens])
+        if self.pool is not None or last:
+            xs = ops.maxpool2d(xs, self.pooling[0], self.pooling[1], to_btcf=last)
+        if self.pool is not None:
+            xlens = torch.IntTensor([_pool_len_ceil(int(x), self.pooling[0], self.pooling[0]) for x in xlens])
+        return xs, xlens
+
+
+class ConvEncoder(EncoderBase):
+    """conv.py:18-195 (2-D CNN variant)."""
+
+    def __init__(self, input_dim, in_channel, channels, kernel_sizes, strides, poolings,
+                 dropout, normalization, residual, bottleneck_dim, param_init):
+        super().__init__()
+        assert channels
+        (channels, kernel_sizes, strides, poolings), is_1dconv = parse_cnn_config(
+            channels, kernel_sizes, strides, poolings)
+        if is_1dconv:
+            raise NotImplementedError('Conv1dBlock frontend is not on the benchmarked path')
+        self.is_1dconv = False
+        self.in_channel = in_channel
+        assert input_dim % in_channel == 0
+        self.input_freq = input_dim // in_channel
+        self.residual = residual
+        assert len(channels) > 0
+        assert len(channels) == len(kernel_sizes) == len(strides) == len(poolings)
+        self.layers = nn.ModuleList()
+        C_i = in_channel
+        in_freq = self.input_freq
+        for lth in range(len(channels)):
+            block = Conv2dBlock(input_dim=in_freq, in_channel=C_i, out_channel=channels[lth],
+                                kernel_size=kernel_sizes[lth], stride=strides[lth],
+                                pooling=poolings[lth], dropout=dropout,
+                                normalization=normalization, residual=residual)
+            self.layers += [block]
+            in_freq = block.output_dim
+            C_i = channels[lth]
+        self._odim = int(C_i * in_freq)
+        self.bridge = None
+        if bottleneck_dim > 0 and bottleneck_dim != self._odim:
+            self.bridge = nn.Linear(self._odim, bottleneck_dim)
+            self._odim = bottleneck_dim
+        self._factor = 1
+        for s in strides:
+            self._factor *= s[0]
+        for p in poolings:
+            self._factor *= p[0]
+        for n, p in self.named_parameters():
+            init_with_lecun_normal(n, p, param_init)
+
+    def forward(self, xs, xlens, lookback=False, lookahead=False):
+        """xs `[B,T,F]`, xlens IntTensor (CPU) -> (`[B,T',d]`, xlens)."""
+        B, T, F = xs.size()
+        if self.in_channel != 1:
+            raise NotImplementedError('conv_in_channel > 1')
+        xs = xs.reshape(B, T, F, 1)  # channels-last view of [B,1,T,F]
+        for i, block in enumerate(self.layers):
+            xs, xlens = block(xs, xlens, lookback=lookback, lookahead=lookahead,
+                              last=(i == len(self.layers) - 1))
+        B, To, Co, Fo = xs.size()
+        xs = xs.reshape(B, To, Co * Fo)  # == transpose(2,1).view(B,T',C*F') of conv.py:189
+        if self.bridge is not None:
+            xs = ops.linear(xs, self.bridge.weight, self.bridge.bias)
+        return xs, xlens
+
+
+class MaxPoolSubsampler(nn.Module):
+    """subsampling.py:175-209"""
+
+    def __init__(self, subsampling_factor):
+        super().__init__()
+        self.factor = subsampling_factor
+
+    def forward(self, xs, xlens, batch_first=True):
+        if self.factor == 1:
+            return xs, xlens
+        assert batch_first
+        xs = ops.maxpool1d_time(xs, self.factor)
+        xlens = torch.IntTensor([_pool_len_ceil(int(x), self.factor, self.factor) for x in xlens])
+        return xs, xlens
+
+
+# --------------------------------------------------------------------------- blocks
+class TransformerEncoderBlock(nn.Module):
+    """transformer_block.py:20-141.  The reference's typo 'relaive' (:46) is kept: only
+    pe_type 'relative_xl' selects RelMHA here."""
+
+    def __init__(self, d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer,
+                 layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len, ffn_bottleneck_dim):
+        super().__init__()
+        self.n_heads = n_heads
+        self.rel_attn = pe_type in ['relaive', 'relative_xl']
+        self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        mha = RelMHA if self.rel_attn else MHA
+        self.self_attn = mha(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, n_heads=n_heads,
+                             dropout=dropout_att, param_init=param_init,
+                             xl_like=pe_type == 'relative_xl', clamp_len=clamp_len)
+        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.feed_forward = FFN(d_model, d_ff, dropout, ffn_activation, param_init, ffn_bottleneck_dim)
+        self.dropout_p = dropout
+        self.dropout_layer = dropout_layer
+        self._xx_aws = None
+
+    @property
+    def xx_aws(self):
+        return self._xx_aws
+
+    def forward(self, xs, xx_mask=None, cache=None, pos_embs=None, rel_bias=(None, None)):
+        if cache is not None:
+            raise NotImplementedError('streaming cache')
+        self._xx_aws = None
+        u_bias, v_bias = rel_bias
+        if self.dropout_layer > 0:
+            if self.training and random.random() < self.dropout_layer:
+                return xs, {}
+            else:
+                xs = ops.scale(xs, 1.0 / (1 - self.dropout_layer))
+        residual = xs
+        xn = ops.layer_norm(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        if self.rel_attn:
+            xs, self._xx_aws = self.self_attn(xn, xn, pos_embs, xx_mask, u_bias, v_bias,
+                                              residual=residual, out_dropout=self.dropout_p)
+        else:
+            xs, self._xx_aws = self.self_attn(xn, xn, xn, mask=xx_mask, residual=residual,
+                                              out_dropout=self.dropout_p)[:2]
+        residual = xs
+        xn = ops.layer_norm(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        xs = self.feed_forward(xn, residual=residual, alpha=1.0, out_dropout=self.dropout_p)
+        return xs, {}
+
+
+class ConformerEncoderBlock(nn.Module):
+    """conformer_block.py:20-182: x += 1/2 FFN(LN x); x += RelMHA(LN x); x += Conv(LN x);
+    x += 1/2 FFN(LN x); x = LN x.  Every `alpha*dropout(.) + residual` is the epilogue of
+    the sub-block's last GEMM."""
+
+    def __init__(self, d_model, d_ff, n_heads, kernel_size, dropout, dropout_att, dropout_layer,
+                 layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
+                 ffn_bottleneck_dim, unidirectional, normalization='layer_norm'):
+        super().__init__()
+        self.n_heads = n_heads
+        self.fc_factor = 0.5
+        self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.feed_forward_macaron = FFN(d_model, d_ff, dropout, ffn_activation, param_init, ffn_bottleneck_dim)
+        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.self_attn = RelMHA(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, n_heads=n_heads,
+                                dropout=dropout_att, param_init=param_init,
+                                xl_like=pe_type == 'relative_xl', clamp_len=clamp_len)
+        self.norm3 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.conv = ConformerConvBlock(d_model, kernel_size, param_init, normalization, causal=unidirectional)
+        self.conv_context = kernel_size
+        self.norm4 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.feed_forward = FFN(d_model, d_ff, dropout, ffn_activation, param_init, ffn_bottleneck_dim)
+        self.norm5 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.dropout_p = dropout
+        self.dropout_layer = dropout_layer
+        self._xx_aws = None
+
+    @property
+    def xx_aws(self):
+        return self._xx_aws
+
+    def forward(self, xs, xx_mask=None, cache=None, pos_embs=None, rel_bias=(None, None)):
+        if cache is not None:
+            raise NotImplementedError('streaming cache')
+        self._xx_aws = None
+        u_bias, v_bias = rel_bias
+        if self.dropout_layer > 0:
+            if self.training and random.random() < self.dropout_layer:
+                return xs, {}
+            else:
+                xs = ops.scale(xs, 1.0 / (1 - self.dropout_layer))
+        p = self.dropout_p
+        xn = ops.layer_norm(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        xs = self.feed_forward_macaron(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
+        xn = ops.layer_norm(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        xs, self._xx_aws = self.self_attn(xn, xn, pos_embs, xx_mask, u_bias, v_bias,
+                                          residual=xs, out_dropout=p)
+        xn = ops.layer_norm(xs, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        xs = self.conv(xn, residual=xs, out_dropout=p)
+        xn = ops.layer_norm(xs, self.norm4.weight, self.norm4.bias, self.norm4.eps)
+        xs = self.feed_forward(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
+        xs = ops.layer_norm(xs, self.norm5.weight, self.norm5.bias, self.norm5.eps)
+        return xs, {}
+
+
+class ConformerEncoderBlock_v2(nn.Module):
+    """conformer_block_v2.py:20-183: FFN -> Conv -> plain MHA -> FFN -> LN."""
+
+    def __init__(self, d_model, d_ff, n_heads, kernel_size, dropout, dropout_att, dropout_layer,
+                 layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
+                 ffn_bottleneck_dim, unidirectional, normalization='layer_norm'):
+        super().__init__()
+        self.n_heads = n_heads
+        self.fc_factor = 0.5
+        self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.feed_forward_macaron = FFN(d_model, d_ff, dropout, ffn_activation, param_init, ffn_bottleneck_dim)
+        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.conv = ConformerConvBlock(d_model, kernel_size, param_init, normalization, causal=unidirectional)
+        self.conv_context = kernel_size
+        self.norm3 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.self_attn = MHA(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, n_heads=n_heads,
+                             dropout=dropout_att, param_init=param_init)
+        self.norm4 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.feed_forward = FFN(d_model, d_ff, dropout, ffn_activation, param_init, ffn_bottleneck_dim)
+        self.norm5 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.dropout_p = dropout
+        self.dropout_layer = dropout_layer
+        self._xx_aws = None
+
+    @property
+    def xx_aws(self):
+        return self._xx_aws
+
+    def forward(self, xs, xx_mask=None, cache=None, pos_embs=None, rel_bias=(None, None)):
+        if cache is not None:
+            raise NotImplementedError('streaming cache')
+        self._xx_aws = None
+        assert rel_bias[0] is None and rel_bias[1] is None
+        if self.dropout_layer > 0:
+            if self.training and random.random() < self.dropout_layer:
+                return xs, {}
+            else:
+                xs = ops.scale(xs, 1.0 / (1 - self.dropout_layer))
+        p = self.dropout_p
+        xn = ops.layer_norm(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        xs = self.feed_forward_macaron(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
+        xn = ops.layer_norm(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        xs = self.conv(xn, residual=xs, out_dropout=p)
+        xn = ops.layer_norm(xs, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        xs, self._xx_aws = self.self_attn(xn, xn, xn, mask=xx_mask, residual=xs, out_dropout=p)[:2]
+        xn = ops.layer_norm(xs, self.norm4.weight, self.norm4.bias, self.norm4.eps)
+        xs = self.feed_forward(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
+        xs = ops.layer_norm(xs, self.norm5.weight, self.norm5.bias, self.norm5.eps)
+        return xs, {}
+
+
+# --------------------------------------------------------------------------- encoder stacks
+def chunkwise(xs, N_l, N_c, N_r, padding=True):
+    """utils.py:13-45: fold overlapping windows into the batch dim (pure data movement)."""
+    bs, xmax, idim = xs.size()
+    n_chunks = math.ceil(xmax / N_c) if padding else xmax // (N_l + N_c + N_r)
+    xs_tmp = xs.new_zeros(bs, n_chunks, N_l + N_c + N_r, idim)
+    if padding:
+        xs = torch.cat([xs.new_zeros(bs, N_l, idim), xs, xs.new_zeros(bs, N_r, idim)], dim=1)
+    t = N_l
+    for chunk_idx in range(n_chunks):
+        xs_chunk = xs[:, t - N_l:t + (N_c + N_r)]
+        xs_tmp[:, chunk_idx, :xs_chunk.size(1), :] = xs_chunk
+        t += N_c
+    return xs_tmp.view(bs * n_chunks, N_l + N_c + N_r, idim)
+
+
+class TransformerEncoder(EncoderBase):
+    """transformer.py:40-617 (training / full-utterance evaluation path)."""
+
+    def __init__(self, input_dim, enc_type, n_heads, n_layers, n_layers_sub1, n_layers_sub2,
+                 d_model, d_ff, ffn_bottleneck_dim, ffn_activation, pe_type, layer_norm_eps,
+                 last_proj_dim, dropout_in, dropout, dropout_att, dropout_layer,
+                 subsample, subsample_type, n_stacks, n_splices, frontend_conv,
+                 task_specific_layer, param_init, clamp_len, lookahead,
+                 chunk_size_left, chunk_size_current, chunk_size_right, streaming_type):
+        super().__init__()
+        self.subsample_factors = [1] * n_layers
+        for lth, s in enumerate(list(map(int, subsample.split('_')[:n_layers]))):
+            self.subsample_factors[lth] = s
+        lookaheads = [0] * n_layers
+        for lth, s in enumerate(list(map(int, lookahead.split('_')[:n_layers]))):
+            lookaheads[lth] = s
+        if n_layers_sub1 < 0 or (n_layers_sub1 > 1 and n_layers < n_layers_sub1):
+            raise Warning('Set n_layers_sub1 between 1 to n_layers.')
+        if n_layers_sub2 < 0 or (n_layers_sub2 > 1 and n_layers_sub1 < n_layers_sub2):
+            raise Warning('Set n_layers_sub2 between 1 to n_layers_sub1.')
+        self.enc_type = enc_type
+        self.d_model = d_model
+        self.n_layers = n_layers
+        self.n_heads = n_heads
+        self.pe_type = pe_type
+        self.scale = math.sqrt(d_model)
+        chunk_size_left = str(chunk_size_left)
+        chunk_size_current = str(chunk_size_current)
+        chunk_size_right = str(chunk_size_right)
+        self.unidir = 'uni' in enc_type
+        self.lookaheads = lookaheads
+        if sum(lookaheads) > 0:
+            assert self.unidir
+        self.N_l = int(chunk_size_left.split('_')[-1]) // n_stacks
+        self.N_c = int(chunk_size_current.split('_')[-1]) // n_stacks
+        self.N_r = int(chunk_size_right.split('_')[-1]) // n_stacks
+        self.lc_bidir = self.N_c > 0 and enc_type != 'conv' and 'uni' not in enc_type
+        self.cnn_lookahead = self.unidir or enc_type == 'conv'
+        self.streaming_type = streaming_type if self.lc_bidir else ''
+        self.causal = self.unidir or self.streaming_type == 'mask'
+        if self.unidir:
+            assert self.N_l == self.N_c == self.N_r == 0
+        if self.streaming_type == 'mask':
+            assert self.N_r == 0
+            assert self.N_l % self.N_c == 0
+        if self.lc_bidir:
+            assert n_layers_sub1 == 0 and n_layers_sub2 == 0 and not self.unidir
+        self.n_layers_sub1 = n_layers_sub1
+        self.n_layers_sub2 = n_layers_sub2
+        self.task_specific_layer = task_specific_layer
+        self.bridge = None
+        self.bridge_sub1 = None
+        self.bridge_sub2 = None
+        self.aws_dict = {}
+        self.data_dict = {}
+        self.conv = frontend_conv
+        if self.conv is not None:
+            self._odim = self.conv.output_dim
+        else:
+            self._odim = input_dim * n_splices * n_stacks
+            self.embed = nn.Linear(self._odim, d_model)
+        self._factor = 1
+        self.conv_factor = self.conv.subsampling_factor if self.conv is not None else 1
+        self._factor *= self.conv_factor
+        self.subsample_layers = None
+        if np.prod(self.subsample_factors) > 1:
+            self._factor *= np.prod(self.subsample_factors)
+            if subsample_type == 'max_pool':
+                self.subsample_layers = nn.ModuleList([MaxPoolSubsampler(factor)
+                                                       for factor in self.subsample_factors])
+            else:
+                raise NotImplementedError('subsample_type=%s (only max_pool is built)' % subsample_type)
+        assert self.N_l % self._factor == 0
+        assert self.N_c % self._factor == 0
+        assert self.N_r % self._factor == 0
+        self.pos_enc, self.pos_emb = None, None
+        self.u_bias, self.v_bias = None, None
+        if pe_type in ['relative', 'relative_xl']:
+            self.pos_emb = XLPositionalEmbedding(d_model, dropout)
+            if pe_type == 'relative_xl':
+                self.u_bias = nn.Parameter(torch.Tensor(n_heads, d_model // n_heads))
+                self.v_bias = nn.Parameter(torch.Tensor(n_heads, d_model // n_heads))
+        else:
+            self.pos_enc = PositionalEncoding(d_model, dropout_in, pe_type, param_init)
+        self.layers = self._make_layers(d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer,
+                                        layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
+                                        ffn_bottleneck_dim, n_layers)
+        self.norm_out = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self._odim = d_model
+        if n_layers_sub1 > 0 or n_layers_sub2 > 0:
+            raise NotImplementedError('auxiliary-task outputs (sub1/sub2) are not on the benchmarked path')
+        if last_proj_dim > 0 and last_proj_dim != self.output_dim:
+            self.bridge = nn.Linear(self._odim, last_proj_dim)
+            self._odim = last_proj_dim
+        self.reset_parameters(param_init)
+        self.reset_cache()
+
+    def _make_layers(self, d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer,
+                     layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
+                     ffn_bottleneck_dim, n_layers):
+        return nn.ModuleList([copy.deepcopy(TransformerEncoderBlock(
+            d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer * (lth + 1) / n_layers,
+            layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len, ffn_bottleneck_dim))
+            for lth in range(n_layers)])
+
+    def reset_parameters(self, param_init):
+        """transformer.py:346-364"""
+        if param_init == 'xavier_uniform':
+            if self.conv is None:
+                nn.init.xavier_uniform_(self.embed.weight)
+                nn.init.constant_(self.embed.bias, 0.)
+            if self.bridge is not None:
+                nn.init.xavier_uniform_(self.bridge.weight)
+                nn.init.constant_(self.bridge.bias, 0.)
+            if self.pe_type == 'relative_xl':
+                nn.init.xavier_uniform_(self.u_bias)
+                nn.init.xavier_uniform_(self.v_bias)
+
+    def reset_cache(self):
+        self.cache = [None] * self.n_layers
+        self.offset = 0
+
+    def _mask(self, xlens, lookahead, N_l=0, N_c=0):
+        klens = xlens.to(device=self.device, dtype=torch.int32, non_blocking=True)
+        if self.streaming_type == 'mask':
+            return AttnMask(klens, False, 0, N_l, N_c)
+        return AttnMask(klens, self.unidir, lookahead)
+
+    def forward(self, xs, xlens, task, streaming=False, lookback=False, lookahead=False):
+        """xs `[B,T,input_dim]` fp32 on the device, xlens IntTensor on the CPU ->
+        {'ys': {'xs': `[B,T'',d]`, 'xlens': IntTensor}, 'ys_sub1': ..., 'ys_sub2': ...}"""
+        if streaming:
+            raise NotImplementedError('streaming encoding is inference-only (out of scope)')
+        eouts = {'ys': {'xs': None, 'xlens': None},
+                 'ys_sub1': {'xs': None, 'xlens': None},
+                 'ys_sub2': {'xs': None, 'xlens': None}}
+        bs, xmax = xs.size()[:2]
+        n_chunks = 0
+        lc_bidir = self.lc_bidir
+        N_l, N_c, N_r = self.N_l, self.N_c, self.N_r
+        if lc_bidir:
+            if self.streaming_type == 'mask':
+                xs = chunkwise(xs, 0, N_c, 0, padding=True)
+            elif self.streaming_type == 'reshape':
+                xs = chunkwise(xs, N_l, N_c, N_r, padding=True)
+            n_chunks = xs.size(0) // bs
+            assert bs * n_chunks == xs.size(0)
+        if self.conv is None:
+            xs = ops.linear(xs, self.embed.weight, self.embed.bias)
+        else:
+            xs, xlens = self.conv(xs, xlens, lookback=False if lc_bidir else lookback,
+                                  lookahead=False if lc_bidir else lookahead)
+            N_l = max(0, N_l // self.conv_factor)
+            N_c = N_c // self.conv_factor
+            N_r = N_r // self.conv_factor
+        if self.streaming_type == 'mask':
+            xs = xs.contiguous().view(bs, -1, xs.size(2))[:, :int(xlens.max())].contiguous()
+        if self.enc_type == 'conv':
+            eouts['ys']['xs'] = xs
+            eouts['ys']['xlens'] = xlens
+            return eouts
+        self.reset_cache()
+        if 'relative' in self.pe_type:
+            xs, rel_pos_embs = self.pos_emb(xs, scale=True)
+        else:
+            xs = self.pos_enc(xs, scale=True, offset=self.offset)
+            rel_pos_embs = None
+        rel_bias = (self.u_bias, self.v_bias)
+        if lc_bidir:
+            xx_mask = self._mask(xlens, 0, N_l, N_c) if self.streaming_type == 'mask' else None
+            for lth, layer in enumerate(self.layers):
+                xs, _ = layer(xs, xx_mask, cache=None, pos_embs=rel_pos_embs, rel_bias=rel_bias)
+                if lth < len(self.layers) - 1 and self.subsample_factors[lth] > 1:
+                    xs, xlens = self.subsample_layers[lth](xs, xlens)
+                    N_l = max(0, N_l // self.subsample_factors[lth])
+                    N_c //= self.subsample_factors[lth]
+                    N_r //= self.subsample_factors[lth]
+                    if 'relative' in self.pe_type:
+                        xs, rel_pos_embs = self.pos_emb(xs)
+                    if self.streaming_type == 'mask':
+                        xx_mask = self._mask(xlens, 0, N_l, N_c)
+            if self.streaming_type == 'reshape':
+                xs = xs[:, N_l:N_l + N_c]
+                xs = xs.contiguous().view(bs, -1, xs.size(2))
+                xs = xs[:, :int(xlens.max())].contiguous()
+        else:
+            xx_mask = self._mask(xlens, self.lookaheads[0])
+            for lth, layer in enumerate(self.layers):
+                xs, _ = layer(xs, xx_mask, cache=None, pos_embs=rel_pos_embs, rel_bias=rel_bias)
+                if not self.training:
+                    self.aws_dict['xx_aws_layer%d' % lth] = layer.xx_aws  # device tensor (plot on demand)
+                    self.data_dict['elens%d' % lth] = xlens.numpy()
+                if lth < len(self.layers) - 1:
+                    if self.subsample_factors[lth] > 1:
+                        xs, xlens = self.subsample_layers[lth](xs, xlens)
+                        if 'relative' in self.pe_type:
+                            xs, rel_pos_embs = self.pos_emb(xs)
+                        xx_mask = self._mask(xlens, self.lookaheads[lth + 1])
+                    elif self.lookaheads[lth] != self.lookaheads[lth + 1]:
+                        xx_mask = self._mask(xlens, self.lookaheads[lth + 1])
+        xs = ops.layer_norm(xs, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps)
+        if self.bridge is not None:
+            xs = ops.linear(xs, self.bridge.weight, self.bridge.bias)
+        if task in ['all', 'ys']:
+            eouts['ys']['xs'], eouts['ys']['xlens'] = xs, xlens
+        return eouts
+
+
+class ConformerEncoder(TransformerEncoder):
+    """conformer.py:18-111"""
+
+    def __init__(self, input_dim, enc_type, n_heads, kernel_size, normalization,
+                 n_layers, n_layers_sub1, n_layers_sub2, d_model, d_ff, ffn_bottleneck_dim,
+                 ffn_activation, pe_type, layer_norm_eps, last_proj_dim,
+                 dropout_in, dropout, dropout_att, dropout_layer,
+                 subsample, subsample_type, n_stacks, n_splices, frontend_conv,
+                 task_specific_layer, param_init, clamp_len, lookahead,
+                 chunk_size_left, chunk_size_current, chunk_size_right, streaming_type):
+        self._conformer_cfg = (kernel_size, normalization, 'conformer_v2' in enc_type)
+        if 'conformer_v2' not in enc_type:
+            assert pe_type in ['relative', 'relative_xl']
+        super().__init__(input_dim, enc_type, n_heads, n_layers, n_layers_sub1, n_layers_sub2,
+                         d_model, d_ff, ffn_bottleneck_dim, ffn_activation, pe_type, layer_norm_eps,
+                         last_proj_dim, dropout_in, dropout, dropout_att, dropout_layer,
+                         subsample, subsample_type, n_stacks, n_splices, frontend_conv,
+                         task_specific_layer, param_init, clamp_len, lookahead,
+                         chunk_size_left, chunk_size_current, chunk_size_right, streaming_type)
+
+    def _make_layers(self, d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer,
+                     layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
+                     ffn_bottleneck_dim, n_layers):
+        kernel_size, normalization, v2 = self._conformer_cfg
+        causal = self.unidir or (self.streaming_type == 'mask')
+        block = ConformerEncoderBlock_v2 if v2 else ConformerEncoderBlock
+        return nn.ModuleList([copy.deepcopy(block(
+            d_model, d_ff, n_heads, kernel_size, dropout, dropout_att,
+            dropout_layer * (lth + 1) / n_layers, layer_norm_eps, ffn_activation, param_init,
+            pe_type, clamp_len, ffn_bottleneck_dim, causal, normalization))
+            for lth in range(n_layers)])
+
+
+def build_encoder(args):
+    """build.py:7-152 for the conv / transformer / conformer families."""
+    if 'conv' in args.enc_type:
+        assert args.n_stacks == 1 and args.n_splices == 1
+        conv = ConvEncoder(args.input_dim, in_channel=args.conv_in_channel, channels=args.conv_channels,
+                           kernel_sizes=args.conv_kernel_sizes, strides=args.conv_strides,
+                           poolings=args.conv_poolings, dropout=0., normalization=args.conv_normalization,
+                           residual=False,
+                           bottleneck_dim=args.transformer_enc_d_model if 'former' in args.enc_type else args.conv_bottleneck_dim,
+                           param_init=args.param_init)
+    else:
+        conv = None
+    if not hasattr(args, 'transformer_enc_d_model') and hasattr(args, 'transformer_d_model'):
+        args.transformer_enc_d_model = args.transformer_d_model
+        args.transformer_dec_d_model = args.transformer_d_model
+    if not hasattr(args, 'transformer_enc_d_ff') and hasattr(args, 'transformer_d_ff'):
+        args.transformer_enc_d_ff = args.transformer_d_ff
+    if not hasattr(args, 'transformer_enc_n_heads') and hasattr(args, 'transformer_n_heads'):
+        args.transformer_enc_n_heads = args.transformer_n_heads
+    common = dict(
+        input_dim=args.input_dim if args.input_type == 'speech' else args.emb_dim,
+        enc_type=args.enc_type, n_heads=args.transformer_enc_n_heads if hasattr(args, 'transformer_enc_n_heads') else None,
+        n_layers=args.enc_n_layers, n_layers_sub1=args.enc_n_layers_sub1, n_layers_sub2=args.enc_n_layers_sub2)
+    if 'transformer' in args.enc_type:
+        return TransformerEncoder(
+            d_model=args.transformer_enc_d_model, d_ff=args.transformer_enc_d_ff,
+            ffn_bottleneck_dim=args.transformer_ffn_bottleneck_dim,
+            ffn_activation=args.transformer_ffn_activation, pe_type=args.transformer_enc_pe_type,
+            layer_norm_eps=args.transformer_layer_norm_eps,
+            last_proj_dim=args.transformer_dec_d_model if 'transformer' in args.dec_type else 0,
+            dropout_in=args.dropout_in, dropout=args.dropout_enc, dropout_att=args.dropout_att,
+            dropout_layer=args.dropout_enc_layer, subsample=args.subsample,
+            subsample_type=args.subsample_type, n_stacks=args.n_stacks, n_splices=args.n_splices,
+            frontend_conv=conv, task_specific_layer=args.task_specific_layer,
+            param_init=args.transformer_param_init, clamp_len=args.transformer_enc_clamp_len,
+            lookahead=args.transformer_enc_lookaheads, chunk_size_left=args.lc_chunk_size_left,
+            chunk_size_current=args.lc_chunk_size_current, chunk_size_right=args.lc_chunk_size_right,
+            streaming_type=args.lc_type, **common)
+    elif 'conformer' in args.enc_type:
+        return ConformerEncoder(
+            kernel_size=args.conformer_kernel_size, normalization=args.conformer_normalization,
+            d_model=args.transformer_enc_d_model, d_ff=args.transformer_enc_d_ff,
+            ffn_bottleneck_dim=args.transformer_ffn_bottleneck_dim, ffn_activation='swish',
+            pe_type=args.transformer_enc_pe_type, layer_norm_eps=args.transformer_layer_norm_eps,
+            last_proj_dim=args.transformer_dec_d_model if 'transformer' in args.dec_type else 0,
+            dropout_in=args.dropout_in, dropout=args.dropout_enc, dropout_att=args.dropout_att,
+            dropout_layer=args.dropout_enc_layer, subsample=args.subsample,
+            subsample_type=args.subsample_type, n_stacks=args.n_stacks, n_splices=args.n_splices,
+            frontend_conv=conv, task_specific_layer=args.task_specific_layer,
+            param_init=args.transformer_param_init, clamp_len=args.transformer_enc_clamp_len,
+            lookahead=args.transformer_enc_lookaheads, chunk_size_left=args.lc_chunk_size_left,
+            chunk_size_current=args.lc_chunk_size_current, chunk_size_right=args.lc_chunk_size_right,
+            streaming_type=args.lc_type, **common)
+    elif args.enc_type == 'conv':
+        raise NotImplementedError("enc_type='conv' alone")
+    raise NotImplementedError(
+        'enc_type=%s: RNN/TDS/gated-conv encoders are outside the hot-path scope '
+        '(SURVEY.md section 2 row 17); use the reference implementation' % args.enc_type)

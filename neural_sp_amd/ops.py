@@ -153,46 +153,123 @@ def colsum(x2d, alpha=1.0):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = res + alpha * act(x W^T + b); x is [..., K] (nn.Linear semantics)."""
+    """y = res + dropout(alpha * act(x W^T + b)); x is [..., K] (nn.Linear semantics).
+
+    Everything after the contraction (bias, activation, scale, dropout mask, residual) is
+    the GEMM epilogue; backward regenerates the dropout mask from (seed, offset)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, res, alpha):
+    def forward(ctx, x, weight, bias, act, res, alpha, dropout_p):
         x2d = _f32c(x).reshape(-1, x.shape[-1])
         weight = _f32c(weight)
-        res2d = _f32c(res).reshape(-1, weight.shape[0]) if res is not None else None
+        N = weight.shape[0]
+        res2d = _f32c(res).reshape(-1, N) if res is not None else None
         pre = None
-        if act != 0 and (x.requires_grad or weight.requires_grad):
-            pre = torch.empty((x2d.shape[0], weight.shape[0]), device=x.device, dtype=torch.float32)
-        y = linear_fwd(x2d, weight, bias, act, res2d, alpha, pre_out=pre)
+        if act != 0:
+            pre = torch.empty((x2d.shape[0], N), device=x.device, dtype=torch.float32)
+        seed, offset = next_dropout_seed() if dropout_p > 0 else (0, 0)
+        y = torch.empty((x2d.shape[0], N), device=x.device, dtype=torch.float32)
+        gemm_raw(x2d.shape[0], N, x2d.shape[1], x2d, x2d.stride(0), 1, weight, 1, weight.stride(0),
+                 y, N, bias=bias, act=act, res=res2d, alpha=alpha, pre_out=pre,
+                 dropout_p=dropout_p, seed=seed, offset=offset)
         ctx.save_for_backward(x2d, weight, pre)
         ctx.act, ctx.alpha = act, alpha
+        ctx.drop = (dropout_p, seed, offset)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         ctx.xshape = x.shape
-        return y.view(*x.shape[:-1], weight.shape[0])
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2d, weight, pre = ctx.saved_tensors
         dy2d = _f32c(dy).reshape(-1, weight.shape[0])
         dres = dy if ctx.has_res else None
+        alpha = ctx.alpha
+        g = dy2d
+        p, seed, offset = ctx.drop
+        if p > 0:
+            g = dropout_raw(g, p, seed, offset, alpha)
+            alpha = 1.0
         if ctx.act != 0:
-            dpre = dact_mul(dy2d, pre, ctx.act, ctx.alpha)
-        elif ctx.alpha != 1.0:
-            dpre = dy2d * ctx.alpha
-        else:
-            dpre = dy2d
+            g = dact_mul(g, pre, ctx.act, alpha)
+        elif alpha != 1.0:
+            g = axpby(g, None, alpha, 0.0)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = linear_dgrad(dpre, weight).view(ctx.xshape)
+            dx = linear_dgrad(g, weight).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = linear_wgrad(dpre, x2d)
+            dw = linear_wgrad(g, x2d)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dpre)
-        return dx, dw, db, None, dres, None
+            db = colsum(g)
+        return dx, dw, db, None, dres, None, None
 
 
-def linear(x, weight, bias=None, act='none', res=None, alpha=1.0):
-    return LinearFn.apply(x, weight, bias, ACT[act] if not isinstance(act, int) else act, res, alpha)
+def linear(x, weight, bias=None, act='none', res=None, alpha=1.0, dropout_p=0.0):
+    return LinearFn.apply(x, weight, bias, ACT[act] if not isinstance(act, int) else act, res,
+                          float(alpha), float(dropout_p))
+
+
+def dropout_raw(x, p, seed, offset, alpha=1.0):
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _check(_lib.lib().nsp_dropout(_p(x), _p(y), ctypes.c_float(p), ctypes.c_float(alpha),
+                                  ctypes.c_ulonglong(seed), ctypes.c_ulonglong(offset),
+                                  ctypes.c_longlong(x.numel()), _stream()), 'nsp_dropout')
+    return y
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        seed, offset = next_dropout_seed()
+        ctx.drop = (p, seed, offset)
+        return dropout_raw(x, p, seed, offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset = ctx.drop
+        return dropout_raw(dy, p, seed, offset), None
+
+
+def dropout(x, p, training):
+    """nn.Dropout semantics with the counter-based mask of the HIP kernels."""
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p))
+
+
+class ScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return axpby(x, None, alpha, 0.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return axpby(dy, None, ctx.alpha, 0.0), None
+
+
+def scale(x, alpha):
+    return ScaleFn.apply(x, float(alpha))
+
+
+class AddFn(torch.autograd.Function):
+    """alpha*x + beta*z (both same shape)."""
+
+    @staticmethod
+    def forward(ctx, x, z, alpha, beta):
+        ctx.ab = (alpha, beta)
+        return axpby(x, z, alpha, beta)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.ab
+        return ((dy if a == 1.0 else axpby(dy, None, a, 0.0)),
+                (dy if b == 1.0 else axpby(dy, None, b, 0.0)), None, None)
+
+
+def add(x, z, alpha=1.0, beta=1.0):
+    return AddFn.apply(x, z, float(alpha), float(beta))
 
 
 def dact_mul(dy, pre, act, alpha=1.0):
@@ -714,3 +791,74 @@ class RNNTJointLossFn(torch.autograd.Function):
 
 def rnnt_joint_loss(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blank=0):
     return RNNTJointLossFn.apply(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, int(blank))
+
+
+# --------------------------------------------------------------------------
+# positional tables / input glue
+# --------------------------------------------------------------------------
+def xl_pos_table(inv_freq, L):
+    d = inv_freq.numel() * 2
+    out = torch.empty((L, d), device=inv_freq.device, dtype=torch.float32)
+    _check(_lib.lib().nsp_xl_pos_table(_p(inv_freq), _p(out), ctypes.c_int(L), ctypes.c_int(d), _stream()),
+           'nsp_xl_pos_table')
+    return out
+
+
+class ScaleAddBcastFn(torch.autograd.Function):
+    """alpha*x + z broadcast over the leading (batch) dim; z carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, z, alpha):
+        x = _f32c(x)
+        z = _f32c(z)
+        y = torch.empty_like(x)
+        _check(_lib.lib().nsp_scale_add_bcast(_p(x), _p(z), _p(y), ctypes.c_float(alpha),
+                                              ctypes.c_longlong(x.numel()), ctypes.c_longlong(z.numel()),
+                                              _stream()), 'nsp_scale_add_bcast')
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return axpby(dy, None, ctx.alpha, 0.0), None, None
+
+
+def scale_add_bcast(x, z, alpha):
+    return ScaleAddBcastFn.apply(x, z, float(alpha))
+
+
+def specaug_apply_(xs, freq_bands, time_bands):
+    """Zero [start,end) bands in place on [B,T,F] (spec_augment.py:112-140)."""
+    B, T, F = xs.shape
+    fb = torch.tensor(freq_bands, dtype=torch.int32, device=xs.device).view(-1) if len(freq_bands) else None
+    tb = torch.tensor(time_bands, dtype=torch.int32, device=xs.device).view(-1) if len(time_bands) else None
+    _check(_lib.lib().nsp_specaug_apply(_p(xs), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(F),
+                                        _p(fb), ctypes.c_int(len(freq_bands)), _p(tb),
+                                        ctypes.c_int(len(time_bands)), _stream()), 'nsp_specaug_apply')
+    return xs
+
+
+def pad_batch(packed, offsets, lens, B, Tmax, F, pad_value=0.0):
+    """Ragged -> padded [B,Tmax,F] on device from ONE packed H2D copy (pad_list, torch_utils.py:56)."""
+    out = torch.empty((B, Tmax, F), device=packed.device, dtype=torch.float32)
+    _check(_lib.lib().nsp_pad_batch(_p(packed), _p(offsets), _p(lens), _p(out), ctypes.c_int(B),
+                                    ctypes.c_int(Tmax), ctypes.c_int(F), ctypes.c_float(pad_value),
+                                    _stream()), 'nsp_pad_batch')
+    return out
+
+
+def ctc_forced_align(logits, labels, elens, ylens, blank=0):
+    """CTC forced alignment (ctc.py:628-753) -> trigger points IntTensor `[B, Lmax+1]` (device).
+    NOTE: trigger_points has Lmax+1 columns where Lmax = labels.shape[1] (>= 1)."""
+    logits = _f32c(logits)
+    B, T, V = logits.shape
+    Lmax = max(1, labels.shape[1])
+    L = _lib.lib()
+    L.nsp_ctc_align_workspace_bytes.restype = ctypes.c_longlong
+    nbytes = L.nsp_ctc_align_workspace_bytes(ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(Lmax))
+    ws = torch.empty((nbytes // 4 + 1,), device=logits.device, dtype=torch.float32)
+    tp = torch.empty((B, Lmax + 1), device=logits.device, dtype=torch.int32)
+    _check(L.nsp_ctc_forced_align(_p(logits), _p(labels), _p(elens), _p(ylens), _p(tp), _p(ws),
+                                  ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(V), ctypes.c_int(Lmax),
+                                  ctypes.c_int(blank), _stream()), 'nsp_ctc_forced_align')
+    return tp

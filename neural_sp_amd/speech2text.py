@@ -1,0 +1,261 @@
+"""Speech2Text: the drop-in boundary of the hot path.
+
+Mirrors neural_sp/models/seq2seq/speech2text.py: `__init__(args, save_path, idx2token)`
+(:45-204), `forward(batch, task, is_eval, teacher, teacher_lm) -> (loss[1], observation)`
+(:239-269), `_forward` (:271-345), `encode` (:369-431), with the same submodule /
+parameter names (`enc.*`, `dec_fwd.*`) so `state_dict`s are interchangeable and
+neural_sp/bin/asr/train.py drives it unchanged.  Everything below `encode()` runs on the
+HIP kernels (neural_sp_amd.ops); there is no CPU path.  Decoding / streaming / plotting
+members are inference-side and raise NotImplementedError.
+"""
+import logging
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from neural_sp_amd import ops
+from neural_sp_amd.decoders import RNNTransducer as RNNT
+from neural_sp_amd.decoders import build_decoder
+from neural_sp_amd.encoders import build_encoder
+
+random.seed(1)  # speech2text.py:37
+
+logger = logging.getLogger(__name__)
+
+
+class SpecAugment(object):
+    """spec_augment.py:11-140: frequency / time band zeroing with ONE mask set per batch,
+    drawn from np.random in the reference's call order; the zeroing is a HIP kernel."""
+
+    def __init__(self, F, T, n_freq_masks, n_time_masks, p=1.0, W=40,
+                 adaptive_number_ratio=0, adaptive_size_ratio=0, max_n_time_masks=20):
+        self.W, self.F, self.T = W, F, T
+        self.n_freq_masks, self.n_time_masks, self.p = n_freq_masks, n_time_masks, p
+        self.adaptive_number_ratio = adaptive_number_ratio
+        self.adaptive_size_ratio = adaptive_size_ratio
+        self.max_n_time_masks = max_n_time_masks
+        if adaptive_number_ratio > 0:
+            self.n_time_masks = 0
+        if adaptive_size_ratio > 0:
+            self.T = 0
+        self._freq_mask = None
+        self._time_mask = None
+
+    def draw(self, n_frames, n_bins):
+        fb, tb = [], []
+        for _ in range(self.n_freq_masks):
+            f = int(np.random.uniform(low=0, high=self.F))
+            f_0 = int(np.random.uniform(low=0, high=n_bins - f))
+            fb.append((f_0, f_0 + f))
+            self._freq_mask = (f_0, f_0 + f)
+        if self.adaptive_number_ratio > 0:
+            n_masks = min(int(n_frames * self.adaptive_number_ratio), self.max_n_time_masks)
+        else:
+            n_masks = self.n_time_masks
+        T = self.adaptive_size_ratio * n_frames if self.adaptive_size_ratio > 0 else self.T
+        for _ in range(n_masks):
+            t = int(np.random.uniform(low=0, high=T))
+            t = min(t, int(n_frames * self.p))
+            t_0 = int(np.random.uniform(low=0, high=n_frames - t))
+            tb.append((t_0, t_0 + t))
+            self._time_mask = (t_0, t_0 + t)
+        return fb, tb
+
+    def __call__(self, xs):
+        fb, tb = self.draw(xs.size(1), xs.size(2))
+        return ops.specaug_apply_(xs, fb, tb)
+
+
+class Speech2Text(nn.Module):
+    """Speech to text sequence-to-sequence model (training hot path on MI355X)."""
+
+    def __init__(self, args, save_path=None, idx2token=None):
+        super().__init__()
+        self.save_path = save_path
+        self.input_type = args.input_type
+        self.input_dim = args.input_dim
+        self.enc_type = args.enc_type
+        self.dec_type = args.dec_type
+        self.enc_n_layers = args.enc_n_layers
+        self.enc_n_layers_sub1 = args.enc_n_layers_sub1
+        self.subsample = [int(s) for s in args.subsample.split('_')]
+        self.vocab = args.vocab
+        self.vocab_sub1 = args.vocab_sub1
+        self.vocab_sub2 = args.vocab_sub2
+        self.blank, self.unk, self.eos, self.pad = 0, 1, 2, 3
+        self.main_weight = args.total_weight - args.sub1_weight - args.sub2_weight
+        self.sub1_weight = args.sub1_weight
+        self.sub2_weight = args.sub2_weight
+        self.mtl_per_batch = args.mtl_per_batch
+        self.task_specific_layer = args.task_specific_layer
+        self.ctc_weight = min(args.ctc_weight, self.main_weight)
+        self.ctc_weight_sub1 = min(args.ctc_weight_sub1, self.sub1_weight)
+        self.ctc_weight_sub2 = min(args.ctc_weight_sub2, self.sub2_weight)
+        self.bwd_weight = min(args.bwd_weight, self.main_weight)
+        self.fwd_weight = self.main_weight - self.bwd_weight - self.ctc_weight
+        self.fwd_weight_sub1 = self.sub1_weight - self.ctc_weight_sub1
+        self.fwd_weight_sub2 = self.sub2_weight - self.ctc_weight_sub2
+        self.mbr_training = args.mbr_training
+        self.recog_params = vars(args) if not isinstance(args, dict) else args
+        self.idx2token = idx2token
+        self.utt_id_prev = None
+        if self.input_type != 'speech':
+            raise NotImplementedError("input_type='text'")
+        if self.sub1_weight > 0 or self.sub2_weight > 0 or self.bwd_weight > 0 or self.mbr_training:
+            raise NotImplementedError('sub-task / backward / MBR decoders are outside the hot path')
+        self.input_noise_std = args.input_noise_std
+        self.n_stacks = args.n_stacks
+        self.n_skips = args.n_skips
+        self.n_splices = args.n_splices
+        self.weight_noise_std = args.weight_noise_std
+        if self.n_stacks > 1 or self.n_splices > 1:
+            raise NotImplementedError('frame stacking / splicing (numpy frontends) are out of scope')
+        if self.weight_noise_std > 0:
+            raise NotImplementedError('weight noise')
+        self.specaug = None
+        if args.n_freq_masks > 0 or args.n_time_masks > 0:
+            assert args.n_stacks == 1 and args.n_skips == 1
+            assert args.n_splices == 1
+            self.specaug = SpecAugment(F=args.freq_width, T=args.time_width,
+                                       n_freq_masks=args.n_freq_masks, n_time_masks=args.n_time_masks,
+                                       p=args.time_width_upper,
+                                       adaptive_number_ratio=args.adaptive_number_ratio,
+                                       adaptive_size_ratio=args.adaptive_size_ratio,
+                                       max_n_time_masks=args.max_n_time_masks)
+        self.ssn = None
+        if args.sequence_summary_network:
+            raise NotImplementedError('sequence summary network')
+        self.enc = build_encoder(args)
+        if args.freeze_encoder:
+            for n, p in self.enc.named_parameters():
+                if 'bridge' in n or 'sub1' in n:
+                    continue
+                p.requires_grad = False
+        special_symbols = {'blank': self.blank, 'unk': self.unk, 'eos': self.eos, 'pad': self.pad}
+        if args.external_lm:
+            raise NotImplementedError('external LM fusion / initialisation')
+        directions = []
+        if self.fwd_weight > 0 or (self.bwd_weight == 0 and self.ctc_weight > 0):
+            directions.append('fwd')
+        for dir in directions:
+            dec = build_decoder(args, special_symbols, self.enc.output_dim, args.vocab,
+                                self.ctc_weight, self.main_weight - self.bwd_weight, None)
+            setattr(self, 'dec_' + dir, dec)
+
+    # ---- bookkeeping members touched by neural_sp/bin/asr/train.py (speech2text.py:206-237, base.py)
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def device_id(self):
+        return torch.cuda.device_of(next(self.parameters())).idx
+
+    @property
+    def use_cuda(self):
+        return torch.cuda.is_available()
+
+    @property
+    def num_params_dict(self):
+        if not hasattr(self, '_nparams_dict'):
+            self._nparams_dict = {n: p.view(-1).size(0) for n, p in self.named_parameters()}
+        return self._nparams_dict
+
+    @property
+    def total_parameters(self):
+        if not hasattr(self, '_nparams'):
+            self._nparams = sum(p.view(-1).size(0) for p in self.parameters())
+        return self._nparams
+
+    def cudnn_setting(self, deterministic=False, benchmark=True):
+        pass  # no cuDNN/MIOpen autotuning on the hand-written path
+
+    def trigger_scheduled_sampling(self):
+        pass
+
+    def trigger_quantity_loss(self):
+        pass
+
+    def trigger_stableemit(self):
+        pass
+
+    def reset_session(self):
+        pass
+
+    def plot_attention(self):
+        raise NotImplementedError('plotting is out of scope')
+
+    def plot_ctc(self):
+        raise NotImplementedError('plotting is out of scope')
+
+    def decode(self, *a, **k):
+        raise NotImplementedError('decoding is inference-side and out of scope; load the '
+                                  'state_dict into the reference model to decode')
+
+    # ---- hot path
+    def forward(self, batch, task, is_eval=False, teacher=None, teacher_lm=None):
+        if teacher is not None or teacher_lm is not None:
+            raise NotImplementedError('knowledge distillation')
+        if is_eval:
+            self.eval()
+            with torch.no_grad():
+                loss, observation = self._forward(batch, task)
+        else:
+            self.train()
+            loss, observation = self._forward(batch, task)
+        return loss, observation
+
+    def _forward(self, batch, task):
+        eout_dict = self.encode(batch['xs'], task if self.mtl_per_batch else 'all')
+        observation = {}
+        loss = torch.zeros((1,), dtype=torch.float32, device=self.device)
+        if (self.fwd_weight > 0 or (self.bwd_weight == 0 and self.ctc_weight > 0)) \
+                and task in ['all', 'ys', 'ys.ctc', 'ys.mbr']:
+            loss_fwd, obs_fwd = self.dec_fwd(eout_dict['ys']['xs'], eout_dict['ys']['xlens'],
+                                             batch['ys'], task, None, self.recog_params,
+                                             self.idx2token, batch['trigger_points'])
+            loss = loss + loss_fwd
+            if isinstance(self.dec_fwd, RNNT):
+                observation['loss.transducer'] = obs_fwd['loss_transducer']
+            else:
+                observation['acc.att'] = obs_fwd['acc_att']
+                observation['ppl.att'] = obs_fwd['ppl_att']
+                observation['loss.att'] = obs_fwd['loss_att']
+                observation['loss.mbr'] = obs_fwd['loss_mbr']
+                observation['loss.quantity'] = obs_fwd.get('loss_quantity')
+                observation['loss.latency'] = obs_fwd.get('loss_latency')
+            observation['loss.ctc'] = obs_fwd['loss_ctc']
+        return loss, observation
+
+    def encode(self, xs, task='all', streaming=False, cnn_lookback=False, cnn_lookahead=False,
+               xlen_block=-1):
+        """xs: list of np.float32 `[T_i, input_dim]`.  One packed H2D copy, padding on the
+        device (pad_list + np2tensor of speech2text.py:397 without the per-utterance loop)."""
+        if streaming:
+            raise NotImplementedError('streaming encoding')
+        xlens = torch.IntTensor([len(x) for x in xs])
+        dev = self.device
+        B, Tmax, F = len(xs), int(xlens.max()), self.input_dim
+        packed = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in xs]))
+        offs = torch.zeros(B, dtype=torch.int64)
+        offs[1:] = torch.cumsum(xlens[:-1].long() * F, 0)
+        xs = ops.pad_batch(packed.to(dev, non_blocking=True), offs.to(dev, non_blocking=True),
+                           xlens.to(dev, non_blocking=True), B, Tmax, F, 0.)
+        if self.specaug is not None and self.training:
+            xs = self.specaug(xs)
+        if self.input_noise_std > 0 and self.training:
+            noise = torch.normal(xs.new_zeros(xs.shape[-1]), self.input_noise_std)  # input_noise.py
+            xs = ops.scale_add_bcast(xs, noise, 1.0)
+        return self.enc(xs, xlens, task.split('.')[0], streaming, cnn_lookback, cnn_lookahead)
+
+    def ctc_forced_align(self, xs, ys, task='ys'):
+        """speech2text.py:470-492: CTC forced alignment -> trigger points `[B,L+1]` (np.int32)."""
+        self.eval()
+        with torch.no_grad():
+            eout_dict = self.encode(xs, 'ys')
+            ctc = self.dec_fwd.ctc
+            logits = ctc.logits(eout_dict[task]['xs'])
+            tp = ctc.forced_aligner(logits, eout_dict[task]['xlens'], ys)
+        return tp.cpu().numpy()

@@ -1,0 +1,78 @@
+"""End-to-end parity of neural_sp_amd.Speech2Text (HIP kernels) against fixtures produced by
+the REFERENCE model on CPU (oracle/gen_golden.py): same state_dict, same batch ->
+loss, encoder output and every parameter gradient.
+
+Tolerances (stated, fp32): loss 1e-4 relative (north-star bar is 1e-3), encoder output
+2e-4 of its max magnitude, gradients 2e-3 of each tensor's max magnitude in the exact
+fp32-MFMA mode.  In bf16-MFMA mode (the throughput mode): loss 1e-2 relative, gradients
+compared by cosine similarity >= 0.995."""
+import argparse
+import glob
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*.pt')))
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+
+
+def _run(fix, mode):
+    from neural_sp_amd import ops
+    from neural_sp_amd.speech2text import Speech2Text
+    args = argparse.Namespace(**fix['args'])
+    model = Speech2Text(args)
+    model.load_state_dict(fix['state_dict'], strict=True)
+    model.cuda(0)
+    batch = dict(fix['batch'])
+    batch.update(xlens=[len(x) for x in batch['xs']], ys_sub1=[], ys_sub2=[], trigger_points=None)
+    with ops.compute_mode(mode):
+        model.zero_grad()
+        loss, obs = model(batch, task='all')
+        loss.backward()
+        grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        model.eval()
+        with torch.no_grad():
+            eout = model.encode(batch['xs'], 'all')
+            loss_eval, _ = model(batch, task='all', is_eval=True)
+    return loss.item(), obs, eout['ys']['xs'].cpu(), eout['ys']['xlens'], grads, loss_eval.item()
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_golden_fp32(name):
+    fix = _load(name)
+    loss, obs, eout, elens, grads, loss_eval = _run(fix, 'f32')
+    ref = fix['loss'].item()
+    assert abs(loss - ref) / abs(ref) < 1e-4, (loss, ref)
+    assert abs(loss_eval - fix['loss_eval'].item()) / abs(ref) < 1e-4
+    for k, v in fix['observation'].items():
+        if v is not None:
+            assert abs(obs[k] - v) / abs(v) < 1e-4, (k, obs[k], v)
+    assert torch.equal(elens.int(), fix['elens'].int())
+    assert eout.shape == fix['eout'].shape
+    assert (eout - fix['eout']).abs().max() / fix['eout'].abs().max() < 2e-4
+    assert set(grads) == set(fix['grads'])
+    worst = max(((grads[n] - g).abs().max() / (g.abs().max() + 1e-8)).item() for n, g in fix['grads'].items())
+    bad = {n: ((grads[n] - g).abs().max() / (g.abs().max() + 1e-8)).item() for n, g in fix['grads'].items()
+           if ((grads[n] - g).abs().max() / (g.abs().max() + 1e-8)).item() > 2e-3}
+    assert not bad, (worst, bad)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_golden_bf16(name):
+    fix = _load(name)
+    loss, obs, eout, elens, grads, _ = _run(fix, 'bf16')
+    ref = fix['loss'].item()
+    assert abs(loss - ref) / abs(ref) < 1e-2, (loss, ref)
+    cos = {}
+    for n, g in fix['grads'].items():
+        if g.numel() < 16 or g.abs().max() < 1e-6:
+            continue
+        cos[n] = torch.nn.functional.cosine_similarity(grads[n].flatten(), g.flatten(), dim=0).item()
+    bad = {n: c for n, c in cos.items() if c < 0.995}
+    assert not bad, bad

@@ -50,26 +50,33 @@ def test_glu_dwconv_maxpool1d():
         assert _rel(torch.autograd.grad(y, xm, g)[0], torch.autograd.grad(ref, xm, g)[0]) < 1e-6
 
 
-@pytest.mark.parametrize('mode,tol', [('f32', 1e-4), ('bf16', 3e-2)])
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('Ci', [1, 32])
-def test_conv3x3(mode, tol, Ci):
+def test_conv3x3(mode, Ci):
+    """bf16 mode is checked on bf16-representable inputs so that products are exact and
+    ReLU masks cannot flip: any residual error is indexing, not rounding."""
     from neural_sp_amd import ops
     torch.manual_seed(1)
     B, T, Fq, Co = 2, 37, 40, 32
-    x = torch.randn(B, Ci, T, Fq, device=_dev(), requires_grad=True)
-    w = (torch.randn(Co, Ci, 3, 3, device=_dev()) / math.sqrt(9 * Ci)).requires_grad_()
+
+    def q(t):
+        return t.bfloat16().float() if mode == 'bf16' else t
+    x = q(torch.randn(B, Ci, T, Fq, device=_dev())).requires_grad_(Ci > 1)
+    w = q(torch.randn(Co, Ci, 3, 3, device=_dev()) / math.sqrt(9 * Ci)).requires_grad_()
     b = torch.randn(Co, device=_dev(), requires_grad=True)
     ref = torch.relu(F.conv2d(x, w, b, padding=1))
-    g = torch.randn_like(ref)
-    rx, rw, rb = torch.autograd.grad(ref, (x, w, b), g)
-    xcl = x.detach().permute(0, 2, 3, 1).contiguous().requires_grad_()
+    g = q(torch.randn_like(ref))
+    ins = (x, w, b) if Ci > 1 else (w, b)
+    rgrads = torch.autograd.grad(ref, ins, g)
+    xcl = x.detach().permute(0, 2, 3, 1).contiguous().requires_grad_(Ci > 1)
     with ops.compute_mode(mode):
         y = ops.conv3x3_relu(xcl, w, b)
-        assert _rel(y.permute(0, 3, 1, 2), ref) < tol
-        gx, gw, gb = torch.autograd.grad(y, (xcl, w, b), g.permute(0, 2, 3, 1).contiguous())
-    assert _rel(gx.permute(0, 3, 1, 2), rx) < tol
-    assert _rel(gw, rw) < max(tol, 1e-3 if mode == 'f32' else tol)
-    assert _rel(gb, rb) < 1e-4
+        assert _rel(y.permute(0, 3, 1, 2), ref) < 1e-4
+        grads = torch.autograd.grad(y, (xcl, w, b) if Ci > 1 else (w, b), g.permute(0, 2, 3, 1).contiguous())
+    if Ci > 1:
+        assert _rel(grads[0].permute(0, 3, 1, 2), rgrads[0]) < 1e-4
+    assert _rel(grads[-2], rgrads[-2]) < 1e-3
+    assert _rel(grads[-1], rgrads[-1]) < 1e-4
 
 
 def test_maxpool2d():
@@ -157,3 +164,14 @@ def test_rnnt_joint_loss():
     assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-5, (loss.item(), ref.item())
     for a, r in zip(grads, rg):
         assert _rel(a.cpu().double(), r) < 2e-4
+
+
+def test_ctc_forced_align_vs_reference_golden():
+    """trigger points must equal the reference CTCForcedAligner's output (fixture generated by
+    oracle/gen_golden.py run_align from neural_sp/models/seq2seq/decoders/ctc.py:628-753)."""
+    import os
+    from neural_sp_amd.decoders import CTCForcedAligner
+    fix = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'ctc_align.pt'), weights_only=False)
+    tp = CTCForcedAligner()(fix['logits'].to(_dev()), fix['elens'], fix['ys'])
+    assert tp.dtype == torch.int32
+    assert torch.equal(tp.cpu(), fix['trigger_points'].int()), (tp.cpu().tolist(), fix['trigger_points'].tolist())
