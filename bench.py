@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- speech-frames/sec/node of the Speech2Text training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full training step (neural_sp/bin/asr/train.py:414-452): H2D of a synthetic
+batch, Conformer encoder fwd, CTC + RNN-T loss, backward (RCCL gradient all-reduce under
+DDP when N>1), grad clipping, Adam.  Workload = BASELINE.json configs[3] per GPU:
+Conformer-L (d=512, d_ff=2048, H=8, k=15, 12 layers, x8 subsampling) + CTC(0.3) + RNN-T
+(2x1024 LSTM prediction net, joint 512, V=1000), B=16 utterances of T~U[1200,1600] 80-dim
+frames, U~U[120,200] labels, dropout 0.1, bf16 MFMA operands / fp32 accumulate.
+Weak scaling: every rank owns its own batch (seed = rank); value = valid frames of all
+ranks / wall time (max over ranks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=8)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--batch', type=int, default=16, help='utterances per GPU')
+    p.add_argument('--size', default='L', choices=['L', 'M', 'S', 'XS'])
+    p.add_argument('--tmin', type=int, default=1200)
+    p.add_argument('--tmax', type=int, default=1600)
+    p.add_argument('--umin', type=int, default=120)
+    p.add_argument('--umax', type=int, default=200)
+    p.add_argument('--dropout', type=float, default=0.1)
+    p.add_argument('--mode', default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-kernel-events', action='store_true')
+    p.add_argument('--cpu-batch', type=int, default=1, help='utterances in the CPU-baseline sample')
+    return p.parse_args()
+
+
+def cpu_baseline(args, margs, cores):
+    """Oracle port (oracle/model_ref.py, fp32, torch-CPU threads = all host cores) timed on a
+    bounded sample of the same workload: fwd + loss + bwd of `cpu_batch` utterances."""
+    from neural_sp_amd.configs import synthetic_batch
+    from neural_sp_amd.speech2text import Speech2Text
+    from oracle import model_ref
+    from oracle import rnnt_ref
+    torch.set_num_threads(cores)
+    model_ref.rnnt_loss_ref = rnnt_ref.rnnt_loss_ref_diag  # vectorised lattice (same arithmetic)
+    torch.manual_seed(0)
+    m = Speech2Text(margs)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and 'inv_freq' not in k)
+          for k, v in m.state_dict().items()}
+    batch = synthetic_batch(B=args.cpu_batch, t_range=(args.tmin, args.tmax), u_range=(args.umin, args.umax),
+                            vocab=margs.vocab, seed=123)
+    frames = sum(len(x) for x in batch['xs'])
+    t0 = time.time()
+    loss, _, _, _ = model_ref.speech2text_loss(sd, margs, batch, torch.float32)
+    loss.backward()
+    dt = time.time() - t0
+    return {'value': frames / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d utterance(s), %d frames, fwd+loss+bwd of the same Conformer-%s+CTC+RNN-T '
+                      'model through oracle/model_ref.py in fp32 (%.1f s)' % (args.cpu_batch, frames, args.size, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    assert torch.cuda.is_available(), 'bench.py measures the HIP path; no GPU is visible'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+
+    from neural_sp_amd import ops
+    from neural_sp_amd.configs import conformer_rnnt_args, synthetic_batch
+    from neural_sp_amd.speech2text import Speech2Text
+    from neural_sp_amd import parallel
+
+    ops.set_compute_mode(a.mode)
+    margs = conformer_rnnt_args(a.size, n_layers=12, vocab=1000, dropout=a.dropout, ctc_weight=0.3)
+    torch.manual_seed(1)
+    model = Speech2Text(margs).to(dev)
+    n_params = model.total_parameters
+    train_model = parallel.wrap_ddp(model, local_rank) if distributed else model
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+    batches = [synthetic_batch(B=a.batch, t_range=(a.tmin, a.tmax), u_range=(a.umin, a.umax),
+                               vocab=1000, seed=1000 * rank + i) for i in range(4)]
+
+    def step(i):
+        batch = batches[i % len(batches)]
+        loss, obs = train_model(batch, task='all')
+        if distributed:
+            loss = loss * world  # train.py:423-424
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return sum(batch['xlens'])
+
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    if not a.no_kernel_events:
+        ops.kernel_events_start()
+    t0 = time.perf_counter()
+    frames = 0
+    for i in range(a.steps):
+        frames += step(a.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    kev = ops.kernel_events_stop() if not a.no_kernel_events else None
+
+    tot = torch.tensor([dt, float(frames)], device=dev, dtype=torch.float64)
+    if distributed:
+        tmax = tot[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        fsum = tot[1:2].clone()
+        dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
+        dt, frames = tmax.item(), fsum.item()
+
+    if rank == 0:
+        peak_tf = 2500.0 if a.mode == 'bf16' else 157.3
+        roof = None
+        if kev is not None and kev['launches'] > 0:
+            ach = kev['flops'] / (kev['ms'] * 1e-3) / 1e12
+            roof = {'kernel': 'gemm_kernel<%s> (all %d launches in the timed region, rank 0)' % (a.mode, kev['launches']),
+                    'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak_tf, 4), 'traffic': None,
+                    'avg_launch_us': round(kev['ms'] * 1e3 / kev['launches'], 2),
+                    'gemm_share_of_step': round(kev['ms'] / (dt * 1e3), 3)}
+        out = {
+            'metric': 'speech-frames/sec/node (Conformer-L + CTC+RNN-T, 80-d fbank)',
+            'value': round(frames / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if a.mode == 'bf16' else 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'Conformer-%s 12L conv-subsample x8 + CTC(0.3)+RNN-T(2x1024 LSTM, joint 512, V=1000), '
+                                   'T~U[%d,%d], U~U[%d,%d], dropout %.2f; full train step (fwd+loss+bwd+clip+Adam)'
+                                   % (a.size, a.tmin, a.tmax, a.umin, a.umax, a.dropout),
+                       'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'params': n_params,
+                       'parallelism': 'dp%d' % world},
+            'roofline': roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(a, margs, os.cpu_count() or 1)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -862,3 +862,40 @@ def ctc_forced_align(logits, labels, elens, ylens, blank=0):
                                   ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(V), ctypes.c_int(Lmax),
                                   ctypes.c_int(blank), _stream()), 'nsp_ctc_forced_align')
     return tp
+
+
+# --------------------------------------------------------------------------
+# per-launch timing of the GEMM kernel with HIP events (bench.py roofline)
+# --------------------------------------------------------------------------
+_KEV = {'on': False, 'events': [], 'flops': 0.0}
+_gemm_raw_untimed = gemm_raw
+
+
+def _gemm_raw_timed(M, N, K, *a, **k):
+    if not _KEV['on']:
+        return _gemm_raw_untimed(M, N, K, *a, **k)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _gemm_raw_untimed(M, N, K, *a, **k)
+    e1.record()
+    batch = k.get('batch', (1, 1))
+    _KEV['events'].append((e0, e1))
+    _KEV['flops'] += 2.0 * M * N * K * batch[0] * batch[1]
+
+
+gemm_raw = _gemm_raw_timed
+
+
+def kernel_events_start():
+    _KEV['on'], _KEV['events'], _KEV['flops'] = True, [], 0.0
+
+
+def kernel_events_stop():
+    """-> {'launches', 'ms' (sum of HIP-event durations on the launch stream), 'flops'}."""
+    _KEV['on'] = False
+    torch.cuda.synchronize()
+    ms = sum(e0.elapsed_time(e1) for e0, e1 in _KEV['events'])
+    out = {'launches': len(_KEV['events']), 'ms': ms, 'flops': _KEV['flops']}
+    _KEV['events'] = []
+    return out

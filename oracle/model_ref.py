@@ -1,0 +1,344 @@
+"""CPU restatement of the reference Speech2Text training hot path (TEST ORACLE ONLY).
+
+Plain torch-CPU ops in any float dtype (fp64 for a tight oracle), functional over a
+reference-named state_dict, so the same weights drive the reference, this oracle and the
+HIP path.  Each function cites the reference lines it follows.  Pinned against fixtures
+produced by the reference itself (tests/golden/*.pt via oracle/gen_golden.py); see
+tests/test_oracle_cpu.py.  Nothing under neural_sp_amd/ imports this file.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle.rnnt_ref import rnnt_loss_ref
+
+NEG_INF32 = float(torch.finfo(torch.float32).min)
+
+
+def _lin(x, sd, name, bias=True):
+    w = sd[name + '.weight']
+    b = sd.get(name + '.bias') if bias else None
+    return F.linear(x, w, b)
+
+
+def _ln(x, sd, name, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[name + '.weight'], sd[name + '.bias'], eps)
+
+
+def _act(x, name):
+    if name == 'swish':
+        return x * torch.sigmoid(x)
+    if name == 'relu':
+        return torch.relu(x)
+    if name == 'gelu_accurate':
+        return F.gelu(x)
+    if name == 'gelu':
+        return F.gelu(x, approximate='tanh')
+    raise NotImplementedError(name)
+
+
+def _pool_len(n, k):  # conv.py:471-474 ceil-mode max-pool length
+    return int(math.ceil((n + 1 - (k - 1) - 1) // k + 1))
+
+
+# ----------------------------------------------------------------------------- conv frontend
+def conv_frontend(xs, xlens, sd, args, prefix='enc.conv'):
+    """conv.py:167-195 + Conv2dBlock.forward :347-396 (3x3, pad 1, ReLU, MaxPool2d ceil)."""
+    B, T, Fq = xs.shape
+    x = xs.view(B, T, args.conv_in_channel, Fq // args.conv_in_channel).transpose(2, 1)
+    pools = [[int(v) for v in p.strip('()').split(',')] for p in args.conv_poolings.split('_')]
+    xlens = list(xlens)
+    for i, pool in enumerate(pools):
+        p = '%s.layers.%d' % (prefix, i)
+        x = torch.relu(F.conv2d(x, sd[p + '.conv1.weight'], sd[p + '.conv1.bias'], padding=1))
+        x = torch.relu(F.conv2d(x, sd[p + '.conv2.weight'], sd[p + '.conv2.bias'], padding=1))
+        if pool[0] * pool[1] > 1:
+            x = F.max_pool2d(x, tuple(pool), tuple(pool), ceil_mode=True)
+            xlens = [_pool_len(n, pool[0]) for n in xlens]
+    B, C, T2, F2 = x.shape
+    x = x.transpose(2, 1).contiguous().view(B, T2, C * F2)
+    if (prefix + '.bridge.weight') in sd:
+        x = _lin(x, sd, prefix + '.bridge')
+    return x, xlens
+
+
+# ----------------------------------------------------------------------------- attention
+def visible_mask(xlens, T, unidir=False, lookahead=0, N_l=0, N_c=0):
+    """transformer.py:633-686 -> bool `[B,T,T]` (True = visible)."""
+    j = torch.arange(T)[None, None, :]
+    i = torch.arange(T)[None, :, None]
+    vis = j < torch.tensor(xlens)[:, None, None]
+    vis = vis.expand(len(xlens), T, T).clone()
+    if unidir:
+        vis &= (j <= i + lookahead)
+    if N_c > 0:
+        c0 = (i // N_c) * N_c
+        vis &= (j >= (c0 - N_l).clamp(min=0)) & (j < c0 + N_c)
+    return vis
+
+
+def rel_mha(x, pos_embs, vis, sd, p, H, clamp_len, xl_like=False, u_bias=None, v_bias=None):
+    """relative_multihead_attention.py:146-220 (incl. _rel_shift :112-144)."""
+    B, T, d = x.shape
+    dk = d // H
+    k = F.linear(x, sd[p + '.w_key.weight']).view(B, T, H, dk)
+    v = F.linear(x, sd[p + '.w_value.weight']).view(B, T, H, dk)
+    q = F.linear(x, sd[p + '.w_query.weight']).view(B, T, H, dk)
+    wp = sd[p + ('.w_pos.weight' if xl_like else '.w_value.weight')]
+    pe = F.linear(pos_embs, wp).view(-1, H, dk)
+    qa = q + u_bias[None, None] if u_bias is not None else q
+    qb = q + v_bias[None, None] if v_bias is not None else q
+    AC = torch.einsum('bihd,bjhd->bijh', qa, k)
+    BD = torch.einsum('bihd,jhd->bijh', qb, pe)
+    idx = (torch.arange(T)[None, :] - torch.arange(T)[:, None]).abs()
+    if clamp_len > 0:
+        idx = idx.clamp(max=clamp_len)
+    BD = torch.gather(BD, 2, idx[None, :, :, None].expand(B, T, T, H))
+    e = (AC + BD) / math.sqrt(dk)
+    if vis is not None:
+        e = e.masked_fill(~vis[:, :, :, None], NEG_INF32)
+    aw = torch.softmax(e, dim=2)
+    cv = torch.einsum('bijh,bjhd->bihd', aw, v).reshape(B, T, d)
+    return F.linear(cv, sd[p + '.w_out.weight'])
+
+
+def mha(x, vis, sd, p, H):
+    """multihead_attention.py:93-157 (scaled_dot, bias=True)."""
+    B, T, d = x.shape
+    dk = d // H
+    k = _lin(x, sd, p + '.w_key').view(B, T, H, dk)
+    v = _lin(x, sd, p + '.w_value').view(B, T, H, dk)
+    q = _lin(x, sd, p + '.w_query').view(B, T, H, dk)
+    e = torch.einsum('bihd,bjhd->bijh', q, k) / math.sqrt(dk)
+    if vis is not None:
+        e = e.masked_fill(~vis[:, :, :, None], NEG_INF32)
+    aw = torch.softmax(e, dim=2)
+    cv = torch.einsum('bijh,bjhd->bihd', aw, v).reshape(B, T, d)
+    return _lin(cv, sd, p + '.w_out')
+
+
+def ffn(x, sd, p, act):
+    """positionwise_feed_forward.py:77-89"""
+    return _lin(_act(_lin(x, sd, p + '.w_1'), act), sd, p + '.w_2')
+
+
+def conformer_conv(x, sd, p, k, causal):
+    """conformer_convolution.py:98-129 (layer_norm variant)."""
+    B, T, C = x.shape
+    h = x.transpose(2, 1)
+    h = F.conv1d(h, sd[p + '.pointwise_conv1.weight'], sd[p + '.pointwise_conv1.bias'])
+    h = F.glu(h, dim=1)
+    pad = (k - 1) if causal else (k - 1) // 2
+    h = F.conv1d(h, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], padding=pad, groups=C)
+    if causal:
+        h = h[:, :, :-pad]
+    h = h.transpose(2, 1)
+    h = F.layer_norm(h, (C,), sd[p + '.norm.weight'], sd[p + '.norm.bias'], 1e-12)
+    h = (h * torch.sigmoid(h)).transpose(2, 1)
+    h = F.conv1d(h, sd[p + '.pointwise_conv2.weight'], sd[p + '.pointwise_conv2.bias'])
+    return h.transpose(2, 1)
+
+
+def xl_pos_emb(T, inv_freq, dtype):
+    """positional_embedding.py:131-138"""
+    pos = torch.arange(-1, -T - 1, -1.0, dtype=torch.float32)
+    s = torch.einsum('i,j->ij', pos, inv_freq.float())
+    return torch.cat([s.sin(), s.cos()], dim=-1).to(dtype)
+
+
+# ----------------------------------------------------------------------------- encoder
+def encoder_forward(xs, xlens, sd, args):
+    """transformer.py:419-617 / conformer_block.py:95-182 / transformer_block.py:79-141,
+    eval-mode semantics (no dropout, LayerDrop scaling only if dropout_enc_layer > 0)."""
+    dtype = xs.dtype
+    enc_type = args.enc_type
+    is_conf = 'conformer' in enc_type
+    v2 = 'conformer_v2' in enc_type
+    unidir = 'uni' in enc_type
+    d, H = args.transformer_enc_d_model, args.transformer_enc_n_heads
+    eps = args.transformer_layer_norm_eps
+    n_layers = args.enc_n_layers
+    sub = [1] * n_layers
+    for i, s in enumerate(map(int, args.subsample.split('_')[:n_layers])):
+        sub[i] = s
+    las = [0] * n_layers
+    for i, s in enumerate(map(int, args.transformer_enc_lookaheads.split('_')[:n_layers])):
+        las[i] = s
+    N_l = int(str(args.lc_chunk_size_left).split('_')[-1])
+    N_c = int(str(args.lc_chunk_size_current).split('_')[-1])
+    N_r = int(str(args.lc_chunk_size_right).split('_')[-1])
+    lc = N_c > 0 and not unidir
+    stype = args.lc_type if lc else ''
+    causal_conv = unidir or stype == 'mask'
+    B = xs.shape[0]
+    if lc:
+        from neural_sp_amd.encoders import chunkwise  # pure data movement, same as utils.py:13-45
+        xs = chunkwise(xs, 0, N_c, 0) if stype == 'mask' else chunkwise(xs, N_l, N_c, N_r)
+    if 'conv' in enc_type:
+        xs, xlens = conv_frontend(xs, xlens, sd, args)
+        fac = 1
+        for p in args.conv_poolings.split('_'):
+            fac *= int(p.strip('()').split(',')[0])
+        N_l, N_c, N_r = max(0, N_l // fac), N_c // fac, N_r // fac
+    else:
+        xs = _lin(xs, sd, 'enc.embed')
+    if stype == 'mask':
+        xs = xs.contiguous().view(B, -1, xs.size(2))[:, :max(xlens)]
+    pe_type = args.transformer_enc_pe_type
+    rel = 'relative' in pe_type
+    xs = xs * math.sqrt(d)
+    pos = None
+    if rel:
+        pos = xl_pos_emb(xs.shape[1], sd['enc.pos_emb.inv_freq'], dtype)
+    elif pe_type == 'add':
+        xs = xs + sd['enc.pos_enc.pe'][:, :xs.shape[1]].to(dtype)
+    u_bias = sd.get('enc.u_bias')
+    v_bias = sd.get('enc.v_bias')
+    ld = args.dropout_enc_layer
+
+    def mask(lth):
+        if stype == 'reshape':
+            return None
+        if stype == 'mask':
+            return visible_mask(xlens, xs.shape[1], False, 0, N_l, N_c)
+        return visible_mask(xlens, xs.shape[1], unidir, las[lth])
+
+    vis = mask(0)
+    for l in range(n_layers):
+        p = 'enc.layers.%d' % l
+        if ld > 0:
+            xs = xs / (1 - ld * (l + 1) / n_layers)
+        if is_conf and not v2:
+            xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm1', eps), sd, p + '.feed_forward_macaron', 'swish')
+            xs = xs + rel_mha(_ln(xs, sd, p + '.norm2', eps), pos, vis, sd, p + '.self_attn', H,
+                              args.transformer_enc_clamp_len, pe_type == 'relative_xl', u_bias, v_bias)
+            xs = xs + conformer_conv(_ln(xs, sd, p + '.norm3', eps), sd, p + '.conv',
+                                     args.conformer_kernel_size, causal_conv)
+            xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm4', eps), sd, p + '.feed_forward', 'swish')
+            xs = _ln(xs, sd, p + '.norm5', eps)
+        elif is_conf:
+            xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm1', eps), sd, p + '.feed_forward_macaron', 'swish')
+            xs = xs + conformer_conv(_ln(xs, sd, p + '.norm2', eps), sd, p + '.conv',
+                                     args.conformer_kernel_size, causal_conv)
+            xs = xs + mha(_ln(xs, sd, p + '.norm3', eps), vis, sd, p + '.self_attn', H)
+            xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm4', eps), sd, p + '.feed_forward', 'swish')
+            xs = _ln(xs, sd, p + '.norm5', eps)
+        else:
+            xn = _ln(xs, sd, p + '.norm1', eps)
+            if pe_type == 'relative_xl':  # the 'relaive' typo: only relative_xl is RelMHA here
+                xs = xs + rel_mha(xn, pos, vis, sd, p + '.self_attn', H, args.transformer_enc_clamp_len,
+                                  True, u_bias, v_bias)
+            else:
+                xs = xs + mha(xn, vis, sd, p + '.self_attn', H)
+            xs = xs + ffn(_ln(xs, sd, p + '.norm2', eps), sd, p + '.feed_forward',
+                          args.transformer_ffn_activation)
+        if l < n_layers - 1 and sub[l] > 1:
+            xs = F.max_pool1d(xs.transpose(2, 1), sub[l], sub[l], ceil_mode=True).transpose(2, 1)
+            xlens = [_pool_len(n, sub[l]) for n in xlens]
+            N_l, N_c, N_r = max(0, N_l // sub[l]), N_c // sub[l], N_r // sub[l]
+            if rel:
+                pos = xl_pos_emb(xs.shape[1], sd['enc.pos_emb.inv_freq'], dtype)
+            vis = mask(l + 1)
+        elif l < n_layers - 1 and las[l] != las[l + 1]:
+            vis = mask(l + 1)
+    if stype == 'reshape':
+        xs = xs[:, N_l:N_l + N_c].contiguous().view(B, -1, xs.size(2))[:, :max(xlens)]
+    xs = _ln(xs, sd, 'enc.norm_out', eps)
+    if 'enc.bridge.weight' in sd:
+        xs = _lin(xs, sd, 'enc.bridge')
+    return xs, xlens
+
+
+# ----------------------------------------------------------------------------- losses
+def ctc_head(eouts, sd, p):
+    """ctc.py:81-91"""
+    if (p + '.output.weight') in sd:
+        return _lin(eouts, sd, p + '.output')
+    x, i = eouts, 0
+    while (p + '.output.fc%d.weight' % i) in sd:
+        x = _lin(x, sd, p + '.output.fc%d' % i)
+        i += 1
+    return x
+
+
+def ctc_loss_ref(logits, elens, ys, lsm_prob):
+    """ctc.py:105-150 + criterion.py:110-127"""
+    B, T, V = logits.shape
+    ylens = torch.tensor([len(y) for y in ys], dtype=torch.int32)
+    ys_cat = torch.cat([torch.tensor(y, dtype=torch.int32) for y in ys])
+    el = torch.tensor(elens, dtype=torch.int32)
+    loss = F.ctc_loss(logits.transpose(1, 0).log_softmax(2), ys_cat, el, ylens,
+                      reduction='sum', zero_infinity=True) / B
+    if lsm_prob > 0:
+        probs = torch.softmax(logits, dim=-1)
+        lp = torch.log_softmax(logits, dim=-1)
+        kl = probs * (lp - math.log(1 / (V - 1)))
+        kl = sum(kl[b, :elens[b]].sum() for b in range(B)) / sum(elens)
+        loss = loss * (1 - lsm_prob) + kl * lsm_prob
+    return loss
+
+
+def lstm_ref(x, sd, p):
+    """nn.LSTM(1 layer, batch_first) with zero initial state (rnn_transducer.py:278-311)."""
+    B, L, _ = x.shape
+    w_ih, w_hh = sd[p + '.weight_ih_l0'], sd[p + '.weight_hh_l0']
+    b = sd[p + '.bias_ih_l0'] + sd[p + '.bias_hh_l0']
+    n = w_hh.shape[1]
+    h = x.new_zeros(B, n)
+    c = x.new_zeros(B, n)
+    outs = []
+    gi = F.linear(x, w_ih, b)
+    for t in range(L):
+        g = gi[:, t] + F.linear(h, w_hh)
+        i, f, gg, o = g.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
+def rnnt_branch(eouts, elens, ys, sd, args, p='dec_fwd'):
+    """rnn_transducer.py:217-276 with the lattice of oracle/rnnt_ref.py."""
+    B = eouts.shape[0]
+    U = max(len(y) for y in ys)
+    ys_in = torch.full((B, U + 1), 3, dtype=torch.long)
+    lab = torch.zeros((B, max(U, 1)), dtype=torch.long)
+    for b, y in enumerate(ys):
+        ys_in[b, 0] = 2
+        ys_in[b, 1:len(y) + 1] = torch.tensor(y)
+        lab[b, :len(y)] = torch.tensor(y)
+    emb = F.embedding(ys_in, sd[p + '.embed.weight'], padding_idx=3)
+    d = emb
+    for l in range(args.dec_n_layers):
+        d = lstm_ref(d, sd, p + '.rnn.%d' % l)
+        if args.dec_n_projs > 0:
+            d = torch.relu(_lin(d, sd, p + '.proj.%d' % l))
+    h = torch.tanh(_lin(eouts, sd, p + '.w_enc')[:, :, None] + F.linear(d, sd[p + '.w_dec.weight'])[:, None])
+    logits = _lin(h, sd, p + '.output')
+    nll = rnnt_loss_ref(torch.log_softmax(logits, -1), lab, torch.tensor(elens), torch.tensor([len(y) for y in ys]))
+    return nll.mean()
+
+
+def speech2text_loss(sd, args, batch, dtype=torch.float64):
+    """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens)."""
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+    xlens = [len(x) for x in batch['xs']]
+    T = max(xlens)
+    xs = torch.zeros(len(xlens), T, args.input_dim, dtype=dtype)
+    for b, x in enumerate(batch['xs']):
+        xs[b, :len(x)] = torch.as_tensor(x, dtype=dtype)
+    eouts, elens = encoder_forward(xs, xlens, sd, args)
+    main_w = args.total_weight - args.sub1_weight - args.sub2_weight
+    ctc_w = min(args.ctc_weight, main_w)
+    loss = eouts.new_zeros(())
+    obs = {'loss.ctc': None, 'loss.transducer': None}
+    if ctc_w > 0:
+        lc = ctc_loss_ref(ctc_head(eouts, sd, 'dec_fwd.ctc'), elens, batch['ys'], args.ctc_lsm_prob)
+        obs['loss.ctc'] = lc.item()
+        loss = loss + lc * ctc_w
+    if args.dec_type == 'lstm_transducer' and main_w - ctc_w > 0:
+        lt = rnnt_branch(eouts, elens, batch['ys'], sd, args)
+        obs['loss.transducer'] = lt.item()
+        loss = loss + lt * (main_w - ctc_w)
+    return loss, obs, eouts, elens

@@ -70,3 +70,38 @@ def rnnt_loss_bruteforce(log_probs, labels, elen, ylen, blank=0):
         assert t == T and u == U
         total = lp if total is None else torch.logaddexp(total, lp)
     return -total
+
+
+def rnnt_loss_ref_diag(log_probs, labels, elens, ylens, blank=0):
+    """Same recursion as rnnt_loss_ref, vectorised over anti-diagonals (t+u = const) so that a
+    T=200,U=200 lattice costs ~400 tensor ops instead of 40k Python iterations.  Used as the
+    CPU-baseline implementation of the loss in bench.py; validated against rnnt_loss_ref in
+    tests/test_oracle_cpu.py."""
+    B = log_probs.size(0)
+    out = []
+    for b in range(B):
+        T, U = int(elens[b]), int(ylens[b])
+        lp = log_probs[b, :T, :U + 1]
+        lpb = lp[:, :, blank]                                            # [T,U+1]
+        if U > 0:
+            lpl = lp[:, :U].gather(2, labels[b, :U].view(1, U, 1).expand(T, U, 1)).squeeze(2)  # [T,U]
+        neg = lp.new_full((1,), float('-inf'))
+        prev = lp.new_zeros(1)          # diagonal 0: alpha(0,0)
+        prev_u0 = 0                     # u index of prev[0]
+        for d in range(1, T + U):
+            u_lo, u_hi = max(0, d - (T - 1)), min(U, d)
+            us = torch.arange(u_lo, u_hi + 1)
+            ts = d - us
+            # from (t-1,u): valid when t>0 ; index in prev = u - prev_u0
+            x = torch.cat([neg.expand(1), prev, neg.expand(1)])  # padded: prev index i -> x[i+1]
+            ix = (us - prev_u0 + 1).clamp(0, x.numel() - 1)
+            a_t = torch.where(ts > 0, x[ix] + lpb[(ts - 1).clamp(min=0), us], neg.expand(len(us)))
+            iy = (us - 1 - prev_u0 + 1).clamp(0, x.numel() - 1)
+            if U > 0:
+                a_u = torch.where(us > 0, x[iy] + lpl[ts, (us - 1).clamp(min=0)], neg.expand(len(us)))
+            else:
+                a_u = neg.expand(len(us))
+            prev = torch.logaddexp(a_t, a_u)
+            prev_u0 = u_lo
+        out.append(-(prev[-1] + lpb[T - 1, U]))
+    return torch.stack(out)

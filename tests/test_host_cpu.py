@@ -1,0 +1,69 @@
+"""Host-side logic that needs no GPU: constructor parity of names/shapes with the fixtures
+(= the reference's state_dict), length bookkeeping, SpecAugment RNG stream, configs."""
+import argparse
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt')))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_state_dict_names_and_shapes_match_reference(name):
+    from neural_sp_amd.speech2text import Speech2Text
+    fix = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    model = Speech2Text(argparse.Namespace(**fix['args']))
+    sd = model.state_dict()
+    assert set(sd) == set(fix['state_dict'])
+    for k, v in fix['state_dict'].items():
+        assert sd[k].shape == v.shape, k
+    model.load_state_dict(fix['state_dict'], strict=True)
+
+
+def test_conformer_large_parameter_count():
+    """90,572,656 parameters for Conformer-L + lstm_transducer (V=1000)."""
+    from neural_sp_amd.configs import conformer_rnnt_args
+    from neural_sp_amd.speech2text import Speech2Text
+    m = Speech2Text(conformer_rnnt_args('L'))
+    assert m.total_parameters == 90572656
+    assert sum(p.numel() for n, p in m.named_parameters() if n.startswith('enc.')) == 73288608
+
+
+def test_length_bookkeeping_matches_torch_pooling():
+    from neural_sp_amd.encoders import _conv_len, _pool_len_ceil
+    for n in range(1, 70):
+        x = torch.zeros(1, 1, n)
+        assert _pool_len_ceil(n, 2, 2) == torch.nn.functional.max_pool1d(x, 2, 2, ceil_mode=True).shape[-1]
+        assert _conv_len(n, 3, 1, 1) == n
+
+
+def test_specaugment_draws_follow_reference_rng_stream():
+    """Same np.random call order as spec_augment.py:112-140 -> same bands for the same seed."""
+    from neural_sp_amd.speech2text import SpecAugment
+    sa = SpecAugment(F=27, T=100, n_freq_masks=2, n_time_masks=2, p=1.0)
+    np.random.seed(5)
+    fb, tb = sa.draw(n_frames=700, n_bins=80)
+    np.random.seed(5)
+    exp_f, exp_t = [], []
+    for _ in range(2):
+        f = int(np.random.uniform(0, 27))
+        f0 = int(np.random.uniform(0, 80 - f))
+        exp_f.append((f0, f0 + f))
+    for _ in range(2):
+        t = min(int(np.random.uniform(0, 100)), 700)
+        t0 = int(np.random.uniform(0, 700 - t))
+        exp_t.append((t0, t0 + t))
+    assert fb == exp_f and tb == exp_t
+
+
+def test_unsupported_configurations_fail_loudly():
+    from neural_sp_amd.configs import conformer_rnnt_args
+    from neural_sp_amd.speech2text import Speech2Text
+    with pytest.raises(NotImplementedError):
+        Speech2Text(conformer_rnnt_args('XS', n_layers=2, enc_type='blstm'))
+    with pytest.raises(NotImplementedError):
+        Speech2Text(conformer_rnnt_args('XS', n_layers=2, conformer_normalization='batch_norm'))
