@@ -32,6 +32,9 @@ extern "C" {
 #define NSP_COMPUTE_BF16 0
 #define NSP_COMPUTE_F32 1
 
+#define NSP_DT_F32 0
+#define NSP_DT_BF16 1
+
 /* activations understood by the GEMM epilogue and the elementwise kernels */
 #define NSP_ACT_NONE 0
 #define NSP_ACT_RELU 1
@@ -63,15 +66,15 @@ int nsp_version(void);
  * ------------------------------------------------------------------------ */
 typedef struct {
   int M, N, K;
-  const float* A; long long a_rs, a_cs;
-  const float* B; long long b_ks, b_ns;
-  float* C; long long ldc;
+  const void* A; long long a_rs, a_cs;   /* float* or bf16 (uint16) storage, see a_dtype */
+  const void* B; long long b_ks, b_ns;
+  void* C; long long ldc;
   int batch1, batch2;
   long long a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
   const float* bias;      /* [N] or NULL */
   int act;                /* NSP_ACT_* applied after bias */
-  float* pre_out;         /* optional: value before activation, layout of C */
-  const float* dact_src;  /* optional: multiply by act'(dact_src), layout of C */
+  void* pre_out;          /* optional: value before activation, layout of C */
+  const void* dact_src;   /* optional: multiply by act'(dact_src), layout of C */
   int dact;               /* NSP_ACT_* of the derivative */
   const float* res;       /* optional residual, layout of C (may alias C) */
   float alpha;
@@ -79,6 +82,11 @@ typedef struct {
   int mode;               /* NSP_COMPUTE_* */
   float dropout_p;        /* 0 => off; else philox-style keep mask regenerated from seed */
   unsigned long long seed, offset;
+  /* element types: NSP_DT_F32 (0) or NSP_DT_BF16 (1).  A and B must agree.  With bf16
+   * operands (NSP_COMPUTE_BF16 only) the strides are in bf16 elements, the contiguous
+   * index must have unit stride, leading dims / K (KC) resp. the row extent (RC) must be
+   * multiples of 8 and bases 16-B aligned. */
+  int a_dtype, b_dtype, c_dtype, pre_dtype, dact_dtype;
 } nsp_gemm_params;
 
 int nsp_gemm(const nsp_gemm_params* p, void* stream);
@@ -105,6 +113,11 @@ int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
 /* ------------------------------------------------------------------------ *
  * Elementwise helpers (vectorised, grid-stride).                           *
  * ------------------------------------------------------------------------ */
+/* fp32 -> bf16 (round-to-nearest-even) copy of a [rows, cols] matrix (row stride ld_in) into
+ * [rows, ld_out] with zero fill of columns cols..ld_out-1: the bf16 shadow copies of weights
+ * and activations that feed the MFMA GEMM.  out is uint16 storage. */
+int nsp_cast_bf16(const float* x, void* out, long long rows, int cols, long long ld_in,
+                  long long ld_out, void* stream);
 /* y = alpha*x + beta*z (z may be NULL) */
 int nsp_axpby(const float* x, const float* z, float* y, float alpha, float beta,
               long long n, void* stream);
@@ -127,6 +140,14 @@ int nsp_xl_pos_table(const float* inv_freq, float* out, int L, int d, void* stre
 /* column sum: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
 int nsp_colsum(const float* x, float* out, int rows, int cols, long long ld,
                int accumulate, void* stream);
+int nsp_colsum_bf16(const void* x /*bf16*/, float* out, int rows, int cols, long long ld,
+                    int accumulate, void* stream);
+/* out = alpha * dy * dropout_keep(seed, offset+i)/(1-p) * act'(pre): turns the gradient that
+ * arrives at a Linear's fused epilogue into the dgrad/wgrad operand in ONE pass
+ * (pre may be NULL; pre/out are fp32 or bf16; n % 4 == 0) */
+int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, void* out, int out_bf16,
+                  int act, float alpha, float p, unsigned long long seed,
+                  unsigned long long offset, long long n, void* stream);
 /* GLU over the channel dim of [rows, 2C] -> [rows, C]: a*sigmoid(b)
  * (conformer_convolution.py:109, F.glu(dim=1) on [B,2C,T]) */
 int nsp_glu_fwd(const float* x, float* y, long long rows, int C, void* stream);

@@ -90,6 +90,8 @@ class GemmParams(ctypes.Structure):
         ('splitk', ctypes.c_int), ('mode', ctypes.c_int),
         ('dropout_p', ctypes.c_float),
         ('seed', ctypes.c_ulonglong), ('offset', ctypes.c_ulonglong),
+        ('a_dtype', ctypes.c_int), ('b_dtype', ctypes.c_int), ('c_dtype', ctypes.c_int),
+        ('pre_dtype', ctypes.c_int), ('dact_dtype', ctypes.c_int),
     ]
 
 

@@ -67,6 +67,43 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     y[i] = alpha * x[i] * nsp_keep_scale(seed, offset + (unsigned long long)i, p);
 }
 
+// g = alpha * dy * keep(seed, offset+i)/(1-p) * act'(pre): the one pass that turns the incoming
+// gradient of a Linear's epilogue into the operand of its dgrad/wgrad GEMMs (fp32 or bf16 out)
+__global__ void grad_prep_kernel(const float* __restrict__ dy, const void* __restrict__ pre,
+                                 int pre_bf16, void* __restrict__ out, int out_bf16, int act,
+                                 float alpha, float p, unsigned long long seed,
+                                 unsigned long long offset, long long n) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 g4 = reinterpret_cast<const float4*>(dy)[i];
+    float g[4] = {g4.x * alpha, g4.y * alpha, g4.z * alpha, g4.w * alpha};
+    if (p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= nsp_keep_scale(seed, offset + (unsigned long long)(i * 4 + e), p);
+    }
+    if (pre) {
+      float q[4];
+      if (pre_bf16) {
+        const bf16x4 h = reinterpret_cast<const bf16x4*>(pre)[i];
+        q[0] = (float)h[0]; q[1] = (float)h[1]; q[2] = (float)h[2]; q[3] = (float)h[3];
+      } else {
+        const float4 f = reinterpret_cast<const float4*>(pre)[i];
+        q[0] = f.x; q[1] = f.y; q[2] = f.z; q[3] = f.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= nsp_dact(q[e], act);
+    }
+    if (out_bf16) {
+      bf16x4 h;
+      h[0] = (__bf16)g[0]; h[1] = (__bf16)g[1]; h[2] = (__bf16)g[2]; h[3] = (__bf16)g[3];
+      reinterpret_cast<bf16x4*>(out)[i] = h;
+    } else {
+      reinterpret_cast<float4*>(out)[i] = make_float4(g[0], g[1], g[2], g[3]);
+    }
+  }
+}
+
 // relu backward from the OUTPUT y (y > 0)
 __global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                 float* __restrict__ dx, long long n) {
@@ -77,7 +114,8 @@ __global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __rest
 
 // column sums: each block reduces a slab of rows for 64 columns (one wave-width),
 // 4 waves stride over rows; partials are combined in LDS then atomically added.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x,
                                                      float* __restrict__ out, int rows, int cols,
                                                      long long ld, int rows_per_block) {
   __shared__ float sh[4][64];
@@ -87,7 +125,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int r1 = min(rows, r0 + rows_per_block);
   float s = 0.f;
   if (c < cols)
-    for (int r = r0 + w; r < r1; r += 4) s += x[(long long)r * ld + c];
+    for (int r = r0 + w; r < r1; r += 4) s += (float)x[(long long)r * ld + c];
   sh[w][lane] = s;
   __syncthreads();
   if (w == 0 && c < cols) unsafeAtomicAdd(out + c, sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]);
@@ -242,7 +280,38 @@ extern "C" int nsp_colsum(const float* x, float* out, int rows, int cols, long l
   int rpb = nsp_cdiv(rows, gy);
   if (rpb < 32) rpb = 32;
   gy = nsp_cdiv(rows, rpb);
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, out, rows, cols, ld, rpb);
+  hipLaunchKernelGGL(colsum_kernel<float>, dim3(gx, gy), dim3(256), 0, st, x, out, rows, cols, ld, rpb);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_colsum_bf16(const void* x, float* out, int rows, int cols, long long ld,
+                               int accumulate, void* stream) {
+  if (rows <= 0 || cols <= 0) return NSP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * cols, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  int gx = nsp_cdiv(cols, 64);
+  int gy = 2048 / gx;
+  if (gy < 1) gy = 1;
+  int rpb = nsp_cdiv(rows, gy);
+  if (rpb < 32) rpb = 32;
+  gy = nsp_cdiv(rows, rpb);
+  hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(gx, gy), dim3(256), 0, st,
+                     reinterpret_cast<const __bf16*>(x), out, rows, cols, ld, rpb);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, void* out, int out_bf16,
+                             int act, float alpha, float p, unsigned long long seed,
+                             unsigned long long offset, long long n, void* stream) {
+  if (n <= 0) return NSP_OK;
+  if (n % 4) return NSP_EUNSUPPORTED;
+  hipLaunchKernelGGL(grad_prep_kernel, dim3(ew_grid(n / 4)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     dy, pre, pre_bf16, out, out_bf16, act, alpha, p, seed, offset, n);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -162,8 +162,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const nsp_gemm_params p,
   const int split = z % p.splitk;
   z /= p.splitk;
   const int z2 = z % p.batch2, z1 = z / p.batch2;
-  const float* A = p.A + z1 * p.a_b1 + z2 * p.a_b2;
-  const float* B = p.B + z1 * p.b_b1 + z2 * p.b_b2;
+  const float* A = reinterpret_cast<const float*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
+  const float* B = reinterpret_cast<const float*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
+  float* const Cp = reinterpret_cast<float*>(p.C);
+  float* const preo = reinterpret_cast<float*>(p.pre_out);
+  const float* const dsrc = reinterpret_cast<const float*>(p.dact_src);
   const long long coff = z1 * p.c_b1 + z2 * p.c_b2;
 
   // reduction range of this split (multiples of BK)
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const nsp_gemm_params p,
       float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
       const int nv = min(4, p.N - n);
       if (atomic) {
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) unsafeAtomicAdd(p.C + off + e, v[e] * p.alpha);
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) unsafeAtomicAdd(Cp + off + e, v[e] * p.alpha);
         continue;
       }
       const bool vec = c_vec && nv == 4;
@@ -257,8 +260,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const nsp_gemm_params p,
         }
       }
       if (p.pre_out) {
-        if (vec) *reinterpret_cast<float4*>(p.pre_out + off) = make_float4(v[0], v[1], v[2], v[3]);
-        else { _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) p.pre_out[off + e] = v[e]; }
+        if (vec) *reinterpret_cast<float4*>(preo + off) = make_float4(v[0], v[1], v[2], v[3]);
+        else { _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) preo[off + e] = v[e]; }
       }
       if (p.act != NSP_ACT_NONE) {
 #pragma unroll
@@ -267,10 +270,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const nsp_gemm_params p,
       if (p.dact_src) {
         float d[4] = {0.f, 0.f, 0.f, 0.f};
         if (vec) {
-          float4 d4 = *reinterpret_cast<const float4*>(p.dact_src + off);
+          float4 d4 = *reinterpret_cast<const float4*>(dsrc + off);
           d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
         } else {
-          _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) d[e] = p.dact_src[off + e];
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) d[e] = dsrc[off + e];
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], p.dact);
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const nsp_gemm_params p,
           _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) v[e] += p.res[off + e];
         }
       }
-      if (vec) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
-      else { _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) p.C[off + e] = v[e]; }
+      if (vec) *reinterpret_cast<float4*>(Cp + off) = make_float4(v[0], v[1], v[2], v[3]);
+      else { _Pragma("unroll") for (int e = 0; e < 4; ++e) if (e < nv) Cp[off + e] = v[e]; }
     }
   }
 }
@@ -305,7 +308,7 @@ int launch_mode(const nsp_gemm_params& p, hipStream_t st) {
   const bool b_kc = (p.b_ks == 1) || (p.b_ns != 1);
   // vector (float4) global access is legal when the contiguous index has unit
   // stride and base / leading dim / batch strides keep 16-B alignment.
-  auto vec_ok = [&](const float* base, long long unit, long long ld, long long s1, long long s2) {
+  auto vec_ok = [&](const void* base, long long unit, long long ld, long long s1, long long s2) {
     return unit == 1 && aligned16(base) && ld % 4 == 0 && s1 % 4 == 0 && s2 % 4 == 0;
   };
   const int a_vec = a_kc ? vec_ok(p.A, p.a_cs, p.a_rs, p.a_b1, p.a_b2) : vec_ok(p.A, p.a_rs, p.a_cs, p.a_b1, p.a_b2);
@@ -330,6 +333,8 @@ int launch_mode(const nsp_gemm_params& p, hipStream_t st) {
 
 }  // namespace
 
+int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st);  // gemm_bf16.hip
+
 extern "C" int nsp_gemm(const nsp_gemm_params* pp, void* stream) {
   if (!pp) return NSP_EINVAL;
   nsp_gemm_params p = *pp;
@@ -342,6 +347,13 @@ extern "C" int nsp_gemm(const nsp_gemm_params* pp, void* stream) {
     return NSP_EINVAL;
   // a non-unit/non-unit operand is handled by the KC loader's scalar path
   hipStream_t st = (hipStream_t)stream;
+  if (p.a_dtype != p.b_dtype) return NSP_EINVAL;
+  if (p.a_dtype == NSP_DT_BF16) {
+    if (p.mode != NSP_COMPUTE_BF16) return NSP_EINVAL;
+    if (p.splitk > 1 && p.c_dtype != NSP_DT_F32) return NSP_EINVAL;
+    return nsp_gemm_bf16_launch(p, st);
+  }
+  if (p.c_dtype != NSP_DT_F32 || p.pre_dtype != NSP_DT_F32 || p.dact_dtype != NSP_DT_F32) return NSP_EINVAL;
   if (p.mode == NSP_COMPUTE_BF16) return launch_mode<0>(p, st);
   if (p.mode == NSP_COMPUTE_F32) return launch_mode<1>(p, st);
   return NSP_EINVAL;

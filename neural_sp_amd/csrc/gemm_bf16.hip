@@ -1,0 +1,333 @@
+// gemm_bf16.hip -- the throughput GEMM: bf16 operands in HBM, fp32 accumulate on
+// v_mfma_f32_16x16x32_bf16, fused epilogue, fp32 or bf16 output.
+//
+// Why a second kernel: the fp32-operand kernel (gemm.hip) moves 4 B per operand
+// element HBM/L2 -> LDS and converts on the fly; at a 128x128 tile that is
+// 32 B per KFLOP, i.e. more L2 bandwidth than the chip has at MFMA rates (it
+// measures ~120-250 TFLOP/s).  With bf16 shadow copies of weights / activations
+// the same tile needs 16 B/KFLOP and no VALU conversion.
+//
+// Tile 128x128x64, 4 waves (2x2), wave tile 64x64 = 4x4 MFMA fragments, 32 MFMAs
+// per wave per k-tile.  Global loads are 16 B/lane straight into registers for
+// tile t+1 while tile t is multiplied (register software pipeline), then 16-B
+// LDS stores.  Two LDS images:
+//   KC operand (reduction index contiguous in memory): [128 rows][64 k], pitch
+//      144 B (128 + 16 pad => 16 rows x ds_read_b128 hit 16 distinct 4-bank slots).
+//   RC operand (row index contiguous, e.g. both operands of a weight gradient):
+//      kept k-major as in memory, [64 k][128 rows], pitch 288 B; the MFMA fragment
+//      (row r, 8 consecutive k) is assembled by two ds_read_b64_tr_b16 transpose
+//      reads -- no register transposes, no strided LDS traffic.
+//      Lane mapping of ds_read_b64_tr_b16 (probed on gfx950, tools/probe): within a
+//      16-lane group, lane 4a+b supplies the address of matrix row a, columns
+//      4b..4b+3; lane i receives column i of the 4x16 block.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int PITCH_KC = 144;  // bytes per row  (64 bf16 + 16 B pad)
+constexpr int PITCH_RC = 288;  // bytes per k    (128 bf16 + 32 B pad)
+constexpr int TILE_BYTES = 128 * PITCH_KC;  // == 64 * PITCH_RC == 18432
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <bool KC>
+struct Bf16TileLoader {
+  u32x4 r[4];
+  // element (row, k): KC: base[row*ld + k] ; RC: base[k*ld + row]
+  __device__ __forceinline__ void load(const __bf16* __restrict__ base, long long ld, int row0, int R,
+                                       int k0, int Kend) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * NTHREADS;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (KC) {
+        const int row = idx >> 3, c = idx & 7;
+        const int gr = row0 + row, gk = k0 + c * 8;
+        if (gr < R && gk < Kend) v = *reinterpret_cast<const u32x4*>(base + (long long)gr * ld + gk);
+      } else {
+        const int kk = idx >> 4, cb = idx & 15;
+        const int gk = k0 + kk, gr = row0 + cb * 8;
+        if (gk < Kend && gr < R) v = *reinterpret_cast<const u32x4*>(base + (long long)gk * ld + gr);
+      }
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* lds) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * NTHREADS;
+      if (KC) {
+        const int row = idx >> 3, c = idx & 7;
+        *reinterpret_cast<u32x4*>(lds + row * PITCH_KC + c * 16) = r[i];
+      } else {
+        const int kk = idx >> 4, cb = idx & 15;
+        *reinterpret_cast<u32x4*>(lds + kk * PITCH_RC + cb * 16) = r[i];
+      }
+    }
+  }
+};
+
+// MFMA operand fragment for 16 rows starting at `rbase`, k-step s (32 k), lane (r, g)
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int rbase, int s, int r, int g) {
+  if (KC) {
+    return *reinterpret_cast<const bf16x8*>(lds + (rbase + r) * PITCH_KC + (s * 4 + g) * 16);
+  } else {
+    const int a = r >> 2, b = r & 3;
+    const unsigned char* p = lds + (s * 32 + g * 8 + a) * PITCH_RC + (rbase + b * 4) * 2;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * PITCH_RC));
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+  }
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int NX = 8;
+  if (nwg < NX * 2) return bid;
+  int q = nwg / NX, rem = nwg % NX;
+  int xcd = bid % NX, slot = bid / NX;
+  int base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  return base + slot;
+}
+
+__device__ __forceinline__ void store4(void* base, int dtype, long long off, const float* v, int nv,
+                                       bool vec) {
+  if (dtype == NSP_DT_BF16) {
+    __bf16* o = reinterpret_cast<__bf16*>(base) + off;
+    if (vec) {
+      bf16x4 h;
+      h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+      *reinterpret_cast<bf16x4*>(o) = h;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) o[e] = (__bf16)v[e];
+    }
+  } else {
+    float* o = reinterpret_cast<float*>(base) + off;
+    if (vec) {
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) o[e] = v[e];
+    }
+  }
+}
+
+__device__ __forceinline__ void load4(const void* base, int dtype, long long off, float* v, int nv,
+                                      bool vec) {
+  if (dtype == NSP_DT_BF16) {
+    const __bf16* o = reinterpret_cast<const __bf16*>(base) + off;
+    if (vec) {
+      bf16x4 h = *reinterpret_cast<const bf16x4*>(o);
+      v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) v[e] = (float)o[e];
+    }
+  } else {
+    const float* o = reinterpret_cast<const float*>(base) + off;
+    if (vec) {
+      float4 f = *reinterpret_cast<const float4*>(o);
+      v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) v[e] = o[e];
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_params p, int tiles_m,
+                                                             int tiles_n, int c_vec) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+  unsigned char* smA = smem;
+  unsigned char* smB = smem + TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  int z = blockIdx.z;
+  const int split = z % p.splitk;
+  z /= p.splitk;
+  const int z2 = z % p.batch2, z1 = z / p.batch2;
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
+  const long long coff = z1 * p.c_b1 + z2 * p.c_b2;
+  const long long lda = A_KC ? p.a_rs : p.a_cs;
+  const long long ldb = B_KC ? p.b_ns : p.b_ks;
+
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    int nkt = (p.K + BK - 1) / BK;
+    int per = (nkt + p.splitk - 1) / p.splitk;
+    kbeg = split * per * BK;
+    kend = min(p.K, (split + 1) * per * BK);
+    if (kbeg >= kend) return;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Bf16TileLoader<A_KC> la;
+  Bf16TileLoader<B_KC> lb;
+  la.load(A, lda, m0, p.M, kbeg, kend);
+  lb.load(B, ldb, n0, p.N, kbeg, kend);
+  const int fr = lane & 15, fg = lane >> 4;
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    la.store(smA);
+    lb.store(smB);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      la.load(A, lda, m0, p.M, k0 + BK, kend);
+      lb.load(B, ldb, n0, p.N, k0 + BK, kend);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = read_frag<A_KC>(smA, wm * 64 + i * 16, s, fr, fg);
+        bf[i] = read_frag<B_KC>(smB, wn * 64 + i * 16, s, fr, fg);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const bool atomic = p.splitk > 1;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+      if (n >= p.N) continue;
+      const long long off = coff + (long long)m * p.ldc + n;
+      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      const int nv = min(4, p.N - n);
+      if (atomic) {
+        float* c = reinterpret_cast<float*>(p.C) + off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) unsafeAtomicAdd(c + e, v[e] * p.alpha);
+        continue;
+      }
+      const bool vec = c_vec && nv == 4;
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) v[e] += p.bias[n + e];
+      }
+      if (p.pre_out) store4(p.pre_out, p.pre_dtype, off, v, nv, vec);
+      if (p.act != NSP_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], p.act);
+      }
+      if (p.dact_src) {
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+        load4(p.dact_src, p.dact_dtype, off, d, nv, vec);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], p.dact);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      if (p.dropout_p > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] *= nsp_keep_scale(p.seed, p.offset + (unsigned long long)(off + e), p.dropout_p);
+      }
+      if (p.res) {
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        load4(p.res, NSP_DT_F32, off, r4, nv, vec);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r4[e];
+      }
+      store4(p.C, p.c_dtype, off, v, nv, vec);
+    }
+  }
+}
+
+// fp32 [rows, cols] (row stride ld_in) -> bf16 [rows, ld_out] with zero fill; 8 elements per lane
+__global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long long rows,
+                                 int cols, long long ld_in, long long ld_out, int vec_in) {
+  const long long chunks_per_row = ld_out >> 3;
+  const long long total = rows * chunks_per_row;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / chunks_per_row;
+    const int c = (int)(i % chunks_per_row) * 8;
+    float v[8];
+    const float* src = x + r * ld_in + c;
+    if (vec_in && c + 8 <= cols) {
+      float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (c + e < cols) ? src[e] : 0.f;
+    }
+    bf16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8*>(out + r * ld_out + c) = h;
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// called from nsp_gemm (gemm.hip) when both operands are bf16
+int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
+  const bool a_kc = p.a_cs == 1, b_kc = p.b_ks == 1;
+  if (!a_kc && p.a_rs != 1) return NSP_EINVAL;
+  if (!b_kc && p.b_ns != 1) return NSP_EINVAL;
+  const long long lda = a_kc ? p.a_rs : p.a_cs, ldb = b_kc ? p.b_ns : p.b_ks;
+  if (lda % 8 || ldb % 8 || p.a_b1 % 8 || p.a_b2 % 8 || p.b_b1 % 8 || p.b_b2 % 8) return NSP_EINVAL;
+  if (!aligned16(p.A) || !aligned16(p.B)) return NSP_EINVAL;
+  // the contiguous extent of every 16-B chunk must lie inside the matrix
+  if ((a_kc ? p.K : p.M) % 8 || (b_kc ? p.K : p.N) % 8) return NSP_EINVAL;
+  const int tiles_m = nsp_cdiv(p.M, BM), tiles_n = nsp_cdiv(p.N, BN);
+  const int csz = p.c_dtype == NSP_DT_BF16 ? 2 : 4;
+  int c_vec = (reinterpret_cast<uintptr_t>(p.C) % (4 * csz) == 0) && p.ldc % 4 == 0 && p.c_b1 % 4 == 0 &&
+              p.c_b2 % 4 == 0;
+  if (p.pre_out && reinterpret_cast<uintptr_t>(p.pre_out) % 16) c_vec = 0;
+  if (p.dact_src && reinterpret_cast<uintptr_t>(p.dact_src) % 16) c_vec = 0;
+  if (p.res && !aligned16(p.res)) c_vec = 0;
+  dim3 grid(tiles_m * tiles_n, 1, p.batch1 * p.batch2 * p.splitk), block(NTHREADS);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_cast_bf16(const float* x, void* out, long long rows, int cols, long long ld_in,
+                             long long ld_out, void* stream) {
+  if (rows <= 0 || cols <= 0) return NSP_OK;
+  if (ld_out % 8 || ld_out < cols || (reinterpret_cast<uintptr_t>(out) & 15)) return NSP_EINVAL;
+  const int vec_in = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ld_in % 4 == 0;
+  long long n = rows * (ld_out / 8);
+  long long g = (n + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<__bf16*>(out), rows, cols, ld_in, ld_out, vec_in);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

@@ -49,7 +49,7 @@ def _p(t):
     if t is None:
         return None
     assert t.is_cuda, 'neural_sp_amd ops are HIP-only: got a CPU tensor (no CPU fallback exists)'
-    assert t.dtype in (torch.float32, torch.int32, torch.int64), t.dtype
+    assert t.dtype in (torch.float32, torch.bfloat16, torch.int32, torch.int64), t.dtype
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -66,19 +66,24 @@ def _f32c(t):
 # --------------------------------------------------------------------------
 # GEMM
 # --------------------------------------------------------------------------
+def _dt(t):
+    return 1 if t is not None and t.dtype == torch.bfloat16 else 0
+
+
 def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
              batch=(1, 1), a_b=(0, 0), b_b=(0, 0), c_b=(0, 0),
              bias=None, act=0, pre_out=None, dact_src=None, dact=0, res=None,
              alpha=1.0, splitk=1, mode=None, a_off=0, b_off=0, c_off=0,
              dropout_p=0.0, seed=0, offset=0):
-    """C = epi(A @ B) with arbitrary strides (element offsets *_off into the tensors)."""
+    """C = epi(A @ B) with arbitrary strides (element offsets *_off into the tensors).
+    A/B are both fp32 or both bf16; C / pre_out / dact_src may be fp32 or bf16 with bf16 operands."""
     p = GemmParams()
     p.M, p.N, p.K = int(M), int(N), int(K)
-    p.A = A.data_ptr() + 4 * a_off
+    p.A = A.data_ptr() + A.element_size() * a_off
     p.a_rs, p.a_cs = int(a_rs), int(a_cs)
-    p.B = B.data_ptr() + 4 * b_off
+    p.B = B.data_ptr() + B.element_size() * b_off
     p.b_ks, p.b_ns = int(b_ks), int(b_ns)
-    p.C = C.data_ptr() + 4 * c_off
+    p.C = C.data_ptr() + C.element_size() * c_off
     p.ldc = int(ldc)
     p.batch1, p.batch2 = int(batch[0]), int(batch[1])
     p.a_b1, p.a_b2 = int(a_b[0]), int(a_b[1])
@@ -86,8 +91,8 @@ def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
     p.c_b1, p.c_b2 = int(c_b[0]), int(c_b[1])
     p.bias = bias.data_ptr() if bias is not None else None
     p.act = int(act)
-    p.pre_out = pre_out.data_ptr() + 4 * c_off if pre_out is not None else None
-    p.dact_src = dact_src.data_ptr() + 4 * c_off if dact_src is not None else None
+    p.pre_out = pre_out.data_ptr() + pre_out.element_size() * c_off if pre_out is not None else None
+    p.dact_src = dact_src.data_ptr() + dact_src.element_size() * c_off if dact_src is not None else None
     p.dact = int(dact)
     p.res = res.data_ptr() + 4 * c_off if res is not None else None
     p.alpha = float(alpha)
@@ -95,10 +100,47 @@ def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
     p.mode = _COMPUTE_MODE['mode'] if mode is None else int(mode)
     p.dropout_p = float(dropout_p)
     p.seed, p.offset = int(seed), int(offset)
-    for t in (A, B, C, bias, pre_out, dact_src, res):
+    p.a_dtype, p.b_dtype, p.c_dtype = _dt(A), _dt(B), _dt(C)
+    p.pre_dtype, p.dact_dtype = _dt(pre_out), _dt(dact_src)
+    for t in (A, B, C, pre_out, dact_src):
+        if t is not None:
+            assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16)
+    for t in (bias, res):
         if t is not None:
             assert t.is_cuda and t.dtype == torch.float32
     _check(_lib.lib().nsp_gemm(ctypes.byref(p), _stream()), 'nsp_gemm')
+
+
+def bf16_mode():
+    return _COMPUTE_MODE['mode'] == 0
+
+
+def to_bf16(x2d):
+    """bf16 shadow copy [rows, roundup8(cols)] (zero padded) of a 2-D fp32 tensor."""
+    if x2d.dtype == torch.bfloat16:
+        return x2d
+    rows, cols = x2d.shape
+    ld = (cols + 7) // 8 * 8
+    out = torch.empty((rows, ld), device=x2d.device, dtype=torch.bfloat16)
+    _check(_lib.lib().nsp_cast_bf16(_p(x2d), _p(out), ctypes.c_longlong(rows), ctypes.c_int(cols),
+                                    ctypes.c_longlong(x2d.stride(0)), ctypes.c_longlong(ld), _stream()),
+           'nsp_cast_bf16')
+    return out
+
+
+_W16 = {}
+
+
+def weight_bf16(w):
+    """bf16 shadow of a parameter, refreshed when the parameter is updated in place
+    (keyed on storage + version counter: one cast per optimizer step)."""
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _W16.get(key)
+    if ent is not None and ent[0] == w._version:
+        return ent[1]
+    wb = to_bf16(w.detach().reshape(w.shape[0], -1))
+    _W16[key] = (w._version, wb)
+    return wb
 
 
 def _pick_splitk(M, N, K, batch=1):
@@ -110,43 +152,92 @@ def _pick_splitk(M, N, K, batch=1):
     return int(max(1, min(want, K // 256, 64)))
 
 
-def linear_fwd(x2d, weight, bias=None, act=0, res=None, alpha=1.0, pre_out=None, out=None):
-    """y[M,N] = res + alpha*act(x2d[M,K] @ weight[N,K]^T + bias)."""
-    M, K = x2d.shape
-    N = weight.shape[0]
-    assert weight.shape[1] == K and x2d.stride(1) == 1 and weight.stride(1) == 1
-    y = out if out is not None else torch.empty((M, N), device=x2d.device, dtype=torch.float32)
-    gemm_raw(M, N, K, x2d, x2d.stride(0), 1, weight, 1, weight.stride(0), y, y.stride(0),
-             bias=bias, act=act, res=res, alpha=alpha, pre_out=pre_out)
-    return y
+def linear_fwd(x2d, weight, bias=None, act=0, res=None, alpha=1.0, pre_out=None, out=None,
+               dropout_p=0.0, seed=0, offset=0, out_bf16=False):
+    """y[M,N] = res + dropout(alpha*act(x2d[M,K] @ weight[N,K]^T + bias)).  In bf16 mode the
+    operands are bf16 shadows (x2d may already be bf16, weight is cached)."""
+    M = x2d.shape[0]
+    N, K = weight.shape[0], weight.shape[1]
+    if bf16_mode() and K % 8 == 0:
+        xa, wb = to_bf16(x2d), weight_bf16(weight)
+    else:
+        assert x2d.dtype == torch.float32
+        xa, wb = x2d, weight
+    assert xa.stride(1) == 1 and wb.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), device=x2d.device,
+                          dtype=torch.bfloat16 if (out_bf16 and xa.dtype == torch.bfloat16) else torch.float32)
+    gemm_raw(M, N, K, xa, xa.stride(0), 1, wb, 1, wb.stride(0), out, out.stride(0),
+             bias=bias, act=act, res=res, alpha=alpha, pre_out=pre_out,
+             dropout_p=dropout_p, seed=seed, offset=offset)
+    return out
 
 
-def linear_dgrad(dy2d, weight, dact_src=None, dact=0, alpha=1.0, res=None, out=None):
+def linear_dgrad(dy2d, weight, dact_src=None, dact=0, alpha=1.0, res=None, out=None, out_bf16=False):
     """dx[M,K] = res + alpha*(dy2d[M,N] @ weight[N,K]) * act'(dact_src)."""
-    M, N = dy2d.shape
-    K = weight.shape[1]
-    dx = out if out is not None else torch.empty((M, K), device=dy2d.device, dtype=torch.float32)
-    gemm_raw(M, K, N, dy2d, dy2d.stride(0), 1, weight, weight.stride(0), 1, dx, dx.stride(0),
+    M = dy2d.shape[0]
+    N, K = weight.shape[0], weight.shape[1]
+    if bf16_mode() and K % 8 == 0 and N % 8 == 0:
+        ga, wb = to_bf16(dy2d), weight_bf16(weight)
+    else:
+        assert dy2d.dtype == torch.float32
+        ga, wb = dy2d, weight
+    if out is None:
+        out = torch.empty((M, K), device=dy2d.device,
+                          dtype=torch.bfloat16 if (out_bf16 and ga.dtype == torch.bfloat16) else torch.float32)
+    gemm_raw(M, K, N, ga, ga.stride(0), 1, wb, wb.stride(0), 1, out, out.stride(0),
              dact_src=dact_src, dact=dact, alpha=alpha, res=res)
-    return dx
+    return out
 
 
 def linear_wgrad(dy2d, x2d, alpha=1.0):
     """dW[N,K] = alpha * dy2d[M,N]^T @ x2d[M,K] (split over M, atomically reduced)."""
-    M, N = dy2d.shape
+    M, N = dy2d.shape[0], dy2d.shape[1]
     K = x2d.shape[1]
+    if bf16_mode() and (dy2d.dtype == torch.bfloat16 or N % 8 == 0) and (x2d.dtype == torch.bfloat16 or K % 8 == 0):
+        ga, xa = to_bf16(dy2d), to_bf16(x2d)
+        N, K = min(N, ga.shape[1]), min(K, xa.shape[1])
+    else:
+        ga, xa = dy2d, x2d
+    if ga.dtype != xa.dtype:
+        ga, xa = ga.float(), xa.float()
     sk = _pick_splitk(N, K, M)
     dw = (torch.zeros if sk > 1 else torch.empty)((N, K), device=dy2d.device, dtype=torch.float32)
-    gemm_raw(N, K, M, dy2d, 1, dy2d.stride(0), x2d, x2d.stride(0), 1, dw, K, alpha=alpha, splitk=sk)
+    gemm_raw(N, K, M, ga, 1, ga.stride(0), xa, xa.stride(0), 1, dw, K, alpha=alpha, splitk=sk)
     return dw
+
+
+def grad_prep(dy2d, pre, act, alpha, p, seed, offset, out_bf16):
+    """alpha * dy * dropout_mask * act'(pre) in one pass; bf16 output feeds the MFMA GEMMs."""
+    if pre is None and p <= 0 and alpha == 1.0 and not out_bf16:
+        return dy2d
+    n = dy2d.numel()
+    if n % 4 or (out_bf16 and dy2d.shape[1] % 8):
+        # rare odd widths: unfused path
+        g = dy2d
+        if p > 0:
+            g = dropout_raw(g, p, seed, offset, alpha)
+            alpha = 1.0
+        if pre is not None:
+            g = dact_mul(g, pre if pre.dtype == torch.float32 else pre.float(), act, alpha)
+        elif alpha != 1.0:
+            g = axpby(g, None, alpha, 0.0)
+        return to_bf16(g) if out_bf16 else g
+    out = torch.empty(dy2d.shape, device=dy2d.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _check(_lib.lib().nsp_grad_prep(_p(dy2d), _p(pre), ctypes.c_int(_dt(pre)), _p(out),
+                                    ctypes.c_int(int(out_bf16)), ctypes.c_int(act if pre is not None else 0),
+                                    ctypes.c_float(alpha), ctypes.c_float(p), ctypes.c_ulonglong(seed),
+                                    ctypes.c_ulonglong(offset), ctypes.c_longlong(n), _stream()),
+           'nsp_grad_prep')
+    return out
 
 
 def colsum(x2d, alpha=1.0):
     rows, cols = x2d.shape
     out = torch.zeros((cols,), device=x2d.device, dtype=torch.float32)
-    _check(_lib.lib().nsp_colsum(_p(x2d), _p(out), ctypes.c_int(rows), ctypes.c_int(cols),
-                                 ctypes.c_longlong(x2d.stride(0)), ctypes.c_int(1), _stream()),
-           'nsp_colsum')
+    fn = _lib.lib().nsp_colsum_bf16 if x2d.dtype == torch.bfloat16 else _lib.lib().nsp_colsum
+    _check(fn(_p(x2d), _p(out), ctypes.c_int(rows), ctypes.c_int(cols),
+              ctypes.c_longlong(x2d.stride(0)), ctypes.c_int(1), _stream()), 'nsp_colsum')
     if alpha != 1.0:
         out.mul_(alpha)
     return out
@@ -156,23 +247,26 @@ class LinearFn(torch.autograd.Function):
     """y = res + dropout(alpha * act(x W^T + b)); x is [..., K] (nn.Linear semantics).
 
     Everything after the contraction (bias, activation, scale, dropout mask, residual) is
-    the GEMM epilogue; backward regenerates the dropout mask from (seed, offset)."""
+    the GEMM epilogue; backward regenerates the dropout mask from (seed, offset).  In bf16
+    mode the input's bf16 shadow (not the fp32 tensor) is what is saved for backward."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, res, alpha, dropout_p):
-        x2d = _f32c(x).reshape(-1, x.shape[-1])
+        K = x.shape[-1]
+        x2d = (x if x.dtype == torch.bfloat16 else _f32c(x)).reshape(-1, K)
         weight = _f32c(weight)
         N = weight.shape[0]
+        use16 = bf16_mode() and K % 8 == 0
+        xa = to_bf16(x2d) if use16 else x2d
         res2d = _f32c(res).reshape(-1, N) if res is not None else None
         pre = None
         if act != 0:
-            pre = torch.empty((x2d.shape[0], N), device=x.device, dtype=torch.float32)
+            pre = torch.empty((x2d.shape[0], N), device=x.device,
+                              dtype=torch.bfloat16 if use16 else torch.float32)
         seed, offset = next_dropout_seed() if dropout_p > 0 else (0, 0)
-        y = torch.empty((x2d.shape[0], N), device=x.device, dtype=torch.float32)
-        gemm_raw(x2d.shape[0], N, x2d.shape[1], x2d, x2d.stride(0), 1, weight, 1, weight.stride(0),
-                 y, N, bias=bias, act=act, res=res2d, alpha=alpha, pre_out=pre,
-                 dropout_p=dropout_p, seed=seed, offset=offset)
-        ctx.save_for_backward(x2d, weight, pre)
+        y = linear_fwd(xa, weight, bias, act, res2d, alpha, pre_out=pre,
+                       dropout_p=dropout_p, seed=seed, offset=offset)
+        ctx.save_for_backward(xa, weight, pre)
         ctx.act, ctx.alpha = act, alpha
         ctx.drop = (dropout_p, seed, offset)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
@@ -181,24 +275,16 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x2d, weight, pre = ctx.saved_tensors
+        xa, weight, pre = ctx.saved_tensors
         dy2d = _f32c(dy).reshape(-1, weight.shape[0])
         dres = dy if ctx.has_res else None
-        alpha = ctx.alpha
-        g = dy2d
         p, seed, offset = ctx.drop
-        if p > 0:
-            g = dropout_raw(g, p, seed, offset, alpha)
-            alpha = 1.0
-        if ctx.act != 0:
-            g = dact_mul(g, pre, ctx.act, alpha)
-        elif alpha != 1.0:
-            g = axpby(g, None, alpha, 0.0)
+        g = grad_prep(dy2d, pre, ctx.act, ctx.alpha, p, seed, offset, xa.dtype == torch.bfloat16)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = linear_dgrad(g, weight).view(ctx.xshape)
+            dx = linear_dgrad(g, weight)[:, :ctx.xshape[-1]].reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = linear_wgrad(g, x2d)
+            dw = linear_wgrad(g, xa)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(g)
         return dx, dw, db, None, dres, None, None

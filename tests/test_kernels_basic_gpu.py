@@ -172,3 +172,32 @@ def test_elementwise():
         assert _rel(ops.act_fwd(x, ops.ACT[name]), ref.detach()) < 1e-5, name
         g, = torch.autograd.grad(ref, xr, z)
         assert _rel(ops.dact_mul(z, x, ops.ACT[name]), g) < 1e-4, name
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (300, 1000, 512), (1024, 512, 2048), (77, 136, 72)])
+def test_gemm_bf16_operands_all_layouts(M, N, K):
+    """bf16-operand MFMA kernel (KC glds-free loader and RC ds_read_tr loader) vs fp32 matmul of
+    the same bf16-rounded operands (products exact => only accumulation order differs)."""
+    from neural_sp_amd import ops
+    torch.manual_seed(7)
+    x = torch.randn(M, K, device=_dev()).bfloat16()
+    w = (torch.randn(N, K, device=_dev()) / math.sqrt(K)).bfloat16()
+    dy = torch.randn(M, N, device=_dev()).bfloat16()
+    b = torch.randn(N, device=_dev())
+    with ops.compute_mode('bf16'):
+        y = torch.empty(M, N, device=_dev())
+        ops.gemm_raw(M, N, K, x, K, 1, w, 1, K, y, N, bias=b)                      # KC x KC
+        assert _rel(y, x.float() @ w.float().t() + b) < 1e-5
+        yb = torch.empty(M, N, device=_dev(), dtype=torch.bfloat16)
+        ops.gemm_raw(M, N, K, x, K, 1, w, 1, K, yb, N, bias=b)                     # bf16 output
+        assert _rel(yb.float(), x.float() @ w.float().t() + b) < 1e-2
+        dx = torch.empty(M, K, device=_dev())
+        ops.gemm_raw(M, K, N, dy, N, 1, w, K, 1, dx, K)                            # KC x RC (dgrad)
+        assert _rel(dx, dy.float() @ w.float()) < 1e-5
+        dw = torch.zeros(N, K, device=_dev())
+        ops.gemm_raw(N, K, M, dy, 1, N, x, K, 1, dw, K, splitk=2)                   # RC x RC (wgrad)
+        assert _rel(dw, dy.float().t() @ x.float()) < 1e-5
+        xt = x.t().contiguous()                                                      # [K, M]
+        y2 = torch.empty(M, N, device=_dev())
+        ops.gemm_raw(M, N, K, xt, 1, M, w, 1, K, y2, N)                             # RC x KC
+        assert _rel(y2, x.float() @ w.float().t()) < 1e-5
