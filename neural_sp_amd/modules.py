@@ -270,12 +270,12 @@ class ConformerConvBlock(nn.Module):
 
     def forward(self, xs, residual=None, out_dropout=0.0):
         C = xs.shape[-1]
-        h = ops.linear(xs, self.pointwise_conv1.weight.view(2 * C, C), self.pointwise_conv1.bias)
+        h = ops.linear(xs, self.pointwise_conv1.weight, self.pointwise_conv1.bias)  # [2C,C,1] == [2C,C]
         h = ops.glu(h)
         h = ops.depthwise_conv1d(h, self.depthwise_conv.weight, self.depthwise_conv.bias, self.causal)
         h = ops.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act='swish')
         po = out_dropout if self.training else 0.0
-        return ops.linear(h, self.pointwise_conv2.weight.view(C, C), self.pointwise_conv2.bias,
+        return ops.linear(h, self.pointwise_conv2.weight, self.pointwise_conv2.bias,
                           res=residual, dropout_p=po)
 
 

@@ -128,18 +128,18 @@ def to_bf16(x2d):
     return out
 
 
-_W16 = {}
-
-
 def weight_bf16(w):
-    """bf16 shadow of a parameter, refreshed when the parameter is updated in place
-    (keyed on storage + version counter: one cast per optimizer step)."""
-    key = (w.data_ptr(), tuple(w.shape))
-    ent = _W16.get(key)
-    if ent is not None and ent[0] == w._version:
+    """bf16 shadow [N, roundup8(K)] of a parameter (any dim >= 2, flattened to 2-D), cached ON
+    the parameter object and refreshed when its version counter moves (one cast per optimizer
+    step).  Callers must pass the Parameter itself, not a temporary view of it."""
+    ent = getattr(w, '_nsp_bf16', None)
+    if ent is not None and ent[0] == w._version and ent[1].device == w.device:
         return ent[1]
     wb = to_bf16(w.detach().reshape(w.shape[0], -1))
-    _W16[key] = (w._version, wb)
+    try:
+        w._nsp_bf16 = (w._version, wb)
+    except Exception:
+        pass
     return wb
 
 
@@ -157,12 +157,12 @@ def linear_fwd(x2d, weight, bias=None, act=0, res=None, alpha=1.0, pre_out=None,
     """y[M,N] = res + dropout(alpha*act(x2d[M,K] @ weight[N,K]^T + bias)).  In bf16 mode the
     operands are bf16 shadows (x2d may already be bf16, weight is cached)."""
     M = x2d.shape[0]
-    N, K = weight.shape[0], weight.shape[1]
+    N, K = weight.shape[0], weight[0].numel()
     if bf16_mode() and K % 8 == 0:
         xa, wb = to_bf16(x2d), weight_bf16(weight)
     else:
         assert x2d.dtype == torch.float32
-        xa, wb = x2d, weight
+        xa, wb = x2d, weight.reshape(N, K)
     assert xa.stride(1) == 1 and wb.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), device=x2d.device,
@@ -176,12 +176,12 @@ def linear_fwd(x2d, weight, bias=None, act=0, res=None, alpha=1.0, pre_out=None,
 def linear_dgrad(dy2d, weight, dact_src=None, dact=0, alpha=1.0, res=None, out=None, out_bf16=False):
     """dx[M,K] = res + alpha*(dy2d[M,N] @ weight[N,K]) * act'(dact_src)."""
     M = dy2d.shape[0]
-    N, K = weight.shape[0], weight.shape[1]
+    N, K = weight.shape[0], weight[0].numel()
     if bf16_mode() and K % 8 == 0 and N % 8 == 0:
         ga, wb = to_bf16(dy2d), weight_bf16(weight)
     else:
         assert dy2d.dtype == torch.float32
-        ga, wb = dy2d, weight
+        ga, wb = dy2d, weight.reshape(N, K)
     if out is None:
         out = torch.empty((M, K), device=dy2d.device,
                           dtype=torch.bfloat16 if (out_bf16 and ga.dtype == torch.bfloat16) else torch.float32)
@@ -254,7 +254,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act, res, alpha, dropout_p):
         K = x.shape[-1]
         x2d = (x if x.dtype == torch.bfloat16 else _f32c(x)).reshape(-1, K)
-        weight = _f32c(weight)
+        assert weight.dtype == torch.float32 and weight.is_contiguous()
         N = weight.shape[0]
         use16 = bf16_mode() and K % 8 == 0
         xa = to_bf16(x2d) if use16 else x2d
@@ -284,7 +284,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(g, weight)[:, :ctx.xshape[-1]].reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = linear_wgrad(g, xa)
+            dw = linear_wgrad(g, xa).view(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(g)
         return dx, dw, db, None, dres, None, None
