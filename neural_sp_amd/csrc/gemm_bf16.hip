@@ -211,17 +211,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
     __syncthreads();
   }
 
+  // ---- epilogue.  The MFMA leaves lane (fr, fg) with C[m0+..+fr][n .. n+3]: storing that
+  // directly makes every store instruction touch 16 different rows with 16..64 B each
+  // (partial cache lines).  Each wave therefore stages 16 rows x 64 cols through its private
+  // LDS slab and re-reads it row-major, so that 16 consecutive lanes cover 256 contiguous
+  // bytes of one output row: all epilogue loads (bias, residual, act' source) and stores are
+  // full-line, 16 B per lane.
   const bool atomic = p.splitk > 1;
+  constexpr int SP = 68;  // floats per staged row (64 + 4 pad)
+  float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
+  const int er = lane >> 4, ec = (lane & 15) * 4;  // read-back: row er + 4*j, cols ec..ec+3
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + fr;
-    if (m >= p.M) continue;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-      if (n >= p.N) continue;
+    for (int ni = 0; ni < 4; ++ni)
+      *reinterpret_cast<float4*>(stage + fr * SP + ni * 16 + fg * 4) =
+          make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = er + 4 * j;
+      const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
+      const int m = m0 + wm * 64 + mi * 16 + row;
+      const int n = n0 + wn * 64 + ec;
+      if (m >= p.M || n >= p.N) continue;
       const long long off = coff + (long long)m * p.ldc + n;
-      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
       const int nv = min(4, p.N - n);
       if (atomic) {
         float* c = reinterpret_cast<float*>(p.C) + off;
@@ -231,8 +246,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
       }
       const bool vec = c_vec && nv == 4;
       if (p.bias) {
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        load4(p.bias, NSP_DT_F32, n, b4, nv, vec);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) v[e] += p.bias[n + e];
+        for (int e = 0; e < 4; ++e) v[e] += b4[e];
       }
       if (p.pre_out) store4(p.pre_out, p.pre_dtype, off, v, nv, vec);
       if (p.act != NSP_ACT_NONE) {
@@ -260,6 +277,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
       }
       store4(p.C, p.c_dtype, off, v, nv, vec);
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -309,6 +327,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   if (p.pre_out && reinterpret_cast<uintptr_t>(p.pre_out) % 16) c_vec = 0;
   if (p.dact_src && reinterpret_cast<uintptr_t>(p.dact_src) % 16) c_vec = 0;
   if (p.res && !aligned16(p.res)) c_vec = 0;
+  if (p.bias && !aligned16(p.bias)) c_vec = 0;
   dim3 grid(tiles_m * tiles_n, 1, p.batch1 * p.batch2 * p.splitk), block(NTHREADS);
   if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
