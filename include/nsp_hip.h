@@ -87,7 +87,13 @@ typedef struct {
    * index must have unit stride, leading dims / K (KC) resp. the row extent (RC) must be
    * multiples of 8 and bases 16-B aligned. */
   int a_dtype, b_dtype, c_dtype, pre_dtype, dact_dtype;
+  /* split-K without atomics: if c_ss != 0 split s stores its alpha-scaled partial tile at
+   * C + s*c_ss (fp32); the caller sums the splitk slabs with nsp_splitk_reduce. */
+  long long c_ss;
 } nsp_gemm_params;
+
+/* out[i] = sum_s part[s*n + i] (i < n): the deterministic reduction of split-K slabs */
+int nsp_splitk_reduce(const float* part, float* out, int splits, long long n, void* stream);
 
 int nsp_gemm(const nsp_gemm_params* p, void* stream);
 
@@ -284,6 +290,22 @@ int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h,
 /* dh is overwritten with dz = dh*(1-h^2); de[b,t,:] = sum_u dz, dg[b,u,:] = sum_t dz */
 int nsp_rnnt_joint_tanh_bwd(const float* h, float* dh, float* de, float* dg,
                             int B, int T, int U1, int J, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * LSTM recurrence of the RNN-T prediction network (rnn_transducer.py:101-111,  *
+ * 278-311: nn.LSTM(in, H, 1 layer, batch_first), zero initial state).         *
+ * gi = x W_ih^T + b_ih + b_hh for all steps is a GEMM done by the caller;      *
+ * nsp_lstm_fwd runs the L sequential steps h_{t-1} W_hh^T + cell update and    *
+ * saves the activated gates (i,f,g,o) and cell states; nsp_lstm_bwd walks back *
+ * and emits dgates [B,L,4H], from which dx, dW_ih, dW_hh, db are GEMMs/colsums.*
+ * Whh / WhhT / *shadow are bf16 in NSP_COMPUTE_BF16 and fp32 in NSP_COMPUTE_F32*
+ * ------------------------------------------------------------------------ */
+int nsp_lstm_fwd(const float* gi, const void* Whh /*[4H,H]*/, float* y /*[B,L,H]*/,
+                 void* yshadow /*bf16 [B,L,H]*/, float* c_all /*[B,L,H]*/,
+                 float* gates /*[B,L,4H]*/, int B, int L, int H, int mode, void* stream);
+int nsp_lstm_bwd(const float* dy /*[B,L,H]*/, const void* WhhT /*[H,4H]*/, const float* c_all,
+                 const float* gates, float* dgates /*[B,L,4H]*/, void* dgshadow /*bf16*/,
+                 float* dc /*[B,H] scratch*/, int B, int L, int H, int mode, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * SpecAugment band zeroing in place on [B,T,F] (spec_augment.py:112-140).  *

@@ -92,6 +92,7 @@ class GemmParams(ctypes.Structure):
         ('seed', ctypes.c_ulonglong), ('offset', ctypes.c_ulonglong),
         ('a_dtype', ctypes.c_int), ('b_dtype', ctypes.c_int), ('c_dtype', ctypes.c_int),
         ('pre_dtype', ctypes.c_int), ('dact_dtype', ctypes.c_int),
+        ('c_ss', ctypes.c_longlong),
     ]
 
 

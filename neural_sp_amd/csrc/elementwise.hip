@@ -104,6 +104,20 @@ __global__ void grad_prep_kernel(const float* __restrict__ dy, const void* __res
   }
 }
 
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                     int splits, long long n) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(part + (long long)s * n)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+}
+
 // relu backward from the OUTPUT y (y > 0)
 __global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                 float* __restrict__ dx, long long n) {
@@ -254,6 +268,15 @@ extern "C" int nsp_dropout(const float* x, float* y, float p, float alpha, unsig
   if (p < 0.f || p >= 1.f) return NSP_EINVAL;
   hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y,
                      p, alpha, seed, offset, n);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_splitk_reduce(const float* part, float* out, int splits, long long n, void* stream) {
+  if (n <= 0 || splits < 1) return NSP_OK;
+  if (n % 4) return NSP_EUNSUPPORTED;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ew_grid(n / 4)), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, part, out, splits, n);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

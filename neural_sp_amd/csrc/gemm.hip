@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const nsp_gemm_params p,
   float* const Cp = reinterpret_cast<float*>(p.C);
   float* const preo = reinterpret_cast<float*>(p.pre_out);
   const float* const dsrc = reinterpret_cast<const float*>(p.dact_src);
-  const long long coff = z1 * p.c_b1 + z2 * p.c_b2;
+  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
 
   // reduction range of this split (multiples of BK)
   int kbeg = 0, kend = p.K;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const nsp_gemm_params p,
 
   // ---- epilogue: lane holds C[m][n..n+3], m = m0+wm*64+mi*16+(lane&15),
   //      n = n0+wn*64+ni*16+(lane>>4)*4
-  const bool atomic = p.splitk > 1;
+  const bool atomic = p.splitk > 1 && p.c_ss == 0;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int m = m0 + wm * 64 + mi * 16 + frow;

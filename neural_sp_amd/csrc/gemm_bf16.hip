@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
   const int z2 = z % p.batch2, z1 = z / p.batch2;
   const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
   const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
-  const long long coff = z1 * p.c_b1 + z2 * p.c_b2;
+  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
   const long long lda = A_KC ? p.a_rs : p.a_cs;
   const long long ldb = B_KC ? p.b_ns : p.b_ks;
 
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
   // LDS slab and re-reads it row-major, so that 16 consecutive lanes cover 256 contiguous
   // bytes of one output row: all epilogue loads (bias, residual, act' source) and stores are
   // full-line, 16 B per lane.
-  const bool atomic = p.splitk > 1;
+  const bool atomic = p.splitk > 1 && p.c_ss == 0;
   constexpr int SP = 68;  // floats per staged row (64 + 4 pad)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   const int er = lane >> 4, ec = (lane & 15) * 4;  // read-back: row er + 4*j, cols ec..ec+3

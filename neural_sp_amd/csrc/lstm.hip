@@ -1,0 +1,198 @@
+// lstm.hip -- single-layer LSTM recurrence (the RNN-T prediction network,
+// reference rnn_transducer.py:101-111,278-311: nn.LSTM(1 layer, batch_first)).
+//
+// The input projection x W_ih^T + b for all time steps, and all weight / input
+// gradients, are plain GEMMs over [B*L, .] done by the MFMA GEMM kernels.  What
+// is inherently sequential is h_{t-1} W_hh^T: one small kernel per time step.
+// A workgroup owns 16 hidden units (all four gates i,f,g,o of them) for up to 16
+// batch rows: wave w multiplies h_{t-1}[16 x H] by the 16 rows of W_hh that
+// belong to gate w with MFMA (operands straight from L2 into registers -- W_hh
+// is 8 MB in bf16 and stays L2/MALL resident across steps), the four 16x16
+// pre-activation tiles meet in LDS, and 256 threads apply the cell update.
+// Backward walks t = L-1..0 with the transposed recurrence
+// dh_{t} += dgates_{t+1} W_hh (reduction over 4H split across the 4 waves).
+// Gate order is PyTorch's (i, f, g, o).  Latency-bound by construction:
+// ~2 x L launches per layer and direction.
+#include "common.h"
+
+namespace {
+
+template <int MODE>
+__device__ __forceinline__ f32x4 dot_tile(const void* __restrict__ arow, bool a_valid,
+                                          const void* __restrict__ brow, int K, int lane) {
+  // returns D[i][j] = sum_k A[i][k] B[j][k] for the lane's (A row i = lane&15 | B row j = lane&15)
+  // layout: D lane holds j = lane&15, i = (lane>>4)*4 + reg  (A is the SECOND mfma operand)
+  const int g = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 0) {
+    const __bf16* a = reinterpret_cast<const __bf16*>(arow);
+    const __bf16* b = reinterpret_cast<const __bf16*>(brow);
+    for (int k0 = 0; k0 < K; k0 += 256) {
+      bf16x8 af[8], bf[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int k = k0 + s * 32 + g * 8;
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+        af[s] = (a_valid && k < K) ? *reinterpret_cast<const bf16x8*>(a + k) : z;
+        bf[s] = (k < K) ? *reinterpret_cast<const bf16x8*>(b + k) : z;
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bf[s], acc, 0, 0, 0);
+    }
+  } else {
+    const float* a = reinterpret_cast<const float*>(arow);
+    const float* b = reinterpret_cast<const float*>(brow);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      float af[16], bf[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int k = k0 + s * 4 + g;
+        af[s] = (a_valid && k < K) ? a[k] : 0.f;
+        bf[s] = (k < K) ? b[k] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+// grid: (H/16, ceil(B/16)); block 256
+template <int MODE>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(
+    const float* __restrict__ gi, const void* __restrict__ Whh, float* __restrict__ y,
+    void* __restrict__ yshadow, float* __restrict__ c_all, float* __restrict__ gates, int B, int L,
+    int H, int t) {
+  __shared__ float pre[4][16][17];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int r = lane & 15;
+  const size_t esz = MODE == 0 ? 2 : 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (t > 0) {
+    // A rows = batch (h_{t-1}), B rows = W_hh rows of gate w
+    const bool a_valid = (b0 + r) < B;
+    const char* arow = reinterpret_cast<const char*>(yshadow) +
+                       ((long long)(min(b0 + r, B - 1)) * L + (t - 1)) * H * esz;
+    const char* brow = reinterpret_cast<const char*>(Whh) + ((long long)(w * H + u0 + r)) * H * esz;
+    // mfma(a = A frag, b = B frag): D[i = A row][j = B row]; lane: j = lane&15, i = (lane>>4)*4+reg
+    acc = dot_tile<MODE>(arow, a_valid, brow, H, lane);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pre[w][(lane >> 4) * 4 + e][r] = acc[e];
+  __syncthreads();
+  const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
+  const int b = b0 + bb, u = u0 + uu;
+  if (b < B && u < H) {
+    const long long row = (long long)b * L + t;
+    const float* g = gi + row * 4 * H;
+    const float pi = g[u] + pre[0][bb][uu];
+    const float pf = g[H + u] + pre[1][bb][uu];
+    const float pg = g[2 * H + u] + pre[2][bb][uu];
+    const float po = g[3 * H + u] + pre[3][bb][uu];
+    const float ig = 1.f / (1.f + expf(-pi));
+    const float fg = 1.f / (1.f + expf(-pf));
+    const float gg = tanhf(pg);
+    const float og = 1.f / (1.f + expf(-po));
+    const float cp = t > 0 ? c_all[(row - 1) * H + u] : 0.f;
+    const float c = fg * cp + ig * gg;
+    const float h = og * tanhf(c);
+    c_all[row * H + u] = c;
+    y[row * H + u] = h;
+    if (MODE == 0) reinterpret_cast<__bf16*>(yshadow)[row * H + u] = (__bf16)h;
+    float* gs = gates + row * 4 * H;
+    gs[u] = ig; gs[H + u] = fg; gs[2 * H + u] = gg; gs[3 * H + u] = og;
+  }
+}
+
+// backward step t.  dgates (fp32) and its shadow (bf16 in MODE 0, unused in MODE 1) are
+// [B, L, 4H]; WhhT is W_hh^T [H, 4H]; dc is [B, H] (carried across steps).
+template <int MODE>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(
+    const float* __restrict__ dy, const void* __restrict__ WhhT, const float* __restrict__ c_all,
+    const float* __restrict__ gates, float* __restrict__ dgates, void* __restrict__ dgshadow,
+    float* __restrict__ dc, int B, int L, int H, int t) {
+  __shared__ float part[4][16][17];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int r = lane & 15;
+  const size_t esz = MODE == 0 ? 2 : 4;
+  const int K4 = 4 * H;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (t + 1 < L) {
+    // dh_rec[b][u] = sum_k dgates_{t+1}[b][k] * W_hh[k][u]; wave w reduces k in [w*H, (w+1)*H)
+    const bool a_valid = (b0 + r) < B;
+    const void* ag = MODE == 0 ? (const void*)dgshadow : (const void*)dgates;
+    const char* arow = reinterpret_cast<const char*>(ag) +
+                       (((long long)(min(b0 + r, B - 1)) * L + (t + 1)) * K4 + (long long)w * H) * esz;
+    const char* brow = reinterpret_cast<const char*>(WhhT) + ((long long)(u0 + r) * K4 + (long long)w * H) * esz;
+    acc = dot_tile<MODE>(arow, a_valid, brow, H, lane);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[w][(lane >> 4) * 4 + e][r] = acc[e];
+  __syncthreads();
+  const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
+  const int b = b0 + bb, u = u0 + uu;
+  if (b < B && u < H) {
+    const long long row = (long long)b * L + t;
+    const float dh = dy[row * H + u] + part[0][bb][uu] + part[1][bb][uu] + part[2][bb][uu] + part[3][bb][uu];
+    const float* gs = gates + row * K4;
+    const float ig = gs[u], fg = gs[H + u], gg = gs[2 * H + u], og = gs[3 * H + u];
+    const float c = c_all[row * H + u];
+    const float cp = t > 0 ? c_all[(row - 1) * H + u] : 0.f;
+    const float tc = tanhf(c);
+    const float dcn = (t + 1 < L) ? dc[(long long)b * H + u] : 0.f;
+    const float dct = dcn + dh * og * (1.f - tc * tc);
+    const float d_o = dh * tc * og * (1.f - og);
+    const float d_i = dct * gg * ig * (1.f - ig);
+    const float d_f = dct * cp * fg * (1.f - fg);
+    const float d_g = dct * ig * (1.f - gg * gg);
+    dc[(long long)b * H + u] = dct * fg;
+    float* dg = dgates + row * K4;
+    dg[u] = d_i; dg[H + u] = d_f; dg[2 * H + u] = d_g; dg[3 * H + u] = d_o;
+    if (MODE == 0) {
+      __bf16* ds = reinterpret_cast<__bf16*>(dgshadow) + row * K4;
+      ds[u] = (__bf16)d_i; ds[H + u] = (__bf16)d_f; ds[2 * H + u] = (__bf16)d_g; ds[3 * H + u] = (__bf16)d_o;
+    }
+  }
+}
+
+}  // namespace
+
+// Runs all L steps.  Whh: [4H,H] (bf16 shadow in NSP_COMPUTE_BF16, fp32 in NSP_COMPUTE_F32);
+// yshadow: bf16 [B,L,H] written alongside y (mode bf16; pass y itself in mode f32).
+extern "C" int nsp_lstm_fwd(const float* gi, const void* Whh, float* y, void* yshadow, float* c_all,
+                            float* gates, int B, int L, int H, int mode, void* stream) {
+  if (B <= 0 || L <= 0 || H <= 0 || H % 16) return NSP_EUNSUPPORTED;
+  if (mode == NSP_COMPUTE_BF16 && H % 8) return NSP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(H / 16, nsp_cdiv(B, 16)), block(256);
+  for (int t = 0; t < L; ++t) {
+    if (mode == NSP_COMPUTE_BF16)
+      hipLaunchKernelGGL((lstm_step_fwd_kernel<0>), grid, block, 0, st, gi, Whh, y, yshadow, c_all, gates, B, L, H, t);
+    else
+      hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, gi, Whh, y, (void*)y, c_all, gates, B, L, H, t);
+  }
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+// dy: [B,L,H] gradient w.r.t. the outputs; produces dgates [B,L,4H] (+ bf16 shadow) from which
+// the caller derives dx, dW_ih, dW_hh, db with GEMMs.  dc: [B,H] scratch.
+extern "C" int nsp_lstm_bwd(const float* dy, const void* WhhT, const float* c_all, const float* gates,
+                            float* dgates, void* dgshadow, float* dc, int B, int L, int H, int mode,
+                            void* stream) {
+  if (B <= 0 || L <= 0 || H <= 0 || H % 16) return NSP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(H / 16, nsp_cdiv(B, 16)), block(256);
+  for (int t = L - 1; t >= 0; --t) {
+    if (mode == NSP_COMPUTE_BF16)
+      hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), grid, block, 0, st, dy, WhhT, c_all, gates, dgates, dgshadow, dc, B, L, H, t);
+    else
+      hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), grid, block, 0, st, dy, WhhT, c_all, gates, dgates, (void*)dgates, dc, B, L, H, t);
+  }
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

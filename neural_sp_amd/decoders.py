@@ -131,10 +131,9 @@ class CTCForcedAligner(object):
 
 class RNNTransducer(DecoderBase):
     """rnn_transducer.py:32-311 (training part).  The joint network, its log-softmax and
-    the lattice loss run as HIP kernels (ops.rnnt_joint_loss); the prediction network
-    (Embedding + LSTM stack) is a strictly sequential recurrence over U+1 <= ~200 label
-    steps and is left on torch.nn.LSTM (MIOpen) for now -- DESIGN.md lists it as the next
-    row to move."""
+    the lattice loss run as HIP kernels (ops.rnnt_joint_loss); the prediction network's
+    LSTM recurrence runs on per-step MFMA kernels (ops.lstm); nn.LSTM modules are kept only
+    as parameter containers so that state_dict names match the reference."""
 
     def __init__(self, special_symbols, enc_n_units, n_units, n_projs, n_layers, bottleneck_dim,
                  emb_dim, vocab, dropout, dropout_emb, ctc_weight, ctc_lsm_prob, ctc_fc_list,
@@ -212,20 +211,22 @@ class RNNTransducer(DecoderBase):
         return loss
 
     def embed_token_id(self, indices):
-        return self.dropout_emb(self.embed(indices))
+        # embedding lookup = row gather of a [V, emb] table (host-side indexing glue)
+        return ops.dropout(self.embed(indices), self.dropout_emb.p, self.training)
 
     def recurrency(self, ys_emb, dstate):
         if dstate is None:
             dstate = self.zero_state(ys_emb.size(0))
         new_hxs, new_cxs = [], []
         for lth in range(self.n_layers):
-            ys_emb, (h, c) = self.rnn[lth](ys_emb, hx=(dstate['hxs'][lth:lth + 1],
-                                                       dstate['cxs'][lth:lth + 1]))
-            new_hxs.append(h)
-            new_cxs.append(c)
-            ys_emb = self.dropout(ys_emb)
+            rnn = self.rnn[lth]
+            # zero initial state (training path); the recurrence runs on the HIP step kernels
+            ys_emb = ops.lstm(ys_emb, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
+            new_hxs.append(ys_emb[:, -1:].transpose(0, 1))
+            new_cxs.append(ys_emb.new_zeros(1, ys_emb.size(0), self.dec_n_units))  # not tracked in training
+            ys_emb = ops.dropout(ys_emb, self.dropout.p, self.training)
             if self.proj is not None:
-                ys_emb = torch.relu(self.proj[lth](ys_emb))
+                ys_emb = ops.linear(ys_emb, self.proj[lth].weight, self.proj[lth].bias, act='relu')
         return ys_emb, {'hxs': torch.cat(new_hxs, dim=0), 'cxs': torch.cat(new_cxs, dim=0)}
 
     def zero_state(self, batch_size):

@@ -74,7 +74,7 @@ def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
              batch=(1, 1), a_b=(0, 0), b_b=(0, 0), c_b=(0, 0),
              bias=None, act=0, pre_out=None, dact_src=None, dact=0, res=None,
              alpha=1.0, splitk=1, mode=None, a_off=0, b_off=0, c_off=0,
-             dropout_p=0.0, seed=0, offset=0):
+             dropout_p=0.0, seed=0, offset=0, c_ss=0):
     """C = epi(A @ B) with arbitrary strides (element offsets *_off into the tensors).
     A/B are both fp32 or both bf16; C / pre_out / dact_src may be fp32 or bf16 with bf16 operands."""
     p = GemmParams()
@@ -102,6 +102,7 @@ def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
     p.seed, p.offset = int(seed), int(offset)
     p.a_dtype, p.b_dtype, p.c_dtype = _dt(A), _dt(B), _dt(C)
     p.pre_dtype, p.dact_dtype = _dt(pre_out), _dt(dact_src)
+    p.c_ss = int(c_ss)
     for t in (A, B, C, pre_out, dact_src):
         if t is not None:
             assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16)
@@ -202,6 +203,15 @@ def linear_wgrad(dy2d, x2d, alpha=1.0):
     if ga.dtype != xa.dtype:
         ga, xa = ga.float(), xa.float()
     sk = _pick_splitk(N, K, M)
+    if sk > 1 and (N * K) % 4 == 0:
+        # split slabs + deterministic reduction (no atomics, no zero fill)
+        part = torch.empty((sk, N, K), device=dy2d.device, dtype=torch.float32)
+        gemm_raw(N, K, M, ga, 1, ga.stride(0), xa, xa.stride(0), 1, part, K, alpha=alpha, splitk=sk,
+                 c_ss=N * K)
+        dw = torch.empty((N, K), device=dy2d.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_splitk_reduce(_p(part), _p(dw), ctypes.c_int(sk), ctypes.c_longlong(N * K),
+                                            _stream()), 'nsp_splitk_reduce')
+        return dw
     dw = (torch.zeros if sk > 1 else torch.empty)((N, K), device=dy2d.device, dtype=torch.float32)
     gemm_raw(N, K, M, ga, 1, ga.stride(0), xa, xa.stride(0), 1, dw, K, alpha=alpha, splitk=sk)
     return dw
@@ -985,3 +995,78 @@ def kernel_events_stop():
     out = {'launches': len(_KEV['events']), 'ms': ms, 'flops': _KEV['flops']}
     _KEV['events'] = []
     return out
+
+
+# --------------------------------------------------------------------------
+# LSTM (RNN-T prediction network)
+# --------------------------------------------------------------------------
+def _weight_t_shadow(w, bf16):
+    """W^T [K, N] (bf16 or fp32) cached on the parameter like weight_bf16."""
+    name = '_nsp_t16' if bf16 else '_nsp_t32'
+    ent = getattr(w, name, None)
+    if ent is not None and ent[0] == w._version and ent[1].device == w.device:
+        return ent[1]
+    wt = w.detach().t().contiguous()
+    if bf16:
+        wt = to_bf16(wt)
+    try:
+        setattr(w, name, (w._version, wt))
+    except Exception:
+        pass
+    return wt
+
+
+class LSTMFn(torch.autograd.Function):
+    """y = LSTM(x) for one layer, batch_first, zero initial state (PyTorch gate order i,f,g,o)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        B, L, I = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        use16 = bf16_mode()
+        bias = axpby(b_ih, b_hh, 1.0, 1.0)
+        x2d = _f32c(x).reshape(B * L, I)
+        xa = to_bf16(x2d) if (use16 and I % 8 == 0) else x2d
+        gi = linear_fwd(xa, w_ih, bias)                                  # [B*L, 4H]
+        y = torch.empty((B, L, H), device=dev, dtype=torch.float32)
+        ysh = torch.empty((B, L, H), device=dev, dtype=torch.bfloat16) if use16 else y
+        c_all = torch.empty((B, L, H), device=dev, dtype=torch.float32)
+        gates = torch.empty((B, L, 4 * H), device=dev, dtype=torch.float32)
+        whh = weight_bf16(w_hh) if use16 else w_hh
+        _check(_lib.lib().nsp_lstm_fwd(_p(gi), _p(whh), _p(y), _p(ysh), _p(c_all), _p(gates),
+                                       ctypes.c_int(B), ctypes.c_int(L), ctypes.c_int(H),
+                                       ctypes.c_int(_COMPUTE_MODE['mode']), _stream()), 'nsp_lstm_fwd')
+        ctx.save_for_backward(xa, w_ih, w_hh, ysh, c_all, gates)
+        ctx.dims = (B, L, I, H)
+        ctx.use16 = use16
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, w_ih, w_hh, ysh, c_all, gates = ctx.saved_tensors
+        B, L, I, H = ctx.dims
+        dev = dy.device
+        use16 = ctx.use16
+        dy = _f32c(dy)
+        dgates = torch.empty((B, L, 4 * H), device=dev, dtype=torch.float32)
+        dgsh = torch.empty((B, L, 4 * H), device=dev, dtype=torch.bfloat16) if use16 else dgates
+        dc = torch.empty((B, H), device=dev, dtype=torch.float32)
+        whh_t = _weight_t_shadow(w_hh, use16)
+        mode = 0 if use16 else 1
+        _check(_lib.lib().nsp_lstm_bwd(_p(dy), _p(whh_t), _p(c_all), _p(gates), _p(dgates), _p(dgsh),
+                                       _p(dc), ctypes.c_int(B), ctypes.c_int(L), ctypes.c_int(H),
+                                       ctypes.c_int(mode), _stream()), 'nsp_lstm_bwd')
+        g2d = dgsh.view(B * L, 4 * H)
+        # h_{t-1} for every (b,t): the outputs shifted by one step (zeros at t=0)
+        hprev = torch.zeros_like(ysh)
+        hprev[:, 1:] = ysh[:, :-1]
+        dx = linear_dgrad(g2d, w_ih)[:, :I].reshape(B, L, I) if ctx.needs_input_grad[0] else None
+        dw_ih = linear_wgrad(g2d, xa).view(w_ih.shape)
+        dw_hh = linear_wgrad(g2d, hprev.view(B * L, H)).view(w_hh.shape)
+        db = colsum(g2d)
+        return dx, dw_ih, dw_hh, db, db
+
+
+def lstm(x, w_ih, w_hh, b_ih, b_hh):
+    return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh)

@@ -175,3 +175,22 @@ def test_ctc_forced_align_vs_reference_golden():
     tp = CTCForcedAligner()(fix['logits'].to(_dev()), fix['elens'], fix['ys'])
     assert tp.dtype == torch.int32
     assert torch.equal(tp.cpu(), fix['trigger_points'].int()), (tp.cpu().tolist(), fix['trigger_points'].tolist())
+
+
+@pytest.mark.parametrize('mode,tol', [('f32', 1e-4), ('bf16', 3e-2)])
+def test_lstm_vs_torch(mode, tol):
+    from neural_sp_amd import ops
+    torch.manual_seed(5)
+    B, L, I, H = 5, 23, 48, 64
+    ref = torch.nn.LSTM(I, H, 1, batch_first=True).to(_dev())
+    x = torch.randn(B, L, I, device=_dev(), requires_grad=True)
+    dy = torch.randn(B, L, H, device=_dev())
+    yr, _ = ref(x)
+    params = [ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0]
+    gr = torch.autograd.grad(yr, [x] + params, dy)
+    with ops.compute_mode(mode):
+        y = ops.lstm(x, *params)
+        assert _rel(y, yr) < tol
+        g = torch.autograd.grad(y, [x] + params, dy)
+    for a, r in zip(g, gr):
+        assert _rel(a, r) < tol
