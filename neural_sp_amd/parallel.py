@@ -23,7 +23,33 @@ class CPUWrapperASR(nn.Module):
         return self.module(*args, **kwargs)
 
 
-def wrap_ddp(model, local_rank, bucket_cap_mb=128):
+def wrap_ddp(model, local_rank=None, bucket_cap_mb=128):
+    """DDP(model) with the settings above; local_rank=None wraps a CPU module (gloo tests)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    return DDP(model, device_ids=[local_rank], broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb,
-               gradient_as_bucket_view=True)
+    kw = dict(broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+    if local_rank is None:
+        return DDP(model, **kw)
+    return DDP(model, device_ids=[local_rank], **kw)
+
+
+def shard_batch(indices, rank, world):
+    """Rank-strided split of a length-sorted bucket (datasets/asr/sampler.py:96)."""
+    return indices[rank::world]
+
+
+def scale_loss_for_ddp(loss, world):
+    """train.py:423-424: DDP averages gradients while every rank normalises by its own
+    batch, so the loss is pre-multiplied by the number of replicas."""
+    return loss * world if world > 1 else loss
+
+
+def aggregate_timing(dt, units, device=None):
+    """(max over ranks of dt, sum over ranks of units) -- bench.py's whole-job numbers."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dt, units
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    u = torch.tensor([float(units)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return t.item(), u.item()
