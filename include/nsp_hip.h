@@ -103,12 +103,13 @@ int nsp_gemm(const nsp_gemm_params* p, void* stream);
  * transformer_block.py:109,132, transformer.py:600,                        *
  * conformer_convolution.py:64,119.                                         *
  *   y = (x-mean)*rstd*gamma + beta ; optional fused activation on y.       *
- *   mean/rstd [rows] are saved for backward.                               *
+ *   mean/rstd [rows] are saved for backward.  y16 (optional) receives a    *
+ *   bf16 copy of y for the consuming MFMA GEMM; y itself may be NULL then. *
  * ------------------------------------------------------------------------ */
 int nsp_layernorm_fwd(const float* x, const float* gamma, const float* beta,
                       float* y, float* mean, float* rstd,
                       int rows, int d, float eps, int act, float* y_pre,
-                      void* stream);
+                      void* y16, void* stream);
 /* dx (may alias dy), dgamma/dbeta accumulated via atomics into zeroed buffers.
  * If act != NONE, y_pre is the pre-activation LN output saved by fwd. */
 int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,

@@ -14,7 +14,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta,
                                                      float* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int rows, int d,
-                                                     float eps, int act, float* __restrict__ y_pre) {
+                                                     float eps, int act, float* __restrict__ y_pre,
+                                                     __bf16* __restrict__ y16) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int d4 = d >> 2;
   const float inv_d = 1.f / (float)d;
@@ -44,8 +45,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       mean[row] = mu;
       rstd[row] = rs;
     }
-    float4* yr = reinterpret_cast<float4*>(y + row * d);
+    float4* yr = y ? reinterpret_cast<float4*>(y + row * d) : nullptr;
     float4* ypr = y_pre ? reinterpret_cast<float4*>(y_pre + row * d) : nullptr;
+    bf16x4* y16r = y16 ? reinterpret_cast<bf16x4*>(y16 + row * d) : nullptr;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       int c = lane + i * 64;
@@ -57,7 +59,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (ypr) ypr[c] = o;
         if (act != NSP_ACT_NONE)
           o = make_float4(nsp_act(o.x, act), nsp_act(o.y, act), nsp_act(o.z, act), nsp_act(o.w, act));
-        yr[c] = o;
+        if (yr) yr[c] = o;
+        if (y16r) {
+          bf16x4 h;
+          h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+          y16r[c] = h;
+        }
       }
     }
   }
@@ -150,13 +157,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
 
 extern "C" int nsp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                                  float* mean, float* rstd, int rows, int d, float eps, int act,
-                                 float* y_pre, void* stream) {
+                                 float* y_pre, void* y16v, void* stream) {
   if (d % 4 || d > 2048 || rows <= 0) return NSP_EUNSUPPORTED;
+  if (!y && !y16v) return NSP_EINVAL;
+  __bf16* y16 = reinterpret_cast<__bf16*>(y16v);
   hipStream_t st = (hipStream_t)stream;
   int grid = nsp_cdiv(rows, 4);
   if (grid > 4096) grid = 4096;
   const int vpl = nsp_cdiv(d, 256);
-#define LN_FWD(V) hipLaunchKernelGGL((ln_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps, act, y_pre)
+#define LN_FWD(V) hipLaunchKernelGGL((ln_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps, act, y_pre, y16)
   if (vpl <= 1) LN_FWD(1);
   else if (vpl <= 2) LN_FWD(2);
   else if (vpl <= 4) LN_FWD(4);

@@ -107,8 +107,8 @@ class PositionwiseFeedForward(nn.Module):
             h = ops.linear(h, self.w_1_d.weight, self.w_1_d.bias, act=self.activation, dropout_p=p)
             h = ops.linear(h, self.w_2_e.weight, self.w_2_e.bias)
             return ops.linear(h, self.w_2_d.weight, self.w_2_d.bias, res=residual, alpha=alpha, dropout_p=po)
-        h = ops.linear(xs, self.w_1.weight, self.w_1.bias, act=self.activation, dropout_p=p)
-        return ops.linear(h, self.w_2.weight, self.w_2.bias, res=residual, alpha=alpha, dropout_p=po)
+        return ops.ffn(xs, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
+                       self.activation, p, residual, alpha, po)
 
 
 # ---------------------------------------------------------------- attention

@@ -263,11 +263,15 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, res, alpha, dropout_p):
         K = x.shape[-1]
-        x2d = (x if x.dtype == torch.bfloat16 else _f32c(x)).reshape(-1, K)
         assert weight.dtype == torch.float32 and weight.is_contiguous()
         N = weight.shape[0]
         use16 = bf16_mode() and K % 8 == 0
-        xa = to_bf16(x2d) if use16 else x2d
+        sh = getattr(x, '_nsp16', None)
+        if use16 and sh is not None and sh.shape[-1] == K:
+            x2d = xa = sh.reshape(-1, K)
+        else:
+            x2d = (x if x.dtype == torch.bfloat16 else _f32c(x)).reshape(-1, K)
+            xa = to_bf16(x2d) if use16 else x2d
         res2d = _f32c(res).reshape(-1, N) if res is not None else None
         pre = None
         if act != 0:
@@ -397,16 +401,17 @@ def act_fwd(x, act):
 # --------------------------------------------------------------------------
 # LayerNorm
 # --------------------------------------------------------------------------
-def layernorm_fwd_raw(x2d, gamma, beta, eps, act=0, want_pre=False):
+def layernorm_fwd_raw(x2d, gamma, beta, eps, act=0, want_pre=False, want16=False, want32=True):
     rows, d = x2d.shape
-    y = torch.empty_like(x2d)
+    y = torch.empty_like(x2d) if want32 else None
+    y16 = torch.empty((rows, d), device=x2d.device, dtype=torch.bfloat16) if want16 else None
     mean = torch.empty((rows,), device=x2d.device, dtype=torch.float32)
     rstd = torch.empty((rows,), device=x2d.device, dtype=torch.float32)
     y_pre = torch.empty_like(x2d) if (act != 0 and want_pre) else None
     _check(_lib.lib().nsp_layernorm_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
                                         ctypes.c_int(rows), ctypes.c_int(d), ctypes.c_float(eps),
-                                        ctypes.c_int(act), _p(y_pre), _stream()), 'nsp_layernorm_fwd')
-    return y, mean, rstd, y_pre
+                                        ctypes.c_int(act), _p(y_pre), _p(y16), _stream()), 'nsp_layernorm_fwd')
+    return y, mean, rstd, y_pre, y16
 
 
 def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0):
@@ -425,10 +430,14 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, act):
         x2d = _f32c(x).reshape(-1, x.shape[-1])
-        y, mean, rstd, y_pre = layernorm_fwd_raw(x2d, gamma, beta, eps, act, want_pre=True)
+        want16 = bf16_mode() and x2d.shape[1] % 8 == 0
+        y, mean, rstd, y_pre, y16 = layernorm_fwd_raw(x2d, gamma, beta, eps, act, want_pre=True, want16=want16)
         ctx.save_for_backward(x2d, gamma, mean, rstd, y_pre)
         ctx.act = act
-        return y.view(x.shape)
+        out = y.view(x.shape)
+        if y16 is not None:
+            out._nsp16 = y16  # bf16 shadow [rows, d] for the consuming GEMM (saves its cast pass)
+        return out
 
     @staticmethod
     def backward(ctx, dy):
@@ -1070,3 +1079,63 @@ class LSTMFn(torch.autograd.Function):
 
 def lstm(x, w_ih, w_hh, b_ih, b_hh):
     return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh)
+
+
+# --------------------------------------------------------------------------
+# fused position-wise feed-forward (two GEMMs, everything else in their epilogues)
+# --------------------------------------------------------------------------
+class FFNFn(torch.autograd.Function):
+    """out = res + dropout_o(alpha * (dropout_h(act(x W1^T + b1)) W2^T + b2))
+    (positionwise_feed_forward.py:89 + conformer_block.py:131-134).  In bf16 mode the hidden
+    activation and its pre-activation live only as bf16 tensors; backward gets d(pre) straight
+    out of the W2 data-gradient GEMM epilogue (x act'(pre) x dropout mask), so no elementwise
+    pass ever touches a [M, d_ff] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, p_h, res, alpha, p_o):
+        K = x.shape[-1]
+        dff, N = w1.shape[0], w2.shape[0]
+        use16 = bf16_mode() and K % 8 == 0 and dff % 8 == 0
+        sh = getattr(x, '_nsp16', None)
+        if use16 and sh is not None:
+            xa = sh.reshape(-1, K)
+        else:
+            x2d = _f32c(x).reshape(-1, K)
+            xa = to_bf16(x2d) if use16 else x2d
+        M = xa.shape[0]
+        dt = torch.bfloat16 if use16 else torch.float32
+        pre = torch.empty((M, dff), device=x.device, dtype=dt)
+        h = torch.empty((M, dff), device=x.device, dtype=dt)
+        s1 = next_dropout_seed() if p_h > 0 else (0, 0)
+        s2 = next_dropout_seed() if p_o > 0 else (0, 0)
+        linear_fwd(xa, w1, b1, act, None, 1.0, pre_out=pre, out=h, dropout_p=p_h, seed=s1[0], offset=s1[1])
+        res2d = _f32c(res).reshape(-1, N) if res is not None else None
+        y = linear_fwd(h, w2, b2, 0, res2d, alpha, dropout_p=p_o, seed=s2[0], offset=s2[1])
+        ctx.save_for_backward(xa, w1, w2, pre, h)
+        ctx.cfg = (act, p_h, s1, alpha, p_o, s2, res is not None, x.shape, use16)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, w1, w2, pre, h = ctx.saved_tensors
+        act, p_h, s1, alpha, p_o, s2, has_res, xshape, use16 = ctx.cfg
+        N = w2.shape[0]
+        dy2d = _f32c(dy).reshape(-1, N)
+        g2 = grad_prep(dy2d, None, 0, alpha, p_o, s2[0], s2[1], use16)
+        dw2 = linear_wgrad(g2, h).view(w2.shape)
+        db2 = colsum(g2)
+        # d(pre) = (g2 W2) * dropout_h mask * act'(pre): all in the data-gradient epilogue
+        M, dff = pre.shape
+        ga, wb = (g2, weight_bf16(w2)) if use16 else (g2, w2)
+        dpre = torch.empty((M, dff), device=dy.device, dtype=pre.dtype)
+        gemm_raw(M, dff, N, ga, ga.stride(0), 1, wb, wb.stride(0), 1, dpre, dff,
+                 dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1])
+        dw1 = linear_wgrad(dpre, xa).view(w1.shape)
+        db1 = colsum(dpre)
+        dx = linear_dgrad(dpre, w1)[:, :xshape[-1]].reshape(xshape) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None
+
+
+def ffn(x, w1, b1, w2, b2, act, p_h=0.0, res=None, alpha=1.0, p_o=0.0):
+    return FFNFn.apply(x, w1, b1, w2, b2, ACT[act] if not isinstance(act, int) else act,
+                       float(p_h), res, float(alpha), float(p_o))
