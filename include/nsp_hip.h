@@ -120,9 +120,11 @@ int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
 /* ------------------------------------------------------------------------ *
  * Elementwise helpers (vectorised, grid-stride).                           *
  * ------------------------------------------------------------------------ */
-/* fp32 -> bf16 (round-to-nearest-even) copy of a [rows, cols] matrix (row stride ld_in) into
- * [rows, ld_out] with zero fill of columns cols..ld_out-1: the bf16 shadow copies of weights
- * and activations that feed the MFMA GEMM.  out is uint16 storage. */
+/* fp32 -> bf16 (round-to-nearest-even) copy of a [rows, cols] matrix (row stride ld_in) into a
+ * bf16 image with row pitch ld_out >= roundup8(cols); columns cols..roundup8(cols)-1 are
+ * zero filled (columns beyond that are not touched, so the destination may be a column
+ * block of a wider matrix): the bf16 shadow copies of weights and activations that feed the
+ * MFMA GEMM.  out is uint16 storage, 16-B aligned. */
 int nsp_cast_bf16(const float* x, void* out, long long rows, int cols, long long ld_in,
                   long long ld_out, void* stream);
 /* y = alpha*x + beta*z (z may be NULL) */
@@ -185,15 +187,18 @@ typedef struct {
   int causal, lookahead;
   int chunk_nl, chunk_nc;
   float dropout_p; unsigned long long seed, offset;
+  int p_bf16;              /* probabilities / dS are bf16 images with row pitch tk_pitch (zero padded) */
+  int tk_pitch;            /* >= Tk, multiple of 8 when p_bf16 */
+  int r_pitch;             /* row pitch of QP / dQP (>= R; pad columns of dQP are written as 0) */
 } nsp_attn_mask_params;
 
-/* Pdrop: optional second output = dropout(P) (required iff dropout_p > 0);
- * S always receives the un-dropped probabilities needed by backward. */
-int nsp_attn_softmax_fwd(float* S, const float* QP, float* Pdrop,
+/* S: content scores fp32 [B,H,Tq,Tk] (read only).  Pout receives softmax(e) (fp32 pitch Tk, may
+ * alias S; or bf16 pitch tk_pitch), Pdrop (required iff dropout_p > 0) the dropped copy. */
+int nsp_attn_softmax_fwd(const float* S, const float* QP, void* Pout, void* Pdrop,
                          const nsp_attn_mask_params* p, void* stream);
-/* dS (in place over dP) = P*(dP - sum_j P*dP) * scale; dQP[b,i,h,r] = sum of
- * dS(i,j) with rel(i,j)==r (before the scale folded into e). */
-int nsp_attn_softmax_bwd(const float* P, float* dP, float* dQP,
+/* dS (same dtype/pitch as P; may alias dP when fp32) = P*(dP - sum_j P*dP) * scale, 0 on masked
+ * keys; dQP[b,i,h,r] = sum of dS(i,j) with rel(i,j)==r. */
+int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
                          const nsp_attn_mask_params* p, void* stream);
 
 /* ------------------------------------------------------------------------ *

@@ -104,6 +104,7 @@ class AttnMaskParams(ctypes.Structure):
         ('klens', ctypes.c_void_p), ('causal', ctypes.c_int), ('lookahead', ctypes.c_int),
         ('chunk_nl', ctypes.c_int), ('chunk_nc', ctypes.c_int),
         ('dropout_p', ctypes.c_float), ('seed', ctypes.c_ulonglong), ('offset', ctypes.c_ulonglong),
+        ('p_bf16', ctypes.c_int), ('tk_pitch', ctypes.c_int), ('r_pitch', ctypes.c_int),
     ]
 
 

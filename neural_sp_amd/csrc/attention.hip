@@ -31,21 +31,23 @@ __device__ __forceinline__ int rel_index(int i, int j, int clamp) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict__ S,
+__global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(const float* __restrict__ S,
                                                                const float* __restrict__ QP,
-                                                               float* __restrict__ Pdrop,
+                                                               void* __restrict__ Pout,
+                                                               void* __restrict__ Pdrop,
                                                                const nsp_attn_mask_params p) {
   extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // [4][Tk]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long nrows = (long long)p.B * p.H * p.Tq;
   float* buf = rowbuf + (long long)w * p.Tk;
+  const int tkp = p.p_bf16 ? p.tk_pitch : p.Tk;
   for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
     const int i = (int)(row % p.Tq);
     const int h = (int)((row / p.Tq) % p.H);
     const int b = (int)(row / ((long long)p.Tq * p.H));
     const int klen = p.klens ? p.klens[b] : p.Tk;
-    float* s = S + row * p.Tk;
-    const float* qp = QP ? QP + (((long long)b * p.Tq + i) * p.H + h) * p.R : nullptr;
+    const float* s = S + row * p.Tk;
+    const float* qp = QP ? QP + (((long long)b * p.Tq + i) * p.H + h) * p.r_pitch : nullptr;
     float mx = -FLT_MAX;
     for (int j = lane; j < p.Tk; j += 64) {
       float e = s[j];
@@ -64,76 +66,81 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict
     }
     sum = wave_reduce_sum(sum);
     const float inv = 1.f / sum;
-    for (int j = lane; j < p.Tk; j += 64) {
-      float pr = buf[j] * inv;
-      s[j] = pr;
-      if (Pdrop)
-        Pdrop[row * p.Tk + j] =
-            pr * nsp_keep_scale(p.seed, p.offset + (unsigned long long)(row * p.Tk + j), p.dropout_p);
+    for (int j = lane; j < tkp; j += 64) {
+      const float pr = j < p.Tk ? buf[j] * inv : 0.f;  // pad columns of the bf16 image are zero
+      float pd = pr;
+      if (Pdrop && j < p.Tk)
+        pd = pr * nsp_keep_scale(p.seed, p.offset + (unsigned long long)(row * p.Tk + j), p.dropout_p);
+      if (p.p_bf16) {
+        reinterpret_cast<__bf16*>(Pout)[row * tkp + j] = (__bf16)pr;
+        if (Pdrop) reinterpret_cast<__bf16*>(Pdrop)[row * tkp + j] = (__bf16)pd;
+      } else {
+        reinterpret_cast<float*>(Pout)[row * tkp + j] = pr;
+        if (Pdrop) reinterpret_cast<float*>(Pdrop)[row * tkp + j] = pd;
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ P,
-                                                               float* __restrict__ dP,
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const void* __restrict__ P,
+                                                               const float* __restrict__ dP,
+                                                               void* __restrict__ dS,
                                                                float* __restrict__ dQP,
                                                                const nsp_attn_mask_params p) {
   extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // [4][Tk]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long nrows = (long long)p.B * p.H * p.Tq;
   float* buf = rowbuf + (long long)w * p.Tk;
+  const int tkp = p.p_bf16 ? p.tk_pitch : p.Tk;
   for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
     const int i = (int)(row % p.Tq);
     const int h = (int)((row / p.Tq) % p.H);
     const int b = (int)(row / ((long long)p.Tq * p.H));
     const int klen = p.klens ? p.klens[b] : p.Tk;
-    const float* pr = P + row * p.Tk;
-    float* g = dP + row * p.Tk;
+    const float* g = dP + row * p.Tk;
     float t = 0.f;
     for (int j = lane; j < p.Tk; j += 64) {
       float gj = g[j];
       if (p.dropout_p > 0.f)
         gj *= nsp_keep_scale(p.seed, p.offset + (unsigned long long)(row * p.Tk + j), p.dropout_p);
       buf[j] = gj;
-      t += pr[j] * gj;
+      const float pj = p.p_bf16 ? (float)reinterpret_cast<const __bf16*>(P)[row * tkp + j]
+                                : reinterpret_cast<const float*>(P)[row * tkp + j];
+      t += pj * gj;
     }
     t = wave_reduce_sum(t);
     float far = 0.f;  // sum of dS over |i-j| >= clamp
-    for (int j = lane; j < p.Tk; j += 64) {
-      float ds = pr[j] * (buf[j] - t) * p.scale;
-      if (!key_visible(p, klen, i, j)) ds = 0.f;  // masked_fill_ blocks the gradient
-      buf[j] = ds;
-      g[j] = ds;
-      if (p.clamp > 0) {
-        int r = i > j ? i - j : j - i;
-        if (r >= p.clamp) far += ds;
+    for (int j = lane; j < tkp; j += 64) {
+      float ds = 0.f;
+      if (j < p.Tk) {
+        const float pj = p.p_bf16 ? (float)reinterpret_cast<const __bf16*>(P)[row * tkp + j]
+                                  : reinterpret_cast<const float*>(P)[row * tkp + j];
+        ds = pj * (buf[j] - t) * p.scale;
+        if (!key_visible(p, klen, i, j)) ds = 0.f;  // masked_fill_ blocks the gradient
+        buf[j] = ds;
+        if (p.clamp > 0) {
+          int r = i > j ? i - j : j - i;
+          if (r >= p.clamp) far += ds;
+        }
       }
+      if (p.p_bf16) reinterpret_cast<__bf16*>(dS)[row * tkp + j] = (__bf16)ds;
+      else reinterpret_cast<float*>(dS)[row * tkp + j] = ds;
     }
     if (dQP) {
-      float* dq = dQP + (((long long)b * p.Tq + i) * p.H + h) * p.R;
-      if (p.clamp > 0) {
-        far = wave_reduce_sum(far);
-        // make this wave's LDS writes visible to its own other lanes
-        __builtin_amdgcn_wave_barrier();
-        for (int r = lane; r < p.R; r += 64) {
-          float v;
-          if (r == p.clamp) {
+      float* dq = dQP + (((long long)b * p.Tq + i) * p.H + h) * p.r_pitch;
+      __builtin_amdgcn_wave_barrier();
+      if (p.clamp > 0) far = wave_reduce_sum(far);
+      for (int r = lane; r < p.r_pitch; r += 64) {
+        float v = 0.f;
+        if (r < p.R) {
+          if (p.clamp > 0 && r == p.clamp) {
             v = far;
           } else {
-            v = 0.f;
-            if (i - r >= 0) v += buf[i - r];
+            if (i - r >= 0 && i - r < p.Tk) v += buf[i - r];
             if (r > 0 && i + r < p.Tk) v += buf[i + r];
           }
-          dq[r] = v;
         }
-      } else {
-        __builtin_amdgcn_wave_barrier();
-        for (int r = lane; r < p.R; r += 64) {
-          float v = 0.f;
-          if (i - r >= 0 && i - r < p.Tk) v += buf[i - r];
-          if (r > 0 && i + r < p.Tk) v += buf[i + r];
-          dq[r] = v;
-        }
+        dq[r] = v;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -142,10 +149,12 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int nsp_attn_softmax_fwd(float* S, const float* QP, float* Pdrop,
+extern "C" int nsp_attn_softmax_fwd(const float* S, const float* QP, void* Pout, void* Pdrop,
                                     const nsp_attn_mask_params* pp, void* stream) {
-  if (!pp || !S) return NSP_EINVAL;
+  if (!pp || !S || !Pout) return NSP_EINVAL;
   nsp_attn_mask_params p = *pp;
+  if (p.r_pitch < p.R) p.r_pitch = p.R;
+  if (p.p_bf16 && p.tk_pitch < p.Tk) return NSP_EINVAL;
   // the gather index min(|i-j|, clamp) never exceeds min(clamp, Tk-1)
   if (QP && p.R < (p.clamp > 0 && p.clamp + 1 < p.Tk ? p.clamp + 1 : p.Tk)) return NSP_EINVAL;
   if (p.dropout_p > 0.f && !Pdrop) return NSP_EINVAL;
@@ -157,15 +166,17 @@ extern "C" int nsp_attn_softmax_fwd(float* S, const float* QP, float* Pdrop,
   if (shmem > 64 * 1024)
     hipFuncSetAttribute((const void*)attn_softmax_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, S, QP,
-                     p.dropout_p > 0.f ? Pdrop : nullptr, p);
+                     Pout, p.dropout_p > 0.f ? Pdrop : nullptr, p);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
 
-extern "C" int nsp_attn_softmax_bwd(const float* P, float* dP, float* dQP,
+extern "C" int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
                                     const nsp_attn_mask_params* pp, void* stream) {
-  if (!pp || !P || !dP) return NSP_EINVAL;
+  if (!pp || !P || !dP || !dS) return NSP_EINVAL;
   nsp_attn_mask_params p = *pp;
+  if (p.r_pitch < p.R) p.r_pitch = p.R;
+  if (p.p_bf16 && p.tk_pitch < p.Tk) return NSP_EINVAL;
   const size_t shmem = sizeof(float) * 4 * (size_t)p.Tk;
   if (shmem > 150 * 1024) return NSP_EUNSUPPORTED;
   long long nrows = (long long)p.B * p.H * p.Tq;
@@ -174,7 +185,7 @@ extern "C" int nsp_attn_softmax_bwd(const float* P, float* dP, float* dQP,
   if (shmem > 64 * 1024)
     hipFuncSetAttribute((const void*)attn_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(grid), dim3(256), shmem, (hipStream_t)stream, P, dP,
-                     dQP, p);
+                     dS, dQP, p);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
 // fp32 [rows, cols] (row stride ld_in) -> bf16 [rows, ld_out] with zero fill; 8 elements per lane
 __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long long rows,
                                  int cols, long long ld_in, long long ld_out, int vec_in) {
-  const long long chunks_per_row = ld_out >> 3;
+  const long long chunks_per_row = (cols + 7) >> 3;  // pad only inside the last 8-wide chunk
   const long long total = rows * chunks_per_row;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -318,8 +318,12 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   const long long lda = a_kc ? p.a_rs : p.a_cs, ldb = b_kc ? p.b_ns : p.b_ks;
   if (lda % 8 || ldb % 8 || p.a_b1 % 8 || p.a_b2 % 8 || p.b_b1 % 8 || p.b_b2 % 8) return NSP_EINVAL;
   if (!aligned16(p.A) || !aligned16(p.B)) return NSP_EINVAL;
-  // the contiguous extent of every 16-B chunk must lie inside the matrix
-  if ((a_kc ? p.K : p.M) % 8 || (b_kc ? p.K : p.N) % 8) return NSP_EINVAL;
+  // every 16-B chunk along the contiguous index must be readable: either the extent is a
+  // multiple of 8 or the leading dimension is padded to one (pad values must be finite; the
+  // other operand's zero fill of the reduction tail / the epilogue's bounds make them inert)
+  const int a_ext = a_kc ? p.K : p.M, b_ext = b_kc ? p.K : p.N;
+  if ((a_ext % 8) && lda < ((a_ext + 7) / 8) * 8) return NSP_EINVAL;
+  if ((b_ext % 8) && ldb < ((b_ext + 7) / 8) * 8) return NSP_EINVAL;
   const int tiles_m = nsp_cdiv(p.M, BM), tiles_n = nsp_cdiv(p.N, BN);
   const int csz = p.c_dtype == NSP_DT_BF16 ? 2 : 4;
   int c_vec = (reinterpret_cast<uintptr_t>(p.C) % (4 * csz) == 0) && p.ldc % 4 == 0 && p.c_b1 % 4 == 0 &&
@@ -342,7 +346,7 @@ extern "C" int nsp_cast_bf16(const float* x, void* out, long long rows, int cols
   if (rows <= 0 || cols <= 0) return NSP_OK;
   if (ld_out % 8 || ld_out < cols || (reinterpret_cast<uintptr_t>(out) & 15)) return NSP_EINVAL;
   const int vec_in = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && ld_in % 4 == 0;
-  long long n = rows * (ld_out / 8);
+  long long n = rows * ((cols + 7) / 8);
   long long g = (n + 255) / 256;
   if (g > 256 * 16) g = 256 * 16;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x,

@@ -164,6 +164,19 @@ class RelativeMultiheadAttentionMechanism(nn.Module):
         if klen != qlen:
             raise NotImplementedError('streaming cache (klen != qlen) is inference-only and out of scope')
         H, dk = self.n_heads, self.d_k
+        d = H * dk
+        if (ops.bf16_mode() and u_bias is None and v_bias is None and d % 8 == 0 and dk % 8 == 0
+                and self.w_out.weight.shape[0] == d):
+            pe = pos_embs.reshape(-1, pos_embs.shape[-1])
+            R = min(self.clamp_len + 1, klen) if self.clamp_len > 0 else klen
+            w_pos = self.w_pos if self.xl_like else self.w_value
+            cfg = mask.cfg() if mask is not None else {}
+            cfg.update(H=H, clamp=self.clamp_len, dropout=self.dropout_attn_p, training=self.training)
+            return ops.SelfAttnFn.apply(key, self.w_query.weight, self.w_key.weight, self.w_value.weight,
+                                        self.w_query.bias, self.w_key.bias, self.w_value.bias,
+                                        self.w_out.weight, self.w_out.bias, pe[:R], w_pos.weight,
+                                        mask.klens if mask is not None else None, cfg, residual,
+                                        out_dropout if self.training else 0.0)
         k = ops.linear(key, self.w_key.weight, self.w_key.bias).view(bs, klen, H, dk)
         v = ops.linear(key, self.w_value.weight, self.w_value.bias).view(bs, klen, H, dk)
         q = ops.linear(key, self.w_query.weight, self.w_query.bias).view(bs, qlen, H, dk)
@@ -224,6 +237,17 @@ class MultiheadAttentionMechanism(nn.Module):
         H, dk = self.n_heads, self.d_k
         if self.dropout_head > 0 and self.training:
             raise NotImplementedError('HeadDrop in the plain MHA encoder path')
+        d = H * dk
+        if (ops.bf16_mode() and key is value and key is query and d % 8 == 0 and dk % 8 == 0
+                and self.w_out.weight.shape[0] == d and key.shape[-1] == d):
+            cfg = mask.cfg() if mask is not None else {}
+            cfg.update(H=H, clamp=-1, dropout=self.dropout_attn_p, training=self.training)
+            cv, aw = ops.SelfAttnFn.apply(key, self.w_query.weight, self.w_key.weight, self.w_value.weight,
+                                          self.w_query.bias, self.w_key.bias, self.w_value.bias,
+                                          self.w_out.weight, self.w_out.bias, None, None,
+                                          mask.klens if mask is not None else None, cfg, residual,
+                                          out_dropout if self.training else 0.0)
+            return cv, aw, {}
         k = ops.linear(key, self.w_key.weight, self.w_key.bias).view(bs, klen, H, dk)
         v = ops.linear(value, self.w_value.weight, self.w_value.bias).view(bs, klen, H, dk)
         q = ops.linear(query, self.w_query.weight, self.w_query.bias).view(bs, qlen, H, dk)

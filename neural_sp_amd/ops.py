@@ -455,7 +455,7 @@ def layer_norm(x, gamma, beta, eps=1e-12, act='none'):
 # Attention (score GEMMs + fused masked/relative softmax)
 # --------------------------------------------------------------------------
 def _mask_params(B, H, Tq, Tk, R, clamp, scale, klens, causal=False, lookahead=0,
-                 chunk_nl=0, chunk_nc=0, dropout_p=0.0, seed=0, offset=0):
+                 chunk_nl=0, chunk_nc=0, dropout_p=0.0, seed=0, offset=0, p_bf16=0, tk_pitch=0, r_pitch=0):
     p = AttnMaskParams()
     p.B, p.H, p.Tq, p.Tk, p.R = B, H, Tq, Tk, R
     p.clamp = int(clamp)
@@ -465,17 +465,20 @@ def _mask_params(B, H, Tq, Tk, R, clamp, scale, klens, causal=False, lookahead=0
     p.chunk_nl, p.chunk_nc = int(chunk_nl), int(chunk_nc)
     p.dropout_p = float(dropout_p)
     p.seed, p.offset = int(seed), int(offset)
+    p.p_bf16, p.tk_pitch, p.r_pitch = int(p_bf16), int(tk_pitch or Tk), int(r_pitch or R)
     return p
 
 
-def attn_softmax_fwd_raw(S, QP, mp, Pdrop=None):
-    _check(_lib.lib().nsp_attn_softmax_fwd(_p(S), _p(QP), _p(Pdrop), ctypes.byref(mp), _stream()),
-           'nsp_attn_softmax_fwd')
+def attn_softmax_fwd_raw(S, QP, mp, Pdrop=None, Pout=None):
+    """softmax in place over S (fp32) unless Pout (bf16 image) is given."""
+    _check(_lib.lib().nsp_attn_softmax_fwd(_p(S), _p(QP), _p(Pout if Pout is not None else S), _p(Pdrop),
+                                           ctypes.byref(mp), _stream()), 'nsp_attn_softmax_fwd')
 
 
-def attn_softmax_bwd_raw(P, dP, dQP, mp):
-    _check(_lib.lib().nsp_attn_softmax_bwd(_p(P), _p(dP), _p(dQP), ctypes.byref(mp), _stream()),
-           'nsp_attn_softmax_bwd')
+def attn_softmax_bwd_raw(P, dP, dQP, mp, dS=None):
+    """dS in place over dP (fp32) unless dS (bf16 image) is given."""
+    _check(_lib.lib().nsp_attn_softmax_bwd(_p(P), _p(dP), _p(dS if dS is not None else dP), _p(dQP),
+                                           ctypes.byref(mp), _stream()), 'nsp_attn_softmax_bwd')
 
 
 class AttentionFn(torch.autograd.Function):
@@ -1139,3 +1142,154 @@ class FFNFn(torch.autograd.Function):
 def ffn(x, w1, b1, w2, b2, act, p_h=0.0, res=None, alpha=1.0, p_o=0.0):
     return FFNFn.apply(x, w1, b1, w2, b2, ACT[act] if not isinstance(act, int) else act,
                        float(p_h), res, float(alpha), float(p_o))
+
+
+# --------------------------------------------------------------------------
+# fused self-attention block (bf16 throughput mode)
+# --------------------------------------------------------------------------
+def _stacked_weight_bf16(ws):
+    """bf16 [sum N_i, K] stack of several [N_i, K] parameters (e.g. W_q;W_k;W_v), cached on the first."""
+    ver = tuple(w._version for w in ws)
+    ent = getattr(ws[0], '_nsp_stack16', None)
+    if ent is not None and ent[0] == ver and ent[1].device == ws[0].device and ent[2] == len(ws):
+        return ent[1]
+    wb = torch.cat([weight_bf16(w) for w in ws], dim=0).contiguous()
+    try:
+        ws[0]._nsp_stack16 = (ver, wb, len(ws))
+    except Exception:
+        pass
+    return wb
+
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+class SelfAttnFn(torch.autograd.Function):
+    """out = res + dropout_o( softmax((q k^T + shift(q pos^T))/sqrt(dk), masks) v  W_o^T + b_o )
+    with q,k,v = x [W_q;W_k;W_v]^T (+biases), for RelMHA (pos_in given) and plain MHA (pos_in None).
+
+    bf16-mode implementation of relative_multihead_attention.py:146-220 /
+    multihead_attention.py:93-157 as ONE autograd node: one stacked QKV GEMM (bf16 out), score /
+    context / gradient GEMMs on the bf16 MFMA kernel, probabilities kept only as a bf16 image
+    [B,H,Tq,roundup8(Tk)], relative term as a [., roundup8(R)] table.  x may carry a bf16 shadow
+    (from LayerNorm).  w_pos is the matrix that projects the position table (w_value itself in
+    the reference's non-XL mode, :176): its gradient from the table path is returned separately
+    and autograd sums it with the value-projection gradient."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, bq, bk, bv, wo, bo, pos_in, w_pos, klens, cfg, res, p_o):
+        B, T, d = x.shape
+        H = cfg['H']
+        dk = d // H
+        dev = x.device
+        M = B * T
+        sh = getattr(x, '_nsp16', None)
+        x16 = sh.reshape(M, d) if sh is not None else to_bf16(_f32c(x).reshape(M, d))
+        wqkv = _stacked_weight_bf16([wq, wk, wv])
+        bqkv = torch.cat([bq, bk, bv]) if bq is not None else None
+        d3 = 3 * d
+        qkv = torch.empty((M, d3), device=dev, dtype=torch.bfloat16)
+        gemm_raw(M, d3, d, x16, d, 1, wqkv, 1, d, qkv, d3, bias=bqkv)
+        clamp = cfg.get('clamp', -1)
+        Tkp = _r8(T)
+        S = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)
+        gemm_raw(T, T, dk, qkv, d3, 1, qkv, 1, d3, S, T, batch=(B, H), a_b=(T * d3, dk),
+                 b_b=(T * d3, dk), c_b=(H * T * T, T * T), b_off=d)
+        QP = pos16 = pe16 = None
+        R = Rp = 0
+        if pos_in is not None:
+            R = pos_in.shape[0]
+            Rp = _r8(R)
+            pe16 = torch.zeros((Rp, d), device=dev, dtype=torch.bfloat16)  # rows >= R stay zero
+            pe16[:R] = to_bf16(_f32c(pos_in))
+            pos16 = torch.empty((Rp, d), device=dev, dtype=torch.bfloat16)
+            gemm_raw(Rp, d, d, pe16, d, 1, weight_bf16(w_pos), 1, d, pos16, d)
+            QP = torch.empty((B, T, H, Rp), device=dev, dtype=torch.float32)
+            gemm_raw(M, Rp, dk, qkv, d3, 1, pos16, 1, d, QP, H * Rp, batch=(H, 1), a_b=(dk, 0),
+                     b_b=(dk, 0), c_b=(Rp, 0))
+        p_att = cfg.get('dropout', 0.0) if cfg.get('training', False) else 0.0
+        seed, offset = next_dropout_seed() if p_att > 0 else (0, 0)
+        mask_args = (cfg.get('causal', False), cfg.get('lookahead', 0), cfg.get('chunk_nl', 0),
+                     cfg.get('chunk_nc', 0), p_att, seed, offset)
+        scale = 1.0 / math.sqrt(dk)
+        mp = _mask_params(B, H, T, T, R, clamp, scale, klens, *mask_args, p_bf16=1, tk_pitch=Tkp, r_pitch=Rp)
+        P16 = torch.empty((B, H, T, Tkp), device=dev, dtype=torch.bfloat16)
+        Pd16 = torch.empty_like(P16) if p_att > 0 else None
+        attn_softmax_fwd_raw(S, QP, mp, Pd16, Pout=P16)
+        del S
+        Puse = Pd16 if Pd16 is not None else P16
+        cv16 = torch.empty((M, d), device=dev, dtype=torch.bfloat16)
+        gemm_raw(T, dk, T, Puse, Tkp, 1, qkv, d3, 1, cv16, d, batch=(B, H), a_b=(H * T * Tkp, T * Tkp),
+                 b_b=(T * d3, dk), c_b=(T * d, dk), b_off=2 * d)
+        s_o = next_dropout_seed() if p_o > 0 else (0, 0)
+        res2d = _f32c(res).reshape(M, d) if res is not None else None
+        out = linear_fwd(cv16, wo, bo, 0, res2d, 1.0, dropout_p=p_o, seed=s_o[0], offset=s_o[1])
+        ctx.save_for_backward(x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens)
+        ctx.cfg = (B, T, d, H, dk, R, Rp, Tkp, clamp, scale, mask_args, p_o, s_o, res is not None,
+                   bq is not None, bo is not None)
+        ctx.mark_non_differentiable(P16)
+        return out.view(B, T, d), P16
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens = ctx.saved_tensors
+        (B, T, d, H, dk, R, Rp, Tkp, clamp, scale, mask_args, p_o, s_o, has_res, has_qkv_bias,
+         has_o_bias) = ctx.cfg
+        has_pos = pos16 is not None
+        dev = dy.device
+        M, d3 = B * T, 3 * d
+        dy2d = _f32c(dy).reshape(M, d)
+        g = grad_prep(dy2d, None, 0, 1.0, p_o, s_o[0], s_o[1], True)
+        dwo = linear_wgrad(g, cv16).view(wo.shape)
+        dbo = colsum(g) if has_o_bias else None
+        dO = linear_dgrad(g, wo, out_bf16=True)                                   # [M, d] bf16
+        dP = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)           # dP = dO v^T
+        gemm_raw(T, T, dk, dO, d, 1, qkv, 1, d3, dP, T, batch=(B, H), a_b=(T * d, dk),
+                 b_b=(T * d3, dk), c_b=(H * T * T, T * T), b_off=2 * d)
+        dqkv = torch.empty((M, d3), device=dev, dtype=torch.bfloat16)
+        Puse = Pd16 if Pd16 is not None else P16
+        gemm_raw(T, dk, T, Puse, 1, Tkp, dO, d, 1, dqkv, d3, batch=(B, H),           # dV = P^T dO
+                 a_b=(H * T * Tkp, T * Tkp), b_b=(T * d, dk), c_b=(T * d3, dk), c_off=2 * d)
+        mp = _mask_params(B, H, T, T, R, clamp, scale, klens, *mask_args, p_bf16=1, tk_pitch=Tkp, r_pitch=Rp)
+        dS16 = torch.empty((B, H, T, Tkp), device=dev, dtype=torch.bfloat16)
+        dQP = torch.empty((B, T, H, Rp), device=dev, dtype=torch.float32) if has_pos else None
+        attn_softmax_bwd_raw(P16, dP, dQP, mp, dS=dS16)
+        del dP
+        dq_pos = dw_pos = None
+        if has_pos:
+            dQP16 = to_bf16(dQP.view(M * H, Rp)).view(M, H * Rp)
+            dq_pos = torch.empty((M, d), device=dev, dtype=torch.float32)            # dQP pos
+            gemm_raw(M, dk, Rp, dQP16, H * Rp, 1, pos16, d, 1, dq_pos, d, batch=(H, 1), a_b=(Rp, 0),
+                     b_b=(dk, 0), c_b=(dk, 0))
+            if ctx.needs_input_grad[10]:
+                dpos = torch.empty((Rp, d), device=dev, dtype=torch.float32)         # dQP^T q
+                gemm_raw(Rp, dk, M, dQP16, 1, H * Rp, qkv, d3, 1, dpos, d, batch=(H, 1), a_b=(Rp, 0),
+                         b_b=(dk, 0), c_b=(dk, 0))
+                dpos16 = to_bf16(dpos)
+                dw_pos = torch.empty((d, d), device=dev, dtype=torch.float32)        # dpos^T pe
+                gemm_raw(d, d, Rp, dpos16, 1, d, pe16, d, 1, dw_pos, d)
+                dw_pos = dw_pos.view(w_pos.shape)
+        if has_pos:
+            # dq = dS k accumulated in fp32 on top of the position-term gradient, then cast
+            gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dq_pos, d, batch=(B, H),
+                     a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d, dk), b_off=d, res=dq_pos)
+            _check(_lib.lib().nsp_cast_bf16(_p(dq_pos), _p(dqkv), ctypes.c_longlong(M), ctypes.c_int(d),
+                                            ctypes.c_longlong(d), ctypes.c_longlong(d3), _stream()),
+                   'nsp_cast_bf16')
+        else:
+            gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dqkv, d3, batch=(B, H),
+                     a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d3, dk), b_off=d)
+        gemm_raw(T, dk, T, dS16, 1, Tkp, qkv, d3, 1, dqkv, d3, batch=(B, H),           # dk = dS^T q
+                 a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d3, dk), c_off=d)
+        dwqkv = linear_wgrad(dqkv, x16)                                            # [3d, d]
+        dbqkv = colsum(dqkv) if has_qkv_bias else None
+        wqkv = _stacked_weight_bf16([wq, wk, wv])
+        dx = torch.empty((M, d), device=dev, dtype=torch.float32)
+        gemm_raw(M, d, d3, dqkv, d3, 1, wqkv, d, 1, dx, d)
+        dwq, dwk, dwv = dwqkv[:d].view(wq.shape), dwqkv[d:2 * d].view(wk.shape), dwqkv[2 * d:].view(wv.shape)
+        dbq = dbk = dbv = None
+        if has_qkv_bias:
+            dbq, dbk, dbv = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
+        return (dx.view(B, T, d), dwq, dwk, dwv, dbq, dbk, dbv, dwo, dbo, None, dw_pos, None, None,
+                (dy if has_res else None), None)
