@@ -94,7 +94,7 @@ def main():
     model = Speech2Text(margs).to(dev)
     n_params = model.total_parameters
     train_model = parallel.wrap_ddp(model, local_rank) if distributed else model
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, fused=True)
     batches = [synthetic_batch(B=a.batch, t_range=(a.tmin, a.tmax), u_range=(a.umin, a.umax),
                                vocab=1000, seed=1000 * rank + i) for i in range(4)]
 

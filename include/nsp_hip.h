@@ -285,16 +285,21 @@ int nsp_rnnt_logsoftmax_gather(const float* logits, const int* labels, const int
 int nsp_rnnt_lattice(const float* lp_blank, const float* lp_label, const int* elens,
                      const int* ylens, float* alpha, float* beta, float* nll,
                      float* g_blank, float* g_label, int B, int T, int U1, void* stream);
+/* out16 == NULL: logits are overwritten in place with the gradient (fp32); otherwise the
+ * gradient is written as a bf16 image [rows, ld16] (ld16 >= V, zero padded) and logits are
+ * left untouched. */
 int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* labels,
                          const float* g_blank, const float* g_label, const int* elens,
                          const int* ylens, float wscale,
-                         int B, int T, int U1, int V, int blank, void* stream);
+                         int B, int T, int U1, int V, int blank, void* out16, int ld16,
+                         void* stream);
 /* joint pre-activation: h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:]) and its backward
  * reductions (rnn_transducer.py:272-274) */
-int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h,
+/* h (fp32) and/or h16 (bf16) receive the activation */
+int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h, void* h16,
                             int B, int T, int U1, int J, void* stream);
 /* dh is overwritten with dz = dh*(1-h^2); de[b,t,:] = sum_u dz, dg[b,u,:] = sum_t dz */
-int nsp_rnnt_joint_tanh_bwd(const float* h, float* dh, float* de, float* dg,
+int nsp_rnnt_joint_tanh_bwd(const float* h, const void* h16, float* dh, float* de, float* dg,
                             int B, int T, int U1, int J, void* stream);
 
 /* ------------------------------------------------------------------------ *

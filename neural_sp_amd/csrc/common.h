@@ -63,11 +63,15 @@ __device__ __forceinline__ float nsp_dact(float x, int act) {
 // Counter-based RNG for dropout masks: a keep decision is a pure function of
 // (seed, offset + element index), so backward regenerates the forward mask.
 __device__ __forceinline__ uint32_t nsp_hash_u32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  // 32-bit murmur3-style finaliser over (idx_lo, idx_hi ^ seed): three 32-bit multiplies
+  // (the 64-bit splitmix used before cost ~4x more VALU in the GEMM epilogues)
+  uint32_t x = (uint32_t)idx ^ ((uint32_t)seed * 0x9E3779B9u);
+  uint32_t hi = (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32);
+  x ^= hi * 0x85EBCA6Bu + 0x632BE5ABu;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
 }
 __device__ __forceinline__ float nsp_keep_scale(unsigned long long seed, unsigned long long idx,
                                                 float p) {

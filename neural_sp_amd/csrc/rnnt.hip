@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
     float* __restrict__ logits, const float* __restrict__ lse, const int* __restrict__ labels,
     const float* __restrict__ g_blank, const float* __restrict__ g_label,
     const int* __restrict__ elens, const int* __restrict__ ylens, float wscale, int B, int T, int U1,
-    int V, int blank) {
+    int V, int blank, __bf16* __restrict__ out16, int ld16) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long nrows = (long long)B * T * U1;
   const int U = U1 - 1;
@@ -153,19 +153,26 @@ __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
     const int t = (int)((row / U1) % T);
     const int b = (int)(row / ((long long)U1 * T));
     float* xr = logits + row * V;
+    __bf16* o16 = out16 ? out16 + row * ld16 : nullptr;
     if (t >= elens[b] || u > ylens[b]) {
-      for (int v = lane; v < V; v += 64) xr[v] = 0.f;
+      if (o16) { for (int v = lane; v < ld16; v += 64) o16[v] = (__bf16)0.f; }
+      else { for (int v = lane; v < V; v += 64) xr[v] = 0.f; }
       continue;
     }
     const float ls = lse[row];
     const float gb = g_blank[row], gl = g_label[row];
     const int lab = (u < ylens[b] && u < U) ? labels[(long long)b * U + u] : -1;
     const float gsum = gb + gl;
-    for (int v = lane; v < V; v += 64) {
-      float g = -gsum * expf(xr[v] - ls);
-      if (v == blank) g += gb;
-      if (v == lab) g += gl;
-      xr[v] = wscale * g;
+    for (int v = lane; v < (o16 ? ld16 : V); v += 64) {
+      float g = 0.f;
+      if (v < V) {
+        g = -gsum * expf(xr[v] - ls);
+        if (v == blank) g += gb;
+        if (v == lab) g += gl;
+        g *= wscale;
+      }
+      if (o16) o16[v] = (__bf16)g;   // bf16 image (pitch ld16, zero padded) for the MFMA GEMMs
+      else xr[v] = g;
     }
   }
 }
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
 __global__ __launch_bounds__(256) void joint_tanh_fwd_kernel(const float* __restrict__ e,
                                                              const float* __restrict__ g,
                                                              float* __restrict__ h, int B, int T,
-                                                             int U1, int J) {
+                                                             int U1, int J, __bf16* __restrict__ h16) {
   const int J4 = J >> 2;
   const long long total = (long long)B * T * U1 * J4;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -185,13 +192,19 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_kernel(const float* __rest
     const long long b = idx / ((long long)J4 * U1 * T);
     const float4 ev = reinterpret_cast<const float4*>(e + (b * T + t) * J)[j4];
     const float4 gv = reinterpret_cast<const float4*>(g + (b * U1 + u) * J)[j4];
-    reinterpret_cast<float4*>(h)[idx] =
-        make_float4(tanhf(ev.x + gv.x), tanhf(ev.y + gv.y), tanhf(ev.z + gv.z), tanhf(ev.w + gv.w));
+    const float4 o = make_float4(tanhf(ev.x + gv.x), tanhf(ev.y + gv.y), tanhf(ev.z + gv.z), tanhf(ev.w + gv.w));
+    if (h) reinterpret_cast<float4*>(h)[idx] = o;
+    if (h16) {
+      bf16x4 q;
+      q[0] = (__bf16)o.x; q[1] = (__bf16)o.y; q[2] = (__bf16)o.z; q[3] = (__bf16)o.w;
+      reinterpret_cast<bf16x4*>(h16)[idx] = q;
+    }
   }
 }
 
 // dz = dh * (1 - h^2) written in place over dh; de[b,t,:] = sum_u dz
 __global__ __launch_bounds__(256) void joint_tanh_bwd_de_kernel(const float* __restrict__ h,
+                                                                const __bf16* __restrict__ h16,
                                                                 float* __restrict__ dh,
                                                                 float* __restrict__ de, int B, int T,
                                                                 int U1, int J) {
@@ -201,7 +214,13 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_de_kernel(const float* __r
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int u = 0; u < U1; ++u) {
       const long long o = (bt * U1 + u) * J4 + j4;
-      const float4 hv = reinterpret_cast<const float4*>(h)[o];
+      float4 hv;
+      if (h16) {
+        const bf16x4 q = reinterpret_cast<const bf16x4*>(h16)[o];
+        hv = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+      } else {
+        hv = reinterpret_cast<const float4*>(h)[o];
+      }
       float4 dv = reinterpret_cast<float4*>(dh)[o];
       dv.x *= (1.f - hv.x * hv.x); dv.y *= (1.f - hv.y * hv.y);
       dv.z *= (1.f - hv.z * hv.z); dv.w *= (1.f - hv.w * hv.w);
@@ -264,32 +283,36 @@ extern "C" int nsp_rnnt_lattice(const float* lp_blank, const float* lp_label, co
 extern "C" int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* labels,
                                     const float* g_blank, const float* g_label, const int* elens,
                                     const int* ylens, float wscale, int B, int T, int U1, int V,
-                                    int blank, void* stream) {
+                                    int blank, void* out16, int ld16, void* stream) {
+  if (out16 && ld16 < V) return NSP_EINVAL;
   int grid = nsp_cdiv((long long)B * T * U1, 4);
   if (grid > 256 * 32) grid = 256 * 32;
   hipLaunchKernelGGL(rnnt_grad_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits,
-                     lse, labels, g_blank, g_label, elens, ylens, wscale, B, T, U1, V, blank);
+                     lse, labels, g_blank, g_label, elens, ylens, wscale, B, T, U1, V, blank,
+                     reinterpret_cast<__bf16*>(out16), ld16);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
 
-extern "C" int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h, int B, int T, int U1,
-                                       int J, void* stream) {
+extern "C" int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h, void* h16, int B,
+                                       int T, int U1, int J, void* stream) {
   if (J % 4) return NSP_EUNSUPPORTED;
+  if (!h && !h16) return NSP_EINVAL;
   long long n = (long long)B * T * U1 * (J / 4);
   long long gr = (n + 255) / 256;
   if (gr > 256 * 32) gr = 256 * 32;
   hipLaunchKernelGGL(joint_tanh_fwd_kernel, dim3((int)gr), dim3(256), 0, (hipStream_t)stream, e, g, h,
-                     B, T, U1, J);
+                     B, T, U1, J, reinterpret_cast<__bf16*>(h16));
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
 
-extern "C" int nsp_rnnt_joint_tanh_bwd(const float* h, float* dh, float* de, float* dg, int B, int T,
-                                       int U1, int J, void* stream) {
+extern "C" int nsp_rnnt_joint_tanh_bwd(const float* h, const void* h16, float* dh, float* de,
+                                       float* dg, int B, int T, int U1, int J, void* stream) {
   if (J % 4) return NSP_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(joint_tanh_bwd_de_kernel, dim3(B * T), dim3(128), 0, st, h, dh, de, B, T, U1, J);
+  hipLaunchKernelGGL(joint_tanh_bwd_de_kernel, dim3(B * T), dim3(128), 0, st, h,
+                     reinterpret_cast<const __bf16*>(h16), dh, de, B, T, U1, J);
   hipLaunchKernelGGL(joint_tanh_bwd_dg_kernel, dim3(B * U1), dim3(128), 0, st, dh, dg, B, T, U1, J);
   NSP_LAUNCH_CHECK();
   return NSP_OK;

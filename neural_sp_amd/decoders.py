@@ -7,6 +7,7 @@ loss_fn :139-150, CTCForcedAligner :628-753), rnn_transducer.py (RNNTransducer._
 rnn_transducer.py:330-819) is inference and out of scope.
 """
 import logging
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -196,16 +197,47 @@ class RNNTransducer(DecoderBase):
         observation['loss'] = tensor2scalar(loss)
         return loss, observation
 
+    def _prediction_network(self, ys, dev):
+        """ys -> w_dec(recurrency(embed([eos]+y)))  `[B, L+1, J]` (rnn_transducer.py:229-236,273)."""
+        L = max(len(y) for y in ys) + 1
+        ys_in_np = np.full((len(ys), L), self.pad, dtype=np.int64)
+        for b, y in enumerate(ys):
+            ys_in_np[b, 0] = self.eos
+            ys_in_np[b, 1:len(y) + 1] = np.asarray(y, dtype=np.int64)
+        ys_in = torch.from_numpy(ys_in_np).to(dev)
+        dout, _ = self.recurrency(self.embed_token_id(ys_in), None)
+        return ops.linear(dout, self.w_dec.weight, None)
+
+    def start_prediction_network(self, ys):
+        """Launch the prediction network on a side HIP stream.  It depends only on the labels,
+        so its ~400 small sequential LSTM-step kernels (64 workgroups each) overlap with the
+        encoder instead of serialising after it; forward_transducer joins the stream.  The
+        autograd engine replays the backward of these nodes on the same side stream."""
+        if self.rnnt_weight <= 0 or not torch.cuda.is_available() or os.environ.get('NSP_PREDNET_STREAM', '1') == '0':
+            return
+        dev = self.device
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        self._side_stream.wait_stream(cur)
+        with torch.cuda.stream(self._side_stream):
+            dec_proj = self._prediction_network(ys, dev)
+        self._pending_dec_proj = (dec_proj, id(ys))
+
     def forward_transducer(self, eouts, elens, ys):
         dev = eouts.device
-        _ys = [np2tensor(np.fromiter(y, dtype=np.int64), dev) for y in ys]
-        eos = eouts.new_zeros((1,), dtype=torch.int64).fill_(self.eos)
-        ys_in = pad_list([torch.cat([eos, y], dim=0) for y in _ys], self.pad)  # `[B, L+1]`
         lab, ylens_dev, _ = _labels_to_device(ys, dev, pad=self.blank)         # ys_out, blank-padded
         elens_dev = elens.to(device=dev, dtype=torch.int32)
-        dout, _ = self.recurrency(self.embed_token_id(ys_in), None)
+        pending = getattr(self, '_pending_dec_proj', None)
+        self._pending_dec_proj = None
+        if pending is not None and pending[1] == id(ys):
+            dec_proj = pending[0]
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(self._side_stream)
+            dec_proj.record_stream(cur)
+        else:
+            dec_proj = self._prediction_network(ys, dev)                        # `[B,L+1,J]`
         enc_proj = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias)       # `[B,T,J]`
-        dec_proj = ops.linear(dout, self.w_dec.weight, None)                    # `[B,L+1,J]`
         loss, _ = ops.rnnt_joint_loss(enc_proj, dec_proj, self.output.weight, self.output.bias,
                                       lab, elens_dev, ylens_dev, self.blank)
         return loss

@@ -843,21 +843,23 @@ class RNNTJointLossFn(torch.autograd.Function):
     """mean_b -log P(y_b | x_b) of the RNN-Transducer from the joint inputs
     (rnn_transducer.py:239-256,262-276):
         h = tanh(enc_proj[B,T,1,J] + dec_proj[B,1,U+1,J]); logits = h W_out^T + b_out
-    The lattice works on (lse, lp_blank, lp_label) only; backward turns the saved
-    logits into d loss/d logits in place and contracts them with the MFMA GEMMs."""
+    The lattice works on (lse, lp_blank, lp_label) only; backward turns the saved logits into
+    d loss/d logits (a bf16 image in bf16 mode) and contracts them with the MFMA GEMMs."""
 
     @staticmethod
     def forward(ctx, enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blank):
-        enc_proj, dec_proj, w_out = _f32c(enc_proj), _f32c(dec_proj), _f32c(w_out)
+        enc_proj, dec_proj = _f32c(enc_proj), _f32c(dec_proj)
         B, T, J = enc_proj.shape
         U1 = dec_proj.shape[1]
         V = w_out.shape[0]
         dev = enc_proj.device
         L = _lib.lib()
-        h = torch.empty((B, T, U1, J), device=dev, dtype=torch.float32)
-        _check(L.nsp_rnnt_joint_tanh_fwd(_p(enc_proj), _p(dec_proj), _p(h), ctypes.c_int(B), ctypes.c_int(T),
+        use16 = bf16_mode() and J % 8 == 0
+        h = torch.empty((B, T, U1, J), device=dev, dtype=torch.bfloat16 if use16 else torch.float32)
+        _check(L.nsp_rnnt_joint_tanh_fwd(_p(enc_proj), _p(dec_proj), _p(None if use16 else h),
+                                         _p(h if use16 else None), ctypes.c_int(B), ctypes.c_int(T),
                                          ctypes.c_int(U1), ctypes.c_int(J), _stream()), 'nsp_rnnt_joint_tanh_fwd')
-        logits = linear_fwd(h.view(-1, J), w_out, b_out)  # [B*T*U1, V]
+        logits = linear_fwd(h.view(-1, J), w_out, b_out)  # [B*T*U1, V] fp32
         n = B * T * U1
         aux = torch.empty((7, n), device=dev, dtype=torch.float32)  # lse, lpb, lpl, alpha, beta, gb, gl
         nll = torch.empty((B,), device=dev, dtype=torch.float32)
@@ -869,7 +871,7 @@ class RNNTJointLossFn(torch.autograd.Function):
                                   _p(nll), _p(aux[5]), _p(aux[6]), ctypes.c_int(B), ctypes.c_int(T),
                                   ctypes.c_int(U1), _stream()), 'nsp_rnnt_lattice')
         ctx.save_for_backward(h, logits, aux, w_out, labels, elens, ylens)
-        ctx.dims = (B, T, U1, J, V, blank)
+        ctx.dims = (B, T, U1, J, V, blank, use16)
         ctx.has_bias = b_out is not None
         ctx.mark_non_differentiable(nll)
         return nll.mean().view(1), nll
@@ -877,24 +879,45 @@ class RNNTJointLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _dnll):
         h, logits, aux, w_out, labels, elens, ylens = ctx.saved_tensors
-        B, T, U1, J, V, blank = ctx.dims
+        B, T, U1, J, V, blank, use16 = ctx.dims
         L = _lib.lib()
-        # logits <- d loss / d logits (in place; the saved buffer is consumed)
+        n = B * T * U1
         wscale = float(dloss.item()) / B
+        Vp = _r8(V)
+        d16 = torch.empty((n, Vp), device=h.device, dtype=torch.bfloat16) if use16 else None
         _check(L.nsp_rnnt_grad_logits(_p(logits), _p(aux[0]), _p(labels), _p(aux[5]), _p(aux[6]),
                                       _p(elens), _p(ylens), ctypes.c_float(wscale), ctypes.c_int(B),
                                       ctypes.c_int(T), ctypes.c_int(U1), ctypes.c_int(V),
-                                      ctypes.c_int(blank), _stream()), 'nsp_rnnt_grad_logits')
-        dlogits = logits
+                                      ctypes.c_int(blank), _p(d16), ctypes.c_int(Vp), _stream()),
+               'nsp_rnnt_grad_logits')
+        dlogits = d16[:, :V] if use16 else logits   # bf16 image view (pitch Vp) or in-place fp32
         h2d = h.view(-1, J)
-        dw = linear_wgrad(dlogits, h2d)
-        db = colsum(dlogits) if ctx.has_bias else None
-        dh = linear_dgrad(dlogits, w_out)  # [B*T*U1, J]
+        if use16:
+            # operands are already bf16 images: call the GEMMs directly (pitch Vp on dlogits)
+            sk = _pick_splitk(V, J, n)
+            part = torch.empty((sk, V, J), device=h.device, dtype=torch.float32)
+            gemm_raw(V, J, n, d16, 1, Vp, h2d, J, 1, part, J, splitk=sk, c_ss=V * J)
+            dw = torch.empty((V, J), device=h.device, dtype=torch.float32)
+            _check(L.nsp_splitk_reduce(_p(part), _p(dw), ctypes.c_int(sk), ctypes.c_longlong(V * J), _stream()),
+                   'nsp_splitk_reduce')
+            wb = weight_bf16(w_out)
+            dh = torch.empty((n, J), device=h.device, dtype=torch.float32)
+            gemm_raw(n, J, V, d16, Vp, 1, wb, wb.stride(0), 1, dh, J)
+            db = None
+            if ctx.has_bias:
+                db = torch.zeros((V,), device=h.device, dtype=torch.float32)
+                _check(L.nsp_colsum_bf16(_p(d16), _p(db), ctypes.c_int(n), ctypes.c_int(V),
+                                         ctypes.c_longlong(Vp), ctypes.c_int(1), _stream()), 'nsp_colsum_bf16')
+        else:
+            dw = linear_wgrad(dlogits, h2d)
+            db = colsum(dlogits) if ctx.has_bias else None
+            dh = linear_dgrad(dlogits, w_out)  # [B*T*U1, J]
         de = torch.empty((B, T, J), device=h.device, dtype=torch.float32)
         dg = torch.empty((B, U1, J), device=h.device, dtype=torch.float32)
-        _check(L.nsp_rnnt_joint_tanh_bwd(_p(h), _p(dh), _p(de), _p(dg), ctypes.c_int(B), ctypes.c_int(T),
-                                         ctypes.c_int(U1), ctypes.c_int(J), _stream()), 'nsp_rnnt_joint_tanh_bwd')
-        return de, dg, dw, db, None, None, None, None
+        _check(L.nsp_rnnt_joint_tanh_bwd(_p(None if use16 else h), _p(h if use16 else None), _p(dh), _p(de),
+                                         _p(dg), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(U1),
+                                         ctypes.c_int(J), _stream()), 'nsp_rnnt_joint_tanh_bwd')
+        return de, dg, dw.view(w_out.shape), db, None, None, None, None
 
 
 def rnnt_joint_loss(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blank=0):

@@ -208,6 +208,8 @@ class Speech2Text(nn.Module):
         return loss, observation
 
     def _forward(self, batch, task):
+        if isinstance(getattr(self, 'dec_fwd', None), RNNT) and (task == 'all' or 'ctc' not in task):
+            self.dec_fwd.start_prediction_network(batch['ys'])  # overlaps with the encoder
         eout_dict = self.encode(batch['xs'], task if self.mtl_per_batch else 'all')
         observation = {}
         loss = torch.zeros((1,), dtype=torch.float32, device=self.device)
