@@ -96,6 +96,16 @@ typedef struct {
 int nsp_splitk_reduce(const float* part, float* out, int splits, long long n, void* stream);
 
 int nsp_gemm(const nsp_gemm_params* p, void* stream);
+/* same call with the struct fields as positional arguments (cheaper to marshal from ctypes) */
+int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs, long long a_cs,
+                  const void* B, long long b_ks, long long b_ns, void* C, long long ldc,
+                  int batch1, int batch2, long long a_b1, long long a_b2, long long b_b1,
+                  long long b_b2, long long c_b1, long long c_b2, const float* bias, int act,
+                  void* pre_out, const void* dact_src, int dact, const float* res,
+                  float alpha, int splitk, int mode, float dropout_p,
+                  unsigned long long seed, unsigned long long offset, int a_dtype,
+                  int b_dtype, int c_dtype, int pre_dtype, int dact_dtype, long long c_ss,
+                  void* stream);
 
 /* ------------------------------------------------------------------------ *
  * LayerNorm over the last dim (eps inside sqrt, biased variance).          *

@@ -123,8 +123,42 @@ def lib():
             raise RuntimeError('libnsp_hip.so missing and no hipcc to build it: the HIP path is '
                                'mandatory, there is no CPU fallback')
         _lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-        _lib.nsp_version.restype = ctypes.c_int
+        _declare_prototypes(_lib)
     return _lib
+
+
+_CTYPES = {'int': ctypes.c_int, 'float': ctypes.c_float, 'long long': ctypes.c_longlong,
+           'unsigned long long': ctypes.c_ulonglong}
+
+
+def prototypes():
+    """{name: (restype, [argtypes])} parsed from include/nsp_hip.h, so that calls can pass plain
+    Python ints / floats / addresses (ctypes converts them in C, no per-argument objects)."""
+    import re
+    hdr = open(os.path.join(_HERE, '..', 'include', 'nsp_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(int|long long)\s+(nsp_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', hdr, re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = ' '.join(a.split())
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                    continue
+                base = a.rsplit(' ', 1)[0] if ' ' in a else a
+                base = base.replace('const ', '').strip()
+                argtypes.append(_CTYPES[base])
+        out[name] = (_CTYPES[ret], argtypes)
+    return out
+
+
+def _declare_prototypes(lib):
+    for name, (ret, argtypes) in prototypes().items():
+        fn = getattr(lib, name)
+        fn.restype = ret
+        fn.argtypes = argtypes
 
 
 def exported_symbols():

@@ -360,3 +360,29 @@ extern "C" int nsp_gemm(const nsp_gemm_params* pp, void* stream) {
 }
 
 extern "C" int nsp_version(void) { return 100; }
+
+// Positional-argument twin of nsp_gemm for FFI layers where filling a struct field by field is
+// the dominant host cost (ctypes): same semantics, same validation.
+extern "C" int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs, long long a_cs,
+                             const void* B, long long b_ks, long long b_ns, void* C, long long ldc,
+                             int batch1, int batch2, long long a_b1, long long a_b2, long long b_b1,
+                             long long b_b2, long long c_b1, long long c_b2, const float* bias, int act,
+                             void* pre_out, const void* dact_src, int dact, const float* res,
+                             float alpha, int splitk, int mode, float dropout_p,
+                             unsigned long long seed, unsigned long long offset, int a_dtype,
+                             int b_dtype, int c_dtype, int pre_dtype, int dact_dtype, long long c_ss,
+                             void* stream) {
+  nsp_gemm_params p;
+  p.M = M; p.N = N; p.K = K;
+  p.A = A; p.a_rs = a_rs; p.a_cs = a_cs;
+  p.B = B; p.b_ks = b_ks; p.b_ns = b_ns;
+  p.C = C; p.ldc = ldc;
+  p.batch1 = batch1; p.batch2 = batch2;
+  p.a_b1 = a_b1; p.a_b2 = a_b2; p.b_b1 = b_b1; p.b_b2 = b_b2; p.c_b1 = c_b1; p.c_b2 = c_b2;
+  p.bias = bias; p.act = act; p.pre_out = pre_out; p.dact_src = dact_src; p.dact = dact;
+  p.res = res; p.alpha = alpha; p.splitk = splitk; p.mode = mode; p.dropout_p = dropout_p;
+  p.seed = seed; p.offset = offset;
+  p.a_dtype = a_dtype; p.b_dtype = b_dtype; p.c_dtype = c_dtype; p.pre_dtype = pre_dtype;
+  p.dact_dtype = dact_dtype; p.c_ss = c_ss;
+  return nsp_gemm(&p, stream);
+}

@@ -49,12 +49,11 @@ def _p(t):
     if t is None:
         return None
     assert t.is_cuda, 'neural_sp_amd ops are HIP-only: got a CPU tensor (no CPU fallback exists)'
-    assert t.dtype in (torch.float32, torch.bfloat16, torch.int32, torch.int64), t.dtype
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _f32c(t):
@@ -77,39 +76,19 @@ def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
              dropout_p=0.0, seed=0, offset=0, c_ss=0):
     """C = epi(A @ B) with arbitrary strides (element offsets *_off into the tensors).
     A/B are both fp32 or both bf16; C / pre_out / dact_src may be fp32 or bf16 with bf16 operands."""
-    p = GemmParams()
-    p.M, p.N, p.K = int(M), int(N), int(K)
-    p.A = A.data_ptr() + A.element_size() * a_off
-    p.a_rs, p.a_cs = int(a_rs), int(a_cs)
-    p.B = B.data_ptr() + B.element_size() * b_off
-    p.b_ks, p.b_ns = int(b_ks), int(b_ns)
-    p.C = C.data_ptr() + C.element_size() * c_off
-    p.ldc = int(ldc)
-    p.batch1, p.batch2 = int(batch[0]), int(batch[1])
-    p.a_b1, p.a_b2 = int(a_b[0]), int(a_b[1])
-    p.b_b1, p.b_b2 = int(b_b[0]), int(b_b[1])
-    p.c_b1, p.c_b2 = int(c_b[0]), int(c_b[1])
-    p.bias = bias.data_ptr() if bias is not None else None
-    p.act = int(act)
-    p.pre_out = pre_out.data_ptr() + pre_out.element_size() * c_off if pre_out is not None else None
-    p.dact_src = dact_src.data_ptr() + dact_src.element_size() * c_off if dact_src is not None else None
-    p.dact = int(dact)
-    p.res = res.data_ptr() + 4 * c_off if res is not None else None
-    p.alpha = float(alpha)
-    p.splitk = int(splitk)
-    p.mode = _COMPUTE_MODE['mode'] if mode is None else int(mode)
-    p.dropout_p = float(dropout_p)
-    p.seed, p.offset = int(seed), int(offset)
-    p.a_dtype, p.b_dtype, p.c_dtype = _dt(A), _dt(B), _dt(C)
-    p.pre_dtype, p.dact_dtype = _dt(pre_out), _dt(dact_src)
-    p.c_ss = int(c_ss)
-    for t in (A, B, C, pre_out, dact_src):
-        if t is not None:
-            assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16)
-    for t in (bias, res):
-        if t is not None:
-            assert t.is_cuda and t.dtype == torch.float32
-    _check(_lib.lib().nsp_gemm(ctypes.byref(p), _stream()), 'nsp_gemm')
+    for t in (A, B, C, pre_out, dact_src, bias, res):
+        if t is not None and not t.is_cuda:
+            raise AssertionError('neural_sp_amd ops are HIP-only: got a CPU tensor (no CPU fallback exists)')
+    esz = A.element_size()
+    _check(_lib.lib().nsp_gemm_flat(
+        M, N, K, A.data_ptr() + esz * a_off, a_rs, a_cs, B.data_ptr() + B.element_size() * b_off, b_ks, b_ns,
+        C.data_ptr() + C.element_size() * c_off, ldc, batch[0], batch[1], a_b[0], a_b[1], b_b[0], b_b[1],
+        c_b[0], c_b[1], bias.data_ptr() if bias is not None else None, act,
+        pre_out.data_ptr() + pre_out.element_size() * c_off if pre_out is not None else None,
+        dact_src.data_ptr() + dact_src.element_size() * c_off if dact_src is not None else None, dact,
+        res.data_ptr() + 4 * c_off if res is not None else None, alpha, splitk,
+        _COMPUTE_MODE['mode'] if mode is None else mode, dropout_p, seed, offset,
+        _dt(A), _dt(B), _dt(C), _dt(pre_out), _dt(dact_src), c_ss, _stream()), 'nsp_gemm')
 
 
 def bf16_mode():
@@ -123,8 +102,8 @@ def to_bf16(x2d):
     rows, cols = x2d.shape
     ld = (cols + 7) // 8 * 8
     out = torch.empty((rows, ld), device=x2d.device, dtype=torch.bfloat16)
-    _check(_lib.lib().nsp_cast_bf16(_p(x2d), _p(out), ctypes.c_longlong(rows), ctypes.c_int(cols),
-                                    ctypes.c_longlong(x2d.stride(0)), ctypes.c_longlong(ld), _stream()),
+    _check(_lib.lib().nsp_cast_bf16(_p(x2d), _p(out), (rows), (cols),
+                                    (x2d.stride(0)), (ld), _stream()),
            'nsp_cast_bf16')
     return out
 
@@ -209,7 +188,7 @@ def linear_wgrad(dy2d, x2d, alpha=1.0):
         gemm_raw(N, K, M, ga, 1, ga.stride(0), xa, xa.stride(0), 1, part, K, alpha=alpha, splitk=sk,
                  c_ss=N * K)
         dw = torch.empty((N, K), device=dy2d.device, dtype=torch.float32)
-        _check(_lib.lib().nsp_splitk_reduce(_p(part), _p(dw), ctypes.c_int(sk), ctypes.c_longlong(N * K),
+        _check(_lib.lib().nsp_splitk_reduce(_p(part), _p(dw), (sk), (N * K),
                                             _stream()), 'nsp_splitk_reduce')
         return dw
     dw = (torch.zeros if sk > 1 else torch.empty)((N, K), device=dy2d.device, dtype=torch.float32)
@@ -234,10 +213,10 @@ def grad_prep(dy2d, pre, act, alpha, p, seed, offset, out_bf16):
             g = axpby(g, None, alpha, 0.0)
         return to_bf16(g) if out_bf16 else g
     out = torch.empty(dy2d.shape, device=dy2d.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-    _check(_lib.lib().nsp_grad_prep(_p(dy2d), _p(pre), ctypes.c_int(_dt(pre)), _p(out),
-                                    ctypes.c_int(int(out_bf16)), ctypes.c_int(act if pre is not None else 0),
-                                    ctypes.c_float(alpha), ctypes.c_float(p), ctypes.c_ulonglong(seed),
-                                    ctypes.c_ulonglong(offset), ctypes.c_longlong(n), _stream()),
+    _check(_lib.lib().nsp_grad_prep(_p(dy2d), _p(pre), (_dt(pre)), _p(out),
+                                    (int(out_bf16)), (act if pre is not None else 0),
+                                    (alpha), (p), (seed),
+                                    (offset), (n), _stream()),
            'nsp_grad_prep')
     return out
 
@@ -246,8 +225,8 @@ def colsum(x2d, alpha=1.0):
     rows, cols = x2d.shape
     out = torch.zeros((cols,), device=x2d.device, dtype=torch.float32)
     fn = _lib.lib().nsp_colsum_bf16 if x2d.dtype == torch.bfloat16 else _lib.lib().nsp_colsum
-    _check(fn(_p(x2d), _p(out), ctypes.c_int(rows), ctypes.c_int(cols),
-              ctypes.c_longlong(x2d.stride(0)), ctypes.c_int(1), _stream()), 'nsp_colsum')
+    _check(fn(_p(x2d), _p(out), (rows), (cols),
+              (x2d.stride(0)), (1), _stream()), 'nsp_colsum')
     if alpha != 1.0:
         out.mul_(alpha)
     return out
@@ -312,9 +291,9 @@ def linear(x, weight, bias=None, act='none', res=None, alpha=1.0, dropout_p=0.0)
 def dropout_raw(x, p, seed, offset, alpha=1.0):
     x = _f32c(x)
     y = torch.empty_like(x)
-    _check(_lib.lib().nsp_dropout(_p(x), _p(y), ctypes.c_float(p), ctypes.c_float(alpha),
-                                  ctypes.c_ulonglong(seed), ctypes.c_ulonglong(offset),
-                                  ctypes.c_longlong(x.numel()), _stream()), 'nsp_dropout')
+    _check(_lib.lib().nsp_dropout(_p(x), _p(y), (p), (alpha),
+                                  (seed), (offset),
+                                  (x.numel()), _stream()), 'nsp_dropout')
     return y
 
 
@@ -375,8 +354,8 @@ def add(x, z, alpha=1.0, beta=1.0):
 def dact_mul(dy, pre, act, alpha=1.0):
     """dy * act'(pre) * alpha (elementwise)."""
     out = torch.empty_like(dy)
-    _check(_lib.lib().nsp_dact_mul(_p(dy), _p(pre), _p(out), ctypes.c_int(act), ctypes.c_float(alpha),
-                                   ctypes.c_longlong(dy.numel()), _stream()), 'nsp_dact_mul')
+    _check(_lib.lib().nsp_dact_mul(_p(dy), _p(pre), _p(out), (act), (alpha),
+                                   (dy.numel()), _stream()), 'nsp_dact_mul')
     return out
 
 
@@ -385,15 +364,15 @@ def axpby(x, z=None, alpha=1.0, beta=1.0, out=None):
     x = _f32c(x)
     z = _f32c(z) if z is not None else None
     out = torch.empty_like(x) if out is None else out
-    _check(_lib.lib().nsp_axpby(_p(x), _p(z), _p(out), ctypes.c_float(alpha), ctypes.c_float(beta),
-                                ctypes.c_longlong(x.numel()), _stream()), 'nsp_axpby')
+    _check(_lib.lib().nsp_axpby(_p(x), _p(z), _p(out), (alpha), (beta),
+                                (x.numel()), _stream()), 'nsp_axpby')
     return out
 
 
 def act_fwd(x, act):
     x = _f32c(x)
     y = torch.empty_like(x)
-    _check(_lib.lib().nsp_act_fwd(_p(x), _p(y), ctypes.c_int(act), ctypes.c_longlong(x.numel()),
+    _check(_lib.lib().nsp_act_fwd(_p(x), _p(y), (act), (x.numel()),
                                   _stream()), 'nsp_act_fwd')
     return y
 
@@ -409,8 +388,8 @@ def layernorm_fwd_raw(x2d, gamma, beta, eps, act=0, want_pre=False, want16=False
     rstd = torch.empty((rows,), device=x2d.device, dtype=torch.float32)
     y_pre = torch.empty_like(x2d) if (act != 0 and want_pre) else None
     _check(_lib.lib().nsp_layernorm_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
-                                        ctypes.c_int(rows), ctypes.c_int(d), ctypes.c_float(eps),
-                                        ctypes.c_int(act), _p(y_pre), _p(y16), _stream()), 'nsp_layernorm_fwd')
+                                        (rows), (d), (eps),
+                                        (act), _p(y_pre), _p(y16), _stream()), 'nsp_layernorm_fwd')
     return y, mean, rstd, y_pre, y16
 
 
@@ -419,9 +398,9 @@ def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0):
     dx = torch.empty_like(x2d)
     dgb = torch.zeros((2, d), device=x2d.device, dtype=torch.float32)
     _check(_lib.lib().nsp_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(y_pre),
-                                        _p(dx), ctypes.c_void_p(dgb.data_ptr()),
-                                        ctypes.c_void_p(dgb.data_ptr() + 4 * d),
-                                        ctypes.c_int(rows), ctypes.c_int(d), ctypes.c_int(act),
+                                        _p(dx), (dgb.data_ptr()),
+                                        (dgb.data_ptr() + 4 * d),
+                                        (rows), (d), (act),
                                         _stream()), 'nsp_layernorm_bwd')
     return dx, dgb[0], dgb[1]
 
@@ -600,7 +579,7 @@ class GLUFn(torch.autograd.Function):
         C = x.shape[-1] // 2
         rows = x.numel() // (2 * C)
         y = torch.empty(x.shape[:-1] + (C,), device=x.device, dtype=torch.float32)
-        _check(_lib.lib().nsp_glu_fwd(_p(x), _p(y), ctypes.c_longlong(rows), ctypes.c_int(C), _stream()),
+        _check(_lib.lib().nsp_glu_fwd(_p(x), _p(y), (rows), (C), _stream()),
                'nsp_glu_fwd')
         ctx.save_for_backward(x)
         return y
@@ -612,7 +591,7 @@ class GLUFn(torch.autograd.Function):
         C = x.shape[-1] // 2
         rows = x.numel() // (2 * C)
         dx = torch.empty_like(x)
-        _check(_lib.lib().nsp_glu_bwd(_p(x), _p(dy), _p(dx), ctypes.c_longlong(rows), ctypes.c_int(C),
+        _check(_lib.lib().nsp_glu_bwd(_p(x), _p(dy), _p(dx), (rows), (C),
                                       _stream()), 'nsp_glu_bwd')
         return dx
 
@@ -624,9 +603,9 @@ def glu(x):
 def _dwconv_fwd(x, wt, bias, k, pad, flip):
     B, T, C = x.shape
     y = torch.empty_like(x)
-    _check(_lib.lib().nsp_dwconv1d_fwd(_p(x), _p(wt), _p(bias), _p(y), ctypes.c_int(B), ctypes.c_int(T),
-                                       ctypes.c_int(C), ctypes.c_int(k), ctypes.c_int(pad),
-                                       ctypes.c_int(flip), _stream()), 'nsp_dwconv1d_fwd')
+    _check(_lib.lib().nsp_dwconv1d_fwd(_p(x), _p(wt), _p(bias), _p(y), (B), (T),
+                                       (C), (k), (pad),
+                                       (flip), _stream()), 'nsp_dwconv1d_fwd')
     return y
 
 
@@ -652,10 +631,10 @@ class DepthwiseConv1dFn(torch.autograd.Function):
         k, pad = ctx.k, ctx.pad
         dx = _dwconv_fwd(dy, wt, None, k, k - 1 - pad, 1) if ctx.needs_input_grad[0] else None
         buf = torch.zeros((k + 1, C), device=x.device, dtype=torch.float32)
-        _check(_lib.lib().nsp_dwconv1d_wgrad(_p(x), _p(dy), ctypes.c_void_p(buf.data_ptr()),
-                                             ctypes.c_void_p(buf.data_ptr() + 4 * k * C),
-                                             ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(C),
-                                             ctypes.c_int(k), ctypes.c_int(pad), _stream()),
+        _check(_lib.lib().nsp_dwconv1d_wgrad(_p(x), _p(dy), (buf.data_ptr()),
+                                             (buf.data_ptr() + 4 * k * C),
+                                             (B), (T), (C),
+                                             (k), (pad), _stream()),
                'nsp_dwconv1d_wgrad')
         dw = buf[:k].t().contiguous().view(C, 1, k)
         db = buf[k] if ctx.has_bias else None
@@ -676,8 +655,8 @@ class MaxPool1dFn(torch.autograd.Function):
         To = (T + factor - 1) // factor
         y = torch.empty((B, To, C), device=x.device, dtype=torch.float32)
         am = torch.empty((B, To, C), device=x.device, dtype=torch.int32)
-        _check(_lib.lib().nsp_maxpool1d_fwd(_p(x), _p(y), _p(am), ctypes.c_int(B), ctypes.c_int(T),
-                                            ctypes.c_int(C), ctypes.c_int(factor), _stream()),
+        _check(_lib.lib().nsp_maxpool1d_fwd(_p(x), _p(y), _p(am), (B), (T),
+                                            (C), (factor), _stream()),
                'nsp_maxpool1d_fwd')
         ctx.save_for_backward(am)
         ctx.dims = (B, T, C, factor)
@@ -689,8 +668,8 @@ class MaxPool1dFn(torch.autograd.Function):
         B, T, C, factor = ctx.dims
         dy = _f32c(dy)
         dx = torch.empty((B, T, C), device=dy.device, dtype=torch.float32)
-        _check(_lib.lib().nsp_maxpool1d_bwd(_p(dy), _p(am), _p(dx), ctypes.c_int(B), ctypes.c_int(T),
-                                            ctypes.c_int(C), ctypes.c_int(factor), _stream()),
+        _check(_lib.lib().nsp_maxpool1d_bwd(_p(dy), _p(am), _p(dx), (B), (T),
+                                            (C), (factor), _stream()),
                'nsp_maxpool1d_bwd')
         return dx, None
 
@@ -706,10 +685,10 @@ def _conv3x3_fwd(x, w_cl, bias, relu):
     B, T, F, Ci = x.shape
     Co = w_cl.shape[0]
     y = torch.empty((B, T, F, Co), device=x.device, dtype=torch.float32)
-    _check(_lib.lib().nsp_conv2d3x3_fwd(_p(x), _p(w_cl), _p(bias), _p(y), ctypes.c_int(B),
-                                        ctypes.c_int(T), ctypes.c_int(F), ctypes.c_int(Ci),
-                                        ctypes.c_int(Co), ctypes.c_int(int(relu)),
-                                        ctypes.c_int(_COMPUTE_MODE['mode']), _stream()),
+    _check(_lib.lib().nsp_conv2d3x3_fwd(_p(x), _p(w_cl), _p(bias), _p(y), (B),
+                                        (T), (F), (Ci),
+                                        (Co), (int(relu)),
+                                        (_COMPUTE_MODE['mode']), _stream()),
            'nsp_conv2d3x3_fwd (only 3x3, pad 1, stride 1, C_in in {1,32}, C_out=32 are built)')
     return y
 
@@ -733,7 +712,7 @@ class Conv3x3ReLUFn(torch.autograd.Function):
         Co = w_cl.shape[0]
         dy = _f32c(dy)
         dz = torch.empty_like(dy)
-        _check(_lib.lib().nsp_relu_bwd(_p(y), _p(dy), _p(dz), ctypes.c_longlong(dy.numel()), _stream()),
+        _check(_lib.lib().nsp_relu_bwd(_p(y), _p(dy), _p(dz), (dy.numel()), _stream()),
                'nsp_relu_bwd')
         dx = None
         if ctx.needs_input_grad[0]:
@@ -741,10 +720,10 @@ class Conv3x3ReLUFn(torch.autograd.Function):
             w_t = w_cl.flip(1, 2).permute(3, 1, 2, 0).contiguous()  # [Ci,3,3,Co]
             dx = _conv3x3_fwd(dz, w_t, None, False)
         buf = torch.zeros((Co * 9 * Ci + Co,), device=x.device, dtype=torch.float32)
-        _check(_lib.lib().nsp_conv2d3x3_wgrad(_p(x), _p(dz), ctypes.c_void_p(buf.data_ptr()),
-                                              ctypes.c_void_p(buf.data_ptr() + 4 * Co * 9 * Ci),
-                                              ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(F),
-                                              ctypes.c_int(Ci), ctypes.c_int(Co), _stream()),
+        _check(_lib.lib().nsp_conv2d3x3_wgrad(_p(x), _p(dz), (buf.data_ptr()),
+                                              (buf.data_ptr() + 4 * Co * 9 * Ci),
+                                              (B), (T), (F),
+                                              (Ci), (Co), _stream()),
                'nsp_conv2d3x3_wgrad')
         dw = buf[:Co * 9 * Ci].view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
         db = buf[Co * 9 * Ci:]
@@ -767,9 +746,9 @@ class MaxPool2dFn(torch.autograd.Function):
         shape = (B, To, C, Fo) if to_btcf else (B, To, Fo, C)
         y = torch.empty(shape, device=x.device, dtype=torch.float32)
         am = torch.empty(shape, device=x.device, dtype=torch.int32)
-        _check(_lib.lib().nsp_maxpool2d_fwd(_p(x), _p(y), _p(am), ctypes.c_int(B), ctypes.c_int(T),
-                                            ctypes.c_int(F), ctypes.c_int(C), ctypes.c_int(pt),
-                                            ctypes.c_int(pf), ctypes.c_int(int(to_btcf)), _stream()),
+        _check(_lib.lib().nsp_maxpool2d_fwd(_p(x), _p(y), _p(am), (B), (T),
+                                            (F), (C), (pt),
+                                            (pf), (int(to_btcf)), _stream()),
                'nsp_maxpool2d_fwd')
         ctx.save_for_backward(am)
         ctx.dims = (B, T, F, C, pt, pf, to_btcf)
@@ -781,9 +760,9 @@ class MaxPool2dFn(torch.autograd.Function):
         B, T, F, C, pt, pf, to_btcf = ctx.dims
         dy = _f32c(dy)
         dx = torch.empty((B, T, F, C), device=dy.device, dtype=torch.float32)
-        _check(_lib.lib().nsp_maxpool2d_bwd(_p(dy), _p(am), _p(dx), ctypes.c_int(B), ctypes.c_int(T),
-                                            ctypes.c_int(F), ctypes.c_int(C), ctypes.c_int(pt),
-                                            ctypes.c_int(pf), ctypes.c_int(int(to_btcf)), _stream()),
+        _check(_lib.lib().nsp_maxpool2d_bwd(_p(dy), _p(am), _p(dx), (B), (T),
+                                            (F), (C), (pt),
+                                            (pf), (int(to_btcf)), _stream()),
                'nsp_maxpool2d_bwd')
         return dx, None, None, None
 
@@ -808,21 +787,21 @@ class CTCLossFn(torch.autograd.Function):
         dev = logits.device
         L = _lib.lib()
         L.nsp_ctc_workspace_bytes.restype = ctypes.c_longlong
-        ws_bytes = L.nsp_ctc_workspace_bytes(ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(Lmax))
+        ws_bytes = L.nsp_ctc_workspace_bytes((B), (T), (Lmax))
         ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32)
         nll = torch.empty((B,), device=dev, dtype=torch.float32)
         grad = torch.empty_like(logits)
         _check(L.nsp_ctc_loss_fwd_bwd(_p(logits), _p(labels), _p(elens), _p(ylens), _p(nll), _p(grad),
-                                      ctypes.c_float((1.0 - lsm_prob) / B), _p(ws), ctypes.c_int(B),
-                                      ctypes.c_int(T), ctypes.c_int(V), ctypes.c_int(Lmax),
-                                      ctypes.c_int(blank), _stream()), 'nsp_ctc_loss_fwd_bwd')
+                                      ((1.0 - lsm_prob) / B), _p(ws), (B),
+                                      (T), (V), (Lmax),
+                                      (blank), _stream()), 'nsp_ctc_loss_fwd_bwd')
         nll = torch.where(torch.isfinite(nll), nll, torch.zeros_like(nll))  # zero_infinity
         loss = nll.sum() / B
         if lsm_prob > 0:
             kl = torch.zeros((1,), device=dev, dtype=torch.float32)
             _check(L.nsp_ctc_kldiv_fwd_bwd(_p(logits), _p(elens), _p(kl), _p(grad),
-                                           ctypes.c_float(lsm_prob / sum_elens), ctypes.c_int(1),
-                                           ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(V), _stream()),
+                                           (lsm_prob / sum_elens), (1),
+                                           (B), (T), (V), _stream()),
                    'nsp_ctc_kldiv_fwd_bwd')
             loss = loss * (1 - lsm_prob) + kl[0] / sum_elens * lsm_prob
         ctx.save_for_backward(grad)
@@ -857,19 +836,19 @@ class RNNTJointLossFn(torch.autograd.Function):
         use16 = bf16_mode() and J % 8 == 0
         h = torch.empty((B, T, U1, J), device=dev, dtype=torch.bfloat16 if use16 else torch.float32)
         _check(L.nsp_rnnt_joint_tanh_fwd(_p(enc_proj), _p(dec_proj), _p(None if use16 else h),
-                                         _p(h if use16 else None), ctypes.c_int(B), ctypes.c_int(T),
-                                         ctypes.c_int(U1), ctypes.c_int(J), _stream()), 'nsp_rnnt_joint_tanh_fwd')
+                                         _p(h if use16 else None), (B), (T),
+                                         (U1), (J), _stream()), 'nsp_rnnt_joint_tanh_fwd')
         logits = linear_fwd(h.view(-1, J), w_out, b_out)  # [B*T*U1, V] fp32
         n = B * T * U1
         aux = torch.empty((7, n), device=dev, dtype=torch.float32)  # lse, lpb, lpl, alpha, beta, gb, gl
         nll = torch.empty((B,), device=dev, dtype=torch.float32)
         _check(L.nsp_rnnt_logsoftmax_gather(_p(logits), _p(labels), _p(elens), _p(ylens), _p(aux[0]),
-                                            _p(aux[1]), _p(aux[2]), ctypes.c_int(B), ctypes.c_int(T),
-                                            ctypes.c_int(U1), ctypes.c_int(V), ctypes.c_int(blank), _stream()),
+                                            _p(aux[1]), _p(aux[2]), (B), (T),
+                                            (U1), (V), (blank), _stream()),
                'nsp_rnnt_logsoftmax_gather')
         _check(L.nsp_rnnt_lattice(_p(aux[1]), _p(aux[2]), _p(elens), _p(ylens), _p(aux[3]), _p(aux[4]),
-                                  _p(nll), _p(aux[5]), _p(aux[6]), ctypes.c_int(B), ctypes.c_int(T),
-                                  ctypes.c_int(U1), _stream()), 'nsp_rnnt_lattice')
+                                  _p(nll), _p(aux[5]), _p(aux[6]), (B), (T),
+                                  (U1), _stream()), 'nsp_rnnt_lattice')
         ctx.save_for_backward(h, logits, aux, w_out, labels, elens, ylens)
         ctx.dims = (B, T, U1, J, V, blank, use16)
         ctx.has_bias = b_out is not None
@@ -886,9 +865,9 @@ class RNNTJointLossFn(torch.autograd.Function):
         Vp = _r8(V)
         d16 = torch.empty((n, Vp), device=h.device, dtype=torch.bfloat16) if use16 else None
         _check(L.nsp_rnnt_grad_logits(_p(logits), _p(aux[0]), _p(labels), _p(aux[5]), _p(aux[6]),
-                                      _p(elens), _p(ylens), ctypes.c_float(wscale), ctypes.c_int(B),
-                                      ctypes.c_int(T), ctypes.c_int(U1), ctypes.c_int(V),
-                                      ctypes.c_int(blank), _p(d16), ctypes.c_int(Vp), _stream()),
+                                      _p(elens), _p(ylens), (wscale), (B),
+                                      (T), (U1), (V),
+                                      (blank), _p(d16), (Vp), _stream()),
                'nsp_rnnt_grad_logits')
         dlogits = d16[:, :V] if use16 else logits   # bf16 image view (pitch Vp) or in-place fp32
         h2d = h.view(-1, J)
@@ -898,7 +877,7 @@ class RNNTJointLossFn(torch.autograd.Function):
             part = torch.empty((sk, V, J), device=h.device, dtype=torch.float32)
             gemm_raw(V, J, n, d16, 1, Vp, h2d, J, 1, part, J, splitk=sk, c_ss=V * J)
             dw = torch.empty((V, J), device=h.device, dtype=torch.float32)
-            _check(L.nsp_splitk_reduce(_p(part), _p(dw), ctypes.c_int(sk), ctypes.c_longlong(V * J), _stream()),
+            _check(L.nsp_splitk_reduce(_p(part), _p(dw), (sk), (V * J), _stream()),
                    'nsp_splitk_reduce')
             wb = weight_bf16(w_out)
             dh = torch.empty((n, J), device=h.device, dtype=torch.float32)
@@ -906,8 +885,8 @@ class RNNTJointLossFn(torch.autograd.Function):
             db = None
             if ctx.has_bias:
                 db = torch.zeros((V,), device=h.device, dtype=torch.float32)
-                _check(L.nsp_colsum_bf16(_p(d16), _p(db), ctypes.c_int(n), ctypes.c_int(V),
-                                         ctypes.c_longlong(Vp), ctypes.c_int(1), _stream()), 'nsp_colsum_bf16')
+                _check(L.nsp_colsum_bf16(_p(d16), _p(db), (n), (V),
+                                         (Vp), (1), _stream()), 'nsp_colsum_bf16')
         else:
             dw = linear_wgrad(dlogits, h2d)
             db = colsum(dlogits) if ctx.has_bias else None
@@ -915,8 +894,8 @@ class RNNTJointLossFn(torch.autograd.Function):
         de = torch.empty((B, T, J), device=h.device, dtype=torch.float32)
         dg = torch.empty((B, U1, J), device=h.device, dtype=torch.float32)
         _check(L.nsp_rnnt_joint_tanh_bwd(_p(None if use16 else h), _p(h if use16 else None), _p(dh), _p(de),
-                                         _p(dg), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(U1),
-                                         ctypes.c_int(J), _stream()), 'nsp_rnnt_joint_tanh_bwd')
+                                         _p(dg), (B), (T), (U1),
+                                         (J), _stream()), 'nsp_rnnt_joint_tanh_bwd')
         return de, dg, dw.view(w_out.shape), db, None, None, None, None
 
 
@@ -930,7 +909,7 @@ def rnnt_joint_loss(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blan
 def xl_pos_table(inv_freq, L):
     d = inv_freq.numel() * 2
     out = torch.empty((L, d), device=inv_freq.device, dtype=torch.float32)
-    _check(_lib.lib().nsp_xl_pos_table(_p(inv_freq), _p(out), ctypes.c_int(L), ctypes.c_int(d), _stream()),
+    _check(_lib.lib().nsp_xl_pos_table(_p(inv_freq), _p(out), (L), (d), _stream()),
            'nsp_xl_pos_table')
     return out
 
@@ -943,8 +922,8 @@ class ScaleAddBcastFn(torch.autograd.Function):
         x = _f32c(x)
         z = _f32c(z)
         y = torch.empty_like(x)
-        _check(_lib.lib().nsp_scale_add_bcast(_p(x), _p(z), _p(y), ctypes.c_float(alpha),
-                                              ctypes.c_longlong(x.numel()), ctypes.c_longlong(z.numel()),
+        _check(_lib.lib().nsp_scale_add_bcast(_p(x), _p(z), _p(y), (alpha),
+                                              (x.numel()), (z.numel()),
                                               _stream()), 'nsp_scale_add_bcast')
         ctx.alpha = alpha
         return y
@@ -963,17 +942,17 @@ def specaug_apply_(xs, freq_bands, time_bands):
     B, T, F = xs.shape
     fb = torch.tensor(freq_bands, dtype=torch.int32, device=xs.device).view(-1) if len(freq_bands) else None
     tb = torch.tensor(time_bands, dtype=torch.int32, device=xs.device).view(-1) if len(time_bands) else None
-    _check(_lib.lib().nsp_specaug_apply(_p(xs), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(F),
-                                        _p(fb), ctypes.c_int(len(freq_bands)), _p(tb),
-                                        ctypes.c_int(len(time_bands)), _stream()), 'nsp_specaug_apply')
+    _check(_lib.lib().nsp_specaug_apply(_p(xs), (B), (T), (F),
+                                        _p(fb), (len(freq_bands)), _p(tb),
+                                        (len(time_bands)), _stream()), 'nsp_specaug_apply')
     return xs
 
 
 def pad_batch(packed, offsets, lens, B, Tmax, F, pad_value=0.0):
     """Ragged -> padded [B,Tmax,F] on device from ONE packed H2D copy (pad_list, torch_utils.py:56)."""
     out = torch.empty((B, Tmax, F), device=packed.device, dtype=torch.float32)
-    _check(_lib.lib().nsp_pad_batch(_p(packed), _p(offsets), _p(lens), _p(out), ctypes.c_int(B),
-                                    ctypes.c_int(Tmax), ctypes.c_int(F), ctypes.c_float(pad_value),
+    _check(_lib.lib().nsp_pad_batch(_p(packed), _p(offsets), _p(lens), _p(out), (B),
+                                    (Tmax), (F), (pad_value),
                                     _stream()), 'nsp_pad_batch')
     return out
 
@@ -986,12 +965,12 @@ def ctc_forced_align(logits, labels, elens, ylens, blank=0):
     Lmax = max(1, labels.shape[1])
     L = _lib.lib()
     L.nsp_ctc_align_workspace_bytes.restype = ctypes.c_longlong
-    nbytes = L.nsp_ctc_align_workspace_bytes(ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(Lmax))
+    nbytes = L.nsp_ctc_align_workspace_bytes((B), (T), (Lmax))
     ws = torch.empty((nbytes // 4 + 1,), device=logits.device, dtype=torch.float32)
     tp = torch.empty((B, Lmax + 1), device=logits.device, dtype=torch.int32)
     _check(L.nsp_ctc_forced_align(_p(logits), _p(labels), _p(elens), _p(ylens), _p(tp), _p(ws),
-                                  ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(V), ctypes.c_int(Lmax),
-                                  ctypes.c_int(blank), _stream()), 'nsp_ctc_forced_align')
+                                  (B), (T), (V), (Lmax),
+                                  (blank), _stream()), 'nsp_ctc_forced_align')
     return tp
 
 
@@ -1070,8 +1049,8 @@ class LSTMFn(torch.autograd.Function):
         gates = torch.empty((B, L, 4 * H), device=dev, dtype=torch.float32)
         whh = weight_bf16(w_hh) if use16 else w_hh
         _check(_lib.lib().nsp_lstm_fwd(_p(gi), _p(whh), _p(y), _p(ysh), _p(c_all), _p(gates),
-                                       ctypes.c_int(B), ctypes.c_int(L), ctypes.c_int(H),
-                                       ctypes.c_int(_COMPUTE_MODE['mode']), _stream()), 'nsp_lstm_fwd')
+                                       (B), (L), (H),
+                                       (_COMPUTE_MODE['mode']), _stream()), 'nsp_lstm_fwd')
         ctx.save_for_backward(xa, w_ih, w_hh, ysh, c_all, gates)
         ctx.dims = (B, L, I, H)
         ctx.use16 = use16
@@ -1090,8 +1069,8 @@ class LSTMFn(torch.autograd.Function):
         whh_t = _weight_t_shadow(w_hh, use16)
         mode = 0 if use16 else 1
         _check(_lib.lib().nsp_lstm_bwd(_p(dy), _p(whh_t), _p(c_all), _p(gates), _p(dgates), _p(dgsh),
-                                       _p(dc), ctypes.c_int(B), ctypes.c_int(L), ctypes.c_int(H),
-                                       ctypes.c_int(mode), _stream()), 'nsp_lstm_bwd')
+                                       _p(dc), (B), (L), (H),
+                                       (mode), _stream()), 'nsp_lstm_bwd')
         g2d = dgsh.view(B * L, 4 * H)
         # h_{t-1} for every (b,t): the outputs shifted by one step (zeros at t=0)
         hprev = torch.zeros_like(ysh)
@@ -1297,8 +1276,8 @@ class SelfAttnFn(torch.autograd.Function):
             # dq = dS k accumulated in fp32 on top of the position-term gradient, then cast
             gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dq_pos, d, batch=(B, H),
                      a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d, dk), b_off=d, res=dq_pos)
-            _check(_lib.lib().nsp_cast_bf16(_p(dq_pos), _p(dqkv), ctypes.c_longlong(M), ctypes.c_int(d),
-                                            ctypes.c_longlong(d), ctypes.c_longlong(d3), _stream()),
+            _check(_lib.lib().nsp_cast_bf16(_p(dq_pos), _p(dqkv), (M), (d),
+                                            (d), (d3), _stream()),
                    'nsp_cast_bf16')
         else:
             gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dqkv, d3, batch=(B, H),
