@@ -300,7 +300,8 @@ int nsp_rnnt_lattice(const float* lp_blank, const float* lp_label, const int* el
  * left untouched. */
 int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* labels,
                          const float* g_blank, const float* g_label, const int* elens,
-                         const int* ylens, float wscale,
+                         const int* ylens, float wscale, const float* wscale_dev /*optional device
+                         scalar multiplied into wscale: the upstream gradient, no host sync*/,
                          int B, int T, int U1, int V, int blank, void* out16, int ld16,
                          void* stream);
 /* joint pre-activation: h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:]) and its backward

@@ -143,8 +143,10 @@ __global__ __launch_bounds__(1024) void rnnt_lattice_kernel(
 __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
     float* __restrict__ logits, const float* __restrict__ lse, const int* __restrict__ labels,
     const float* __restrict__ g_blank, const float* __restrict__ g_label,
-    const int* __restrict__ elens, const int* __restrict__ ylens, float wscale, int B, int T, int U1,
-    int V, int blank, __bf16* __restrict__ out16, int ld16) {
+    const int* __restrict__ elens, const int* __restrict__ ylens, float wscale_host,
+    const float* __restrict__ wscale_dev, int B, int T, int U1, int V, int blank,
+    __bf16* __restrict__ out16, int ld16) {
+  const float wscale = wscale_dev ? wscale_host * wscale_dev[0] : wscale_host;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long nrows = (long long)B * T * U1;
   const int U = U1 - 1;
@@ -282,13 +284,14 @@ extern "C" int nsp_rnnt_lattice(const float* lp_blank, const float* lp_label, co
 
 extern "C" int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* labels,
                                     const float* g_blank, const float* g_label, const int* elens,
-                                    const int* ylens, float wscale, int B, int T, int U1, int V,
-                                    int blank, void* out16, int ld16, void* stream) {
+                                    const int* ylens, float wscale, const float* wscale_dev, int B,
+                                    int T, int U1, int V, int blank, void* out16, int ld16,
+                                    void* stream) {
   if (out16 && ld16 < V) return NSP_EINVAL;
   int grid = nsp_cdiv((long long)B * T * U1, 4);
   if (grid > 256 * 32) grid = 256 * 32;
   hipLaunchKernelGGL(rnnt_grad_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits,
-                     lse, labels, g_blank, g_label, elens, ylens, wscale, B, T, U1, V, blank,
+                     lse, labels, g_blank, g_label, elens, ylens, wscale, wscale_dev, B, T, U1, V, blank,
                      reinterpret_cast<__bf16*>(out16), ld16);
   NSP_LAUNCH_CHECK();
   return NSP_OK;

@@ -188,13 +188,13 @@ class RNNTransducer(DecoderBase):
         loss = eouts.new_zeros((1,))
         if self.ctc_weight > 0 and (task == 'all' or 'ctc' in task):
             loss_ctc, _ = self.ctc(eouts, elens, ys)
-            observation['loss_ctc'] = tensor2scalar(loss_ctc)
+            observation['loss_ctc'] = loss_ctc.detach()   # device scalar; Speech2Text syncs once
             loss = loss + (loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight)
         if self.rnnt_weight > 0 and (task == 'all' or 'ctc' not in task):
             loss_transducer = self.forward_transducer(eouts, elens, ys)
-            observation['loss_transducer'] = tensor2scalar(loss_transducer)
+            observation['loss_transducer'] = loss_transducer.detach()
             loss = loss + (loss_transducer if self.mtl_per_batch else loss_transducer * self.rnnt_weight)
-        observation['loss'] = tensor2scalar(loss)
+        observation['loss'] = loss.detach()
         return loss, observation
 
     def _prediction_network(self, ys, dev):
@@ -292,9 +292,9 @@ class CTCOnlyDecoder(DecoderBase):
         observation = {'loss': None, 'loss_att': None, 'loss_ctc': None, 'loss_mbr': None,
                        'acc_att': None, 'ppl_att': None}
         loss_ctc, _ = self.ctc(eouts, elens, ys)
-        observation['loss_ctc'] = tensor2scalar(loss_ctc)
+        observation['loss_ctc'] = loss_ctc.detach()
         loss = loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight
-        observation['loss'] = tensor2scalar(loss)
+        observation['loss'] = loss.detach()
         return loss, observation
 
 

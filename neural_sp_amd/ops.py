@@ -861,11 +861,12 @@ class RNNTJointLossFn(torch.autograd.Function):
         B, T, U1, J, V, blank, use16 = ctx.dims
         L = _lib.lib()
         n = B * T * U1
-        wscale = float(dloss.item()) / B
+        wscale = 1.0 / B
+        dl = _f32c(dloss).reshape(-1)  # upstream gradient stays on the device (no host sync)
         Vp = _r8(V)
         d16 = torch.empty((n, Vp), device=h.device, dtype=torch.bfloat16) if use16 else None
         _check(L.nsp_rnnt_grad_logits(_p(logits), _p(aux[0]), _p(labels), _p(aux[5]), _p(aux[6]),
-                                      _p(elens), _p(ylens), (wscale), (B),
+                                      _p(elens), _p(ylens), (wscale), _p(dl), (B),
                                       (T), (U1), (V),
                                       (blank), _p(d16), (Vp), _stream()),
                'nsp_rnnt_grad_logits')

@@ -229,7 +229,19 @@ class Speech2Text(nn.Module):
                 observation['loss.quantity'] = obs_fwd.get('loss_quantity')
                 observation['loss.latency'] = obs_fwd.get('loss_latency')
             observation['loss.ctc'] = obs_fwd['loss_ctc']
-        return loss, observation
+        return loss, self._finalize_observation(observation)
+
+    @staticmethod
+    def _finalize_observation(observation):
+        """The reference calls .item() three times per step inside the decoders
+        (rnn_transducer.py:199,208,214), each a full device sync.  The decoders here hand back
+        device scalars; they become the python floats the Reporter expects with ONE transfer."""
+        keys = [k for k, v in observation.items() if torch.is_tensor(v)]
+        if keys:
+            vals = torch.stack([observation[k].reshape(()).float() for k in keys]).tolist()
+            for k, v in zip(keys, vals):
+                observation[k] = v
+        return observation
 
     def encode(self, xs, task='all', streaming=False, cnn_lookback=False, cnn_lookahead=False,
                xlen_block=-1):
