@@ -143,74 +143,11 @@ __device__ __forceinline__ void load4(const void* base, int dtype, long long off
   }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_params p, int tiles_m,
-                                                             int tiles_n, int c_vec) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
-  unsigned char* smA = smem;
-  unsigned char* smB = smem + TILE_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  int z = blockIdx.z;
-  const int split = z % p.splitk;
-  z /= p.splitk;
-  const int z2 = z % p.batch2, z1 = z / p.batch2;
-  const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
-  const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
-  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
-  const long long lda = A_KC ? p.a_rs : p.a_cs;
-  const long long ldb = B_KC ? p.b_ns : p.b_ks;
-
-  int kbeg = 0, kend = p.K;
-  if (p.splitk > 1) {
-    int nkt = (p.K + BK - 1) / BK;
-    int per = (nkt + p.splitk - 1) / p.splitk;
-    kbeg = split * per * BK;
-    kend = min(p.K, (split + 1) * per * BK);
-    if (kbeg >= kend) return;
-  }
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  Bf16TileLoader<A_KC> la;
-  Bf16TileLoader<B_KC> lb;
-  la.load(A, lda, m0, p.M, kbeg, kend);
-  lb.load(B, ldb, n0, p.N, kbeg, kend);
+// ---- shared epilogue (see the comment inside): acc[mi][ni] -> global with full-line accesses
+__device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[4][4],
+                                              unsigned char* smem, int m0, int n0, int wm, int wn,
+                                              int lane, int wave, long long coff, int c_vec) {
   const int fr = lane & 15, fg = lane >> 4;
-
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    la.store(smA);
-    lb.store(smB);
-    __syncthreads();
-    if (k0 + BK < kend) {
-      la.load(A, lda, m0, p.M, k0 + BK, kend);
-      lb.load(B, ldb, n0, p.N, k0 + BK, kend);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = read_frag<A_KC>(smA, wm * 64 + i * 16, s, fr, fg);
-        bf[i] = read_frag<B_KC>(smB, wn * 64 + i * 16, s, fr, fg);
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
   // ---- epilogue.  The MFMA leaves lane (fr, fg) with C[m0+..+fr][n .. n+3]: storing that
   // directly makes every store instruction touch 16 different rows with 16..64 B each
   // (partial cache lines).  Each wave therefore stages 16 rows x 64 cols through its private
@@ -281,6 +218,163 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
   }
 }
 
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_params p, int tiles_m,
+                                                             int tiles_n, int c_vec) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+  unsigned char* smA = smem;
+  unsigned char* smB = smem + TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  int z = blockIdx.z;
+  const int split = z % p.splitk;
+  z /= p.splitk;
+  const int z2 = z % p.batch2, z1 = z / p.batch2;
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
+  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
+  const long long lda = A_KC ? p.a_rs : p.a_cs;
+  const long long ldb = B_KC ? p.b_ns : p.b_ks;
+
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    int nkt = (p.K + BK - 1) / BK;
+    int per = (nkt + p.splitk - 1) / p.splitk;
+    kbeg = split * per * BK;
+    kend = min(p.K, (split + 1) * per * BK);
+    if (kbeg >= kend) return;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Bf16TileLoader<A_KC> la;
+  Bf16TileLoader<B_KC> lb;
+  la.load(A, lda, m0, p.M, kbeg, kend);
+  lb.load(B, ldb, n0, p.N, kbeg, kend);
+  const int fr = lane & 15, fg = lane >> 4;
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    la.store(smA);
+    lb.store(smB);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      la.load(A, lda, m0, p.M, k0 + BK, kend);
+      lb.load(B, ldb, n0, p.N, k0 + BK, kend);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = read_frag<A_KC>(smA, wm * 64 + i * 16, s, fr, fg);
+        bf[i] = read_frag<B_KC>(smB, wn * 64 + i * 16, s, fr, fg);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+}
+
+// ---- KC x KC with direct-to-LDS loads (global_load_lds_dwordx4): no VGPR staging, no
+// ds_write pass (the 8 ds_write_b128 per thread per k-tile of the register-staged loader cost
+// about as many LDS cycles as the MFMA work they feed).  The DMA writes lane-linear, so the LDS
+// image cannot be padded: rows are exactly 128 B ([128 rows][64 k]) and the 16-B chunk index
+// is XOR-swizzled with (row & 7) on the SOURCE address and on the fragment read, which spreads
+// the 16 rows of a ds_read_b128 group over all banks.  Requires K % 64 == 0.
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_glds_kernel(const nsp_gemm_params p,
+                                                                     int tiles_m, int tiles_n,
+                                                                     int c_vec) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+  unsigned char* smA = smem;
+  unsigned char* smB = smem + 128 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  int z = blockIdx.z;
+  const int split = z % p.splitk;
+  z /= p.splitk;
+  const int z2 = z % p.batch2, z1 = z / p.batch2;
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
+  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    int nkt = p.K / BK;
+    int per = (nkt + p.splitk - 1) / p.splitk;
+    kbeg = split * per * BK;
+    kend = min(p.K, (split + 1) * per * BK);
+    if (kbeg >= kend) return;
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane source rows: wave w, instruction i covers tile rows (w*4+i)*8 .. +7
+  const int lrow = lane >> 3, lpos = lane & 7;
+  const __bf16* asrc[4];
+  const __bf16* bsrc[4];
+  bool aok[4], bok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + lrow;
+    const int chunk = lpos ^ (row & 7);
+    aok[i] = (m0 + row) < p.M;
+    bok[i] = (n0 + row) < p.N;
+    asrc[i] = A + (long long)min(m0 + row, p.M - 1) * p.a_rs + chunk * 8;
+    bsrc[i] = B + (long long)min(n0 + row, p.N - 1) * p.b_ns + chunk * 8;
+  }
+  const int fr = lane & 15, fg = lane >> 4;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // rows beyond M / N keep whatever the slot held: they only feed outputs that are never stored
+      if (aok[i])
+        __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + k0), (lds_void*)(smA + (wave * 4 + i) * 1024), 16, 0, 0);
+      if (bok[i])
+        __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + k0), (lds_void*)(smB + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + fr, rb = wn * 64 + i * 16 + fr;
+        af[i] = *reinterpret_cast<const bf16x8*>(smA + ra * 128 + (((s * 4 + fg) ^ (ra & 7)) << 4));
+        bf[i] = *reinterpret_cast<const bf16x8*>(smB + rb * 128 + (((s * 4 + fg) ^ (rb & 7)) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+}
+
 // fp32 [rows, cols] (row stride ld_in) -> bf16 [rows, ld_out] with zero fill; 8 elements per lane
 __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long long rows,
                                  int cols, long long ld_in, long long ld_out, int vec_in) {
@@ -333,7 +427,9 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   if (p.res && !aligned16(p.res)) c_vec = 0;
   if (p.bias && !aligned16(p.bias)) c_vec = 0;
   dim3 grid(tiles_m * tiles_n, 1, p.batch1 * p.batch2 * p.splitk), block(NTHREADS);
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  if (a_kc && b_kc && p.K % BK == 0 && p.K >= BK)
+    hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);

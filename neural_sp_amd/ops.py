@@ -95,13 +95,16 @@ def bf16_mode():
     return _COMPUTE_MODE['mode'] == 0
 
 
-def to_bf16(x2d):
-    """bf16 shadow copy [rows, roundup8(cols)] (zero padded) of a 2-D fp32 tensor."""
+def to_bf16(x2d, pad_to=8):
+    """bf16 shadow copy [rows, roundup(cols, pad_to)] (zero padded) of a 2-D fp32 tensor."""
     if x2d.dtype == torch.bfloat16:
         return x2d
     rows, cols = x2d.shape
-    ld = (cols + 7) // 8 * 8
-    out = torch.empty((rows, ld), device=x2d.device, dtype=torch.bfloat16)
+    ld = (cols + pad_to - 1) // pad_to * pad_to
+    if ld > (cols + 7) // 8 * 8:
+        out = torch.zeros((rows, ld), device=x2d.device, dtype=torch.bfloat16)
+    else:
+        out = torch.empty((rows, ld), device=x2d.device, dtype=torch.bfloat16)
     _check(_lib.lib().nsp_cast_bf16(_p(x2d), _p(out), (rows), (cols),
                                     (x2d.stride(0)), (ld), _stream()),
            'nsp_cast_bf16')
@@ -157,16 +160,24 @@ def linear_dgrad(dy2d, weight, dact_src=None, dact=0, alpha=1.0, res=None, out=N
     """dx[M,K] = res + alpha*(dy2d[M,N] @ weight[N,K]) * act'(dact_src)."""
     M = dy2d.shape[0]
     N, K = weight.shape[0], weight[0].numel()
-    if bf16_mode() and K % 8 == 0 and N % 8 == 0:
-        ga, wb = to_bf16(dy2d), weight_bf16(weight)
+    use16 = bf16_mode() and K % 8 == 0 and N % 8 == 0
+    if use16:
+        ga = to_bf16(dy2d)
     else:
         assert dy2d.dtype == torch.float32
-        ga, wb = dy2d, weight.reshape(N, K)
+        ga = dy2d
     if out is None:
         out = torch.empty((M, K), device=dy2d.device,
-                          dtype=torch.bfloat16 if (out_bf16 and ga.dtype == torch.bfloat16) else torch.float32)
-    gemm_raw(M, K, N, ga, ga.stride(0), 1, wb, wb.stride(0), 1, out, out.stride(0),
-             dact_src=dact_src, dact=dact, alpha=alpha, res=res)
+                          dtype=torch.bfloat16 if (out_bf16 and use16) else torch.float32)
+    if use16:
+        # W^T shadow [K, roundup64(N)] makes the data gradient a KC x KC product
+        wt = _weight_t_shadow(weight, True)
+        gemm_raw(M, K, N, ga, ga.stride(0), 1, wt, 1, wt.stride(0), out, out.stride(0),
+                 dact_src=dact_src, dact=dact, alpha=alpha, res=res)
+    else:
+        wb = weight.reshape(N, K)
+        gemm_raw(M, K, N, ga, ga.stride(0), 1, wb, wb.stride(0), 1, out, out.stride(0),
+                 dact_src=dact_src, dact=dact, alpha=alpha, res=res)
     return out
 
 
@@ -863,7 +874,7 @@ class RNNTJointLossFn(torch.autograd.Function):
         n = B * T * U1
         wscale = 1.0 / B
         dl = _f32c(dloss).reshape(-1)  # upstream gradient stays on the device (no host sync)
-        Vp = _r8(V)
+        Vp = (V + 63) // 64 * 64
         d16 = torch.empty((n, Vp), device=h.device, dtype=torch.bfloat16) if use16 else None
         _check(L.nsp_rnnt_grad_logits(_p(logits), _p(aux[0]), _p(labels), _p(aux[5]), _p(aux[6]),
                                       _p(elens), _p(ylens), (wscale), _p(dl), (B),
@@ -880,9 +891,9 @@ class RNNTJointLossFn(torch.autograd.Function):
             dw = torch.empty((V, J), device=h.device, dtype=torch.float32)
             _check(L.nsp_splitk_reduce(_p(part), _p(dw), (sk), (V * J), _stream()),
                    'nsp_splitk_reduce')
-            wb = weight_bf16(w_out)
+            wt = _weight_t_shadow(w_out, True)                      # [J, roundup64(V)]
             dh = torch.empty((n, J), device=h.device, dtype=torch.float32)
-            gemm_raw(n, J, V, d16, Vp, 1, wb, wb.stride(0), 1, dh, J)
+            gemm_raw(n, J, Vp, d16, Vp, 1, wt, 1, wt.stride(0), dh, J)
             db = None
             if ctx.has_bias:
                 db = torch.zeros((V,), device=h.device, dtype=torch.float32)
@@ -1021,9 +1032,9 @@ def _weight_t_shadow(w, bf16):
     ent = getattr(w, name, None)
     if ent is not None and ent[0] == w._version and ent[1].device == w.device:
         return ent[1]
-    wt = w.detach().t().contiguous()
+    wt = w.detach().reshape(w.shape[0], -1).t().contiguous()   # [K, N]
     if bf16:
-        wt = to_bf16(wt)
+        wt = to_bf16(wt, pad_to=64)                              # [K, roundup64(N)], zero padded
     try:
         setattr(w, name, (w._version, wt))
     except Exception:
@@ -1132,10 +1143,14 @@ class FFNFn(torch.autograd.Function):
         db2 = colsum(g2)
         # d(pre) = (g2 W2) * dropout_h mask * act'(pre): all in the data-gradient epilogue
         M, dff = pre.shape
-        ga, wb = (g2, weight_bf16(w2)) if use16 else (g2, w2)
         dpre = torch.empty((M, dff), device=dy.device, dtype=pre.dtype)
-        gemm_raw(M, dff, N, ga, ga.stride(0), 1, wb, wb.stride(0), 1, dpre, dff,
-                 dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1])
+        if use16:
+            wt = _weight_t_shadow(w2, True)   # [dff, roundup64(N)]
+            gemm_raw(M, dff, N, g2, g2.stride(0), 1, wt, 1, wt.stride(0), dpre, dff,
+                     dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1])
+        else:
+            gemm_raw(M, dff, N, g2, g2.stride(0), 1, w2, w2.stride(0), 1, dpre, dff,
+                     dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1])
         dw1 = linear_wgrad(dpre, xa).view(w1.shape)
         db1 = colsum(dpre)
         dx = linear_dgrad(dpre, w1)[:, :xshape[-1]].reshape(xshape) if ctx.needs_input_grad[0] else None
@@ -1162,6 +1177,20 @@ def _stacked_weight_bf16(ws):
     except Exception:
         pass
     return wb
+
+
+def _stacked_weight_t_bf16(ws):
+    """bf16 [K, sum N_i] = [W_1^T | W_2^T | ...] (the data-gradient operand of a stacked projection)."""
+    ver = tuple(w._version for w in ws)
+    ent = getattr(ws[0], '_nsp_stackt16', None)
+    if ent is not None and ent[0] == ver and ent[1].device == ws[0].device and ent[2] == len(ws):
+        return ent[1]
+    wt = to_bf16(torch.cat([w.detach().reshape(w.shape[0], -1).t() for w in ws], dim=1).contiguous())
+    try:
+        ws[0]._nsp_stackt16 = (ver, wt, len(ws))
+    except Exception:
+        pass
+    return wt
 
 
 def _r8(n):
@@ -1287,9 +1316,9 @@ class SelfAttnFn(torch.autograd.Function):
                  a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d3, dk), c_off=d)
         dwqkv = linear_wgrad(dqkv, x16)                                            # [3d, d]
         dbqkv = colsum(dqkv) if has_qkv_bias else None
-        wqkv = _stacked_weight_bf16([wq, wk, wv])
+        wqkv_t = _stacked_weight_t_bf16([wq, wk, wv])                              # [d, 3d]
         dx = torch.empty((M, d), device=dev, dtype=torch.float32)
-        gemm_raw(M, d, d3, dqkv, d3, 1, wqkv, d, 1, dx, d)
+        gemm_raw(M, d, d3, dqkv, d3, 1, wqkv_t, 1, d3, dx, d)
         dwq, dwk, dwv = dwqkv[:d].view(wq.shape), dwqkv[d:2 * d].view(wk.shape), dwqkv[2 * d:].view(wv.shape)
         dbq = dbk = dbv = None
         if has_qkv_bias:
