@@ -17,17 +17,25 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 static inline int nsp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-__device__ __forceinline__ float nsp_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_rcp_f32 / v_exp_f32 based: an IEEE divide costs ~10 VALU ops and doubled the time of
+// activation-carrying GEMM epilogues; 1-ulp reciprocal error is far inside every tolerance here
+__device__ __forceinline__ float nsp_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float nsp_sigmoid(float x) { return nsp_rcp(1.f + __expf(-x)); }
+__device__ __forceinline__ float nsp_tanh(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); saturates correctly for |x| large (exp -> inf or 0)
+  const float e = __expf(2.f * x);
+  return 1.f - 2.f * nsp_rcp(e + 1.f);
+}
 
 __device__ __forceinline__ float nsp_act(float v, int act) {
   switch (act) {
     case NSP_ACT_RELU: return v > 0.f ? v : 0.f;
     case NSP_ACT_SWISH: return v * nsp_sigmoid(v);
-    case NSP_ACT_TANH: return tanhf(v);
+    case NSP_ACT_TANH: return nsp_tanh(v);
     case NSP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     case NSP_ACT_GELU_TANH: {
       float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-      return 0.5f * v * (1.f + tanhf(u));
+      return 0.5f * v * (1.f + nsp_tanh(u));
     }
     default: return v;
   }
@@ -42,7 +50,7 @@ __device__ __forceinline__ float nsp_dact(float x, int act) {
       return s * (1.f + x * (1.f - s));
     }
     case NSP_ACT_TANH: {
-      float t = tanhf(x);
+      float t = nsp_tanh(x);
       return 1.f - t * t;
     }
     case NSP_ACT_GELU: {
@@ -52,7 +60,7 @@ __device__ __forceinline__ float nsp_dact(float x, int act) {
     }
     case NSP_ACT_GELU_TANH: {
       float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-      float t = tanhf(u);
+      float t = nsp_tanh(u);
       float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
       return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
     }
@@ -77,7 +85,7 @@ __device__ __forceinline__ float nsp_keep_scale(unsigned long long seed, unsigne
                                                 float p) {
   // returns 0 (dropped) or 1/(1-p)
   float u = (float)(nsp_hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
-  return u < p ? 0.f : 1.f / (1.f - p);
+  return u < p ? 0.f : nsp_rcp(1.f - p);
 }
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {

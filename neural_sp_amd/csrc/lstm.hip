@@ -92,13 +92,13 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(
     const float pf = g[H + u] + pre[1][bb][uu];
     const float pg = g[2 * H + u] + pre[2][bb][uu];
     const float po = g[3 * H + u] + pre[3][bb][uu];
-    const float ig = 1.f / (1.f + expf(-pi));
-    const float fg = 1.f / (1.f + expf(-pf));
-    const float gg = tanhf(pg);
-    const float og = 1.f / (1.f + expf(-po));
+    const float ig = nsp_sigmoid(pi);
+    const float fg = nsp_sigmoid(pf);
+    const float gg = nsp_tanh(pg);
+    const float og = nsp_sigmoid(po);
     const float cp = t > 0 ? c_all[(row - 1) * H + u] : 0.f;
     const float c = fg * cp + ig * gg;
-    const float h = og * tanhf(c);
+    const float h = og * nsp_tanh(c);
     c_all[row * H + u] = c;
     y[row * H + u] = h;
     if (MODE == 0) reinterpret_cast<__bf16*>(yshadow)[row * H + u] = (__bf16)h;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(
     const float ig = gs[u], fg = gs[H + u], gg = gs[2 * H + u], og = gs[3 * H + u];
     const float c = c_all[row * H + u];
     const float cp = t > 0 ? c_all[(row - 1) * H + u] : 0.f;
-    const float tc = tanhf(c);
+    const float tc = nsp_tanh(c);
     const float dcn = (t + 1 < L) ? dc[(long long)b * H + u] : 0.f;
     const float dct = dcn + dh * og * (1.f - tc * tc);
     const float d_o = dh * tc * og * (1.f - og);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void rnnt_lsm_gather_kernel(
     for (int v = lane; v < V; v += 64) mx = fmaxf(mx, xr[v]);
     mx = wave_reduce_max(mx);
     float s = 0.f;
-    for (int v = lane; v < V; v += 64) s += expf(xr[v] - mx);
+    for (int v = lane; v < V; v += 64) s += __expf(xr[v] - mx);
     s = wave_reduce_sum(s);
     if (lane == 0) {
       const float ls = mx + logf(s);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
     for (int v = lane; v < (o16 ? ld16 : V); v += 64) {
       float g = 0.f;
       if (v < V) {
-        g = -gsum * expf(xr[v] - ls);
+        g = -gsum * __expf(xr[v] - ls);
         if (v == blank) g += gb;
         if (v == lab) g += gl;
         g *= wscale;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_kernel(const float* __rest
     const long long b = idx / ((long long)J4 * U1 * T);
     const float4 ev = reinterpret_cast<const float4*>(e + (b * T + t) * J)[j4];
     const float4 gv = reinterpret_cast<const float4*>(g + (b * U1 + u) * J)[j4];
-    const float4 o = make_float4(tanhf(ev.x + gv.x), tanhf(ev.y + gv.y), tanhf(ev.z + gv.z), tanhf(ev.w + gv.w));
+    const float4 o = make_float4(nsp_tanh(ev.x + gv.x), nsp_tanh(ev.y + gv.y), nsp_tanh(ev.z + gv.z), nsp_tanh(ev.w + gv.w));
     if (h) reinterpret_cast<float4*>(h)[idx] = o;
     if (h16) {
       bf16x4 q;
