@@ -95,8 +95,11 @@ def main():
     n_params = model.total_parameters
     train_model = parallel.wrap_ddp(model, local_rank) if distributed else model
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, fused=True)
+    # distinct synthetic batches (different T_max / U_max); at most as many as warm-up steps so
+    # that every shape has been through the caching allocator before the timed region
+    n_distinct = max(1, min(4, a.warmup))
     batches = [synthetic_batch(B=a.batch, t_range=(a.tmin, a.tmax), u_range=(a.umin, a.umax),
-                               vocab=1000, seed=1000 * rank + i) for i in range(4)]
+                               vocab=1000, seed=1000 * rank + i) for i in range(n_distinct)]
 
     def step(i):
         batch = batches[i % len(batches)]

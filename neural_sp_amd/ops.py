@@ -1295,9 +1295,9 @@ class SelfAttnFn(torch.autograd.Function):
             gemm_raw(M, dk, Rp, dQP16, H * Rp, 1, pos16, d, 1, dq_pos, d, batch=(H, 1), a_b=(Rp, 0),
                      b_b=(dk, 0), c_b=(dk, 0))
             if ctx.needs_input_grad[10]:
-                dpos = torch.empty((Rp, d), device=dev, dtype=torch.float32)         # dQP^T q
+                dpos = torch.zeros((Rp, d), device=dev, dtype=torch.float32)         # dQP^T q
                 gemm_raw(Rp, dk, M, dQP16, 1, H * Rp, qkv, d3, 1, dpos, d, batch=(H, 1), a_b=(Rp, 0),
-                         b_b=(dk, 0), c_b=(dk, 0))
+                         b_b=(dk, 0), c_b=(dk, 0), splitk=max(1, min(64, M // 256)))
                 dpos16 = to_bf16(dpos)
                 dw_pos = torch.empty((d, d), device=dev, dtype=torch.float32)        # dpos^T pe
                 gemm_raw(d, d, Rp, dpos16, 1, d, pe16, d, 1, dw_pos, d)
