@@ -41,6 +41,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-kernel-events', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=1, help='utterances in the CPU-baseline sample')
+    p.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL); 'gloo' only for single-GPU smoke tests of the N>1 code path")
+    p.add_argument('--same-device', action='store_true', help='testing only: every rank uses cuda:0')
     return p.parse_args()
 
 
@@ -76,12 +78,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1
     assert torch.cuda.is_available(), 'bench.py measures the HIP path; no GPU is visible'
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if a.dist_backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend=a.dist_backend)
 
     from neural_sp_amd import ops
     from neural_sp_amd.configs import conformer_rnnt_args, synthetic_batch
