@@ -229,23 +229,27 @@ int nsp_dwconv1d_wgrad(const float* x, const float* dy, float* dwt, float* dbias
  * VGG-style Conv2d frontend on channels-last [B,T,F,C] (conv.py:289-396).  *
  * 3x3, padding 1, stride 1, fused bias + ReLU; MaxPool2d(ceil_mode).       *
  * ------------------------------------------------------------------------ */
+/* mask_src (optional, layout of y): y = mask_src > 0 ? y : 0 -- lets the data-gradient call
+ * apply the ReLU backward of the layer below in its epilogue. */
 int nsp_conv2d3x3_fwd(const float* x, const float* w /*[Co,3,3,Ci]*/, const float* bias,
                       float* y, int B, int T, int F, int Ci, int Co, int relu,
-                      int mode, void* stream);
+                      const float* mask_src, int mode, void* stream);
 /* dw [Co,3,3,Ci] and dbias [Co] accumulated atomically into caller-zeroed
  * buffers; dy must already be masked by the ReLU (nsp_relu_bwd).  The data
  * gradient is nsp_conv2d3x3_fwd on dy with the tap-flipped, channel-transposed
  * filter bank (built by the host, 9K floats). */
 int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, float* dbias,
-                        int B, int T, int F, int Ci, int Co, void* stream);
+                        int B, int T, int F, int Ci, int Co, int mode, void* stream);
 int nsp_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);
 /* MaxPool2d(kernel=stride=(pt,pf), ceil_mode=True) on [B,T,F,C]; if
  * to_btcf != 0 the output is written as [B,T',C,F'] (= the reference's
  * transpose(2,1).view(B,T',C*F'), conv.py:189) */
 int nsp_maxpool2d_fwd(const float* x, float* y, int* argmax, int B, int T, int F, int C,
                       int pt, int pf, int to_btcf, void* stream);
+/* relu_src (optional, layout of dx): dx = relu_src > 0 ? dx : 0 (ReLU backward of the conv that
+ * fed the pool, fused) */
 int nsp_maxpool2d_bwd(const float* dy, const int* argmax, float* dx, int B, int T, int F,
-                      int C, int pt, int pf, int from_btcf, void* stream);
+                      int C, int pt, int pf, int from_btcf, const float* relu_src, void* stream);
 /* MaxPool1d(k=s=factor, ceil_mode=True) over time of [B,T,C]
  * (subsampling.py:188-209) */
 int nsp_maxpool1d_fwd(const float* x, float* y, int* argmax, int B, int T, int C, int factor,
@@ -303,6 +307,8 @@ int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* labels,
                          const int* ylens, float wscale, const float* wscale_dev /*optional device
                          scalar multiplied into wscale: the upstream gradient, no host sync*/,
                          int B, int T, int U1, int V, int blank, void* out16, int ld16,
+                         float* dbias /*optional [V], zeroed by the caller: column sums of the
+                         gradient = output-bias gradient, accumulated in the same pass*/,
                          void* stream);
 /* joint pre-activation: h[b,t,u,:] = tanh(e[b,t,:] + g[b,u,:]) and its backward
  * reductions (rnn_transducer.py:272-274) */

@@ -30,40 +30,22 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ y, int B, int T, int F,
-                                                          int relu) {
+                                                          int relu, const float* __restrict__ mask_src,
+                                                          int tiles_f, int tiles_t) {
+  // Persistent workgroups: the 32x288 filter bank (36 x 16 B per lane) is fetched ONCE per
+  // workgroup and kept in registers (bf16 mode) / LDS (fp32 mode) while the workgroup walks
+  // over output tiles; re-fetching it per 128-pixel tile cost 6x the input traffic.
+  // mask_src (optional): out = mask_src > 0 ? out : 0 -- the ReLU backward of the PREVIOUS
+  // layer fused into this layer's data-gradient pass.
   constexpr int PP = ConvCfg<MODE>::PIX_PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xs = smem;                                          // [HT*HF][PP]
   float* ws = reinterpret_cast<float*>(smem + HT * HF * PP);          // MODE 1 only: [32][W_PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f0 = blockIdx.x * TF, t0 = blockIdx.y * TT, b = blockIdx.z;
   const int r = lane & 15, g = lane >> 4;
 
-  // ---- stage the halo tile: HT*HF pixels x 8 float4
-  for (int idx = tid; idx < HT * HF * 8; idx += 256) {
-    const int c4 = idx & 7, pix = idx >> 3;
-    const int ht = pix / HF, hf = pix % HF;
-    const int t = t0 + ht - 1, f = f0 + hf - 1;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t >= 0 && t < T && f >= 0 && f < F)
-      v = reinterpret_cast<const float4*>(x + (((long long)b * T + t) * F + f) * CH)[c4];
-    if (MODE == 0) {
-      bf16x4 h;
-      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-      *reinterpret_cast<bf16x4*>(xs + pix * PP + c4 * 8) = h;
-    } else {
-      *reinterpret_cast<float4*>(xs + pix * PP + c4 * 16) = v;
-    }
-  }
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) acc[a][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+  bf16x8 bfrag[9][2];
   if (MODE == 0) {
-    // filter bank -> registers: bfrag[tap][nb] = w[nb*16+r][tap][g*8 .. g*8+7]
-    bf16x8 bfrag[9][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -76,64 +58,101 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
         h[4] = (__bf16)hi.x; h[5] = (__bf16)hi.y; h[6] = (__bf16)hi.z; h[7] = (__bf16)hi.w;
         bfrag[tap][nb] = h;
       }
-    __syncthreads();
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dt = tap / 3, df = tap % 3;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int pix = (wave * 2 + a + dt) * HF + r + df;
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(xs + pix * PP + g * 16);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-          acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[tap][nb], af, acc[a][nb], 0, 0, 0);
-      }
-    }
   } else {
     for (int idx = tid; idx < CH * 288 / 4; idx += 256) {
       const int co = idx / 72, q = idx % 72;
       *reinterpret_cast<float4*>(ws + co * W_PITCH + q * 4) =
           reinterpret_cast<const float4*>(w + (long long)co * 288)[q];
     }
+  }
+  const long long ntiles = (long long)B * tiles_t * tiles_f;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tf = (int)(tile % tiles_f);
+    const int tt = (int)((tile / tiles_f) % tiles_t);
+    const long long b = tile / ((long long)tiles_f * tiles_t);
+    const int f0 = tf * TF, t0 = tt * TT;
+    __syncthreads();  // previous tile's fragment reads are done
+    // ---- stage the halo tile: HT*HF pixels x 8 float4
+    for (int idx = tid; idx < HT * HF * 8; idx += 256) {
+      const int c4 = idx & 7, pix = idx >> 3;
+      const int ht = pix / HF, hf = pix % HF;
+      const int t = t0 + ht - 1, f = f0 + hf - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < T && f >= 0 && f < F)
+        v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
+      if (MODE == 0) {
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(xs + pix * PP + c4 * 8) = h;
+      } else {
+        *reinterpret_cast<float4*>(xs + pix * PP + c4 * 16) = v;
+      }
+    }
     __syncthreads();
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dt = tap / 3, df = tap % 3;
+    f32x4 acc[2][2];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        float af[2], bf[2];
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) acc[a][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dt = tap / 3, df = tap % 3;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const int pix = (wave * 2 + a + dt) * HF + r + df;
-          af[a] = *reinterpret_cast<const float*>(xs + pix * PP + (s * 4 + g) * 4);
-        }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bf[nb] = ws[(nb * 16 + r) * W_PITCH + tap * CH + s * 4 + g];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(xs + pix * PP + g * 16);
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nb], af[a], acc[a][nb], 0, 0, 0);
+            acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[tap][nb], af, acc[a][nb], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dt = tap / 3, df = tap % 3;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          float af[2], bf[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int pix = (wave * 2 + a + dt) * HF + r + df;
+            af[a] = *reinterpret_cast<const float*>(xs + pix * PP + (s * 4 + g) * 4);
+          }
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) bf[nb] = ws[(nb * 16 + r) * W_PITCH + tap * CH + s * 4 + g];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nb], af[a], acc[a][nb], 0, 0, 0);
+        }
       }
     }
-  }
-  // ---- epilogue: lane holds pixel (t0+2*wave+a, f0+r), co = nb*16 + g*4 .. +3
-  const int f = f0 + r;
+    // ---- epilogue: lane holds pixel (t0+2*wave+a, f0+r), co = nb*16 + g*4 .. +3
+    const int f = f0 + r;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int t = t0 + wave * 2 + a;
-    if (t >= T || f >= F) continue;
+    for (int a = 0; a < 2; ++a) {
+      const int t = t0 + wave * 2 + a;
+      if (t >= T || f >= F) continue;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int co = nb * 16 + g * 4;
-      float4 v = make_float4(acc[a][nb][0], acc[a][nb][1], acc[a][nb][2], acc[a][nb][3]);
-      if (bias) {
-        const float4 bb = reinterpret_cast<const float4*>(bias + co)[0];
-        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      for (int nb = 0; nb < 2; ++nb) {
+        const int co = nb * 16 + g * 4;
+        const long long off = ((b * T + t) * F + f) * CH + co;
+        float4 v = make_float4(acc[a][nb][0], acc[a][nb][1], acc[a][nb][2], acc[a][nb][3]);
+        if (bias) {
+          const float4 bb = reinterpret_cast<const float4*>(bias + co)[0];
+          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (mask_src) {
+          const float4 m = *reinterpret_cast<const float4*>(mask_src + off);
+          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+          v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(y + off) = v;
       }
-      if (relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
-      *reinterpret_cast<float4*>(y + (((long long)b * T + t) * F + f) * CH + co) = v;
     }
   }
 }
@@ -185,6 +204,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
   float acc[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+#pragma unroll 4
   for (long long p = p0 + pl; p < p1; p += 8) {
     const int f = (int)(p % F);
     const int t = (int)((p / F) % T);
@@ -271,6 +291,120 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_kernel(const float* __r
     for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dbias + cog * 4 + j, accb[j]);
 }
 
+// ---- weight gradient, 32 -> 32, bf16 MFMA: dw[co][tap][ci] = sum_p dy[p][co] * x[p+tap][ci].
+// The reduction index of the MFMA is the PIXEL, which is the strided index of both
+// channels-last operands; ds_read_b64_tr_b16 turns 4 consecutive pixels x 16 channels of the LDS
+// tiles into the 4 k-values a lane needs (lane mapping in gemm_bf16.hip).  Wave w owns the 32
+// pixels of tile rows 2w, 2w+1 (one MFMA k-step) for all 9 taps: 36 MFMAs per wave per tile, 36
+// accumulator fragments kept across the persistent tile loop, one cross-wave LDS reduction and
+// one atomic flush per workgroup at the end.
+__global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+    float* __restrict__ dbias, int B, int T, int F, int tiles_f, int tiles_t) {
+  constexpr int PP = 80;  // bytes per pixel: 32 bf16 + 16 B pad
+  __shared__ __attribute__((aligned(16))) unsigned char xs[HT * HF * PP];
+  __shared__ __attribute__((aligned(16))) unsigned char ds[TT * TF * PP];
+  __shared__ float red[4][16][68];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4, a4 = r >> 2, b4 = r & 3;
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread always stages channel quad tid&7
+  const long long ntiles = (long long)B * tiles_t * tiles_f;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tf = (int)(tile % tiles_f);
+    const int tt = (int)((tile / tiles_f) % tiles_t);
+    const long long b = tile / ((long long)tiles_f * tiles_t);
+    const int f0 = tf * TF, t0 = tt * TT;
+    __syncthreads();
+    for (int idx = tid; idx < HT * HF * 8; idx += 256) {
+      const int c4 = idx & 7, pix = idx >> 3;
+      const int t = t0 + pix / HF - 1, f = f0 + pix % HF - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t >= 0 && t < T && f >= 0 && f < F)
+        v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
+      bf16x4 h;
+      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(xs + pix * PP + c4 * 8) = h;
+    }
+    for (int idx = tid; idx < TT * TF * 8; idx += 256) {
+      const int c4 = idx & 7, pix = idx >> 3;
+      const int t = t0 + pix / TF, f = f0 + pix % TF;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T && f < F) v = reinterpret_cast<const float4*>(dy + ((b * T + t) * F + f) * CH)[c4];
+      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+      bf16x4 h;
+      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(ds + pix * PP + c4 * 8) = h;
+    }
+    __syncthreads();
+    // this wave's 32 pixels: tile-local pixel k = 32*wave + 8g + a4 (+4)
+    const int kloc = 8 * g + a4;                 // 0..31 within the wave's two tile rows
+    const int trow = 2 * wave + (kloc >> 4), fcol = kloc & 15;
+    bf16x8 dfrag[2];
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf) {
+      const unsigned char* p = ds + (trow * TF + fcol) * PP + (cf * 16 + b4 * 4) * 2;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * PP));
+      bf16x8 o;
+      o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+      o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+      dfrag[cf] = o;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dt = tap / 3, df = tap % 3;
+#pragma unroll
+      for (int cif = 0; cif < 2; ++cif) {
+        const unsigned char* p = xs + ((trow + dt) * HF + fcol + df) * PP + (cif * 16 + b4 * 4) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * PP));
+        bf16x8 xf;
+        xf[0] = lo[0]; xf[1] = lo[1]; xf[2] = lo[2]; xf[3] = lo[3];
+        xf[4] = hi[0]; xf[5] = hi[1]; xf[6] = hi[2]; xf[7] = hi[3];
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf)
+          acc[tap][cf][cif] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfrag[cf], xf, acc[tap][cf][cif], 0, 0, 0);
+      }
+    }
+  }
+  // ---- reduce the 4 waves' fragments and flush: lane holds D[co = cf*16 + 4g + e][ci = cif*16 + r]
+  for (int tap = 0; tap < 9; ++tap) {
+    for (int cf = 0; cf < 2; ++cf) {
+      __syncthreads();
+#pragma unroll
+      for (int cif = 0; cif < 2; ++cif)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][4 * g + e][cif * 16 + r] = acc[tap][cf][cif][e];
+      __syncthreads();
+      for (int i = tid; i < 16 * 32; i += 256) {
+        const int co = i >> 5, ci = i & 31;
+        const float v = red[0][co][ci] + red[1][co][ci] + red[2][co][ci] + red[3][co][ci];
+        unsafeAtomicAdd(dw + ((long long)(cf * 16 + co) * 9 + tap) * CH + ci, v);
+      }
+    }
+  }
+  if (dbias) {
+    __syncthreads();
+    float* rb = &red[0][0][0];  // [256][4]
+    rb[tid * 4 + 0] = bsum.x; rb[tid * 4 + 1] = bsum.y; rb[tid * 4 + 2] = bsum.z; rb[tid * 4 + 3] = bsum.w;
+    __syncthreads();
+    if (tid < 32) {
+      const int c4 = tid >> 2, e = tid & 3;
+      float s2 = 0.f;
+      for (int k = c4; k < 256; k += 8) s2 += rb[k * 4 + e];
+      unsafeAtomicAdd(dbias + tid, s2);
+    }
+  }
+}
+
 // ---- MaxPool2d(kernel=stride=(pt,pf), ceil_mode) on [B,T,F,C]
 __global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                      int* __restrict__ argmax, int B, int T, int F, int C, int To,
@@ -316,7 +450,8 @@ __global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restr
 
 __global__ void maxpool2d_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ argmax,
                                      float* __restrict__ dx, int B, int T, int F, int C, int To,
-                                     int Fo, int pt, int pf, int from_btcf) {
+                                     int Fo, int pt, int pf, int from_btcf,
+                                     const float* __restrict__ relu_src) {
   const int C4 = C >> 2;
   const long long total = (long long)B * T * F * C4;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -334,6 +469,11 @@ __global__ void maxpool2d_bwd_kernel(const float* __restrict__ dy, const int* __
                                      : ((b * To + to) * Fo + fo) * C + c4 * 4 + e;
       o[e] = argmax[oi] == self ? dy[oi] : 0.f;
     }
+    if (relu_src) {  // fused ReLU backward of the layer that fed the pool (its output is relu_src)
+      const float4 m = reinterpret_cast<const float4*>(relu_src)[idx];
+      o[0] = m.x > 0.f ? o[0] : 0.f; o[1] = m.y > 0.f ? o[1] : 0.f;
+      o[2] = m.z > 0.f ? o[2] : 0.f; o[3] = m.w > 0.f ? o[3] : 0.f;
+    }
     reinterpret_cast<float4*>(dx)[idx] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
@@ -348,22 +488,27 @@ inline int ew_grid(long long n) {
 }  // namespace
 
 extern "C" int nsp_conv2d3x3_fwd(const float* x, const float* w, const float* bias, float* y, int B,
-                                 int T, int F, int Ci, int Co, int relu, int mode, void* stream) {
+                                 int T, int F, int Ci, int Co, int relu, const float* mask_src,
+                                 int mode, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (Co != CH) return NSP_EUNSUPPORTED;
   if (Ci == 1) {
+    if (mask_src) return NSP_EUNSUPPORTED;
     hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(ew_grid((long long)B * T * F * 8)), dim3(256), 0, st, x,
                        w, bias, y, B, T, F, relu);
   } else if (Ci == CH) {
-    dim3 grid(nsp_cdiv(F, TF), nsp_cdiv(T, TT), B);
-    if (grid.y > 65535 || grid.z > 65535) return NSP_EUNSUPPORTED;
+    const int tiles_f = nsp_cdiv(F, TF), tiles_t = nsp_cdiv(T, TT);
+    const long long ntiles = (long long)B * tiles_f * tiles_t;
+    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // 4 persistent workgroups per CU
     if (mode == NSP_COMPUTE_BF16) {
       const size_t sh = HT * HF * ConvCfg<0>::PIX_PITCH;
-      hipLaunchKernelGGL((conv3x3_c32_kernel<0>), grid, dim3(256), sh, st, x, w, bias, y, B, T, F, relu);
+      hipLaunchKernelGGL((conv3x3_c32_kernel<0>), dim3(grid), dim3(256), sh, st, x, w, bias, y, B, T, F,
+                         relu, mask_src, tiles_f, tiles_t);
     } else {
       const size_t sh = HT * HF * ConvCfg<1>::PIX_PITCH + sizeof(float) * CH * W_PITCH;
       hipFuncSetAttribute((const void*)conv3x3_c32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      hipLaunchKernelGGL((conv3x3_c32_kernel<1>), grid, dim3(256), sh, st, x, w, bias, y, B, T, F, relu);
+      hipLaunchKernelGGL((conv3x3_c32_kernel<1>), dim3(grid), dim3(256), sh, st, x, w, bias, y, B, T, F,
+                         relu, mask_src, tiles_f, tiles_t);
     }
   } else {
     return NSP_EUNSUPPORTED;
@@ -374,7 +519,7 @@ extern "C" int nsp_conv2d3x3_fwd(const float* x, const float* w, const float* bi
 
 // dw / dbias must be zeroed by the caller (atomic accumulation)
 extern "C" int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B,
-                                   int T, int F, int Ci, int Co, void* stream) {
+                                   int T, int F, int Ci, int Co, int mode, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (Co != CH) return NSP_EUNSUPPORTED;
   if (Ci == 1) {
@@ -388,9 +533,15 @@ extern "C" int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, f
   } else if (Ci == CH) {
     const int tiles_f = nsp_cdiv(F, TF), tiles_t = nsp_cdiv(T, TT);
     long long ntiles = (long long)B * tiles_f * tiles_t;
-    int blocks = ntiles < 1024 ? (int)ntiles : 1024;
-    hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dy, dw, dbias, B, T,
-                       F, tiles_f, tiles_t);
+    if (mode == NSP_COMPUTE_BF16) {
+      int blocks = ntiles < 512 ? (int)ntiles : 512;
+      hipLaunchKernelGGL(conv3x3_c32_wgrad_mfma_kernel, dim3(blocks), dim3(256), 0, st, x, dy, dw, dbias,
+                         B, T, F, tiles_f, tiles_t);
+    } else {
+      int blocks = ntiles < 1024 ? (int)ntiles : 1024;
+      hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dy, dw, dbias, B, T,
+                         F, tiles_f, tiles_t);
+    }
   } else {
     return NSP_EUNSUPPORTED;
   }
@@ -409,11 +560,12 @@ extern "C" int nsp_maxpool2d_fwd(const float* x, float* y, int* argmax, int B, i
 }
 
 extern "C" int nsp_maxpool2d_bwd(const float* dy, const int* argmax, float* dx, int B, int T, int F,
-                                 int C, int pt, int pf, int from_btcf, void* stream) {
+                                 int C, int pt, int pf, int from_btcf, const float* relu_src,
+                                 void* stream) {
   if (C % 4) return NSP_EUNSUPPORTED;
   const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
   hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(ew_grid((long long)B * T * F * (C / 4))), dim3(256), 0,
-                     (hipStream_t)stream, dy, argmax, dx, B, T, F, C, To, Fo, pt, pf, from_btcf);
+                     (hipStream_t)stream, dy, argmax, dx, B, T, F, C, To, Fo, pt, pf, from_btcf, relu_src);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

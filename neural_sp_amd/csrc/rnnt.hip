@@ -145,11 +145,19 @@ __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
     const float* __restrict__ g_blank, const float* __restrict__ g_label,
     const int* __restrict__ elens, const int* __restrict__ ylens, float wscale_host,
     const float* __restrict__ wscale_dev, int B, int T, int U1, int V, int blank,
-    __bf16* __restrict__ out16, int ld16) {
+    __bf16* __restrict__ out16, int ld16, float* __restrict__ dbias) {
+  // One wave per lattice node (row of V logits).  Each lane also accumulates the column sums
+  // of its columns over all rows it visits (= gradient of the output bias), flushed once per
+  // block: saves a separate 1.3 GB pass over the gradient image.
+  extern __shared__ __attribute__((aligned(16))) float colacc[];  // [4 waves][Vpad]
   const float wscale = wscale_dev ? wscale_host * wscale_dev[0] : wscale_host;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long nrows = (long long)B * T * U1;
   const int U = U1 - 1;
+  const int ncol = out16 ? ld16 : V;
+  float* myacc = colacc + (long long)w * ncol;
+  if (dbias)
+    for (int v = lane; v < ncol; v += 64) myacc[v] = 0.f;
   for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
     const int u = (int)(row % U1);
     const int t = (int)((row / U1) % T);
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
     const float gb = g_blank[row], gl = g_label[row];
     const int lab = (u < ylens[b] && u < U) ? labels[(long long)b * U + u] : -1;
     const float gsum = gb + gl;
-    for (int v = lane; v < (o16 ? ld16 : V); v += 64) {
+    for (int v = lane; v < ncol; v += 64) {
       float g = 0.f;
       if (v < V) {
         g = -gsum * __expf(xr[v] - ls);
@@ -175,6 +183,14 @@ __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
       }
       if (o16) o16[v] = (__bf16)g;   // bf16 image (pitch ld16, zero padded) for the MFMA GEMMs
       else xr[v] = g;
+      if (dbias) myacc[v] += g;
+    }
+  }
+  if (dbias) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      const float s4 = colacc[v] + colacc[ncol + v] + colacc[2 * ncol + v] + colacc[3 * ncol + v];
+      if (s4 != 0.f) unsafeAtomicAdd(dbias + v, s4);
     }
   }
 }
@@ -286,13 +302,18 @@ extern "C" int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* 
                                     const float* g_blank, const float* g_label, const int* elens,
                                     const int* ylens, float wscale, const float* wscale_dev, int B,
                                     int T, int U1, int V, int blank, void* out16, int ld16,
-                                    void* stream) {
+                                    float* dbias, void* stream) {
   if (out16 && ld16 < V) return NSP_EINVAL;
   int grid = nsp_cdiv((long long)B * T * U1, 4);
-  if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(rnnt_grad_logits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits,
+  const int cap = dbias ? 256 * 4 : 256 * 32;  // fewer, longer-lived blocks when column sums are kept
+  if (grid > cap) grid = cap;
+  const size_t sh = dbias ? sizeof(float) * 4 * (size_t)(out16 ? ld16 : V) : 0;
+  if (sh > 150 * 1024) return NSP_EUNSUPPORTED;
+  if (sh > 64 * 1024)
+    hipFuncSetAttribute((const void*)rnnt_grad_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL(rnnt_grad_logits_kernel, dim3(grid), dim3(256), sh, (hipStream_t)stream, logits,
                      lse, labels, g_blank, g_label, elens, ylens, wscale, wscale_dev, B, T, U1, V, blank,
-                     reinterpret_cast<__bf16*>(out16), ld16);
+                     reinterpret_cast<__bf16*>(out16), ld16, dbias);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -692,28 +692,36 @@ def maxpool1d_time(x, factor):
 # --------------------------------------------------------------------------
 # Conv2d frontend (channels-last)
 # --------------------------------------------------------------------------
-def _conv3x3_fwd(x, w_cl, bias, relu):
+def _conv3x3_fwd(x, w_cl, bias, relu, mask_src=None):
     B, T, F, Ci = x.shape
     Co = w_cl.shape[0]
     y = torch.empty((B, T, F, Co), device=x.device, dtype=torch.float32)
-    _check(_lib.lib().nsp_conv2d3x3_fwd(_p(x), _p(w_cl), _p(bias), _p(y), (B),
-                                        (T), (F), (Ci),
-                                        (Co), (int(relu)),
-                                        (_COMPUTE_MODE['mode']), _stream()),
+    _check(_lib.lib().nsp_conv2d3x3_fwd(_p(x), _p(w_cl), _p(bias), _p(y), B, T, F, Ci, Co, int(relu),
+                                        _p(mask_src), _COMPUTE_MODE['mode'], _stream()),
            'nsp_conv2d3x3_fwd (only 3x3, pad 1, stride 1, C_in in {1,32}, C_out=32 are built)')
     return y
 
 
 class Conv3x3ReLUFn(torch.autograd.Function):
     """relu(conv2d(x, w, b, padding=1)) on channels-last x [B,T,F,Ci]; weight in the
-    reference's nn.Conv2d layout [Co,Ci,3,3] (conv.py:303-307,317-321)."""
+    reference's nn.Conv2d layout [Co,Ci,3,3] (conv.py:303-307,317-321).
+
+    ReLU backward is fused into whoever produces this node's incoming gradient: the output
+    carries a flag object; a consumer that knows its input is a ReLU output (next conv's data
+    gradient epilogue, max-pool backward) masks with it and sets flag['masked']."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        x_in = x
         x = _f32c(x)
         w_cl = weight.permute(0, 2, 3, 1).contiguous()  # [Co,3,3,Ci]
         y = _conv3x3_fwd(x, w_cl, bias, True)
         ctx.save_for_backward(x, w_cl, y)
+        ctx.flag = {'masked': False, 'consumers': 0}
+        y._nsp_relu = ctx.flag
+        ctx.in_flag = getattr(x_in, '_nsp_relu', None)
+        if ctx.in_flag is not None:
+            ctx.in_flag['consumers'] += 1
         return y
 
     @staticmethod
@@ -722,19 +730,23 @@ class Conv3x3ReLUFn(torch.autograd.Function):
         B, T, F, Ci = x.shape
         Co = w_cl.shape[0]
         dy = _f32c(dy)
-        dz = torch.empty_like(dy)
-        _check(_lib.lib().nsp_relu_bwd(_p(y), _p(dy), _p(dz), (dy.numel()), _stream()),
-               'nsp_relu_bwd')
+        if ctx.flag['masked'] and ctx.flag['consumers'] == 1:
+            dz = dy  # the single consumer already applied (y > 0)
+        else:
+            dz = torch.empty_like(dy)
+            _check(_lib.lib().nsp_relu_bwd(_p(y), _p(dy), _p(dz), dy.numel(), _stream()), 'nsp_relu_bwd')
         dx = None
         if ctx.needs_input_grad[0]:
-            # data gradient = conv of dz with the tap-flipped, channel-transposed bank
+            # data gradient = conv of dz with the tap-flipped, channel-transposed bank; if x is
+            # itself a ReLU output its backward mask (x > 0) rides in this kernel's epilogue
             w_t = w_cl.flip(1, 2).permute(3, 1, 2, 0).contiguous()  # [Ci,3,3,Co]
-            dx = _conv3x3_fwd(dz, w_t, None, False)
+            fuse = ctx.in_flag is not None and ctx.in_flag['consumers'] == 1
+            dx = _conv3x3_fwd(dz, w_t, None, False, mask_src=x if fuse else None)
+            if fuse:
+                ctx.in_flag['masked'] = True
         buf = torch.zeros((Co * 9 * Ci + Co,), device=x.device, dtype=torch.float32)
-        _check(_lib.lib().nsp_conv2d3x3_wgrad(_p(x), _p(dz), (buf.data_ptr()),
-                                              (buf.data_ptr() + 4 * Co * 9 * Ci),
-                                              (B), (T), (F),
-                                              (Ci), (Co), _stream()),
+        _check(_lib.lib().nsp_conv2d3x3_wgrad(_p(x), _p(dz), buf.data_ptr(), buf.data_ptr() + 4 * Co * 9 * Ci,
+                                              B, T, F, Ci, Co, _COMPUTE_MODE['mode'], _stream()),
                'nsp_conv2d3x3_wgrad')
         dw = buf[:Co * 9 * Ci].view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
         db = buf[Co * 9 * Ci:]
@@ -751,30 +763,36 @@ class MaxPool2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pt, pf, to_btcf):
+        in_flag = getattr(x, '_nsp_relu', None)
         x = _f32c(x)
         B, T, F, C = x.shape
         To, Fo = (T + pt - 1) // pt, (F + pf - 1) // pf
         shape = (B, To, C, Fo) if to_btcf else (B, To, Fo, C)
         y = torch.empty(shape, device=x.device, dtype=torch.float32)
         am = torch.empty(shape, device=x.device, dtype=torch.int32)
-        _check(_lib.lib().nsp_maxpool2d_fwd(_p(x), _p(y), _p(am), (B), (T),
-                                            (F), (C), (pt),
-                                            (pf), (int(to_btcf)), _stream()),
+        _check(_lib.lib().nsp_maxpool2d_fwd(_p(x), _p(y), _p(am), B, T, F, C, pt, pf, int(to_btcf), _stream()),
                'nsp_maxpool2d_fwd')
-        ctx.save_for_backward(am)
+        ctx.in_flag = in_flag
+        if in_flag is not None:
+            in_flag['consumers'] += 1
+            ctx.save_for_backward(am, x)
+        else:
+            ctx.save_for_backward(am)
         ctx.dims = (B, T, F, C, pt, pf, to_btcf)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        am, = ctx.saved_tensors
+        am = ctx.saved_tensors[0]
         B, T, F, C, pt, pf, to_btcf = ctx.dims
         dy = _f32c(dy)
         dx = torch.empty((B, T, F, C), device=dy.device, dtype=torch.float32)
-        _check(_lib.lib().nsp_maxpool2d_bwd(_p(dy), _p(am), _p(dx), (B), (T),
-                                            (F), (C), (pt),
-                                            (pf), (int(to_btcf)), _stream()),
-               'nsp_maxpool2d_bwd')
+        fuse = ctx.in_flag is not None and ctx.in_flag['consumers'] == 1
+        relu_src = ctx.saved_tensors[1] if fuse else None
+        _check(_lib.lib().nsp_maxpool2d_bwd(_p(dy), _p(am), _p(dx), B, T, F, C, pt, pf, int(to_btcf),
+                                            _p(relu_src), _stream()), 'nsp_maxpool2d_bwd')
+        if fuse:
+            ctx.in_flag['masked'] = True
         return dx, None, None, None
 
 
@@ -876,10 +894,11 @@ class RNNTJointLossFn(torch.autograd.Function):
         dl = _f32c(dloss).reshape(-1)  # upstream gradient stays on the device (no host sync)
         Vp = (V + 63) // 64 * 64
         d16 = torch.empty((n, Vp), device=h.device, dtype=torch.bfloat16) if use16 else None
+        db_fused = torch.zeros((V,), device=h.device, dtype=torch.float32) if ctx.has_bias else None
         _check(L.nsp_rnnt_grad_logits(_p(logits), _p(aux[0]), _p(labels), _p(aux[5]), _p(aux[6]),
                                       _p(elens), _p(ylens), (wscale), _p(dl), (B),
                                       (T), (U1), (V),
-                                      (blank), _p(d16), (Vp), _stream()),
+                                      (blank), _p(d16), (Vp), _p(db_fused), _stream()),
                'nsp_rnnt_grad_logits')
         dlogits = d16[:, :V] if use16 else logits   # bf16 image view (pitch Vp) or in-place fp32
         h2d = h.view(-1, J)
@@ -894,14 +913,10 @@ class RNNTJointLossFn(torch.autograd.Function):
             wt = _weight_t_shadow(w_out, True)                      # [J, roundup64(V)]
             dh = torch.empty((n, J), device=h.device, dtype=torch.float32)
             gemm_raw(n, J, Vp, d16, Vp, 1, wt, 1, wt.stride(0), dh, J)
-            db = None
-            if ctx.has_bias:
-                db = torch.zeros((V,), device=h.device, dtype=torch.float32)
-                _check(L.nsp_colsum_bf16(_p(d16), _p(db), (n), (V),
-                                         (Vp), (1), _stream()), 'nsp_colsum_bf16')
+            db = db_fused
         else:
             dw = linear_wgrad(dlogits, h2d)
-            db = colsum(dlogits) if ctx.has_bias else None
+            db = db_fused
             dh = linear_dgrad(dlogits, w_out)  # [B*T*U1, J]
         de = torch.empty((B, T, J), device=h.device, dtype=torch.float32)
         dg = torch.empty((B, U1, J), device=h.device, dtype=torch.float32)
