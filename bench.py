@@ -101,7 +101,8 @@ def main():
     model = Speech2Text(margs).to(dev)
     n_params = model.total_parameters
     train_model = parallel.wrap_ddp(model, local_rank) if distributed else model
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, fused=True)
+    params = list(model.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, fused=True)
     # distinct synthetic batches (different T_max / U_max); at most as many as warm-up steps so
     # that every shape has been through the caching allocator before the timed region
     n_distinct = max(1, min(4, a.warmup))
@@ -114,7 +115,7 @@ def main():
         if distributed:
             loss = loss * world  # train.py:423-424
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        parallel.clip_grad_norm_(params, 5.0)
         opt.step()
         opt.zero_grad(set_to_none=True)
         return sum(batch['xlens'])

@@ -53,3 +53,17 @@ def aggregate_timing(dt, units, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return t.item(), u.item()
+
+
+def clip_grad_norm_(parameters, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (train.py:442) without its per-parameter Python loop
+    (380 `.to()` calls = ~5 ms of host time per step on this model): two foreach launches and
+    one stacked norm, no host sync.  Returns the total norm as a device scalar."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    norms = torch._foreach_norm(grads)
+    total = torch.linalg.vector_norm(torch.stack(norms))
+    coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
+    torch._foreach_mul_(grads, coef)
+    return total
