@@ -212,6 +212,23 @@ int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
                          const nsp_attn_mask_params* p, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * Fused self-attention (flash style), d_k = 64, bf16 MFMA: the whole of      *
+ * relative_multihead_attention.py:179-215 without materialising [B,H,T,T].  *
+ *   qkv  bf16 [B*T, 3d]: q | k | v column blocks, head h at +h*64           *
+ *   QP   fp32 [B,T,H,r_pitch] position scores (NULL for plain MHA); needs    *
+ *        clamp > 0 and R <= 16                                              *
+ *   O    bf16 [B*T, d] context; LSE fp32 [B,H,T] (max + log sum, scaled)     *
+ * Backward: dqkv bf16 [B*T,3d] receives dK (block d) and dV (block 2d);      *
+ * dq32 fp32 [B*T,d] and dQP are ACCUMULATED atomically (caller zeroes them); *
+ * D is scratch [B,H,T].  Masks / dropout as in nsp_attn_softmax_*.          *
+ * ------------------------------------------------------------------------ */
+int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* LSE,
+                       const nsp_attn_mask_params* p, void* stream);
+int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const void* O,
+                       const float* LSE, float* D, void* dqkv, float* dq32, float* dQP,
+                       const nsp_attn_mask_params* p, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * Conformer convolution module core: depthwise Conv1d over time on         *
  * channels-last [B,T,C] (conformer_convolution.py:111-113; groups=C,       *
  * padding (k-1)/2, or causal: left pad k-1).                               *

@@ -1,0 +1,395 @@
+// flash_attn.hip -- fused relative-position self-attention for d_k = 64 (bf16 MFMA).
+//
+// Replaces the score / softmax / context pipeline of
+// relative_multihead_attention.py:179-215 (and multihead_attention.py:124-153 when there is
+// no position term) without ever writing the [B,H,T,T] score or probability tensors:
+//
+//   forward : per (64-query tile, head, utterance) workgroup, 4 waves x 16 queries; K/V tiles
+//             of 64 keys staged in LDS; S^T = K Q^T on MFMA with the QUERY index on lane&15, so
+//             the row statistics (online max / sum) need only two cross-lane shuffles and the
+//             probabilities are already laid out as the MFMA operand of P V (no LDS round trip);
+//             V is consumed through ds_read_b64_tr_b16 transpose reads.
+//             e(i,j) = (q_i.k_j + QP[i, min(|i-j|, clamp)]) * scale with the reference's mask
+//             semantics (masked = -FLT_MAX, finite) and counter-based dropout.
+//             Saves LSE[b,h,i] = max + log(sum) for backward.
+//   backward: per (64-key tile, head, utterance) workgroup looping over query tiles: recomputes
+//             P from LSE, dP^T = V dO^T, dS = P (dP - D) scale; dV += P_drop^T dO and
+//             dK += dS^T Q over the workgroup's keys (accumulated in registers, the P / dS
+//             tiles transposed through LDS with transpose reads), dQ += dS K and the
+//             relative-table gradient dQP via fp32 atomics.
+// The 11-entry (clamp_len = 10) position table per query lives in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int DK = 64;
+constexpr int KP = 144;  // LDS row pitch in bytes for [rows][64] bf16 tiles (128 + 16 pad)
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bool fa_visible(const nsp_attn_mask_params& p, int klen, int i, int j) {
+  bool ok = j < klen;
+  if (p.causal) ok = ok && (j <= i + p.lookahead);
+  if (p.chunk_nc > 0) {
+    int c0 = (i / p.chunk_nc) * p.chunk_nc;
+    int lo = c0 - p.chunk_nl;
+    if (lo < 0) lo = 0;
+    ok = ok && (j >= lo) && (j < c0 + p.chunk_nc);
+  }
+  return ok;
+}
+
+// MFMA X operand (rows = `rbase + r`, k = 8 consecutive at 32*s + 8*g) from a KC tile
+__device__ __forceinline__ bf16x8 frag_kc(const unsigned char* tile, int rbase, int s, int r, int g) {
+  return *reinterpret_cast<const bf16x8*>(tile + (rbase + r) * KP + (s * 4 + g) * 16);
+}
+
+// MFMA operand whose rows are COLUMNS cbase..cbase+15 of a k-major tile [k rows][64 cols] and whose
+// 8 k-values are tile rows {k0 + 0..3} and {k1 + 0..3}: two transpose reads
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int cbase, int k0, int k1, int r) {
+  const int a = r >> 2, b = r & 3;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + (k0 + a) * KP + (cbase + 4 * b) * 2));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + (k1 + a) * KP + (cbase + 4 * b) * 2));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+
+// stage 64 rows x 64 bf16 (rows row0.., clipped to T -> zero rows) of a [B*T, ld] matrix column block
+__device__ __forceinline__ void stage_tile(unsigned char* tile, const __bf16* __restrict__ src, long long ld,
+                                           long long brow0, int row0, int T) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int j = idx >> 3, c = idx & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + j < T) v = *reinterpret_cast<const u32x4*>(src + (brow0 + row0 + j) * ld + c * 8);
+    *reinterpret_cast<u32x4*>(tile + j * KP + c * 16) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict__ qkv, int d,
+                                                        const float* __restrict__ QP,
+                                                        __bf16* __restrict__ O, float* __restrict__ LSE,
+                                                        const nsp_attn_mask_params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * KP];
+  __shared__ float QPs[64][17];
+  const int T = p.Tq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const long long ld3 = 3LL * d;
+  const long long brow0 = (long long)b * T;
+  const int klen = p.klens ? p.klens[b] : T;
+  const int qi = q0 + wave * 16 + r;            // this lane's query
+  const int qrow = min(qi, T - 1);
+  const __bf16* qp_ = qkv + (brow0 + qrow) * ld3 + h * DK;
+  bf16x8 Qf[2];
+  Qf[0] = *reinterpret_cast<const bf16x8*>(qp_ + g * 8);
+  Qf[1] = *reinterpret_cast<const bf16x8*>(qp_ + 32 + g * 8);
+  if (QP) {
+    for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
+      const int ql = idx / p.r_pitch, rr = idx % p.r_pitch;
+      const int q = min(q0 + ql, T - 1);
+      QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr];
+    }
+  }
+  f32x4 o_acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const unsigned long long drow = (unsigned long long)(((long long)b * p.H + h) * T + qi) * T;
+  const int nkt = (T + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_tile(Ks, qkv + d + h * DK, ld3, brow0, kt * 64, T);
+    stage_tile(Vs, qkv + 2 * d + h * DK, ld3, brow0, kt * 64, T);
+    __syncthreads();
+    f32x4 s_acc[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      s_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Ks, kf * 16, s, r, g), Qf[s], s_acc[kf], 0, 0, 0);
+    }
+    // lane: query qi, keys kt*64 + kf*16 + 4g + e
+    float ev[4][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kt * 64 + kf * 16 + 4 * g + e;
+        float v = s_acc[kf][e];
+        if (QP) {
+          int rel = qi > key ? qi - key : key - qi;
+          if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+          v += QPs[wave * 16 + r][rel];
+        }
+        v *= p.scale;
+        if (!fa_visible(p, klen, qi, key)) v = -FLT_MAX;
+        if (key >= T) v = -INFINITY;   // tile padding: not part of the softmax at all
+        ev[kf][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);   // m_run = -inf on the first tile -> 0
+    float rs = 0.f;
+    bf16x8 Pf[2];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kt * 64 + kf * 16 + 4 * g + e;
+        float pr = (key < T) ? __expf(ev[kf][e] - m_new) : 0.f;
+        rs += pr;
+        if (p.dropout_p > 0.f) pr *= nsp_keep_scale(p.seed, p.offset + drow + (unsigned long long)key, p.dropout_p);
+        Pf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)pr;
+      }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o_acc[i][0] *= alpha; o_acc[i][1] *= alpha; o_acc[i][2] *= alpha; o_acc[i][3] *= alpha;
+    }
+    // O^T[dd][query] += V^T P^T : X = V^T fragment (rows dd), Y = P fragment (rows queries)
+#pragma unroll
+    for (int ddf = 0; ddf < 4; ++ddf)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        o_acc[ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            frag_tr(Vs, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), Pf[s], o_acc[ddf], 0, 0, 0);
+  }
+  if (qi < T) {
+    const float inv = nsp_rcp(l_run);
+    __bf16* op = O + (brow0 + qi) * d + h * DK;
+#pragma unroll
+    for (int ddf = 0; ddf < 4; ++ddf) {
+      bf16x4 o4;
+      o4[0] = (__bf16)(o_acc[ddf][0] * inv); o4[1] = (__bf16)(o_acc[ddf][1] * inv);
+      o4[2] = (__bf16)(o_acc[ddf][2] * inv); o4[3] = (__bf16)(o_acc[ddf][3] * inv);
+      *reinterpret_cast<bf16x4*>(op + ddf * 16 + 4 * g) = o4;
+    }
+    if (g == 0) LSE[((long long)b * p.H + h) * T + qi] = m_run + __logf(l_run);
+  }
+}
+
+// D[b,h,i] = sum_dd dO[i,dd] * O[i,dd]   (one wave per (b,i,h) row of 64)
+__global__ __launch_bounds__(256) void flash_dot_kernel(const __bf16* __restrict__ dO,
+                                                        const __bf16* __restrict__ O, float* __restrict__ D,
+                                                        int B, int T, int H, int d) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long n = (long long)B * T * H;
+  for (long long row = (long long)blockIdx.x * 4 + w; row < n; row += (long long)gridDim.x * 4) {
+    const int hh = (int)(row % H);
+    const long long bt = row / H;
+    const float v = (float)dO[bt * d + hh * DK + lane] * (float)O[bt * d + hh * DK + lane];
+    const float s = wave_reduce_sum(v);
+    if (lane == 0) {
+      const long long b = bt / T, i = bt % T;
+      D[(b * H + hh) * T + i] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void flash_bwd_kernel(
+    const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
+    const float* __restrict__ LSE, const float* __restrict__ Drow, __bf16* __restrict__ dqkv,
+    float* __restrict__ dq32, float* __restrict__ dQP, const nsp_attn_mask_params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char dOs[64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Ps[64 * KP];   // dropped probabilities [query][key]
+  __shared__ __attribute__((aligned(16))) unsigned char dSs[64 * KP];  // dS                    [query][key]
+  __shared__ float QPs[64][17];
+  __shared__ float dQPs[64][17];
+  const int T = p.Tq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const long long ld3 = 3LL * d;
+  const long long brow0 = (long long)b * T;
+  const int klen = p.klens ? p.klens[b] : T;
+  stage_tile(Ks, qkv + d + h * DK, ld3, brow0, k0, T);
+  stage_tile(Vs, qkv + 2 * d + h * DK, ld3, brow0, k0, T);
+  // dK / dV accumulators of this wave's 16 keys (k0 + 16*wave + ...): [4 dk-frags]
+  f32x4 dk_acc[4], dv_acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int nqt = (T + 63) / 64;
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int q0 = qt * 64;
+    __syncthreads();
+    stage_tile(Qs, qkv + h * DK, ld3, brow0, q0, T);
+    stage_tile(dOs, dO + h * DK, d, brow0, q0, T);
+    if (QP) {
+      for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
+        const int ql = idx / p.r_pitch, rr = idx % p.r_pitch;
+        const int q = min(q0 + ql, T - 1);
+        QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr];
+        dQPs[ql][rr] = 0.f;
+      }
+    }
+    __syncthreads();
+    const int ql = wave * 16 + r;
+    const int qi = q0 + ql;
+    const int qc = min(qi, T - 1);
+    const float lse = LSE[((long long)b * p.H + h) * T + qc];
+    const float dsum = Drow[((long long)b * p.H + h) * T + qc];
+    const unsigned long long drow = (unsigned long long)(((long long)b * p.H + h) * T + qi) * T;
+    // S^T and dP^T for this wave's 16 queries x 64 keys
+    f32x4 s_acc[4], dp_acc[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      s_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Ks, kf * 16, s, r, g),
+                                                            frag_kc(Qs, wave * 16, s, r, g), s_acc[kf], 0, 0, 0);
+        dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Vs, kf * 16, s, r, g),
+                                                             frag_kc(dOs, wave * 16, s, r, g), dp_acc[kf], 0, 0, 0);
+      }
+    }
+    bf16x8 dSf[2];
+    float far = 0.f;
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      bf16x4 p4, ds4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = k0 + kf * 16 + 4 * g + e;
+        int rel = qi > key ? qi - key : key - qi;
+        if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+        float v = s_acc[kf][e];
+        if (QP) v += QPs[ql][rel];
+        v *= p.scale;
+        const bool vis = fa_visible(p, klen, qi, key);
+        if (!vis) v = -FLT_MAX;
+        float pr = (key < T && qi < T) ? __expf(v - lse) : 0.f;
+        float keep = 1.f;
+        if (p.dropout_p > 0.f) keep = nsp_keep_scale(p.seed, p.offset + drow + (unsigned long long)key, p.dropout_p);
+        float ds = pr * (dp_acc[kf][e] * keep - dsum) * p.scale;
+        if (!vis) ds = 0.f;
+        p4[e] = (__bf16)(pr * keep);
+        ds4[e] = (__bf16)ds;
+        dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
+        if (QP && ds != 0.f) {
+          if (p.clamp > 0 && rel == p.clamp) far += ds;
+          else atomicAdd(&dQPs[ql][rel], ds);
+        }
+      }
+      *reinterpret_cast<bf16x4*>(Ps + ql * KP + (kf * 16 + 4 * g) * 2) = p4;
+      *reinterpret_cast<bf16x4*>(dSs + ql * KP + (kf * 16 + 4 * g) * 2) = ds4;
+    }
+    if (QP && p.clamp > 0) {
+      far += __shfl_xor(far, 16, 64);
+      far += __shfl_xor(far, 32, 64);
+      if (g == 0 && far != 0.f) atomicAdd(&dQPs[ql][p.clamp], far);
+    }
+    // dQ^T[dk'][query] += K^T dS^T : X = K^T fragment (rows dk', k = keys), Y = dS fragment
+    f32x4 dq_acc[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      dq_acc[df] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        dq_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            frag_tr(Ks, df * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), dSf[s], dq_acc[df], 0, 0, 0);
+    }
+    if (qi < T) {
+      float* dqp = dq32 + (brow0 + qi) * d + h * DK;
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dqp + df * 16 + 4 * g + e, dq_acc[df][e]);
+    }
+    __syncthreads();  // P / dS tiles complete
+    // dV[key][dd] += sum_q Pd[q][key] dO[q][dd] ; dK[key][dk'] += sum_q dS[q][key] Q[q][dk']
+    // wave owns keys 16*wave..; X = P^T fragment (rows = keys, k = queries): transpose reads of Ps
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      // k-values (queries) of this lane group: 32s + 8g + {0..3} and 32s + 8g + {4..7}
+      const bf16x8 pT = frag_tr(Ps, wave * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
+      const bf16x8 dsT = frag_tr(dSs, wave * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const bf16x8 doT = frag_tr(dOs, df * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
+        const bf16x8 qT = frag_tr(Qs, df * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
+        // D[i = X row = key][j = Y row = dd]: lane holds dd = df*16 + r? no: j = lane&15 indexes Y rows
+        dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pT, doT, dv_acc[df], 0, 0, 0);
+        dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsT, qT, dk_acc[df], 0, 0, 0);
+      }
+    }
+    if (QP) {
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
+        const int ql2 = idx / p.r_pitch, rr = idx % p.r_pitch;
+        const float v = dQPs[ql2][rr];
+        if (q0 + ql2 < T && v != 0.f)
+          unsafeAtomicAdd(dQP + ((brow0 + q0 + ql2) * p.H + h) * p.r_pitch + rr, v);
+      }
+    }
+  }
+  // dv_acc / dk_acc: D[i = key (4g+e)][j = lane&15 = channel within frag df]
+#pragma unroll
+  for (int df = 0; df < 4; ++df)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = k0 + wave * 16 + 4 * g + e;
+      if (key < T) {
+        const long long rowoff = (brow0 + key) * ld3 + h * DK + df * 16 + r;
+        dqkv[rowoff + d] = (__bf16)dk_acc[df][e];
+        dqkv[rowoff + 2 * d] = (__bf16)dv_acc[df][e];
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* LSE,
+                                  const nsp_attn_mask_params* pp, void* stream) {
+  if (!pp || !qkv || !O || !LSE) return NSP_EINVAL;
+  nsp_attn_mask_params p = *pp;
+  if (p.Tq != p.Tk || d != p.H * DK) return NSP_EUNSUPPORTED;
+  if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16 && p.R >= (p.clamp + 1 < p.Tk ? p.clamp + 1 : p.Tk)))
+    return NSP_EUNSUPPORTED;
+  if (p.r_pitch < p.R) p.r_pitch = p.R;
+  dim3 grid((p.Tq + 63) / 64, p.H, p.B);
+  hipLaunchKernelGGL(flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), LSE, p);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+// dq32 [B*T, d] fp32 and dQP must be zeroed by the caller (atomic accumulation); dqkv receives
+// dK at column block d and dV at 2d (bf16); D is scratch [B,H,T].
+extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const void* O,
+                                  const float* LSE, float* D, void* dqkv, float* dq32, float* dQP,
+                                  const nsp_attn_mask_params* pp, void* stream) {
+  if (!pp || !qkv || !dO || !O || !LSE || !D || !dqkv || !dq32) return NSP_EINVAL;
+  nsp_attn_mask_params p = *pp;
+  if (p.Tq != p.Tk || d != p.H * DK) return NSP_EUNSUPPORTED;
+  if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16)) return NSP_EUNSUPPORTED;
+  if (QP && !dQP) return NSP_EINVAL;
+  if (p.r_pitch < p.R) p.r_pitch = p.R;
+  hipStream_t st = (hipStream_t)stream;
+  long long n = (long long)p.B * p.Tq * p.H;
+  int g1 = nsp_cdiv(n, 4);
+  if (g1 > 8192) g1 = 8192;
+  hipLaunchKernelGGL(flash_dot_kernel, dim3(g1), dim3(256), 0, st, reinterpret_cast<const __bf16*>(dO),
+                     reinterpret_cast<const __bf16*>(O), D, p.B, p.Tq, p.H, d);
+  dim3 grid((p.Tq + 63) / 64, p.H, p.B);
+  hipLaunchKernelGGL(flash_bwd_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
+                     reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), dq32, dQP, p);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

@@ -140,24 +140,24 @@ __global__ __launch_bounds__(1024) void rnnt_lattice_kernel(
   }
 }
 
+template <int NK>  // lane owns columns lane + 64*k, k < NK (NK*64 >= ncol); NK == 0: no column sums
 __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
     float* __restrict__ logits, const float* __restrict__ lse, const int* __restrict__ labels,
     const float* __restrict__ g_blank, const float* __restrict__ g_label,
     const int* __restrict__ elens, const int* __restrict__ ylens, float wscale_host,
     const float* __restrict__ wscale_dev, int B, int T, int U1, int V, int blank,
     __bf16* __restrict__ out16, int ld16, float* __restrict__ dbias) {
-  // One wave per lattice node (row of V logits).  Each lane also accumulates the column sums
-  // of its columns over all rows it visits (= gradient of the output bias), flushed once per
-  // block: saves a separate 1.3 GB pass over the gradient image.
-  extern __shared__ __attribute__((aligned(16))) float colacc[];  // [4 waves][Vpad]
+  // One wave per lattice node (row of V logits).  With NK > 0 every lane also keeps the running
+  // column sums of its NK columns in registers (= gradient of the output bias) and flushes them
+  // with one atomic per column per wave: no separate pass over the 1.3 GB gradient image.
   const float wscale = wscale_dev ? wscale_host * wscale_dev[0] : wscale_host;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long nrows = (long long)B * T * U1;
   const int U = U1 - 1;
   const int ncol = out16 ? ld16 : V;
-  float* myacc = colacc + (long long)w * ncol;
-  if (dbias)
-    for (int v = lane; v < ncol; v += 64) myacc[v] = 0.f;
+  float csum[NK > 0 ? NK : 1];
+#pragma unroll
+  for (int k = 0; k < (NK > 0 ? NK : 1); ++k) csum[k] = 0.f;
   for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
     const int u = (int)(row % U1);
     const int t = (int)((row / U1) % T);
@@ -173,24 +173,42 @@ __global__ __launch_bounds__(256) void rnnt_grad_logits_kernel(
     const float gb = g_blank[row], gl = g_label[row];
     const int lab = (u < ylens[b] && u < U) ? labels[(long long)b * U + u] : -1;
     const float gsum = gb + gl;
-    for (int v = lane; v < ncol; v += 64) {
-      float g = 0.f;
-      if (v < V) {
-        g = -gsum * __expf(xr[v] - ls);
-        if (v == blank) g += gb;
-        if (v == lab) g += gl;
-        g *= wscale;
+    if (NK > 0) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int v = lane + 64 * k;
+        if (v < ncol) {
+          float g = 0.f;
+          if (v < V) {
+            g = -gsum * __expf(xr[v] - ls);
+            if (v == blank) g += gb;
+            if (v == lab) g += gl;
+            g *= wscale;
+          }
+          if (o16) o16[v] = (__bf16)g;
+          else xr[v] = g;
+          csum[k] += g;
+        }
       }
-      if (o16) o16[v] = (__bf16)g;   // bf16 image (pitch ld16, zero padded) for the MFMA GEMMs
-      else xr[v] = g;
-      if (dbias) myacc[v] += g;
+    } else {
+      for (int v = lane; v < ncol; v += 64) {
+        float g = 0.f;
+        if (v < V) {
+          g = -gsum * __expf(xr[v] - ls);
+          if (v == blank) g += gb;
+          if (v == lab) g += gl;
+          g *= wscale;
+        }
+        if (o16) o16[v] = (__bf16)g;   // bf16 image (pitch ld16, zero padded) for the MFMA GEMMs
+        else xr[v] = g;
+      }
     }
   }
-  if (dbias) {
-    __syncthreads();
-    for (int v = threadIdx.x; v < V; v += blockDim.x) {
-      const float s4 = colacc[v] + colacc[ncol + v] + colacc[2 * ncol + v] + colacc[3 * ncol + v];
-      if (s4 != 0.f) unsafeAtomicAdd(dbias + v, s4);
+  if (NK > 0 && dbias) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int v = lane + 64 * k;
+      if (v < V && csum[k] != 0.f) unsafeAtomicAdd(dbias + v, csum[k]);
     }
   }
 }
@@ -305,15 +323,19 @@ extern "C" int nsp_rnnt_grad_logits(float* logits, const float* lse, const int* 
                                     float* dbias, void* stream) {
   if (out16 && ld16 < V) return NSP_EINVAL;
   int grid = nsp_cdiv((long long)B * T * U1, 4);
-  const int cap = dbias ? 256 * 4 : 256 * 32;  // fewer, longer-lived blocks when column sums are kept
+  const int ncol = out16 ? ld16 : V;
+  const bool sums = dbias && ncol <= 16 * 64;
+  const int cap = sums ? 256 * 4 : 256 * 32;  // fewer, longer-lived waves when column sums are kept
   if (grid > cap) grid = cap;
-  const size_t sh = dbias ? sizeof(float) * 4 * (size_t)(out16 ? ld16 : V) : 0;
-  if (sh > 150 * 1024) return NSP_EUNSUPPORTED;
-  if (sh > 64 * 1024)
-    hipFuncSetAttribute((const void*)rnnt_grad_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  hipLaunchKernelGGL(rnnt_grad_logits_kernel, dim3(grid), dim3(256), sh, (hipStream_t)stream, logits,
-                     lse, labels, g_blank, g_label, elens, ylens, wscale, wscale_dev, B, T, U1, V, blank,
-                     reinterpret_cast<__bf16*>(out16), ld16, dbias);
+  __bf16* o16 = reinterpret_cast<__bf16*>(out16);
+  hipStream_t st = (hipStream_t)stream;
+  if (sums)
+    hipLaunchKernelGGL((rnnt_grad_logits_kernel<16>), dim3(grid), dim3(256), 0, st, logits, lse, labels,
+                       g_blank, g_label, elens, ylens, wscale, wscale_dev, B, T, U1, V, blank, o16, ld16, dbias);
+  else
+    hipLaunchKernelGGL((rnnt_grad_logits_kernel<0>), dim3(grid), dim3(256), 0, st, logits, lse, labels,
+                       g_blank, g_label, elens, ylens, wscale, wscale_dev, B, T, U1, V, blank, o16, ld16,
+                       (float*)nullptr);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -913,10 +913,10 @@ class RNNTJointLossFn(torch.autograd.Function):
             wt = _weight_t_shadow(w_out, True)                      # [J, roundup64(V)]
             dh = torch.empty((n, J), device=h.device, dtype=torch.float32)
             gemm_raw(n, J, Vp, d16, Vp, 1, wt, 1, wt.stride(0), dh, J)
-            db = db_fused
+            db = db_fused if Vp <= 1024 else (colsum(d16[:, :V]) if ctx.has_bias else None)
         else:
             dw = linear_wgrad(dlogits, h2d)
-            db = db_fused
+            db = db_fused if V <= 1024 else (colsum(dlogits) if ctx.has_bias else None)
             dh = linear_dgrad(dlogits, w_out)  # [B*T*U1, J]
         de = torch.empty((B, T, J), device=h.device, dtype=torch.float32)
         dg = torch.empty((B, U1, J), device=h.device, dtype=torch.float32)
@@ -1340,3 +1340,27 @@ class SelfAttnFn(torch.autograd.Function):
             dbq, dbk, dbv = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
         return (dx.view(B, T, d), dwq, dwk, dwv, dbq, dbk, dbv, dwo, dbo, None, dw_pos, None, None,
                 (dy if has_res else None), None)
+
+
+# --------------------------------------------------------------------------
+# fused (flash-style) attention core, d_k = 64
+# --------------------------------------------------------------------------
+def flash_attn_fwd_raw(qkv16, d, QP, mp):
+    M = qkv16.shape[0]
+    O = torch.empty((M, d), device=qkv16.device, dtype=torch.bfloat16)
+    LSE = torch.empty((mp.B, mp.H, mp.Tq), device=qkv16.device, dtype=torch.float32)
+    _check(_lib.lib().nsp_flash_attn_fwd(_p(qkv16), d, _p(QP), _p(O), _p(LSE), ctypes.byref(mp), _stream()),
+           'nsp_flash_attn_fwd')
+    return O, LSE
+
+
+def flash_attn_bwd_raw(qkv16, d, QP, dO16, O16, LSE, mp, dqkv16):
+    """-> (dq32 [M,d] fp32, dQP or None); dK / dV are written into dqkv16 column blocks d / 2d."""
+    M = qkv16.shape[0]
+    dev = qkv16.device
+    dq32 = torch.zeros((M, d), device=dev, dtype=torch.float32)
+    dQP = torch.zeros_like(QP) if QP is not None else None
+    D = torch.empty((mp.B, mp.H, mp.Tq), device=dev, dtype=torch.float32)
+    _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O16), _p(LSE), _p(D), _p(dqkv16),
+                                         _p(dq32), _p(dQP), ctypes.byref(mp), _stream()), 'nsp_flash_attn_bwd')
+    return dq32, dQP

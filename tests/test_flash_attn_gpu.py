@@ -1,0 +1,72 @@
+"""Fused (flash-style) attention kernels vs a plain torch fp32 reference on the same
+bf16-rounded inputs: output, LSE and all gradients (q, k, v, position-score table)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _reference(qkv, QP, klens, H, clamp, scale, causal, lookahead, nl, nc):
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    dk = d // H
+    q, k, v = [t.reshape(B, T, H, dk) for t in qkv.split(d, dim=-1)]
+    i = torch.arange(T, device=qkv.device)[:, None]
+    j = torch.arange(T, device=qkv.device)[None, :]
+    e = torch.einsum('bihd,bjhd->bhij', q, k)
+    if QP is not None:
+        rel = (i - j).abs().clamp(max=clamp)
+        e = e + torch.gather(QP.permute(0, 2, 1, 3), 3, rel[None, None].expand(B, H, T, T))
+    e = e * scale
+    vis = (j[None] < klens[:, None, None])
+    if causal:
+        vis = vis & (j <= i + lookahead)[None]
+    if nc > 0:
+        c0 = (i // nc) * nc
+        vis = vis & ((j >= (c0 - nl).clamp(min=0)) & (j < c0 + nc))[None]
+    e = e.masked_fill(~vis[:, None], torch.finfo(torch.float32).min)
+    P = torch.softmax(e, -1)
+    O = torch.einsum('bhij,bjhd->bihd', P, v).reshape(B, T, d)
+    return O, torch.logsumexp(e, -1)
+
+
+@pytest.mark.parametrize('T,with_pos,causal,nc', [(130, True, False, 0), (64, False, False, 0),
+                                                  (200, True, True, 0), (96, True, False, 16)])
+def test_flash_attention_matches_reference(T, with_pos, causal, nc):
+    from neural_sp_amd import ops
+    torch.manual_seed(T)
+    dev = torch.device('cuda:0')
+    B, H, dk, clamp = 3, 2, 64, 10
+    d = H * dk
+    R, Rp = clamp + 1, 16
+    qkv = (torch.randn(B, T, 3 * d, device=dev) * 0.5).bfloat16()
+    QP = torch.zeros(B, T, H, Rp, device=dev)
+    QP[..., :R] = torch.randn(B, T, H, R, device=dev)
+    klens = torch.tensor([T, max(1, T - 37), max(1, T // 3)], device=dev, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(dk)
+    nl = 32 if nc else 0
+    q32 = qkv.float().requires_grad_()
+    QPr = QP.clone().requires_grad_() if with_pos else None
+    Oref, LSEref = _reference(q32, QPr, klens, H, clamp, scale, causal, 1, nl, nc)
+    dO = torch.randn_like(Oref).bfloat16()
+    grads = torch.autograd.grad(Oref, [q32] + ([QPr] if with_pos else []), dO.float())
+    mp = ops._mask_params(B, H, T, T, R if with_pos else 0, clamp if with_pos else -1, scale, klens, causal, 1,
+                          nl, nc, r_pitch=Rp if with_pos else 0)
+    qkv2 = qkv.view(B * T, 3 * d)
+    O, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP if with_pos else None, mp)
+    assert _rel(O.float().view(B, T, d), Oref.detach()) < 1.5e-2
+    assert _rel(LSE, LSEref.detach()) < 1e-3
+    dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP if with_pos else None, dO.view(B * T, d), O, LSE, mp, dqkv)
+    g = grads[0].view(B * T, 3 * d)
+    assert _rel(dq32, g[:, :d]) < 2e-2, 'dq'
+    assert _rel(dqkv[:, d:2 * d].float(), g[:, d:2 * d]) < 2e-2, 'dk'
+    assert _rel(dqkv[:, 2 * d:].float(), g[:, 2 * d:]) < 2e-2, 'dv'
+    if with_pos:
+        assert _rel(dQP[..., :R], grads[1][..., :R]) < 2e-2, 'dQP'
