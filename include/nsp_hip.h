@@ -217,7 +217,7 @@ int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
  *   qkv  bf16 [B*T, 3d]: q | k | v column blocks, head h at +h*64           *
  *   QP   fp32 [B,T,H,r_pitch] position scores (NULL for plain MHA); needs    *
  *        clamp > 0 and R <= 16                                              *
- *   O    bf16 [B*T, d] context; LSE fp32 [B,H,T] (max + log sum, scaled)     *
+ *   O    bf16 [B*T, d] context; LSE fp32 [2,B,H,T]: row max and 1/row-sum    *
  * Backward: dqkv bf16 [B*T,3d] receives dK (block d) and dV (block 2d);      *
  * dq32 fp32 [B*T,d] and dQP are ACCUMULATED atomically (caller zeroes them); *
  * D is scratch [B,H,T].  Masks / dropout as in nsp_attn_softmax_*.          *

@@ -11,7 +11,7 @@
 //             V is consumed through ds_read_b64_tr_b16 transpose reads.
 //             e(i,j) = (q_i.k_j + QP[i, min(|i-j|, clamp)]) * scale with the reference's mask
 //             semantics (masked = -FLT_MAX, finite) and counter-based dropout.
-//             Saves LSE[b,h,i] = max + log(sum) for backward.
+//             Saves the row max and 1/sum (LSE[0], LSE[1], each [B,H,T]) for backward.
 //   backward: per (64-key tile, head, utterance) workgroup looping over query tiles: recomputes
 //             P from LSE, dP^T = V dO^T, dS = P (dP - D) scale; dV += P_drop^T dO and
 //             dK += dS^T Q over the workgroup's keys (accumulated in registers, the P / dS
@@ -177,7 +177,14 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
       o4[2] = (__bf16)(o_acc[ddf][2] * inv); o4[3] = (__bf16)(o_acc[ddf][3] * inv);
       *reinterpret_cast<bf16x4*>(op + ddf * 16 + 4 * g) = o4;
     }
-    if (g == 0) LSE[((long long)b * p.H + h) * T + qi] = m_run + __logf(l_run);
+    if (g == 0) {
+      // row max and 1/sum are kept SEPARATELY: for a fully masked row max = -FLT_MAX and
+      // max + log(sum) is not representable (the log is absorbed), which would turn the
+      // reference's uniform 1/T probabilities into 1 in the backward recomputation
+      const long long ri = ((long long)b * p.H + h) * T + qi;
+      LSE[ri] = m_run;
+      LSE[(long long)p.B * p.H * T + ri] = inv;
+    }
   }
 }
 
@@ -242,7 +249,8 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(
     const int ql = wave * 16 + r;
     const int qi = q0 + ql;
     const int qc = min(qi, T - 1);
-    const float lse = LSE[((long long)b * p.H + h) * T + qc];
+    const float rmax = LSE[((long long)b * p.H + h) * T + qc];
+    const float rinv = LSE[(long long)p.B * p.H * T + ((long long)b * p.H + h) * T + qc];
     const float dsum = Drow[((long long)b * p.H + h) * T + qc];
     const unsigned long long drow = (unsigned long long)(((long long)b * p.H + h) * T + qi) * T;
     // S^T and dP^T for this wave's 16 queries x 64 keys
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(
         v *= p.scale;
         const bool vis = fa_visible(p, klen, qi, key);
         if (!vis) v = -FLT_MAX;
-        float pr = (key < T && qi < T) ? __expf(v - lse) : 0.f;
+        float pr = (key < T && qi < T) ? __expf(v - rmax) * rinv : 0.f;
         float keep = 1.f;
         if (p.dropout_p > 0.f) keep = nsp_keep_scale(p.seed, p.offset + drow + (unsigned long long)key, p.dropout_p);
         float ds = pr * (dp_acc[kf][e] * keep - dsum) * p.scale;

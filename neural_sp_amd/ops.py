@@ -7,6 +7,7 @@ kernels into autograd.  No op has a CPU/eager fallback: a CPU tensor raises.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -1240,9 +1241,8 @@ class SelfAttnFn(torch.autograd.Function):
         gemm_raw(M, d3, d, x16, d, 1, wqkv, 1, d, qkv, d3, bias=bqkv)
         clamp = cfg.get('clamp', -1)
         Tkp = _r8(T)
-        S = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)
-        gemm_raw(T, T, dk, qkv, d3, 1, qkv, 1, d3, S, T, batch=(B, H), a_b=(T * d3, dk),
-                 b_b=(T * d3, dk), c_b=(H * T * T, T * T), b_off=d)
+        fused = (dk == 64 and os.environ.get('NSP_FLASH_ATTN', '1') != '0'
+                 and (pos_in is None or (clamp > 0 and pos_in.shape[0] <= 16)))
         QP = pos16 = pe16 = None
         R = Rp = 0
         if pos_in is not None:
@@ -1261,29 +1261,42 @@ class SelfAttnFn(torch.autograd.Function):
                      cfg.get('chunk_nc', 0), p_att, seed, offset)
         scale = 1.0 / math.sqrt(dk)
         mp = _mask_params(B, H, T, T, R, clamp, scale, klens, *mask_args, p_bf16=1, tk_pitch=Tkp, r_pitch=Rp)
-        P16 = torch.empty((B, H, T, Tkp), device=dev, dtype=torch.bfloat16)
-        Pd16 = torch.empty_like(P16) if p_att > 0 else None
-        attn_softmax_fwd_raw(S, QP, mp, Pd16, Pout=P16)
-        del S
-        Puse = Pd16 if Pd16 is not None else P16
-        cv16 = torch.empty((M, d), device=dev, dtype=torch.bfloat16)
-        gemm_raw(T, dk, T, Puse, Tkp, 1, qkv, d3, 1, cv16, d, batch=(B, H), a_b=(H * T * Tkp, T * Tkp),
-                 b_b=(T * d3, dk), c_b=(T * d, dk), b_off=2 * d)
+        P16 = Pd16 = LSE = None
+        if fused:
+            # flash-style kernel: scores / probabilities never leave the CU
+            cv16, LSE = flash_attn_fwd_raw(qkv, d, QP, mp)
+            aw = None
+        else:
+            S = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)
+            gemm_raw(T, T, dk, qkv, d3, 1, qkv, 1, d3, S, T, batch=(B, H), a_b=(T * d3, dk),
+                     b_b=(T * d3, dk), c_b=(H * T * T, T * T), b_off=d)
+            P16 = torch.empty((B, H, T, Tkp), device=dev, dtype=torch.bfloat16)
+            Pd16 = torch.empty_like(P16) if p_att > 0 else None
+            attn_softmax_fwd_raw(S, QP, mp, Pd16, Pout=P16)
+            del S
+            Puse = Pd16 if Pd16 is not None else P16
+            cv16 = torch.empty((M, d), device=dev, dtype=torch.bfloat16)
+            gemm_raw(T, dk, T, Puse, Tkp, 1, qkv, d3, 1, cv16, d, batch=(B, H), a_b=(H * T * Tkp, T * Tkp),
+                     b_b=(T * d3, dk), c_b=(T * d, dk), b_off=2 * d)
+            aw = P16
         s_o = next_dropout_seed() if p_o > 0 else (0, 0)
         res2d = _f32c(res).reshape(M, d) if res is not None else None
         out = linear_fwd(cv16, wo, bo, 0, res2d, 1.0, dropout_p=p_o, seed=s_o[0], offset=s_o[1])
-        ctx.save_for_backward(x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens)
+        ctx.save_for_backward(x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens, QP, LSE)
         ctx.cfg = (B, T, d, H, dk, R, Rp, Tkp, clamp, scale, mask_args, p_o, s_o, res is not None,
                    bq is not None, bo is not None)
-        ctx.mark_non_differentiable(P16)
-        return out.view(B, T, d), P16
+        if aw is None:
+            aw = cv16.new_zeros(1)  # the fused path has no probability tensor to hand out
+        ctx.mark_non_differentiable(aw)
+        return out.view(B, T, d), aw
 
     @staticmethod
     def backward(ctx, dy, _unused):
-        x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens = ctx.saved_tensors
+        x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens, QP, LSE = ctx.saved_tensors
         (B, T, d, H, dk, R, Rp, Tkp, clamp, scale, mask_args, p_o, s_o, has_res, has_qkv_bias,
          has_o_bias) = ctx.cfg
         has_pos = pos16 is not None
+        fused = LSE is not None
         dev = dy.device
         M, d3 = B * T, 3 * d
         dy2d = _f32c(dy).reshape(M, d)
@@ -1291,24 +1304,29 @@ class SelfAttnFn(torch.autograd.Function):
         dwo = linear_wgrad(g, cv16).view(wo.shape)
         dbo = colsum(g) if has_o_bias else None
         dO = linear_dgrad(g, wo, out_bf16=True)                                   # [M, d] bf16
-        dP = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)           # dP = dO v^T
-        gemm_raw(T, T, dk, dO, d, 1, qkv, 1, d3, dP, T, batch=(B, H), a_b=(T * d, dk),
-                 b_b=(T * d3, dk), c_b=(H * T * T, T * T), b_off=2 * d)
         dqkv = torch.empty((M, d3), device=dev, dtype=torch.bfloat16)
-        Puse = Pd16 if Pd16 is not None else P16
-        gemm_raw(T, dk, T, Puse, 1, Tkp, dO, d, 1, dqkv, d3, batch=(B, H),           # dV = P^T dO
-                 a_b=(H * T * Tkp, T * Tkp), b_b=(T * d, dk), c_b=(T * d3, dk), c_off=2 * d)
         mp = _mask_params(B, H, T, T, R, clamp, scale, klens, *mask_args, p_bf16=1, tk_pitch=Tkp, r_pitch=Rp)
-        dS16 = torch.empty((B, H, T, Tkp), device=dev, dtype=torch.bfloat16)
-        dQP = torch.empty((B, T, H, Rp), device=dev, dtype=torch.float32) if has_pos else None
-        attn_softmax_bwd_raw(P16, dP, dQP, mp, dS=dS16)
-        del dP
+        if fused:
+            dq_acc, dQP = flash_attn_bwd_raw(qkv, d, QP, dO, cv16, LSE, mp, dqkv)
+        else:
+            dP = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)       # dP = dO v^T
+            gemm_raw(T, T, dk, dO, d, 1, qkv, 1, d3, dP, T, batch=(B, H), a_b=(T * d, dk),
+                     b_b=(T * d3, dk), c_b=(H * T * T, T * T), b_off=2 * d)
+            Puse = Pd16 if Pd16 is not None else P16
+            gemm_raw(T, dk, T, Puse, 1, Tkp, dO, d, 1, dqkv, d3, batch=(B, H),       # dV = P^T dO
+                     a_b=(H * T * Tkp, T * Tkp), b_b=(T * d, dk), c_b=(T * d3, dk), c_off=2 * d)
+            dS16 = torch.empty((B, H, T, Tkp), device=dev, dtype=torch.bfloat16)
+            dQP = torch.empty((B, T, H, Rp), device=dev, dtype=torch.float32) if has_pos else None
+            attn_softmax_bwd_raw(P16, dP, dQP, mp, dS=dS16)
+            del dP
+            dq_acc = None
         dq_pos = dw_pos = None
         if has_pos:
             dQP16 = to_bf16(dQP.view(M * H, Rp)).view(M, H * Rp)
-            dq_pos = torch.empty((M, d), device=dev, dtype=torch.float32)            # dQP pos
+            # dq (position term) = dQP pos, accumulated on top of the fused kernel's dq when present
+            dq_pos = dq_acc if dq_acc is not None else torch.empty((M, d), device=dev, dtype=torch.float32)
             gemm_raw(M, dk, Rp, dQP16, H * Rp, 1, pos16, d, 1, dq_pos, d, batch=(H, 1), a_b=(Rp, 0),
-                     b_b=(dk, 0), c_b=(dk, 0))
+                     b_b=(dk, 0), c_b=(dk, 0), res=dq_acc)
             if ctx.needs_input_grad[10]:
                 dpos = torch.zeros((Rp, d), device=dev, dtype=torch.float32)         # dQP^T q
                 gemm_raw(Rp, dk, M, dQP16, 1, H * Rp, qkv, d3, 1, dpos, d, batch=(H, 1), a_b=(Rp, 0),
@@ -1317,18 +1335,20 @@ class SelfAttnFn(torch.autograd.Function):
                 dw_pos = torch.empty((d, d), device=dev, dtype=torch.float32)        # dpos^T pe
                 gemm_raw(d, d, Rp, dpos16, 1, d, pe16, d, 1, dw_pos, d)
                 dw_pos = dw_pos.view(w_pos.shape)
-        if has_pos:
-            # dq = dS k accumulated in fp32 on top of the position-term gradient, then cast
-            gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dq_pos, d, batch=(B, H),
-                     a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d, dk), b_off=d, res=dq_pos)
-            _check(_lib.lib().nsp_cast_bf16(_p(dq_pos), _p(dqkv), (M), (d),
-                                            (d), (d3), _stream()),
-                   'nsp_cast_bf16')
+        if fused:
+            dq_fin = dq_pos if has_pos else dq_acc
+            _check(_lib.lib().nsp_cast_bf16(_p(dq_fin), _p(dqkv), M, d, d, d3, _stream()), 'nsp_cast_bf16')
         else:
-            gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dqkv, d3, batch=(B, H),
-                     a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d3, dk), b_off=d)
-        gemm_raw(T, dk, T, dS16, 1, Tkp, qkv, d3, 1, dqkv, d3, batch=(B, H),           # dk = dS^T q
-                 a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d3, dk), c_off=d)
+            if has_pos:
+                # dq = dS k accumulated in fp32 on top of the position-term gradient, then cast
+                gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dq_pos, d, batch=(B, H),
+                         a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d, dk), b_off=d, res=dq_pos)
+                _check(_lib.lib().nsp_cast_bf16(_p(dq_pos), _p(dqkv), M, d, d, d3, _stream()), 'nsp_cast_bf16')
+            else:
+                gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dqkv, d3, batch=(B, H),
+                         a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d3, dk), b_off=d)
+            gemm_raw(T, dk, T, dS16, 1, Tkp, qkv, d3, 1, dqkv, d3, batch=(B, H),       # dk = dS^T q
+                     a_b=(H * T * Tkp, T * Tkp), b_b=(T * d3, dk), c_b=(T * d3, dk), c_off=d)
         dwqkv = linear_wgrad(dqkv, x16)                                            # [3d, d]
         dbqkv = colsum(dqkv) if has_qkv_bias else None
         wqkv_t = _stacked_weight_t_bf16([wq, wk, wv])                              # [d, 3d]
@@ -1348,7 +1368,7 @@ class SelfAttnFn(torch.autograd.Function):
 def flash_attn_fwd_raw(qkv16, d, QP, mp):
     M = qkv16.shape[0]
     O = torch.empty((M, d), device=qkv16.device, dtype=torch.bfloat16)
-    LSE = torch.empty((mp.B, mp.H, mp.Tq), device=qkv16.device, dtype=torch.float32)
+    LSE = torch.empty((2, mp.B, mp.H, mp.Tq), device=qkv16.device, dtype=torch.float32)  # max, 1/sum
     _check(_lib.lib().nsp_flash_attn_fwd(_p(qkv16), d, _p(QP), _p(O), _p(LSE), ctypes.byref(mp), _stream()),
            'nsp_flash_attn_fwd')
     return O, LSE

@@ -60,6 +60,12 @@ CASES = {
                                                                transformer_enc_lookaheads='0_1',
                                                                conformer_kernel_size=7),
                                    dict(B=2, t_range=(37, 53), u_range=(2, 5), vocab=40, seed=4)),
+    # d_k = 64 (2 heads x 64): exercises the fused flash-attention kernels in bf16 mode
+    'conformer_ctc_dk64_xs': (lambda: conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=1.0,
+                                                          ctc_fc_list='', ctc_lsm_prob=0.0,
+                                                          transformer_enc_d_model=128, transformer_enc_n_heads=2,
+                                                          transformer_enc_d_ff=256, conformer_kernel_size=7),
+                              dict(B=3, t_range=(150, 290), u_range=(3, 9), vocab=40, seed=6)),
     'lc_conformer_mask_xs': (lambda: conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=1.0,
                                                          ctc_fc_list='', ctc_lsm_prob=0.0,
                                                          conformer_kernel_size=7,

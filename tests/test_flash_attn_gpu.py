@@ -61,7 +61,9 @@ def test_flash_attention_matches_reference(T, with_pos, causal, nc):
     qkv2 = qkv.view(B * T, 3 * d)
     O, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP if with_pos else None, mp)
     assert _rel(O.float().view(B, T, d), Oref.detach()) < 1.5e-2
-    assert _rel(LSE, LSEref.detach()) < 1e-3
+    lse = LSE[0] - torch.log(LSE[1])
+    ok = LSEref.detach() > -1e30  # fully masked rows: max + log(sum) is not representable in fp32
+    assert _rel(lse[ok], LSEref.detach()[ok]) < 1e-3
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
     dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP if with_pos else None, dO.view(B * T, d), O, LSE, mp, dqkv)
     g = grads[0].view(B * T, 3 * d)
