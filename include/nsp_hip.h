@@ -219,7 +219,7 @@ int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
  *        clamp > 0 and R <= 16                                              *
  *   O    bf16 [B*T, d] context; LSE fp32 [2,B,H,T]: row max and 1/row-sum    *
  * Backward: dqkv bf16 [B*T,3d] receives dK (block d) and dV (block 2d);      *
- * dq32 fp32 [B*T,d] and dQP are ACCUMULATED atomically (caller zeroes them); *
+ * dq32 fp32 [B*T,d] and dQP [B,T,H,r_pitch] are written (no zero-init);      *
  * D is scratch [B,H,T].  Masks / dropout as in nsp_attn_softmax_*.          *
  * ------------------------------------------------------------------------ */
 int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* LSE,

@@ -15,8 +15,9 @@
 //   backward: per (64-key tile, head, utterance) workgroup looping over query tiles: recomputes
 //             P from LSE, dP^T = V dO^T, dS = P (dP - D) scale; dV += P_drop^T dO and
 //             dK += dS^T Q over the workgroup's keys (accumulated in registers, the P / dS
-//             tiles transposed through LDS with transpose reads), dQ += dS K and the
-//             relative-table gradient dQP via fp32 atomics.
+//             tiles transposed through LDS with transpose reads); a second, query-parallel
+//             kernel recomputes dS and produces dQ = dS K and the relative-table gradient dQP
+//             with no global atomics.
 // The 11-entry (clamp_len = 10) position table per query lives in LDS.
 #include "common.h"
 
@@ -206,10 +207,11 @@ __global__ __launch_bounds__(256) void flash_dot_kernel(const __bf16* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void flash_bwd_kernel(
+// ---- backward, part 1: dK / dV.  One workgroup per 64-key tile, looping over query tiles.
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, __bf16* __restrict__ dqkv,
-    float* __restrict__ dq32, float* __restrict__ dQP, const nsp_attn_mask_params p) {
+    const nsp_attn_mask_params p) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * KP];
   __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * KP];
@@ -217,17 +219,16 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(
   __shared__ __attribute__((aligned(16))) unsigned char Ps[64 * KP];   // dropped probabilities [query][key]
   __shared__ __attribute__((aligned(16))) unsigned char dSs[64 * KP];  // dS                    [query][key]
   __shared__ float QPs[64][17];
-  __shared__ float dQPs[64][17];
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   const long long ld3 = 3LL * d;
   const long long brow0 = (long long)b * T;
+  const long long nrow = (long long)p.B * p.H * T;
   const int klen = p.klens ? p.klens[b] : T;
   stage_tile(Ks, qkv + d + h * DK, ld3, brow0, k0, T);
   stage_tile(Vs, qkv + 2 * d + h * DK, ld3, brow0, k0, T);
-  // dK / dV accumulators of this wave's 16 keys (k0 + 16*wave + ...): [4 dk-frags]
   f32x4 dk_acc[4], dv_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -242,18 +243,16 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(
         const int ql = idx / p.r_pitch, rr = idx % p.r_pitch;
         const int q = min(q0 + ql, T - 1);
         QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr];
-        dQPs[ql][rr] = 0.f;
       }
     }
     __syncthreads();
     const int ql = wave * 16 + r;
     const int qi = q0 + ql;
     const int qc = min(qi, T - 1);
-    const float rmax = LSE[((long long)b * p.H + h) * T + qc];
-    const float rinv = LSE[(long long)p.B * p.H * T + ((long long)b * p.H + h) * T + qc];
-    const float dsum = Drow[((long long)b * p.H + h) * T + qc];
+    const long long ri = ((long long)b * p.H + h) * T + qc;
+    const float rmax = LSE[ri], rinv = LSE[nrow + ri];
+    const float dsum = Drow[ri];
     const unsigned long long drow = (unsigned long long)(((long long)b * p.H + h) * T + qi) * T;
-    // S^T and dP^T for this wave's 16 queries x 64 keys
     f32x4 s_acc[4], dp_acc[4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
@@ -267,87 +266,49 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(
                                                              frag_kc(dOs, wave * 16, s, r, g), dp_acc[kf], 0, 0, 0);
       }
     }
-    bf16x8 dSf[2];
-    float far = 0.f;
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
       bf16x4 p4, ds4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int key = k0 + kf * 16 + 4 * g + e;
-        int rel = qi > key ? qi - key : key - qi;
-        if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
         float v = s_acc[kf][e];
-        if (QP) v += QPs[ql][rel];
+        if (QP) {
+          int rel = qi > key ? qi - key : key - qi;
+          if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+          v += QPs[ql][rel];
+        }
         v *= p.scale;
         const bool vis = fa_visible(p, klen, qi, key);
         if (!vis) v = -FLT_MAX;
-        float pr = (key < T && qi < T) ? __expf(v - rmax) * rinv : 0.f;
+        const float pr = (key < T && qi < T) ? __expf(v - rmax) * rinv : 0.f;
         float keep = 1.f;
         if (p.dropout_p > 0.f) keep = nsp_keep_scale(p.seed, p.offset + drow + (unsigned long long)key, p.dropout_p);
         float ds = pr * (dp_acc[kf][e] * keep - dsum) * p.scale;
         if (!vis) ds = 0.f;
         p4[e] = (__bf16)(pr * keep);
         ds4[e] = (__bf16)ds;
-        dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
-        if (QP && ds != 0.f) {
-          if (p.clamp > 0 && rel == p.clamp) far += ds;
-          else atomicAdd(&dQPs[ql][rel], ds);
-        }
       }
       *reinterpret_cast<bf16x4*>(Ps + ql * KP + (kf * 16 + 4 * g) * 2) = p4;
       *reinterpret_cast<bf16x4*>(dSs + ql * KP + (kf * 16 + 4 * g) * 2) = ds4;
     }
-    if (QP && p.clamp > 0) {
-      far += __shfl_xor(far, 16, 64);
-      far += __shfl_xor(far, 32, 64);
-      if (g == 0 && far != 0.f) atomicAdd(&dQPs[ql][p.clamp], far);
-    }
-    // dQ^T[dk'][query] += K^T dS^T : X = K^T fragment (rows dk', k = keys), Y = dS fragment
-    f32x4 dq_acc[4];
-#pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      dq_acc[df] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-        dq_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            frag_tr(Ks, df * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), dSf[s], dq_acc[df], 0, 0, 0);
-    }
-    if (qi < T) {
-      float* dqp = dq32 + (brow0 + qi) * d + h * DK;
-#pragma unroll
-      for (int df = 0; df < 4; ++df)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dqp + df * 16 + 4 * g + e, dq_acc[df][e]);
-    }
     __syncthreads();  // P / dS tiles complete
     // dV[key][dd] += sum_q Pd[q][key] dO[q][dd] ; dK[key][dk'] += sum_q dS[q][key] Q[q][dk']
-    // wave owns keys 16*wave..; X = P^T fragment (rows = keys, k = queries): transpose reads of Ps
+    // wave owns keys 16*wave..; X = P^T / dS^T fragments (rows = keys, k = queries) via transpose reads
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      // k-values (queries) of this lane group: 32s + 8g + {0..3} and 32s + 8g + {4..7}
       const bf16x8 pT = frag_tr(Ps, wave * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
       const bf16x8 dsT = frag_tr(dSs, wave * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const bf16x8 doT = frag_tr(dOs, df * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
         const bf16x8 qT = frag_tr(Qs, df * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
-        // D[i = X row = key][j = Y row = dd]: lane holds dd = df*16 + r? no: j = lane&15 indexes Y rows
         dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pT, doT, dv_acc[df], 0, 0, 0);
         dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsT, qT, dk_acc[df], 0, 0, 0);
       }
     }
-    if (QP) {
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
-        const int ql2 = idx / p.r_pitch, rr = idx % p.r_pitch;
-        const float v = dQPs[ql2][rr];
-        if (q0 + ql2 < T && v != 0.f)
-          unsafeAtomicAdd(dQP + ((brow0 + q0 + ql2) * p.H + h) * p.r_pitch + rr, v);
-      }
-    }
   }
-  // dv_acc / dk_acc: D[i = key (4g+e)][j = lane&15 = channel within frag df]
+  // D[i = key (4g+e)][j = lane&15 = channel within fragment df]
 #pragma unroll
   for (int df = 0; df < 4; ++df)
 #pragma unroll
@@ -359,6 +320,122 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(
         dqkv[rowoff + 2 * d] = (__bf16)dv_acc[df][e];
       }
     }
+}
+
+// ---- backward, part 2: dQ and the relative-table gradient dQP.  One workgroup per 64-query
+// tile looping over key tiles (the forward's structure): every output element is owned by exactly
+// one lane, so there is not a single global atomic (the first version accumulated dQ with fp32
+// atomics from the key-parallel kernel: 88 M atomics per call at T = 800 made it 4x slower).
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
+    const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
+    const float* __restrict__ LSE, const float* __restrict__ Drow, float* __restrict__ dq32,
+    float* __restrict__ dQP, const nsp_attn_mask_params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * KP];
+  __shared__ float QPs[64][17];
+  __shared__ float dQPs[64][17];
+  const int T = p.Tq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const long long ld3 = 3LL * d;
+  const long long brow0 = (long long)b * T;
+  const long long nrow = (long long)p.B * p.H * T;
+  const int klen = p.klens ? p.klens[b] : T;
+  const int ql = wave * 16 + r;
+  const int qi = q0 + ql;
+  const int qc = min(qi, T - 1);
+  const __bf16* qp_ = qkv + (brow0 + qc) * ld3 + h * DK;
+  const __bf16* dop = dO + (brow0 + qc) * d + h * DK;
+  bf16x8 Qf[2], dOf[2];
+  Qf[0] = *reinterpret_cast<const bf16x8*>(qp_ + g * 8);
+  Qf[1] = *reinterpret_cast<const bf16x8*>(qp_ + 32 + g * 8);
+  dOf[0] = *reinterpret_cast<const bf16x8*>(dop + g * 8);
+  dOf[1] = *reinterpret_cast<const bf16x8*>(dop + 32 + g * 8);
+  if (QP) {
+    for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
+      const int l2 = idx / p.r_pitch, rr = idx % p.r_pitch;
+      const int q = min(q0 + l2, T - 1);
+      QPs[l2][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr];
+      dQPs[l2][rr] = 0.f;
+    }
+  }
+  const long long ri = ((long long)b * p.H + h) * T + qc;
+  const float rmax = LSE[ri], rinv = LSE[nrow + ri];
+  const float dsum = Drow[ri];
+  const unsigned long long drow = (unsigned long long)(((long long)b * p.H + h) * T + qi) * T;
+  f32x4 dq_acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dq_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float far = 0.f;
+  const int nkt = (T + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_tile(Ks, qkv + d + h * DK, ld3, brow0, kt * 64, T);
+    stage_tile(Vs, qkv + 2 * d + h * DK, ld3, brow0, kt * 64, T);
+    __syncthreads();
+    f32x4 s_acc[4], dp_acc[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      s_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Ks, kf * 16, s, r, g), Qf[s], s_acc[kf], 0, 0, 0);
+        dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Vs, kf * 16, s, r, g), dOf[s], dp_acc[kf], 0, 0, 0);
+      }
+    }
+    bf16x8 dSf[2];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kt * 64 + kf * 16 + 4 * g + e;
+        int rel = qi > key ? qi - key : key - qi;
+        if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+        float v = s_acc[kf][e];
+        if (QP) v += QPs[ql][rel];
+        v *= p.scale;
+        const bool vis = fa_visible(p, klen, qi, key);
+        if (!vis) v = -FLT_MAX;
+        const float pr = (key < T && qi < T) ? __expf(v - rmax) * rinv : 0.f;
+        float keep = 1.f;
+        if (p.dropout_p > 0.f) keep = nsp_keep_scale(p.seed, p.offset + drow + (unsigned long long)key, p.dropout_p);
+        float ds = pr * (dp_acc[kf][e] * keep - dsum) * p.scale;
+        if (!vis) ds = 0.f;
+        dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
+        if (QP && ds != 0.f) {
+          if (p.clamp > 0 && rel == p.clamp) far += ds;
+          else atomicAdd(&dQPs[ql][rel], ds);  // LDS, near-diagonal elements only
+        }
+      }
+    // dQ^T[dk'][query] += K^T dS^T : X = K^T fragment (rows dk', k = keys), Y = dS fragment
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        dq_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            frag_tr(Ks, df * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), dSf[s], dq_acc[df], 0, 0, 0);
+  }
+  if (qi < T) {
+    float* dqp = dq32 + (brow0 + qi) * d + h * DK;
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+      *reinterpret_cast<float4*>(dqp + df * 16 + 4 * g) =
+          make_float4(dq_acc[df][0], dq_acc[df][1], dq_acc[df][2], dq_acc[df][3]);
+  }
+  if (QP) {
+    if (p.clamp > 0) {
+      far += __shfl_xor(far, 16, 64);
+      far += __shfl_xor(far, 32, 64);
+      if (g == 0) atomicAdd(&dQPs[ql][p.clamp], far);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
+      const int l2 = idx / p.r_pitch, rr = idx % p.r_pitch;
+      if (q0 + l2 < T) dQP[((brow0 + q0 + l2) * p.H + h) * p.r_pitch + rr] = dQPs[l2][rr];
+    }
+  }
 }
 
 }  // namespace
@@ -378,8 +455,8 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
   return NSP_OK;
 }
 
-// dq32 [B*T, d] fp32 and dQP must be zeroed by the caller (atomic accumulation); dqkv receives
-// dK at column block d and dV at 2d (bf16); D is scratch [B,H,T].
+// dq32 [B*T, d] fp32 and dQP are plainly written (no zero-init needed); dqkv receives dK at
+// column block d and dV at 2d (bf16); D is scratch [B,H,T].
 extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const void* O,
                                   const float* LSE, float* D, void* dqkv, float* dq32, float* dQP,
                                   const nsp_attn_mask_params* pp, void* stream) {
@@ -396,8 +473,10 @@ extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const
   hipLaunchKernelGGL(flash_dot_kernel, dim3(g1), dim3(256), 0, st, reinterpret_cast<const __bf16*>(dO),
                      reinterpret_cast<const __bf16*>(O), D, p.B, p.Tq, p.H, d);
   dim3 grid((p.Tq + 63) / 64, p.H, p.B);
-  hipLaunchKernelGGL(flash_bwd_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
-                     reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), dq32, dQP, p);
+  hipLaunchKernelGGL(flash_bwd_dkv_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
+                     QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
+  hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
+                     reinterpret_cast<const __bf16*>(dO), LSE, D, dq32, dQP, p);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -1378,8 +1378,8 @@ def flash_attn_bwd_raw(qkv16, d, QP, dO16, O16, LSE, mp, dqkv16):
     """-> (dq32 [M,d] fp32, dQP or None); dK / dV are written into dqkv16 column blocks d / 2d."""
     M = qkv16.shape[0]
     dev = qkv16.device
-    dq32 = torch.zeros((M, d), device=dev, dtype=torch.float32)
-    dQP = torch.zeros_like(QP) if QP is not None else None
+    dq32 = torch.empty((M, d), device=dev, dtype=torch.float32)
+    dQP = torch.empty_like(QP) if QP is not None else None
     D = torch.empty((mp.B, mp.H, mp.Tq), device=dev, dtype=torch.float32)
     _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O16), _p(LSE), _p(D), _p(dqkv16),
                                          _p(dq32), _p(dQP), ctypes.byref(mp), _stream()), 'nsp_flash_attn_bwd')
