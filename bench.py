@@ -118,6 +118,7 @@ def main():
         parallel.clip_grad_norm_(params, 5.0)
         opt.step()
         opt.zero_grad(set_to_none=True)
+        obs.materialize()  # the Reporter's per-step read of the loss values (one D2H transfer)
         return sum(batch['xlens'])
 
     def sync():

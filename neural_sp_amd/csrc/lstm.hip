@@ -4,13 +4,13 @@
 // The input projection x W_ih^T + b for all time steps, and all weight / input
 // gradients, are plain GEMMs over [B*L, .] done by the MFMA GEMM kernels.  What
 // is inherently sequential is h_{t-1} W_hh^T: one small kernel per time step.
-// A workgroup owns 16 hidden units (all four gates i,f,g,o of them) for up to 16
-// batch rows: wave w multiplies h_{t-1}[16 x H] by the 16 rows of W_hh that
-// belong to gate w with MFMA (operands straight from L2 into registers -- W_hh
-// is 8 MB in bf16 and stays L2/MALL resident across steps), the four 16x16
-// pre-activation tiles meet in LDS, and 256 threads apply the cell update.
+// A workgroup owns 4 hidden units (all four gates i,f,g,o of them = one 16-row
+// MFMA tile of W_hh) for up to 16 batch rows; its 4 waves split the reduction
+// over H (operands straight from L2 into registers -- W_hh is 8 MB in bf16 and
+// each XCD's 1/8 of it stays L2 resident across steps), the partial tiles meet
+// in LDS and 64 threads apply the cell update.
 // Backward walks t = L-1..0 with the transposed recurrence
-// dh_{t} += dgates_{t+1} W_hh (reduction over 4H split across the 4 waves).
+// dh_{t} += dgates_{t+1} W_hh (reduction over 4H split across 16 waves).
 // Gate order is PyTorch's (i, f, g, o).  Latency-bound by construction:
 // ~2 x L launches per layer and direction.
 #include "common.h"
@@ -59,44 +59,61 @@ __device__ __forceinline__ f32x4 dot_tile(const void* __restrict__ arow, bool a_
   return acc;
 }
 
-// grid: (H/16, ceil(B/16)); block 256
+// One step's loads must all be in flight at once (the step is a pure latency chain: L2 load ->
+// MFMA -> LDS -> gate math -> store), so the reduction dimension is split across the waves of a
+// workgroup and the units across MANY workgroups: the first version (64 workgroups, each wave
+// walking K = 1024 in four dependent rounds) took 10 us per step.
+
+// forward step t.  grid: (H/4, ceil(B/16)); block 256.  The workgroup owns 4 hidden units = 16
+// gate rows (row j -> gate j>>2, unit u0 + (j&3)); wave w reduces k in [w*Kw, (w+1)*Kw).
 template <int MODE>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(
     const float* __restrict__ gi, const void* __restrict__ Whh, float* __restrict__ y,
     void* __restrict__ yshadow, float* __restrict__ c_all, float* __restrict__ gates, int B, int L,
-    int H, int t) {
-  __shared__ float pre[4][16][17];
+    int H, int t, int Kw) {
+  __shared__ float part[4][16][17];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int u0 = blockIdx.x * 4, b0 = blockIdx.y * 16;
   const int r = lane & 15;
   const size_t esz = MODE == 0 ? 2 : 4;
+  // the cell-update threads fetch their elementwise inputs BEFORE the dot product: these loads do
+  // not depend on it, and issuing them after the barrier put a second full memory latency on the
+  // step's critical path
+  const int bb = threadIdx.x >> 2, uu = threadIdx.x & 3;
+  const bool upd = threadIdx.x < 64 && (b0 + bb) < B;
+  const long long row = (long long)(b0 + bb) * L + t;
+  const int u = u0 + uu;
+  float gin[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f;
+  if (upd) {
+    const float* g = gi + row * 4 * H;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gin[q] = g[q * H + u];
+    if (t > 0) cp = c_all[(row - 1) * H + u];
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (t > 0) {
-    // A rows = batch (h_{t-1}), B rows = W_hh rows of gate w
+  const int kbeg = w * Kw;
+  const int klen = min(Kw, H - kbeg);
+  if (t > 0 && klen > 0) {
     const bool a_valid = (b0 + r) < B;
     const char* arow = reinterpret_cast<const char*>(yshadow) +
-                       ((long long)(min(b0 + r, B - 1)) * L + (t - 1)) * H * esz;
-    const char* brow = reinterpret_cast<const char*>(Whh) + ((long long)(w * H + u0 + r)) * H * esz;
-    // mfma(a = A frag, b = B frag): D[i = A row][j = B row]; lane: j = lane&15, i = (lane>>4)*4+reg
-    acc = dot_tile<MODE>(arow, a_valid, brow, H, lane);
+                       (((long long)(min(b0 + r, B - 1)) * L + (t - 1)) * H + kbeg) * esz;
+    const char* brow = reinterpret_cast<const char*>(Whh) +
+                       ((long long)((r >> 2) * H + u0 + (r & 3)) * H + kbeg) * esz;
+    // D[i = batch row][j = gate row]; lane: j = lane&15, i = (lane>>4)*4+reg
+    acc = dot_tile<MODE>(arow, a_valid, brow, klen, lane);
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) pre[w][(lane >> 4) * 4 + e][r] = acc[e];
+  for (int e = 0; e < 4; ++e) part[w][(lane >> 4) * 4 + e][r] = acc[e];
   __syncthreads();
-  const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
-  const int b = b0 + bb, u = u0 + uu;
-  if (b < B && u < H) {
-    const long long row = (long long)b * L + t;
-    const float* g = gi + row * 4 * H;
-    const float pi = g[u] + pre[0][bb][uu];
-    const float pf = g[H + u] + pre[1][bb][uu];
-    const float pg = g[2 * H + u] + pre[2][bb][uu];
-    const float po = g[3 * H + u] + pre[3][bb][uu];
-    const float ig = nsp_sigmoid(pi);
-    const float fg = nsp_sigmoid(pf);
-    const float gg = nsp_tanh(pg);
-    const float og = nsp_sigmoid(po);
-    const float cp = t > 0 ? c_all[(row - 1) * H + u] : 0.f;
+  if (upd) {
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      pre[q] = part[0][bb][q * 4 + uu] + part[1][bb][q * 4 + uu] + part[2][bb][q * 4 + uu] + part[3][bb][q * 4 + uu];
+    const float ig = nsp_sigmoid(gin[0] + pre[0]);
+    const float fg = nsp_sigmoid(gin[1] + pre[1]);
+    const float gg = nsp_tanh(gin[2] + pre[2]);
+    const float og = nsp_sigmoid(gin[3] + pre[3]);
     const float c = fg * cp + ig * gg;
     const float h = og * nsp_tanh(c);
     c_all[row * H + u] = c;
@@ -109,47 +126,58 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(
 
 // backward step t.  dgates (fp32) and its shadow (bf16 in MODE 0, unused in MODE 1) are
 // [B, L, 4H]; WhhT is W_hh^T [H, 4H]; dc is [B, H] (carried across steps).
+// grid: (H/16, ceil(B/16)); block 1024: the 16 waves split the 4H-long reduction.
 template <int MODE>
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(
+__global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(
     const float* __restrict__ dy, const void* __restrict__ WhhT, const float* __restrict__ c_all,
     const float* __restrict__ gates, float* __restrict__ dgates, void* __restrict__ dgshadow,
-    float* __restrict__ dc, int B, int L, int H, int t) {
-  __shared__ float part[4][16][17];
+    float* __restrict__ dc, int B, int L, int H, int t, int Kw) {
+  __shared__ float part[16][16][17];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
   const int r = lane & 15;
   const size_t esz = MODE == 0 ? 2 : 4;
   const int K4 = 4 * H;
+  // elementwise inputs first (independent of the dot product; see the forward kernel)
+  const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
+  const int u = u0 + uu;
+  const bool upd = threadIdx.x < 256 && (b0 + bb) < B && u < H;
+  const long long row = (long long)(b0 + bb) * L + t;
+  float dyv = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cp = 0.f, dcn = 0.f;
+  if (upd) {
+    const float* gs = gates + row * K4;
+    dyv = dy[row * H + u];
+    ig = gs[u]; fg = gs[H + u]; gg = gs[2 * H + u]; og = gs[3 * H + u];
+    c = c_all[row * H + u];
+    if (t > 0) cp = c_all[(row - 1) * H + u];
+    if (t + 1 < L) dcn = dc[(long long)(b0 + bb) * H + u];
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (t + 1 < L) {
-    // dh_rec[b][u] = sum_k dgates_{t+1}[b][k] * W_hh[k][u]; wave w reduces k in [w*H, (w+1)*H)
+  const int kbeg = w * Kw;
+  const int klen = min(Kw, K4 - kbeg);
+  if (t + 1 < L && klen > 0) {
+    // dh_rec[b][u] = sum_k dgates_{t+1}[b][k] * W_hh[k][u]
     const bool a_valid = (b0 + r) < B;
     const void* ag = MODE == 0 ? (const void*)dgshadow : (const void*)dgates;
     const char* arow = reinterpret_cast<const char*>(ag) +
-                       (((long long)(min(b0 + r, B - 1)) * L + (t + 1)) * K4 + (long long)w * H) * esz;
-    const char* brow = reinterpret_cast<const char*>(WhhT) + ((long long)(u0 + r) * K4 + (long long)w * H) * esz;
-    acc = dot_tile<MODE>(arow, a_valid, brow, H, lane);
+                       (((long long)(min(b0 + r, B - 1)) * L + (t + 1)) * K4 + kbeg) * esz;
+    const char* brow = reinterpret_cast<const char*>(WhhT) + ((long long)(u0 + r) * K4 + kbeg) * esz;
+    acc = dot_tile<MODE>(arow, a_valid, brow, klen, lane);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[w][(lane >> 4) * 4 + e][r] = acc[e];
   __syncthreads();
-  const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
-  const int b = b0 + bb, u = u0 + uu;
-  if (b < B && u < H) {
-    const long long row = (long long)b * L + t;
-    const float dh = dy[row * H + u] + part[0][bb][uu] + part[1][bb][uu] + part[2][bb][uu] + part[3][bb][uu];
-    const float* gs = gates + row * K4;
-    const float ig = gs[u], fg = gs[H + u], gg = gs[2 * H + u], og = gs[3 * H + u];
-    const float c = c_all[row * H + u];
-    const float cp = t > 0 ? c_all[(row - 1) * H + u] : 0.f;
+  if (upd) {
+    float dh = dyv;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dh += part[q][bb][uu];
     const float tc = nsp_tanh(c);
-    const float dcn = (t + 1 < L) ? dc[(long long)b * H + u] : 0.f;
     const float dct = dcn + dh * og * (1.f - tc * tc);
     const float d_o = dh * tc * og * (1.f - og);
     const float d_i = dct * gg * ig * (1.f - ig);
     const float d_f = dct * cp * fg * (1.f - fg);
     const float d_g = dct * ig * (1.f - gg * gg);
-    dc[(long long)b * H + u] = dct * fg;
+    dc[(long long)(b0 + bb) * H + u] = dct * fg;
     float* dg = dgates + row * K4;
     dg[u] = d_i; dg[H + u] = d_f; dg[2 * H + u] = d_g; dg[3 * H + u] = d_o;
     if (MODE == 0) {
@@ -168,12 +196,13 @@ extern "C" int nsp_lstm_fwd(const float* gi, const void* Whh, float* y, void* ys
   if (B <= 0 || L <= 0 || H <= 0 || H % 16) return NSP_EUNSUPPORTED;
   if (mode == NSP_COMPUTE_BF16 && H % 8) return NSP_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(H / 16, nsp_cdiv(B, 16)), block(256);
+  dim3 grid(H / 4, nsp_cdiv(B, 16)), block(256);
+  const int Kw = ((H + 3) / 4 + 7) / 8 * 8;  // per-wave slice of the reduction (whole bf16x8 chunks)
   for (int t = 0; t < L; ++t) {
     if (mode == NSP_COMPUTE_BF16)
-      hipLaunchKernelGGL((lstm_step_fwd_kernel<0>), grid, block, 0, st, gi, Whh, y, yshadow, c_all, gates, B, L, H, t);
+      hipLaunchKernelGGL((lstm_step_fwd_kernel<0>), grid, block, 0, st, gi, Whh, y, yshadow, c_all, gates, B, L, H, t, Kw);
     else
-      hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, gi, Whh, y, (void*)y, c_all, gates, B, L, H, t);
+      hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, gi, Whh, y, (void*)y, c_all, gates, B, L, H, t, Kw);
   }
   NSP_LAUNCH_CHECK();
   return NSP_OK;
@@ -186,12 +215,13 @@ extern "C" int nsp_lstm_bwd(const float* dy, const void* WhhT, const float* c_al
                             void* stream) {
   if (B <= 0 || L <= 0 || H <= 0 || H % 16) return NSP_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(H / 16, nsp_cdiv(B, 16)), block(256);
+  dim3 grid(H / 16, nsp_cdiv(B, 16)), block(1024);
+  const int Kw = ((4 * H + 15) / 16 + 7) / 8 * 8;
   for (int t = L - 1; t >= 0; --t) {
     if (mode == NSP_COMPUTE_BF16)
-      hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), grid, block, 0, st, dy, WhhT, c_all, gates, dgates, dgshadow, dc, B, L, H, t);
+      hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), grid, block, 0, st, dy, WhhT, c_all, gates, dgates, dgshadow, dc, B, L, H, t, Kw);
     else
-      hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), grid, block, 0, st, dy, WhhT, c_all, gates, dgates, (void*)dgates, dc, B, L, H, t);
+      hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), grid, block, 0, st, dy, WhhT, c_all, gates, dgates, (void*)dgates, dc, B, L, H, t, Kw);
   }
   NSP_LAUNCH_CHECK();
   return NSP_OK;

@@ -208,18 +208,31 @@ class RNNTransducer(DecoderBase):
         dout, _ = self.recurrency(self.embed_token_id(ys_in), None)
         return ops.linear(dout, self.w_dec.weight, None)
 
+    def mark_step_start(self):
+        """Record the point on the current stream the prediction network has to wait for
+        (the previous step's optimizer update); everything enqueued later is independent of it."""
+        if self.rnnt_weight <= 0 or not torch.cuda.is_available():
+            return
+        self._step_start_event = torch.cuda.Event()
+        self._step_start_event.record(torch.cuda.current_stream(self.device))
+
     def start_prediction_network(self, ys):
         """Launch the prediction network on a side HIP stream.  It depends only on the labels,
-        so its ~400 small sequential LSTM-step kernels (64 workgroups each) overlap with the
-        encoder instead of serialising after it; forward_transducer joins the stream.  The
-        autograd engine replays the backward of these nodes on the same side stream."""
+        so its ~400 small sequential LSTM-step kernels overlap with the encoder instead of
+        serialising after it; forward_transducer joins the stream.  The autograd engine replays
+        the backward of these nodes on the same side stream (see ops.replay_graph_first for how
+        that backward is made to start before the encoder's, not after it)."""
         if self.rnnt_weight <= 0 or not torch.cuda.is_available() or os.environ.get('NSP_PREDNET_STREAM', '1') == '0':
             return
         dev = self.device
         if getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream(device=dev)
-        cur = torch.cuda.current_stream(dev)
-        self._side_stream.wait_stream(cur)
+            self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('NSP_PREDNET_STREAM_PRIORITY', '-1')))
+        ev = getattr(self, '_step_start_event', None)
+        self._step_start_event = None
+        if ev is not None:
+            self._side_stream.wait_event(ev)
+        else:
+            self._side_stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._side_stream):
             dec_proj = self._prediction_network(ys, dev)
         self._pending_dec_proj = (dec_proj, id(ys))
@@ -235,6 +248,9 @@ class RNNTransducer(DecoderBase):
             cur = torch.cuda.current_stream(dev)
             cur.wait_stream(self._side_stream)
             dec_proj.record_stream(cur)
+            if torch.is_grad_enabled() and dec_proj.requires_grad \
+                    and os.environ.get('NSP_PREDNET_PRIORITY', '1') != '0':
+                dec_proj = ops.replay_graph_first(dec_proj)
         else:
             dec_proj = self._prediction_network(ys, dev)                        # `[B,L+1,J]`
         enc_proj = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias)       # `[B,T,J]`

@@ -553,6 +553,9 @@ class TransformerEncoder(EncoderBase):
             N_l = max(0, N_l // self.conv_factor)
             N_c = N_c // self.conv_factor
             N_r = N_r // self.conv_factor
+        cb = getattr(self, '_after_frontend', None)
+        if cb is not None:
+            cb()  # host-side hook: work that is independent of the encoder gets enqueued here
         if self.streaming_type == 'mask':
             xs = xs.contiguous().view(bs, -1, xs.size(2))[:, :int(xlens.max())].contiguous()
         if self.enc_type == 'conv':

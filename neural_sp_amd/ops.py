@@ -1110,6 +1110,32 @@ class LSTMFn(torch.autograd.Function):
         return dx, dw_ih, dw_hh, db, db
 
 
+class ReplayGraphFirstFn(torch.autograd.Function):
+    """Identity on a detached copy of `y` whose backward replays y's own graph from inside this
+    node.  The autograd engine orders ready nodes by creation time (latest first); a sub-graph
+    that was built EARLY to overlap with other forward work (the prediction network, started on a
+    side stream before the encoder) would therefore run its backward LAST, after the whole
+    encoder backward has been enqueued -- serialising ~5 ms of LSTM step kernels at the end of
+    the step.  This node is created late (at the joint), so the replay starts first and the
+    side-stream backward overlaps with the encoder backward on the main stream."""
+
+    @staticmethod
+    def forward(ctx, leaf, holder):
+        ctx.holder = holder
+        return leaf.view_as(leaf)
+
+    @staticmethod
+    def backward(ctx, dy):
+        y = ctx.holder.pop()
+        torch.autograd.backward(y, dy)
+        return None, None
+
+
+def replay_graph_first(y):
+    leaf = y.detach().requires_grad_(True)
+    return ReplayGraphFirstFn.apply(leaf, [y])
+
+
 def lstm(x, w_ih, w_hh, b_ih, b_hh):
     return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh)
 

@@ -11,6 +11,8 @@ members are inference-side and raise NotImplementedError.
 import logging
 import random
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -66,6 +68,53 @@ class SpecAugment(object):
     def __call__(self, xs):
         fb, tb = self.draw(xs.size(1), xs.size(2))
         return ops.specaug_apply_(xs, fb, tb)
+
+
+class LazyObservation(dict):
+    """The observation dict of Speech2Text.forward (python floats, speech2text.py:262-293) whose
+    single device->host transfer happens on first read instead of inside forward()."""
+
+    def __init__(self, static, keys, stacked):
+        super().__init__(static)
+        self._pending = (keys, stacked)
+
+    def materialize(self):
+        if self._pending is not None:
+            keys, stacked = self._pending
+            self._pending = None
+            for k, v in zip(keys, stacked.tolist()):
+                dict.__setitem__(self, k, v)
+        return self
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self.materialize(), k)
+
+    def get(self, k, default=None):
+        return dict.get(self.materialize(), k, default)
+
+    def items(self):
+        return dict.items(self.materialize())
+
+    def values(self):
+        return dict.values(self.materialize())
+
+    def pop(self, *a):
+        return dict.pop(self.materialize(), *a)
+
+    def copy(self):
+        return dict(self.materialize())
+
+    def __eq__(self, other):
+        return dict.__eq__(self.materialize(), other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __repr__(self):
+        return dict.__repr__(self.materialize())
+
+    def __reduce__(self):
+        return (dict, (dict(self.materialize()),))
 
 
 class Speech2Text(nn.Module):
@@ -209,8 +258,15 @@ class Speech2Text(nn.Module):
 
     def _forward(self, batch, task):
         if isinstance(getattr(self, 'dec_fwd', None), RNNT) and (task == 'all' or 'ctc' not in task):
-            self.dec_fwd.start_prediction_network(batch['ys'])  # overlaps with the encoder
-        eout_dict = self.encode(batch['xs'], task if self.mtl_per_batch else 'all')
+            # the prediction network overlaps with the encoder on a side stream; it is enqueued
+            # right after the encoder's front-end so that neither stream starts the step idle
+            dec, ys = self.dec_fwd, batch['ys']
+            dec.mark_step_start()
+            self.enc._after_frontend = lambda: dec.start_prediction_network(ys)
+        try:
+            eout_dict = self.encode(batch['xs'], task if self.mtl_per_batch else 'all')
+        finally:
+            self.enc._after_frontend = None
         observation = {}
         loss = torch.zeros((1,), dtype=torch.float32, device=self.device)
         if (self.fwd_weight > 0 or (self.bwd_weight == 0 and self.ctc_weight > 0)) \
@@ -234,14 +290,17 @@ class Speech2Text(nn.Module):
     @staticmethod
     def _finalize_observation(observation):
         """The reference calls .item() three times per step inside the decoders
-        (rnn_transducer.py:199,208,214), each a full device sync.  The decoders here hand back
-        device scalars; they become the python floats the Reporter expects with ONE transfer."""
+        (rnn_transducer.py:199,208,214), each a full device sync in the middle of the step.  The
+        decoders here hand back device scalars; they become the python floats the Reporter
+        expects with ONE transfer, made when the dict is first read (LazyObservation): a
+        training loop that reads it after loss.backward() keeps the host ahead of the GPU for
+        the whole step instead of draining the queue between forward and backward."""
         keys = [k for k, v in observation.items() if torch.is_tensor(v)]
-        if keys:
-            vals = torch.stack([observation[k].reshape(()).float() for k in keys]).tolist()
-            for k, v in zip(keys, vals):
-                observation[k] = v
-        return observation
+        if not keys:
+            return observation
+        stacked = torch.stack([observation[k].detach().reshape(()).float() for k in keys])
+        obs = LazyObservation(observation, keys, stacked)
+        return obs.materialize() if os.environ.get('NSP_EAGER_OBSERVATION', '0') == '1' else obs
 
     def encode(self, xs, task='all', streaming=False, cnn_lookback=False, cnn_lookahead=False,
                xlen_block=-1):
