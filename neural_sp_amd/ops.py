@@ -57,6 +57,34 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Small zero-initialised scratch (atomic accumulators for bias / LayerNorm / depthwise-conv
+# gradients: ~230 of them per Conformer-L step) comes out of chunks that are zeroed ONCE with a
+# single fill and handed out as slices.  A chunk is never reused or re-zeroed: it dies with its
+# last slice, so a slice that autograd keeps as a .grad stays valid.  One pool per stream (the
+# fill is only ordered with work on the stream it was enqueued on).  Slices share the chunk's
+# autograd version counter, so they are for backward-side scratch / gradients only -- never for
+# a tensor that is saved for backward.
+_ZERO_POOL = {}
+_ZERO_CHUNK = 1 << 20  # bytes
+
+
+def zeros_small(shape, device, dtype=torch.float32):
+    n = 1
+    for v in shape:
+        n *= int(v)
+    nbytes = (n * (4 if dtype == torch.float32 else 2) + 255) // 256 * 256
+    if nbytes > _ZERO_CHUNK // 4 or dtype not in (torch.float32, torch.bfloat16):
+        return torch.zeros(shape, device=device, dtype=dtype)
+    key = (device.index if device.type == 'cuda' else -1, torch.cuda.current_stream(device).cuda_stream)
+    ent = _ZERO_POOL.get(key)
+    if ent is None or ent[1] + nbytes > _ZERO_CHUNK:
+        ent = [torch.zeros((_ZERO_CHUNK,), device=device, dtype=torch.uint8), 0]
+        _ZERO_POOL[key] = ent
+    off = ent[1]
+    ent[1] = off + nbytes
+    return ent[0][off:off + n * (4 if dtype == torch.float32 else 2)].view(dtype).view(shape)
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
@@ -235,7 +263,7 @@ def grad_prep(dy2d, pre, act, alpha, p, seed, offset, out_bf16):
 
 def colsum(x2d, alpha=1.0):
     rows, cols = x2d.shape
-    out = torch.zeros((cols,), device=x2d.device, dtype=torch.float32)
+    out = zeros_small((cols,), x2d.device)
     fn = _lib.lib().nsp_colsum_bf16 if x2d.dtype == torch.bfloat16 else _lib.lib().nsp_colsum
     _check(fn(_p(x2d), _p(out), (rows), (cols),
               (x2d.stride(0)), (1), _stream()), 'nsp_colsum')
@@ -408,7 +436,7 @@ def layernorm_fwd_raw(x2d, gamma, beta, eps, act=0, want_pre=False, want16=False
 def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0):
     rows, d = x2d.shape
     dx = torch.empty_like(x2d)
-    dgb = torch.zeros((2, d), device=x2d.device, dtype=torch.float32)
+    dgb = zeros_small((2, d), x2d.device)
     _check(_lib.lib().nsp_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(y_pre),
                                         _p(dx), (dgb.data_ptr()),
                                         (dgb.data_ptr() + 4 * d),
@@ -642,7 +670,7 @@ class DepthwiseConv1dFn(torch.autograd.Function):
         B, T, C = x.shape
         k, pad = ctx.k, ctx.pad
         dx = _dwconv_fwd(dy, wt, None, k, k - 1 - pad, 1) if ctx.needs_input_grad[0] else None
-        buf = torch.zeros((k + 1, C), device=x.device, dtype=torch.float32)
+        buf = zeros_small((k + 1, C), x.device)
         _check(_lib.lib().nsp_dwconv1d_wgrad(_p(x), _p(dy), (buf.data_ptr()),
                                              (buf.data_ptr() + 4 * k * C),
                                              (B), (T), (C),
@@ -745,7 +773,7 @@ class Conv3x3ReLUFn(torch.autograd.Function):
             dx = _conv3x3_fwd(dz, w_t, None, False, mask_src=x if fuse else None)
             if fuse:
                 ctx.in_flag['masked'] = True
-        buf = torch.zeros((Co * 9 * Ci + Co,), device=x.device, dtype=torch.float32)
+        buf = zeros_small((Co * 9 * Ci + Co,), x.device)
         _check(_lib.lib().nsp_conv2d3x3_wgrad(_p(x), _p(dz), buf.data_ptr(), buf.data_ptr() + 4 * Co * 9 * Ci,
                                               B, T, F, Ci, Co, _COMPUTE_MODE['mode'], _stream()),
                'nsp_conv2d3x3_wgrad')
@@ -895,7 +923,7 @@ class RNNTJointLossFn(torch.autograd.Function):
         dl = _f32c(dloss).reshape(-1)  # upstream gradient stays on the device (no host sync)
         Vp = (V + 63) // 64 * 64
         d16 = torch.empty((n, Vp), device=h.device, dtype=torch.bfloat16) if use16 else None
-        db_fused = torch.zeros((V,), device=h.device, dtype=torch.float32) if ctx.has_bias else None
+        db_fused = zeros_small((V,), h.device) if ctx.has_bias else None
         _check(L.nsp_rnnt_grad_logits(_p(logits), _p(aux[0]), _p(labels), _p(aux[5]), _p(aux[6]),
                                       _p(elens), _p(ylens), (wscale), _p(dl), (B),
                                       (T), (U1), (V),
@@ -1354,7 +1382,7 @@ class SelfAttnFn(torch.autograd.Function):
             gemm_raw(M, dk, Rp, dQP16, H * Rp, 1, pos16, d, 1, dq_pos, d, batch=(H, 1), a_b=(Rp, 0),
                      b_b=(dk, 0), c_b=(dk, 0), res=dq_acc)
             if ctx.needs_input_grad[10]:
-                dpos = torch.zeros((Rp, d), device=dev, dtype=torch.float32)         # dQP^T q
+                dpos = zeros_small((Rp, d), dev)                                      # dQP^T q
                 gemm_raw(Rp, dk, M, dQP16, 1, H * Rp, qkv, d3, 1, dpos, d, batch=(H, 1), a_b=(Rp, 0),
                          b_b=(dk, 0), c_b=(dk, 0), splitk=max(1, min(64, M // 256)))
                 dpos16 = to_bf16(dpos)
