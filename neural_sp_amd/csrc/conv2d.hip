@@ -191,40 +191,64 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
 }
 
 // ---- weight gradient, C_in = 1: dw[co][tap] += sum_p dy[p][co] x[p+tap]; dbias[co] += sum dy
+// A workgroup owns `rows_per_block` consecutive (b,t) rows: their x rows (+1 halo row each side,
+// zero halo columns) are staged in LDS once, so the only global stream is dy, read as float4 by
+// thread = (4 output channels, one of 32 pixel lanes).  (The first version re-derived (b,t,f)
+// with 64-bit divisions and issued 9 predicated global loads per pixel: 0.3 TB/s.)
 __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ dy,
                                                                float* __restrict__ dw,
                                                                float* __restrict__ dbias, int B, int T,
-                                                               int F, long long pix_per_block) {
-  __shared__ float sh[8][10][CH];
-  const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const long long npix = (long long)B * T * F;
-  const long long p0 = (long long)blockIdx.x * pix_per_block;
-  const long long p1 = min(npix, p0 + pix_per_block);
-  float acc[10];
+                                                               int F, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [(rows_per_block + 2)][F + 2]
+  __shared__ float sh[32][10][CH + 1];
+  const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int BT = B * T, FP = F + 2;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int nr = min(BT, r0 + rows_per_block) - r0;
+  for (int idx = threadIdx.x; idx < (nr + 2) * FP; idx += blockDim.x) {
+    const int gr = r0 + idx / FP - 1, fc = idx % FP - 1;
+    xs[idx] = (gr >= 0 && gr < BT && fc >= 0 && fc < F) ? x[(long long)gr * F + fc] : 0.f;
+  }
+  __syncthreads();
+  float acc[10][4];
 #pragma unroll
-  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-#pragma unroll 4
-  for (long long p = p0 + pl; p < p1; p += 8) {
-    const int f = (int)(p % F);
-    const int t = (int)((p / F) % T);
-    const long long b = p / ((long long)F * T);
-    const float g = dy[p * CH + co];
-    acc[9] += g;
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  const int t0 = r0 % T;
+  int lr = pl / F, f = pl % F;
+  const float* dyb = dy + (long long)r0 * F * CH + cg * 4;
+#pragma unroll 2
+  for (int q = pl; q < nr * F; q += 32) {
+    const float4 g = *reinterpret_cast<const float4*>(dyb + (long long)q * CH);
+    int t = t0 + lr;
+    if (t >= T) t -= T;
+    // a halo row that belongs to the neighbouring utterance (or lies outside) counts as zero
+    const float m_up = t > 0 ? 1.f : 0.f, m_dn = t < T - 1 ? 1.f : 0.f;
+    const float* xc = xs + (lr + 1) * FP + (f + 1);
+    acc[9][0] += g.x; acc[9][1] += g.y; acc[9][2] += g.z; acc[9][3] += g.w;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int tt = t + tap / 3 - 1, ff = f + tap % 3 - 1;
-      if (tt >= 0 && tt < T && ff >= 0 && ff < F) acc[tap] += g * x[(b * T + tt) * F + ff];
+      const int dt = tap / 3 - 1, df = tap % 3 - 1;
+      float xv = xc[dt * FP + df];
+      if (dt < 0) xv *= m_up;
+      if (dt > 0) xv *= m_dn;
+      acc[tap][0] += g.x * xv; acc[tap][1] += g.y * xv; acc[tap][2] += g.z * xv; acc[tap][3] += g.w * xv;
     }
+    f += 32;
+    while (f >= F) { f -= F; ++lr; }
   }
 #pragma unroll
-  for (int i = 0; i < 10; ++i) sh[pl][i][co] = acc[i];
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[pl][i][cg * 4 + e] = acc[i][e];
   __syncthreads();
   for (int i = threadIdx.x; i < 10 * CH; i += blockDim.x) {
     const int tap = i / CH, c = i % CH;
     float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += sh[q][tap][c];
+    for (int q = 0; q < 32; ++q) s += sh[q][tap][c];
     if (tap < 9) unsafeAtomicAdd(dw + c * 9 + tap, s);
     else if (dbias) unsafeAtomicAdd(dbias + c, s);
   }
@@ -523,13 +547,15 @@ extern "C" int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, f
   hipStream_t st = (hipStream_t)stream;
   if (Co != CH) return NSP_EUNSUPPORTED;
   if (Ci == 1) {
-    const long long npix = (long long)B * T * F;
-    int blocks = 1024;
-    long long ppb = (npix + blocks - 1) / blocks;
-    if (ppb < 64) ppb = 64;
-    blocks = nsp_cdiv(npix, ppb);
-    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dy, dw, dbias, B, T,
-                       F, ppb);
+    const int BT = B * T;
+    int rpb = (BT + 1023) / 1024;                       // ~1024 workgroups ...
+    const int cap = (int)((20 * 1024) / (sizeof(float) * (F + 2))) - 2;  // ... within 20 KB of staged rows
+    if (rpb > cap) rpb = cap;
+    if (rpb > T) rpb = T;
+    if (rpb < 1) return NSP_EUNSUPPORTED;
+    const size_t shmem = sizeof(float) * (size_t)(rpb + 2) * (F + 2);
+    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(nsp_cdiv(BT, rpb)), dim3(256), shmem, st, x, dy, dw,
+                       dbias, B, T, F, rpb);
   } else if (Ci == CH) {
     const int tiles_f = nsp_cdiv(F, TF), tiles_t = nsp_cdiv(T, TT);
     long long ntiles = (long long)B * tiles_f * tiles_t;
