@@ -21,6 +21,7 @@
 //      16-lane group, lane 4a+b supplies the address of matrix row a, columns
 //      4b..4b+3; lane i receives column i of the 4x16 block.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -144,7 +145,8 @@ __device__ __forceinline__ void load4(const void* base, int dtype, long long off
 }
 
 // ---- shared epilogue (see the comment inside): acc[mi][ni] -> global with full-line accesses
-__device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[4][4],
+template <int MI>  // MI 16-row fragments per wave along M (wave tile = 16*MI x 64)
+__device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4],
                                               unsigned char* smem, int m0, int n0, int wm, int wn,
                                               int lane, int wave, long long coff, int c_vec) {
   const int fr = lane & 15, fg = lane >> 4;
@@ -159,7 +161,7 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   const int er = lane >> 4, ec = (lane & 15) * 4;  // read-back: row er + 4*j, cols ec..ec+3
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
       *reinterpret_cast<float4*>(stage + fr * SP + ni * 16 + fg * 4) =
@@ -169,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
     for (int j = 0; j < 4; ++j) {
       const int row = er + 4 * j;
       const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
-      const int m = m0 + wm * 64 + mi * 16 + row;
+      const int m = m0 + wm * (16 * MI) + mi * 16 + row;
       const int n = n0 + wn * 64 + ec;
       if (m >= p.M || n >= p.N) continue;
       const long long off = coff + (long long)m * p.ldc + n;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
     __syncthreads();
   }
 
-  gemm_epilogue(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+  gemm_epilogue<4>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
 // ---- KC x KC with direct-to-LDS loads (global_load_lds_dwordx4): no VGPR staging, no
@@ -372,7 +374,117 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_glds_kernel(const nsp_g
     }
     __syncthreads();
   }
-  gemm_epilogue(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+  gemm_epilogue<4>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+}
+
+// ---- the same KC x KC tile with an NS-stage LDS ring.  The single-stage kernel above hides the
+// global->LDS latency only through occupancy (4 workgroups per CU); a grid that puts at most one
+// or two workgroups on a CU (M = 3200 / 6400 encoder rows: 100..400 tiles for 256 CUs) then runs
+// load -> wait -> 32 MFMAs -> load ...: ~12 % of a CU's peak.  Here NS-1 k-tiles are in flight
+// while one is consumed: each wave waits for ITS loads of tile kt with a counted s_waitcnt
+// (vmcnt(8 x tiles issued since), never the compiler's vmcnt(0) that __syncthreads attaches when
+// LDS-DMA is outstanding), a raw s_barrier makes every wave's part visible and proves the stage
+// consumed in the previous iteration free, and only then is that stage re-armed.
+// MI = 2 halves the tile along M (64 x 128; wave tile 32 x 64) to double the workgroup count of
+// grids that would otherwise leave more than half of the CUs idle.
+template <int NS, int MI>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_gemm_params p, int tiles_m,
+                                                                     int tiles_n, int c_vec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // NS x (A tile | B tile 16 KB)
+  constexpr int BM_ = 32 * MI;            // rows of the A tile
+  constexpr int A_BYTES = BM_ * 128;      // 16 KB (MI = 4) or 8 KB (MI = 2)
+  constexpr int STAGE = A_BYTES + 16384;
+  constexpr int NA = MI;                  // A-tile DMA instructions per wave per k-tile (8 rows each)
+  constexpr int NLOAD = NA + 4;           // loads per lane per k-tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM_, n0 = tn * BN;
+  int z = blockIdx.z;
+  const int split = z % p.splitk;
+  z /= p.splitk;
+  const int z2 = z % p.batch2, z1 = z / p.batch2;
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
+  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    int nkt_all = p.K / BK;
+    int per = (nkt_all + p.splitk - 1) / p.splitk;
+    kbeg = split * per * BK;
+    kend = min(p.K, (split + 1) * per * BK);
+    if (kbeg >= kend) return;
+  }
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // every lane issues exactly NLOAD LDS-DMA loads per k-tile (rows beyond M / N re-read the last
+  // valid row: they only feed outputs that are never stored), so the vmcnt arithmetic is uniform
+  const int lrow = lane >> 3, lpos = lane & 7;
+  const __bf16* asrc[NA];
+  const __bf16* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (wave * NA + i) * 8 + lrow;
+    asrc[i] = A + (long long)min(m0 + row, p.M - 1) * p.a_rs + (lpos ^ (row & 7)) * 8 + kbeg;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + lrow;
+    bsrc[i] = B + (long long)min(n0 + row, p.N - 1) * p.b_ns + (lpos ^ (row & 7)) * 8 + kbeg;
+  }
+  const int fr = lane & 15, fg = lane >> 4;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int nkt = (kend - kbeg) / BK;
+  auto issue = [&](int kt) {
+    unsigned char* sa = ring + (kt % NS) * STAGE;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + k0), (lds_void*)(sa + (wave * NA + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + k0), (lds_void*)(sa + A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) issue(s);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int ahead = min(NS - 2, nkt - 1 - kt);  // k-tiles issued after tile kt so far
+    if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
+    else if (NS >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nkt) issue(kt + NS - 1);
+    const unsigned char* smA = ring + (kt % NS) * STAGE;
+    const unsigned char* smB = smA + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[MI], bf[4];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int ra = wm * (16 * MI) + i * 16 + fr;
+        af[i] = *reinterpret_cast<const bf16x8*>(smA + ra * 128 + (((s * 4 + fg) ^ (ra & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rb = wn * 64 + i * 16 + fr;
+        bf[i] = *reinterpret_cast<const bf16x8*>(smB + rb * 128 + (((s * 4 + fg) ^ (rb & 7)) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // the epilogue reuses the ring as its staging area
+  gemm_epilogue(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
 // fp32 [rows, cols] (row stride ld_in) -> bf16 [rows, ld_out] with zero fill; 8 elements per lane
@@ -418,7 +530,8 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   const int a_ext = a_kc ? p.K : p.M, b_ext = b_kc ? p.K : p.N;
   if ((a_ext % 8) && lda < ((a_ext + 7) / 8) * 8) return NSP_EINVAL;
   if ((b_ext % 8) && ldb < ((b_ext + 7) / 8) * 8) return NSP_EINVAL;
-  const int tiles_m = nsp_cdiv(p.M, BM), tiles_n = nsp_cdiv(p.N, BN);
+  int tiles_m = nsp_cdiv(p.M, BM);
+  const int tiles_n = nsp_cdiv(p.N, BN);
   const int csz = p.c_dtype == NSP_DT_BF16 ? 2 : 4;
   int c_vec = (reinterpret_cast<uintptr_t>(p.C) % (4 * csz) == 0) && p.ldc % 4 == 0 && p.c_b1 % 4 == 0 &&
               p.c_b2 % 4 == 0;
@@ -427,8 +540,29 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   if (p.res && !aligned16(p.res)) c_vec = 0;
   if (p.bias && !aligned16(p.bias)) c_vec = 0;
   dim3 grid(tiles_m * tiles_n, 1, p.batch1 * p.batch2 * p.splitk), block(NTHREADS);
-  if (a_kc && b_kc && p.K % BK == 0 && p.K >= BK)
-    hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  if (a_kc && b_kc && p.K % BK == 0 && p.K >= BK) {
+    // how many workgroups would share a CU decides how the load latency gets hidden
+    static int ring_env = -1;
+    if (ring_env < 0) {
+      const char* e = getenv("NSP_GEMM_RING");
+      ring_env = e ? atoi(e) : 1;
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+    }
+    const long long wgs = (long long)grid.x * grid.z;
+    const int nkt = p.K / BK / p.splitk;
+    if (ring_env && wgs < 192 && p.M > 64 && nkt >= 4) {
+      tiles_m = nsp_cdiv(p.M, 64);
+      grid.x = tiles_m * tiles_n;
+      hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 2>), grid, block, 4 * 24576, st, p, tiles_m, tiles_n, c_vec);
+    } else if (ring_env && wgs <= 288 && nkt >= 4)
+      hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 4>), grid, block, 4 * 32768, st, p, tiles_m, tiles_n, c_vec);
+    else if (ring_env && wgs <= 640 && nkt >= 2)
+      hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
+    else
+      hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  }
   else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
