@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -109,16 +111,28 @@ def main():
     batches = [synthetic_batch(B=a.batch, t_range=(a.tmin, a.tmax), u_range=(a.umin, a.umax),
                                vocab=1000, seed=1000 * rank + i) for i in range(n_distinct)]
 
+    reported = []        # what a Reporter would have logged: one dict of python floats per step
+    pending = [None]
+
+    def report_pending():
+        if pending[0] is not None:
+            reported.append(dict(pending[0].materialize()))   # the ONE D2H transfer of that step
+            pending[0] = None
+
     def step(i):
         batch = batches[i % len(batches)]
         loss, obs = train_model(batch, task='all')
         if distributed:
             loss = loss * world  # train.py:423-424
         loss.backward()
+        # the previous step's loss values are read here, one step late: reading step i's values
+        # right after its own forward (the reference's .item() calls) or at the end of the step
+        # drains the HIP queue and lets the GPU idle through the next step's host-bound forward
+        report_pending()
+        pending[0] = obs
         parallel.clip_grad_norm_(params, 5.0)
         opt.step()
         opt.zero_grad(set_to_none=True)
-        obs.materialize()  # the Reporter's per-step read of the loss values (one D2H transfer)
         return sum(batch['xlens'])
 
     def sync():
@@ -128,6 +142,7 @@ def main():
 
     for i in range(a.warmup):
         step(i)
+    report_pending()
     sync()
     if not a.no_kernel_events:
         ops.kernel_events_start()
@@ -135,8 +150,10 @@ def main():
     frames = 0
     for i in range(a.steps):
         frames += step(a.warmup + i)
+    report_pending()     # the last step's values are fetched inside the timed region too
     sync()
     dt = time.perf_counter() - t0
+    assert len(reported) == a.warmup + a.steps and all(np.isfinite(list(r.values())).all() for r in reported)
     kev = ops.kernel_events_stop() if not a.no_kernel_events else None
 
     tot = torch.tensor([dt, float(frames)], device=dev, dtype=torch.float64)

@@ -52,7 +52,7 @@ def _labels_to_device(ys, device, pad=0):
     lab = np.full((len(ys), Lmax), pad, dtype=np.int32)
     for b, y in enumerate(ys):
         lab[b, :len(y)] = np.asarray(y, dtype=np.int32)
-    return (torch.from_numpy(lab).to(device), torch.tensor(ylens, dtype=torch.int32, device=device), ylens)
+    return (ops.h2d(lab, device), ops.h2d(np.asarray(ylens, dtype=np.int32), device), ylens)
 
 
 class CTC(DecoderBase):
@@ -99,7 +99,7 @@ class CTC(DecoderBase):
         (loss `[1]`, trigger_points IntTensor `[B,L+1]` or None)."""
         ys_lab = [y[::-1] if self.bwd else y for y in ys]
         lab, ylens_dev, _ = _labels_to_device(ys_lab, eouts.device, pad=0)
-        elens_dev = elens.to(device=eouts.device, dtype=torch.int32)
+        elens_dev = ops.h2d(elens, eouts.device, torch.int32)
         logits = self.logits(eouts)
         loss, _ = ops.ctc_loss(logits, lab, elens_dev, ylens_dev, self.lsm_prob,
                                int(elens.sum()), self.blank)
@@ -126,7 +126,7 @@ class CTCForcedAligner(object):
 
     def __call__(self, logits, elens, ys, ylens=None):
         lab, ylens_dev, _ = _labels_to_device(ys, logits.device, pad=0)
-        elens_dev = elens.to(device=logits.device, dtype=torch.int32)
+        elens_dev = ops.h2d(elens, logits.device, torch.int32)
         return ops.ctc_forced_align(logits, lab, elens_dev, ylens_dev, self.blank)
 
 
@@ -204,7 +204,7 @@ class RNNTransducer(DecoderBase):
         for b, y in enumerate(ys):
             ys_in_np[b, 0] = self.eos
             ys_in_np[b, 1:len(y) + 1] = np.asarray(y, dtype=np.int64)
-        ys_in = torch.from_numpy(ys_in_np).to(dev)
+        ys_in = ops.h2d(ys_in_np, dev)
         dout, _ = self.recurrency(self.embed_token_id(ys_in), None)
         return ops.linear(dout, self.w_dec.weight, None)
 
@@ -240,7 +240,7 @@ class RNNTransducer(DecoderBase):
     def forward_transducer(self, eouts, elens, ys):
         dev = eouts.device
         lab, ylens_dev, _ = _labels_to_device(ys, dev, pad=self.blank)         # ys_out, blank-padded
-        elens_dev = elens.to(device=dev, dtype=torch.int32)
+        elens_dev = ops.h2d(elens, dev, torch.int32)
         pending = getattr(self, '_pending_dec_proj', None)
         self._pending_dec_proj = None
         if pending is not None and pending[1] == id(ys):

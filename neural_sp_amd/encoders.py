@@ -521,7 +521,7 @@ class TransformerEncoder(EncoderBase):
         self.offset = 0
 
     def _mask(self, xlens, lookahead, N_l=0, N_c=0):
-        klens = xlens.to(device=self.device, dtype=torch.int32, non_blocking=True)
+        klens = ops.h2d(xlens, self.device, torch.int32)
         if self.streaming_type == 'mask':
             return AttnMask(klens, False, 0, N_l, N_c)
         return AttnMask(klens, self.unidir, lookahead)

@@ -9,6 +9,7 @@ import ctypes
 import math
 import os
 
+import numpy as np
 import torch
 
 from neural_sp_amd import _lib
@@ -83,6 +84,36 @@ def zeros_small(shape, device, dtype=torch.float32):
     off = ent[1]
     ent[1] = off + nbytes
     return ent[0][off:off + n * (4 if dtype == torch.float32 else 2)].view(dtype).view(shape)
+
+
+def h2d(x, device, dtype=None):
+    """Host data (numpy array / list / CPU tensor) -> device tensor through a PINNED staging block,
+    asynchronously on the current stream.  A pageable-memory copy blocks the host until everything
+    queued on the stream before it has run (measured: 11 such copies = 7 ms of a 20 ms forward and
+    a drained HIP queue each time); pinned blocks come from torch's caching host allocator, which
+    also keeps a block from being reused before its copy has completed."""
+    t = x if torch.is_tensor(x) else torch.as_tensor(x)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    device = torch.device(device)
+    if t.device.type != 'cpu' or device.type == 'cpu':
+        return t.to(device)
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    return p.to(device, non_blocking=True)
+
+
+def h2d_packed(arrays, device):
+    """List of float arrays -> one flat fp32 device tensor (concatenated), assembled directly in
+    a pinned block: one host pass and one asynchronous copy."""
+    sizes = [int(a.size) for a in arrays]
+    p = torch.empty((sum(sizes),), dtype=torch.float32, pin_memory=True)
+    pn = p.numpy()
+    off = 0
+    for a, n in zip(arrays, sizes):
+        pn[off:off + n] = np.asarray(a, dtype=np.float32).reshape(-1)
+        off += n
+    return p.to(device, non_blocking=True)
 
 
 def _f32c(t):
@@ -996,8 +1027,8 @@ def scale_add_bcast(x, z, alpha):
 def specaug_apply_(xs, freq_bands, time_bands):
     """Zero [start,end) bands in place on [B,T,F] (spec_augment.py:112-140)."""
     B, T, F = xs.shape
-    fb = torch.tensor(freq_bands, dtype=torch.int32, device=xs.device).view(-1) if len(freq_bands) else None
-    tb = torch.tensor(time_bands, dtype=torch.int32, device=xs.device).view(-1) if len(time_bands) else None
+    fb = h2d(np.asarray(freq_bands, dtype=np.int32).reshape(-1), xs.device) if len(freq_bands) else None
+    tb = h2d(np.asarray(time_bands, dtype=np.int32).reshape(-1), xs.device) if len(time_bands) else None
     _check(_lib.lib().nsp_specaug_apply(_p(xs), (B), (T), (F),
                                         _p(fb), (len(freq_bands)), _p(tb),
                                         (len(time_bands)), _stream()), 'nsp_specaug_apply')

@@ -71,18 +71,30 @@ class SpecAugment(object):
 
 
 class LazyObservation(dict):
-    """The observation dict of Speech2Text.forward (python floats, speech2text.py:262-293) whose
-    single device->host transfer happens on first read instead of inside forward()."""
+    """The observation dict of Speech2Text.forward (python floats, speech2text.py:262-293).  The
+    device scalars are copied to a pinned host block asynchronously inside forward(); reading the
+    dict waits on the event recorded right behind that copy -- i.e. only for the forward that
+    produced the values, not for whatever has been enqueued on the stream since (a plain
+    .tolist() is a stream-synchronous copy and would drain the whole queue)."""
 
     def __init__(self, static, keys, stacked):
         super().__init__(static)
-        self._pending = (keys, stacked)
+        if stacked.is_cuda:
+            host = torch.empty(stacked.shape, dtype=stacked.dtype, pin_memory=True)
+            host.copy_(stacked, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(stacked.device))
+        else:
+            host, ev = stacked, None
+        self._pending = (keys, host, ev)
 
     def materialize(self):
         if self._pending is not None:
-            keys, stacked = self._pending
+            keys, host, ev = self._pending
             self._pending = None
-            for k, v in zip(keys, stacked.tolist()):
+            if ev is not None:
+                ev.synchronize()
+            for k, v in zip(keys, host.tolist()):
                 dict.__setitem__(self, k, v)
         return self
 
@@ -311,11 +323,9 @@ class Speech2Text(nn.Module):
         xlens = torch.IntTensor([len(x) for x in xs])
         dev = self.device
         B, Tmax, F = len(xs), int(xlens.max()), self.input_dim
-        packed = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in xs]))
         offs = torch.zeros(B, dtype=torch.int64)
         offs[1:] = torch.cumsum(xlens[:-1].long() * F, 0)
-        xs = ops.pad_batch(packed.to(dev, non_blocking=True), offs.to(dev, non_blocking=True),
-                           xlens.to(dev, non_blocking=True), B, Tmax, F, 0.)
+        xs = ops.pad_batch(ops.h2d_packed(xs, dev), ops.h2d(offs, dev), ops.h2d(xlens, dev), B, Tmax, F, 0.)
         if self.specaug is not None and self.training:
             xs = self.specaug(xs)
         if self.input_noise_std > 0 and self.training:
