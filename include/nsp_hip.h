@@ -353,6 +353,49 @@ int nsp_lstm_bwd(const float* dy /*[B,L,H]*/, const void* WhhT /*[H,4H]*/, const
                  float* dc /*[B,H] scratch*/, int B, int L, int H, int mode, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * The whole LSTM stack of the prediction network as ONE wavefront over        *
+ * (layer, time): stage s runs step t = s - l of every layer l in one launch, *
+ * so n layers of L steps cost L + n - 1 dependent launches instead of n * L  *
+ * (rnn_transducer.py:278-311 runs the layers one after the other).  Layers   *
+ * l >= 1 fold their input projection into the step (K = 2H: [W_ih | W_hh]);  *
+ * the inter-layer dropout (rnn_transducer.py:303) is applied where layer l   *
+ * publishes its output for layer l+1 (counter-based mask from seed/offset).  *
+ * bf16 operands only (NSP_COMPUTE_BF16); H % 64 == 0; nl <= NSP_LSTM_MAX_LAYERS.
+ * Forward fields: gi0 [B,L,4H] = x W_ih0^T + b (GEMM by the caller);         *
+ *   w[0] = W_hh0 bf16 [4H,H]; w[l>=1] = [W_ih_l | W_hh_l] bf16 [4H,2H];      *
+ *   bias[l>=1] = b_ih_l + b_hh_l fp32 [4H] (bias[0] unused);                 *
+ *   y_top fp32 [B,L,H] (output of the last layer, before any dropout);       *
+ *   hp16[l] bf16 [B,L,H]: h shifted by one step (hp16[b,t] = h_{t-1}, 0 at t=0):
+ *     the recurrent operand and, in backward, the W_hh weight-gradient operand;
+ *   yd16[l] bf16 [B,L,H], l < nl-1: dropout(h_l) = layer l+1's input;        *
+ *   c_all[l] fp32 [B,L,H], gates[l] fp32 [B,L,4H] (activated i,f,g,o).       *
+ * Backward fields: dy_top fp32 [B,L,H]; w[nl-1] = W_hh^T bf16 [H,4H];         *
+ *   w[l<nl-1] = [W_ih_{l+1}^T | W_hh_l^T] bf16 [H,8H]; dg16[l] bf16 [B,L,4H]  *
+ *   receives d(pre-activation gates); dc[l] fp32 [B,H] scratch.              *
+ * ------------------------------------------------------------------------ */
+#define NSP_LSTM_MAX_LAYERS 4
+typedef struct {
+  int nl, B, L, H;
+  float dropout_p;
+  int reserved;
+  const float* gi0;
+  const float* dy_top;
+  float* y_top;
+  const void* w[NSP_LSTM_MAX_LAYERS];
+  const float* bias[NSP_LSTM_MAX_LAYERS];
+  void* hp16[NSP_LSTM_MAX_LAYERS];
+  void* yd16[NSP_LSTM_MAX_LAYERS];
+  float* c_all[NSP_LSTM_MAX_LAYERS];
+  float* gates[NSP_LSTM_MAX_LAYERS];
+  void* dg16[NSP_LSTM_MAX_LAYERS];
+  float* dc[NSP_LSTM_MAX_LAYERS];
+  unsigned long long seed[NSP_LSTM_MAX_LAYERS];
+  unsigned long long offset[NSP_LSTM_MAX_LAYERS];
+} nsp_lstm_stack_params;
+int nsp_lstm_stack_fwd(const nsp_lstm_stack_params* p, void* stream);
+int nsp_lstm_stack_bwd(const nsp_lstm_stack_params* p, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * SpecAugment band zeroing in place on [B,T,F] (spec_augment.py:112-140).  *
  * bands are small device arrays of [start,end) pairs (drawn on the host     *
  * with the reference's np.random stream, then copied).                      *

@@ -108,6 +108,23 @@ class AttnMaskParams(ctypes.Structure):
     ]
 
 
+LSTM_MAX_LAYERS = 4
+
+
+class LstmStackParams(ctypes.Structure):
+    """Mirror of nsp_lstm_stack_params."""
+    _fields_ = [
+        ('nl', ctypes.c_int), ('B', ctypes.c_int), ('L', ctypes.c_int), ('H', ctypes.c_int),
+        ('dropout_p', ctypes.c_float), ('reserved', ctypes.c_int),
+        ('gi0', ctypes.c_void_p), ('dy_top', ctypes.c_void_p), ('y_top', ctypes.c_void_p),
+        ('w', ctypes.c_void_p * LSTM_MAX_LAYERS), ('bias', ctypes.c_void_p * LSTM_MAX_LAYERS),
+        ('hp16', ctypes.c_void_p * LSTM_MAX_LAYERS), ('yd16', ctypes.c_void_p * LSTM_MAX_LAYERS),
+        ('c_all', ctypes.c_void_p * LSTM_MAX_LAYERS), ('gates', ctypes.c_void_p * LSTM_MAX_LAYERS),
+        ('dg16', ctypes.c_void_p * LSTM_MAX_LAYERS), ('dc', ctypes.c_void_p * LSTM_MAX_LAYERS),
+        ('seed', ctypes.c_ulonglong * LSTM_MAX_LAYERS), ('offset', ctypes.c_ulonglong * LSTM_MAX_LAYERS),
+    ]
+
+
 _lib = None
 
 

@@ -187,6 +187,155 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wavefront over (layer, time): see nsp_lstm_stack_params in include/nsp_hip.h.
+// forward stage s.  grid: (H/4, nl, ceil(B/16)); block 512 = 8 waves splitting the reduction.
+// Layer l handles t = s - l.  The workgroup owns 4 hidden units (16 gate rows).
+__global__ __launch_bounds__(512) void lstm_stack_fwd_kernel(const nsp_lstm_stack_params p, int s) {
+  __shared__ float part[8][16][17];
+  const int l = blockIdx.y;
+  const int t = s - l;
+  if (t < 0 || t >= p.L) return;
+  const int H = p.H, L = p.L, B = p.B, top = p.nl - 1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int u0 = blockIdx.x * 4, b0 = blockIdx.z * 16;
+  const int r = lane & 15;
+  const int Ktot = l == 0 ? H : 2 * H;
+  const int Kw = Ktot >> 3;
+  // cell-update inputs first (independent of the dot product)
+  const int bb = threadIdx.x >> 2, uu = threadIdx.x & 3;
+  const bool upd = threadIdx.x < 64 && (b0 + bb) < B;
+  const long long row = (long long)(b0 + bb) * L + t;
+  const int u = u0 + uu;
+  float gin[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f;
+  if (upd) {
+    if (l == 0) {
+      const float* g = p.gi0 + row * 4 * H;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gin[q] = g[q * H + u];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gin[q] = p.bias[l][q * H + u];
+    }
+    if (t > 0) cp = p.c_all[l][(row - 1) * H + u];
+  }
+  const int kbeg = w * Kw;
+  const bool a_valid = (b0 + r) < B;
+  const long long arow = (long long)min(b0 + r, B - 1) * L + t;
+  const __bf16* abase;
+  if (l == 0 || kbeg >= H)   // recurrent half: h_{t-1} (hp16 holds h shifted by one step, 0 at t = 0)
+    abase = reinterpret_cast<const __bf16*>(p.hp16[l]) + arow * H + (l == 0 ? kbeg : kbeg - H);
+  else                       // input half: dropout(h_t of the layer below)
+    abase = reinterpret_cast<const __bf16*>(p.yd16[l - 1]) + arow * H + kbeg;
+  const __bf16* brow = reinterpret_cast<const __bf16*>(p.w[l]) +
+                       (long long)((r >> 2) * H + u0 + (r & 3)) * Ktot + kbeg;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (t > 0 || (l > 0 && kbeg < H)) acc = dot_tile<0>(abase, a_valid, brow, Kw, lane);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[w][(lane >> 4) * 4 + e][r] = acc[e];
+  __syncthreads();
+  if (upd) {
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = gin[q];
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) v += part[ww][bb][q * 4 + uu];
+      pre[q] = v;
+    }
+    const float ig = nsp_sigmoid(pre[0]);
+    const float fg = nsp_sigmoid(pre[1]);
+    const float gg = nsp_tanh(pre[2]);
+    const float og = nsp_sigmoid(pre[3]);
+    const float c = fg * cp + ig * gg;
+    const float h = og * nsp_tanh(c);
+    p.c_all[l][row * H + u] = c;
+    float* gs = p.gates[l] + row * 4 * H;
+    gs[u] = ig; gs[H + u] = fg; gs[2 * H + u] = gg; gs[3 * H + u] = og;
+    __bf16* hp = reinterpret_cast<__bf16*>(p.hp16[l]);
+    if (t + 1 < L) hp[(row + 1) * H + u] = (__bf16)h;
+    if (t == 0) hp[row * H + u] = (__bf16)0.f;
+    if (l == top) {
+      p.y_top[row * H + u] = h;
+    } else {
+      float hd = h;
+      if (p.dropout_p > 0.f)
+        hd *= nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
+      reinterpret_cast<__bf16*>(p.yd16[l])[row * H + u] = (__bf16)hd;
+    }
+  }
+}
+
+// backward stage s.  grid: (H/16, nl, ceil(B/16)); block 1024 = 16 waves.  Layer l handles
+// t = L-1 - (s - (top - l)).  dh = [l == top ? dy : mask * (dgates_{l+1}[t] W_ih_{l+1})] +
+// dgates_l[t+1] W_hh_l; for l < top the two products are one reduction over the concatenated
+// [W_ih_{l+1}^T | W_hh_l^T] rows (waves 0-7: input-gradient half, waves 8-15: recurrent half).
+__global__ __launch_bounds__(1024) void lstm_stack_bwd_kernel(const nsp_lstm_stack_params p, int s) {
+  __shared__ float part[16][16][17];
+  const int top = p.nl - 1;
+  const int l = blockIdx.y;
+  const int H = p.H, L = p.L, B = p.B;
+  const int t = L - 1 - (s - (top - l));
+  if (t < 0 || t >= L) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int u0 = blockIdx.x * 16, b0 = blockIdx.z * 16;
+  const int r = lane & 15;
+  const int K4 = 4 * H;
+  const bool has_ext = l < top;
+  const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
+  const int u = u0 + uu;
+  const bool upd = threadIdx.x < 256 && (b0 + bb) < B;
+  const long long row = (long long)(b0 + bb) * L + t;
+  float dyv = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cp = 0.f, dcn = 0.f, keep = 1.f;
+  if (upd) {
+    const float* gs = p.gates[l] + row * K4;
+    if (!has_ext) dyv = p.dy_top[row * H + u];
+    else if (p.dropout_p > 0.f)
+      keep = nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
+    ig = gs[u]; fg = gs[H + u]; gg = gs[2 * H + u]; og = gs[3 * H + u];
+    c = p.c_all[l][row * H + u];
+    if (t > 0) cp = p.c_all[l][(row - 1) * H + u];
+    if (t + 1 < L) dcn = p.dc[l][(long long)(b0 + bb) * H + u];
+  }
+  const int Ktot = has_ext ? 2 * K4 : K4;
+  const int Kw = Ktot >> 4;
+  const int kbeg = w * Kw;
+  const bool a_valid = (b0 + r) < B;
+  const long long arow = (long long)min(b0 + r, B - 1) * L + t;
+  const __bf16* abase;
+  bool live;
+  if (has_ext && kbeg < K4) {   // d(input of layer l+1) at the SAME time step
+    abase = reinterpret_cast<const __bf16*>(p.dg16[l + 1]) + arow * K4 + kbeg;
+    live = true;
+  } else {                      // recurrent: this layer's dgates at t + 1
+    abase = reinterpret_cast<const __bf16*>(p.dg16[l]) + (arow + 1) * K4 + (has_ext ? kbeg - K4 : kbeg);
+    live = t + 1 < L;
+  }
+  const __bf16* brow = reinterpret_cast<const __bf16*>(p.w[l]) + (long long)(u0 + r) * Ktot + kbeg;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (live) acc = dot_tile<0>(abase, a_valid, brow, Kw, lane);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[w][(lane >> 4) * 4 + e][r] = acc[e];
+  __syncthreads();
+  if (upd) {
+    float ext = 0.f, rec = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ext += part[q][bb][uu];
+#pragma unroll
+    for (int q = 8; q < 16; ++q) rec += part[q][bb][uu];
+    const float dh = has_ext ? keep * ext + rec : dyv + ext + rec;
+    const float tc = nsp_tanh(c);
+    const float dct = dcn + dh * og * (1.f - tc * tc);
+    const float d_o = dh * tc * og * (1.f - og);
+    const float d_i = dct * gg * ig * (1.f - ig);
+    const float d_f = dct * cp * fg * (1.f - fg);
+    const float d_g = dct * ig * (1.f - gg * gg);
+    p.dc[l][(long long)(b0 + bb) * H + u] = dct * fg;
+    __bf16* ds = reinterpret_cast<__bf16*>(p.dg16[l]) + row * K4;
+    ds[u] = (__bf16)d_i; ds[H + u] = (__bf16)d_f; ds[2 * H + u] = (__bf16)d_g; ds[3 * H + u] = (__bf16)d_o;
+  }
+}
+
 }  // namespace
 
 // Runs all L steps.  Whh: [4H,H] (bf16 shadow in NSP_COMPUTE_BF16, fp32 in NSP_COMPUTE_F32);
@@ -223,6 +372,34 @@ extern "C" int nsp_lstm_bwd(const float* dy, const void* WhhT, const float* c_al
     else
       hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), grid, block, 0, st, dy, WhhT, c_all, gates, dgates, (void*)dgates, dc, B, L, H, t, Kw);
   }
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+static int lstm_stack_check(const nsp_lstm_stack_params* p) {
+  if (!p || p->nl < 1 || p->nl > NSP_LSTM_MAX_LAYERS) return NSP_EINVAL;
+  if (p->B <= 0 || p->L <= 0 || p->H <= 0 || p->H % 64) return NSP_EUNSUPPORTED;
+  return NSP_OK;
+}
+
+extern "C" int nsp_lstm_stack_fwd(const nsp_lstm_stack_params* p, void* stream) {
+  int rc = lstm_stack_check(p);
+  if (rc != NSP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(p->H / 4, p->nl, nsp_cdiv(p->B, 16)), block(512);
+  for (int s = 0; s < p->L + p->nl - 1; ++s)
+    hipLaunchKernelGGL(lstm_stack_fwd_kernel, grid, block, 0, st, *p, s);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_lstm_stack_bwd(const nsp_lstm_stack_params* p, void* stream) {
+  int rc = lstm_stack_check(p);
+  if (rc != NSP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(p->H / 16, p->nl, nsp_cdiv(p->B, 16)), block(1024);
+  for (int s = 0; s < p->L + p->nl - 1; ++s)
+    hipLaunchKernelGGL(lstm_stack_bwd_kernel, grid, block, 0, st, *p, s);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -205,7 +205,7 @@ class RNNTransducer(DecoderBase):
             ys_in_np[b, 0] = self.eos
             ys_in_np[b, 1:len(y) + 1] = np.asarray(y, dtype=np.int64)
         ys_in = ops.h2d(ys_in_np, dev)
-        dout, _ = self.recurrency(self.embed_token_id(ys_in), None)
+        dout, _ = self.recurrency(self.embed_token_id(ys_in), None, need_state=False)
         return ops.linear(dout, self.w_dec.weight, None)
 
     def mark_step_start(self):
@@ -262,9 +262,18 @@ class RNNTransducer(DecoderBase):
         # embedding lookup = row gather of a [V, emb] table (host-side indexing glue)
         return ops.dropout(self.embed(indices), self.dropout_emb.p, self.training)
 
-    def recurrency(self, ys_emb, dstate):
+    def recurrency(self, ys_emb, dstate, need_state=True):
         if dstate is None:
-            dstate = self.zero_state(ys_emb.size(0))
+            dstate = self.zero_state(ys_emb.size(0)) if need_state else None
+        if (not need_state and self.proj is None and ys_emb.is_cuda
+                and os.environ.get('NSP_LSTM_STACK', '1') != '0'):
+            layers = [(r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0) for r in self.rnn]
+            if ops.lstm_stack_supported(layers, ys_emb):
+                # training path: all layers as one wavefront over (layer, time); the dropout between
+                # layers is fused, the one after the last layer is the ordinary op
+                p = self.dropout.p if self.training else 0.0
+                out = ops.lstm_stack(ys_emb, layers, p)
+                return ops.dropout(out, self.dropout.p, self.training), None
         new_hxs, new_cxs = [], []
         for lth in range(self.n_layers):
             rnn = self.rnn[lth]

@@ -1169,6 +1169,132 @@ class LSTMFn(torch.autograd.Function):
         return dx, dw_ih, dw_hh, db, db
 
 
+def _cat_cached(owner, name, parts, build):
+    """torch.cat of derived weight shadows, cached on `owner` and keyed by the versions of `parts`."""
+    key = tuple(p._version for p in parts)
+    ent = getattr(owner, name, None)
+    if ent is not None and ent[0] == key and ent[1].device == owner.device:
+        return ent[1]
+    t = build()
+    try:
+        setattr(owner, name, (key, t))
+    except Exception:
+        pass
+    return t
+
+
+class LSTMStackFn(torch.autograd.Function):
+    """All LSTM layers of the prediction network as one wavefront over (layer, time)
+    (nsp_lstm_stack_*; bf16 mode).  y = top layer's output, before the decoder's final dropout;
+    the dropout BETWEEN layers (rnn_transducer.py:303) is fused into the recurrence."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop, *ws):
+        nl = len(ws) // 4
+        B, L, I = x.shape
+        H = ws[1].shape[1]
+        dev = x.device
+        x2d = _f32c(x).reshape(B * L, I)
+        xa = to_bf16(x2d) if I % 8 == 0 else x2d
+        gi0 = linear_fwd(xa, ws[0], axpby(ws[2], ws[3], 1.0, 1.0))                # [B*L, 4H] fp32
+        P = _lib.LstmStackParams()
+        P.nl, P.B, P.L, P.H, P.dropout_p = nl, B, L, H, float(p_drop)
+        P.gi0 = gi0.data_ptr()
+        y_top = torch.empty((B, L, H), device=dev, dtype=torch.float32)
+        P.y_top = y_top.data_ptr()
+        keep = [gi0]
+        hp16, yd16, c_all, gates, seeds = [], [], [], [], []
+        for l in range(nl):
+            w_ih, w_hh, b_ih, b_hh = ws[4 * l:4 * l + 4]
+            if l == 0:
+                wl = weight_bf16(w_hh)
+            else:
+                wl = _cat_cached(w_hh, '_nsp_lstm_cat', (w_ih, w_hh),
+                                 lambda a=w_ih, b=w_hh: torch.cat([weight_bf16(a), weight_bf16(b)], dim=1).contiguous())
+                bl = axpby(b_ih, b_hh, 1.0, 1.0)
+                P.bias[l] = bl.data_ptr()
+                keep.append(bl)
+            P.w[l] = wl.data_ptr()
+            keep.append(wl)
+            hp16.append(torch.empty((B, L, H), device=dev, dtype=torch.bfloat16))
+            c_all.append(torch.empty((B, L, H), device=dev, dtype=torch.float32))
+            gates.append(torch.empty((B, L, 4 * H), device=dev, dtype=torch.float32))
+            P.hp16[l], P.c_all[l], P.gates[l] = hp16[l].data_ptr(), c_all[l].data_ptr(), gates[l].data_ptr()
+            if l < nl - 1:
+                yd16.append(torch.empty((B, L, H), device=dev, dtype=torch.bfloat16))
+                P.yd16[l] = yd16[l].data_ptr()
+                sd = next_dropout_seed() if p_drop > 0 else (0, 0)
+                seeds.append(sd)
+                P.seed[l], P.offset[l] = sd
+        _check(_lib.lib().nsp_lstm_stack_fwd(ctypes.byref(P), _stream()), 'nsp_lstm_stack_fwd')
+        ctx.save_for_backward(xa, *ws, *hp16, *yd16, *c_all, *gates)
+        ctx.cfg = (nl, B, L, I, H, float(p_drop), seeds)
+        return y_top
+
+    @staticmethod
+    def backward(ctx, dy):
+        nl, B, L, I, H, p_drop, seeds = ctx.cfg
+        sv = ctx.saved_tensors
+        xa = sv[0]
+        ws = sv[1:1 + 4 * nl]
+        o = 1 + 4 * nl
+        hp16 = sv[o:o + nl]; o += nl
+        yd16 = sv[o:o + nl - 1]; o += nl - 1
+        c_all = sv[o:o + nl]; o += nl
+        gates = sv[o:o + nl]
+        dev = dy.device
+        dy = _f32c(dy)
+        P = _lib.LstmStackParams()
+        P.nl, P.B, P.L, P.H, P.dropout_p = nl, B, L, H, p_drop
+        P.dy_top = dy.data_ptr()
+        keep, dg16 = [], []
+        for l in range(nl):
+            w_hh = ws[4 * l + 1]
+            if l == nl - 1:
+                wt = _weight_t_shadow(w_hh, True)                                 # [H, 4H]
+            else:
+                w_ih_up = ws[4 * (l + 1)]
+                wt = _cat_cached(w_hh, '_nsp_lstm_catT', (w_ih_up, w_hh),
+                                 lambda a=w_ih_up, b=w_hh: torch.cat(
+                                     [_weight_t_shadow(a, True)[:, :4 * H], _weight_t_shadow(b, True)[:, :4 * H]],
+                                     dim=1).contiguous())                         # [H, 8H]
+                P.seed[l], P.offset[l] = seeds[l]
+            keep.append(wt)
+            P.w[l] = wt.data_ptr()
+            dg16.append(torch.empty((B, L, 4 * H), device=dev, dtype=torch.bfloat16))
+            dc = torch.empty((B, H), device=dev, dtype=torch.float32)
+            keep.append(dc)
+            P.dg16[l], P.dc[l] = dg16[l].data_ptr(), dc.data_ptr()
+            P.c_all[l], P.gates[l] = c_all[l].data_ptr(), gates[l].data_ptr()
+        _check(_lib.lib().nsp_lstm_stack_bwd(ctypes.byref(P), _stream()), 'nsp_lstm_stack_bwd')
+        grads = []
+        dx = None
+        for l in range(nl):
+            w_ih, w_hh = ws[4 * l], ws[4 * l + 1]
+            g2d = dg16[l].view(B * L, 4 * H)
+            inp = xa if l == 0 else yd16[l - 1].view(B * L, H)
+            dw_ih = linear_wgrad(g2d, inp).view(w_ih.shape)
+            dw_hh = linear_wgrad(g2d, hp16[l].view(B * L, H)).view(w_hh.shape)
+            db = colsum(g2d)
+            grads += [dw_ih, dw_hh, db, db]
+            if l == 0 and ctx.needs_input_grad[0]:
+                dx = linear_dgrad(g2d, w_ih)[:, :I].reshape(B, L, I)
+        return (dx, None, *grads)
+
+
+def lstm_stack(x, layers, p_drop):
+    """layers: [(w_ih, w_hh, b_ih, b_hh), ...] (nn.LSTM parameters of consecutive 1-layer LSTMs)."""
+    flat = [t for lay in layers for t in lay]
+    return LSTMStackFn.apply(x, float(p_drop), *flat)
+
+
+def lstm_stack_supported(layers, x):
+    H = layers[0][1].shape[1]
+    return (bf16_mode() and len(layers) <= _lib.LSTM_MAX_LAYERS and H % 64 == 0
+            and all(lay[1].shape[1] == H for lay in layers)
+            and all(lay[0].shape[1] == H for lay in layers[1:]))
+
+
 class ReplayGraphFirstFn(torch.autograd.Function):
     """Identity on a detached copy of `y` whose backward replays y's own graph from inside this
     node.  The autograd engine orders ready nodes by creation time (latest first); a sub-graph

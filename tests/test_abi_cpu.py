@@ -39,9 +39,11 @@ def test_struct_mirrors_match_header_field_order():
             first = names[0].split()[-1].lstrip('*')
             out.append(first)
             out += [n.strip().lstrip('*') for n in names[1:]]
-        return out
+        return [re.sub(r'\[.*?\]$', '', n) for n in out]   # array members: name[N] -> name
     assert fields('nsp_gemm_params') == [f[0] for f in _lib.GemmParams._fields_]
     assert fields('nsp_attn_mask_params') == [f[0] for f in _lib.AttnMaskParams._fields_]
+    assert fields('nsp_lstm_stack_params') == [f[0] for f in _lib.LstmStackParams._fields_]
+    assert _lib.LSTM_MAX_LAYERS == int(re.search(r'#define NSP_LSTM_MAX_LAYERS (\d+)', hdr).group(1))
 
 
 def test_cpu_tensor_is_rejected_loudly():

@@ -194,3 +194,46 @@ def test_lstm_vs_torch(mode, tol):
         g = torch.autograd.grad(y, [x] + params, dy)
     for a, r in zip(g, gr):
         assert _rel(a, r) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nl,p_drop,B,L', [(1, 0.0, 5, 9), (2, 0.0, 5, 23), (2, 0.3, 18, 11), (3, 0.2, 4, 6)])
+def test_lstm_stack_wavefront_vs_torch(nl, p_drop, B, L):
+    """The (layer, time) wavefront (all layers in one launch per stage, input projection of the
+    upper layers and the inter-layer dropout fused) against torch.nn.LSTM layers with the SAME
+    dropout masks (regenerated from the op's seed/offset)."""
+    from neural_sp_amd import ops
+    torch.manual_seed(11)
+    I, H = 48, 64
+    refs = [torch.nn.LSTM(I if l == 0 else H, H, 1, batch_first=True).to(_dev()) for l in range(nl)]
+    x = torch.randn(B, L, I, device=_dev(), requires_grad=True)
+    dy = torch.randn(B, L, H, device=_dev())
+    layers = [(r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0) for r in refs]
+    flat = [t for lay in layers for t in lay]
+    seeds = []
+    orig = ops.next_dropout_seed
+
+    def recording():
+        sd = orig()
+        seeds.append(sd)
+        return sd
+    ops.next_dropout_seed = recording
+    try:
+        with ops.compute_mode('bf16'):
+            assert ops.lstm_stack_supported(layers, x)
+            y = ops.lstm_stack(x, layers, p_drop)
+            g = torch.autograd.grad(y, [x] + flat, dy)
+    finally:
+        ops.next_dropout_seed = orig
+    assert len(seeds) == (nl - 1 if p_drop > 0 else 0)
+    h = x
+    for l, r in enumerate(refs):
+        h, _ = r(h)
+        if l < nl - 1 and p_drop > 0:
+            mask = ops.dropout_raw(torch.ones(B, L, H, device=_dev()), p_drop, seeds[l][0], seeds[l][1])
+            assert 0.0 < float((mask == 0).float().mean()) < 2 * p_drop
+            h = h * mask
+    gr = torch.autograd.grad(h, [x] + flat, dy)
+    assert _rel(y, h) < 2e-2
+    for a, r_ in zip(g, gr):
+        assert _rel(a, r_) < 3e-2
