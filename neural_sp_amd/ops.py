@@ -1183,6 +1183,20 @@ def _cat_cached(owner, name, parts, build):
     return t
 
 
+def _lstm_stack_launch(which, P, dev):
+    """Persistent single-launch recurrence when the shape qualifies (B <= 16, H % 256 == 0,
+    H <= 1024; NSP_LSTM_PERSISTENT=0 disables), else one launch per wavefront stage."""
+    lib = _lib.lib()
+    if os.environ.get('NSP_LSTM_PERSISTENT', '1') != '0' and P.B <= 16 and P.H % 256 == 0 and P.H <= 1024 \
+            and P.nl * (P.H // 16) <= 256:
+        sync = torch.empty((2,), device=dev, dtype=torch.int32)   # zeroed by the call itself
+        fn = lib.nsp_lstm_stack_fwd_persistent if which == 'fwd' else lib.nsp_lstm_stack_bwd_persistent
+        _check(fn(ctypes.byref(P), sync.data_ptr(), _stream()), 'nsp_lstm_stack_%s_persistent' % which)
+        return
+    fn = lib.nsp_lstm_stack_fwd if which == 'fwd' else lib.nsp_lstm_stack_bwd
+    _check(fn(ctypes.byref(P), _stream()), 'nsp_lstm_stack_' + which)
+
+
 class LSTMStackFn(torch.autograd.Function):
     """All LSTM layers of the prediction network as one wavefront over (layer, time)
     (nsp_lstm_stack_*; bf16 mode).  y = top layer's output, before the decoder's final dropout;
@@ -1226,7 +1240,7 @@ class LSTMStackFn(torch.autograd.Function):
                 sd = next_dropout_seed() if p_drop > 0 else (0, 0)
                 seeds.append(sd)
                 P.seed[l], P.offset[l] = sd
-        _check(_lib.lib().nsp_lstm_stack_fwd(ctypes.byref(P), _stream()), 'nsp_lstm_stack_fwd')
+        _lstm_stack_launch('fwd', P, dev)
         ctx.save_for_backward(xa, *ws, *hp16, *yd16, *c_all, *gates)
         ctx.cfg = (nl, B, L, I, H, float(p_drop), seeds)
         return y_top
@@ -1266,7 +1280,7 @@ class LSTMStackFn(torch.autograd.Function):
             keep.append(dc)
             P.dg16[l], P.dc[l] = dg16[l].data_ptr(), dc.data_ptr()
             P.c_all[l], P.gates[l] = c_all[l].data_ptr(), gates[l].data_ptr()
-        _check(_lib.lib().nsp_lstm_stack_bwd(ctypes.byref(P), _stream()), 'nsp_lstm_stack_bwd')
+        _lstm_stack_launch('bwd', P, dev)
         grads = []
         dx = None
         for l in range(nl):

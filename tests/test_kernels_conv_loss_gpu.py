@@ -237,3 +237,30 @@ def test_lstm_stack_wavefront_vs_torch(nl, p_drop, B, L):
     assert _rel(y, h) < 2e-2
     for a, r_ in zip(g, gr):
         assert _rel(a, r_) < 3e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nl,p_drop,B,L,H', [(2, 0.0, 16, 40, 256), (2, 0.25, 7, 33, 512), (1, 0.0, 3, 5, 256),
+                                             (3, 0.1, 16, 12, 256)])
+def test_lstm_stack_persistent_matches_wavefront(nl, p_drop, B, L, H, monkeypatch):
+    """The persistent (grid-barrier) recurrence must reproduce the per-stage-launch wavefront:
+    same bf16 operands and the same fp32 accumulation order -> (near) identical outputs and grads;
+    a barrier that timed out would poison the result with NaN."""
+    from neural_sp_amd import ops
+    torch.manual_seed(13)
+    I = 64
+    refs = [torch.nn.LSTM(I if l == 0 else H, H, 1, batch_first=True).to(_dev()) for l in range(nl)]
+    x = torch.randn(B, L, I, device=_dev(), requires_grad=True)
+    dy = torch.randn(B, L, H, device=_dev())
+    layers = [(r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0) for r in refs]
+    flat = [t for lay in layers for t in lay]
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('NSP_LSTM_PERSISTENT', flag)
+        ops._DROPOUT_STATE['counter'] = 77
+        with ops.compute_mode('bf16'):
+            y = ops.lstm_stack(x, layers, p_drop)
+            outs[flag] = [y] + list(torch.autograd.grad(y, [x] + flat, dy))
+    for a, b in zip(outs['1'], outs['0']):
+        assert torch.isfinite(a).all()
+        assert _rel(a, b) < 2e-3
