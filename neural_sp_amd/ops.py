@@ -1088,6 +1088,12 @@ def kernel_events_start():
     _KEV['on'], _KEV['events'], _KEV['flops'] = True, [], 0.0
 
 
+def kernel_events_enable(on):
+    """Pause / resume event recording without dropping what has been collected (bench.py
+    instruments a subset of the timed steps: two event records per GEMM launch cost ~3 ms/step)."""
+    _KEV['on'] = bool(on)
+
+
 def kernel_events_stop():
     """-> {'launches', 'ms' (sum of HIP-event durations on the launch stream), 'flops'}."""
     _KEV['on'] = False
