@@ -177,8 +177,18 @@ def main():
             roof = {'kernel': 'gemm_kernel<%s> (%d launches: every GEMM of every %d-th timed step, rank 0)' % (a.mode, kev['launches'], a.event_stride),
                     'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak_tf, 4), 'traffic': None,
+                    'flop_per_launch': round(kev['flops'] / kev['launches'], 1),
                     'avg_launch_us': round(kev['ms'] * 1e3 / kev['launches'], 2),
                     'gemm_share_of_step': round(kev['ms'] / (dt * 1e3 * len(range(0, a.steps, a.event_stride)) / a.steps), 3)}
+            # HBM bytes per GEMM launch cannot be counted from inside the process: it is the
+            # committed result of the rocprofv3 PMC passes over this same command and workload
+            # (profiles/pmc_gemm_traffic.json; separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2
+            # read correction), valid only for the default workload in bf16 mode
+            tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_gemm_traffic.json')
+            default_wl = (a.size, a.batch, a.tmin, a.tmax, a.umin, a.umax, a.mode) == ('L', 16, 1200, 1600, 120, 200, 'bf16')
+            if default_wl and os.path.exists(tj):
+                roof['traffic'] = round(json.load(open(tj))['hbm_bytes_per_launch'])
+                roof['traffic_source'] = 'profiles/pmc_gemm_traffic.json (rocprofv3 PMC, bytes per launch)'
         out = {
             'metric': 'speech-frames/sec/node (Conformer-L + CTC+RNN-T, 80-d fbank)',
             'value': round(frames / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,

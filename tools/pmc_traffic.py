@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; csv output).
+FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced
+reads (MI355X_MICROARCH.md, HBM section) -> doubled here.  WRITE_SIZE is calibrated against the
+bf16 cast kernel, whose written bytes are known from its grid (see --calib).
+usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv>"""
+import collections
+import csv
+import re
+import sys
+
+
+def load(path, counter):
+    agg = collections.OrderedDict()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r['Counter_Name'] != counter:
+                continue
+            name = re.sub(r'\(anonymous namespace\)::|void ', '', r['Kernel_Name'])
+            name = name.split('(')[0]
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += float(r['Counter_Value'])
+            a[2] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3
+    return agg
+
+
+def main(fp, wp):
+    fe, wr = load(fp, 'FETCH_SIZE'), load(wp, 'WRITE_SIZE')
+    rows = []
+    for k in fe:
+        n, kib, us = fe[k]
+        wk = wr.get(k, [0, 0.0, 0.0])
+        rd = 2.0 * kib * 1024 / n                 # gfx950 correction: x2
+        wrb = wk[1] * 1024 / max(1, wk[0])
+        rows.append((rd * n + wrb * n, k, n, rd, wrb, us / n))
+    rows.sort(reverse=True)
+    print('%-48s %6s %12s %12s %10s %9s' % ('kernel', 'calls', 'read MB/call', 'write MB/call', 'avg us', 'GB/s'))
+    for tot, k, n, rd, wrb, us in rows[:40]:
+        print('%-48s %6d %12.3f %12.3f %10.1f %9.0f' % (k[:48], n, rd / 1e6, wrb / 1e6, us, (rd + wrb) / us / 1e3))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
