@@ -19,6 +19,7 @@
 //             kernel recomputes dS and produces dQ = dS K and the relative-table gradient dQP
 //             with no global atomics.
 // The 11-entry (clamp_len = 10) position table per query lives in LDS.
+// LSE[0] holds the row maximum in the LOG2 domain (logit * log2 e), LSE[1] the reciprocal row sum.
 #include "common.h"
 
 namespace {
@@ -70,6 +71,77 @@ __device__ __forceinline__ void stage_tile(unsigned char* tile, const __bf16* __
   }
 }
 
+
+// ---- per-element work of a (query tile, key tile) pair.  With d_k = 64 the softmax arithmetic,
+// not the MFMA, bounds these kernels (16 logits per lane per tile against 16 MFMAs per wave), so
+// everything that is uniform over a tile is decided once per tile:
+//   plain : no causal / chunk mask and the key tile lies inside min(klen, T) -> no predicates;
+//   far   : every pair is >= clamp apart -> the relative term is the per-query constant QP[i][clamp]
+//           (all but the 1-3 tiles around the diagonal).
+// Logits are kept in the log2 domain (scale * log2(e) folded into one FMA; v_exp_f32 is exp2), and
+// the saved row maximum LSE[0] is in that domain too.  Dropout: one 32-bit mix per PAIR of adjacent
+// keys on top of a per-row hash, 16 bits per decision.
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct FaTile { bool plain, far; };
+__device__ __forceinline__ FaTile fa_tile(const nsp_attn_mask_params& p, bool has_qp, int q0, int k0, int T, int klen) {
+  FaTile t;
+  t.plain = !p.causal && p.chunk_nc == 0 && (k0 + 63 < min(klen, T));
+  t.far = has_qp && p.clamp > 0 && (k0 - (q0 + 63) >= p.clamp || q0 - (k0 + 63) >= p.clamp);
+  return t;
+}
+
+// ev = log2-domain logits of the lane's pairs (query qi, key k0 + 16 kf + 4 g + e); returns the
+// visibility bits (bit 4 kf + e) -- all ones on plain tiles.  qrow = this query's row of the
+// relative table pre-multiplied by scale*log2(e), or nullptr.
+__device__ __forceinline__ unsigned fa_logits(const f32x4 (&s_acc)[4], float (&ev)[4][4], const nsp_attn_mask_params& p,
+                                              const float* qrow, float sl2, int qi, int k0, int g, int klen, FaTile tl) {
+  if (tl.plain && (qrow == nullptr || tl.far)) {
+    const float add = qrow ? qrow[p.clamp] : 0.f;
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ev[kf][e] = fmaf(s_acc[kf][e], sl2, add);
+    return 0xFFFFu;
+  }
+  unsigned vis = 0u;
+#pragma unroll
+  for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = k0 + kf * 16 + 4 * g + e;
+      float v = s_acc[kf][e] * sl2;
+      if (qrow) {
+        int rel = qi > key ? qi - key : key - qi;
+        if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+        v += qrow[rel];
+      }
+      const bool ok = tl.plain || fa_visible(p, klen, qi, key);
+      if (!ok) v = -FLT_MAX;
+      vis |= (ok ? 1u : 0u) << (kf * 4 + e);
+      ev[kf][e] = v;
+    }
+  return vis;
+}
+
+__device__ __forceinline__ void fa_keep(float (&kp)[4][4], unsigned rowhash, int k0, int g, unsigned thr16, float inv_keep) {
+#pragma unroll
+  for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const unsigned key = (unsigned)(k0 + kf * 16 + 4 * g + 2 * pr);
+      unsigned x = rowhash ^ ((key >> 1) * 0x9E3779B9u);
+      x ^= x >> 16; x *= 0x85EBCA6Bu;
+      x ^= x >> 13; x *= 0xC2B2AE35u;
+      x ^= x >> 16;
+      kp[kf][2 * pr] = (x & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
+      kp[kf][2 * pr + 1] = (x >> 16) >= thr16 ? inv_keep : 0.f;
+    }
+}
+__device__ __forceinline__ unsigned fa_rowhash(const nsp_attn_mask_params& p, int b, int h, int T, int qi) {
+  return nsp_hash_u32(p.seed, p.offset + (unsigned long long)(((long long)b * p.H + h) * T + qi));
+}
+
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict__ qkv, int d,
                                                         const float* __restrict__ QP,
                                                         __bf16* __restrict__ O, float* __restrict__ LSE,
@@ -90,18 +162,23 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
   bf16x8 Qf[2];
   Qf[0] = *reinterpret_cast<const bf16x8*>(qp_ + g * 8);
   Qf[1] = *reinterpret_cast<const bf16x8*>(qp_ + 32 + g * 8);
+  const float sl2 = p.scale * LOG2E;
   if (QP) {
     for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
       const int ql = idx / p.r_pitch, rr = idx % p.r_pitch;
       const int q = min(q0 + ql, T - 1);
-      QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr];
+      QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr] * sl2;
     }
   }
+  const float* qprow = QP ? QPs[wave * 16 + r] : nullptr;
+  const bool drop = p.dropout_p > 0.f;
+  const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
+  const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
+  const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
   f32x4 o_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) o_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
-  const unsigned long long drow = (unsigned long long)(((long long)b * p.H + h) * T + qi) * T;
   const int nkt = (T + 63) / 64;
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
@@ -117,39 +194,36 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
         s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Ks, kf * 16, s, r, g), Qf[s], s_acc[kf], 0, 0, 0);
     }
     // lane: query qi, keys kt*64 + kf*16 + 4g + e
+    const FaTile tl = fa_tile(p, QP != nullptr, q0, kt * 64, T, klen);
     float ev[4][4];
+    fa_logits(s_acc, ev, p, qprow, sl2, qi, kt * 64, g, klen, tl);
+    if (!tl.plain && kt * 64 + 63 >= T) {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kt * 64 + kf * 16 + 4 * g + e >= T) ev[kf][e] = -INFINITY;   // tile padding: not in the softmax
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = kt * 64 + kf * 16 + 4 * g + e;
-        float v = s_acc[kf][e];
-        if (QP) {
-          int rel = qi > key ? qi - key : key - qi;
-          if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
-          v += QPs[wave * 16 + r][rel];
-        }
-        v *= p.scale;
-        if (!fa_visible(p, klen, qi, key)) v = -FLT_MAX;
-        if (key >= T) v = -INFINITY;   // tile padding: not part of the softmax at all
-        ev[kf][e] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, ev[kf][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);   // m_run = -inf on the first tile -> 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
     float rs = 0.f;
     bf16x8 Pf[2];
+    float kp[4][4];
+    if (drop) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int key = kt * 64 + kf * 16 + 4 * g + e;
-        float pr = (key < T) ? __expf(ev[kf][e] - m_new) : 0.f;
+        float pr = __builtin_amdgcn_exp2f(ev[kf][e] - m_new);
         rs += pr;
-        if (p.dropout_p > 0.f) pr *= nsp_keep_scale(p.seed, p.offset + drow + (unsigned long long)key, p.dropout_p);
+        if (drop) pr *= kp[kf][e];
         Pf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)pr;
       }
     rs += __shfl_xor(rs, 16, 64);
@@ -229,6 +303,10 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
   const int klen = p.klens ? p.klens[b] : T;
   stage_tile(Ks, qkv + d + h * DK, ld3, brow0, k0, T);
   stage_tile(Vs, qkv + 2 * d + h * DK, ld3, brow0, k0, T);
+  const float sl2 = p.scale * LOG2E;
+  const bool drop = p.dropout_p > 0.f;
+  const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
+  const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
   f32x4 dk_acc[4], dv_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -242,7 +320,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
       for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
         const int ql = idx / p.r_pitch, rr = idx % p.r_pitch;
         const int q = min(q0 + ql, T - 1);
-        QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr];
+        QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr] * sl2;
       }
     }
     __syncthreads();
@@ -250,9 +328,10 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
     const int qi = q0 + ql;
     const int qc = min(qi, T - 1);
     const long long ri = ((long long)b * p.H + h) * T + qc;
-    const float rmax = LSE[ri], rinv = LSE[nrow + ri];
+    const float rmax = LSE[ri];
+    const float rinv = qi < T ? LSE[nrow + ri] : 0.f;   // rows beyond T contribute nothing
     const float dsum = Drow[ri];
-    const unsigned long long drow = (unsigned long long)(((long long)b * p.H + h) * T + qi) * T;
+    const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
     f32x4 s_acc[4], dp_acc[4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
@@ -266,26 +345,20 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
                                                              frag_kc(dOs, wave * 16, s, r, g), dp_acc[kf], 0, 0, 0);
       }
     }
+    const FaTile tl = fa_tile(p, QP != nullptr, q0, k0, T, klen);
+    float ev[4][4], kp[4][4];
+    const unsigned vis = fa_logits(s_acc, ev, p, QP ? QPs[ql] : nullptr, sl2, qi, k0, g, klen, tl);
+    if (drop) fa_keep(kp, rowhash, k0, g, thr16, inv_keep);
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
       bf16x4 p4, ds4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int key = k0 + kf * 16 + 4 * g + e;
-        float v = s_acc[kf][e];
-        if (QP) {
-          int rel = qi > key ? qi - key : key - qi;
-          if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
-          v += QPs[ql][rel];
-        }
-        v *= p.scale;
-        const bool vis = fa_visible(p, klen, qi, key);
-        if (!vis) v = -FLT_MAX;
-        const float pr = (key < T && qi < T) ? __expf(v - rmax) * rinv : 0.f;
-        float keep = 1.f;
-        if (p.dropout_p > 0.f) keep = nsp_keep_scale(p.seed, p.offset + drow + (unsigned long long)key, p.dropout_p);
+        float pr = __builtin_amdgcn_exp2f(ev[kf][e] - rmax) * rinv;
+        if (!tl.plain && k0 + kf * 16 + 4 * g + e >= T) pr = 0.f;
+        const float keep = drop ? kp[kf][e] : 1.f;
         float ds = pr * (dp_acc[kf][e] * keep - dsum) * p.scale;
-        if (!vis) ds = 0.f;
+        if (!tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
         p4[e] = (__bf16)(pr * keep);
         ds4[e] = (__bf16)ds;
       }
@@ -352,18 +425,23 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
   Qf[1] = *reinterpret_cast<const bf16x8*>(qp_ + 32 + g * 8);
   dOf[0] = *reinterpret_cast<const bf16x8*>(dop + g * 8);
   dOf[1] = *reinterpret_cast<const bf16x8*>(dop + 32 + g * 8);
+  const float sl2 = p.scale * LOG2E;
   if (QP) {
     for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
       const int l2 = idx / p.r_pitch, rr = idx % p.r_pitch;
       const int q = min(q0 + l2, T - 1);
-      QPs[l2][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr];
+      QPs[l2][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr] * sl2;
       dQPs[l2][rr] = 0.f;
     }
   }
   const long long ri = ((long long)b * p.H + h) * T + qc;
-  const float rmax = LSE[ri], rinv = LSE[nrow + ri];
+  const float rmax = LSE[ri];
+  const float rinv = qi < T ? LSE[nrow + ri] : 0.f;
   const float dsum = Drow[ri];
-  const unsigned long long drow = (unsigned long long)(((long long)b * p.H + h) * T + qi) * T;
+  const bool drop = p.dropout_p > 0.f;
+  const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
+  const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
+  const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
   f32x4 dq_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) dq_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -386,27 +464,30 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
       }
     }
     bf16x8 dSf[2];
+    const FaTile tl = fa_tile(p, QP != nullptr, q0, kt * 64, T, klen);
+    float ev[4][4], kp[4][4];
+    const unsigned vis = fa_logits(s_acc, ev, p, QP ? QPs[ql] : nullptr, sl2, qi, kt * 64, g, klen, tl);
+    if (drop) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int key = kt * 64 + kf * 16 + 4 * g + e;
-        int rel = qi > key ? qi - key : key - qi;
-        if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
-        float v = s_acc[kf][e];
-        if (QP) v += QPs[ql][rel];
-        v *= p.scale;
-        const bool vis = fa_visible(p, klen, qi, key);
-        if (!vis) v = -FLT_MAX;
-        const float pr = (key < T && qi < T) ? __expf(v - rmax) * rinv : 0.f;
-        float keep = 1.f;
-        if (p.dropout_p > 0.f) keep = nsp_keep_scale(p.seed, p.offset + drow + (unsigned long long)key, p.dropout_p);
+        float pr = __builtin_amdgcn_exp2f(ev[kf][e] - rmax) * rinv;
+        if (!tl.plain && key >= T) pr = 0.f;
+        const float keep = drop ? kp[kf][e] : 1.f;
         float ds = pr * (dp_acc[kf][e] * keep - dsum) * p.scale;
-        if (!vis) ds = 0.f;
+        if (!tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
         dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
-        if (QP && ds != 0.f) {
-          if (p.clamp > 0 && rel == p.clamp) far += ds;
-          else atomicAdd(&dQPs[ql][rel], ds);  // LDS, near-diagonal elements only
+        if (QP) {
+          if (tl.far) {
+            far += ds;
+          } else if (ds != 0.f) {
+            int rel = qi > key ? qi - key : key - qi;
+            if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+            if (p.clamp > 0 && rel == p.clamp) far += ds;
+            else atomicAdd(&dQPs[ql][rel], ds);  // LDS, near-diagonal elements only
+          }
         }
       }
     // dQ^T[dk'][query] += K^T dS^T : X = K^T fragment (rows dk', k = keys), Y = dS fragment

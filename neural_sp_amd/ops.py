@@ -191,7 +191,7 @@ def _pick_splitk(M, N, K, batch=1):
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if tiles >= 256 or K < 1024:
         return 1
-    want = max(1, 512 // tiles)
+    want = max(1, int(os.environ.get('NSP_SPLITK_TARGET', '512')) // tiles)
     return int(max(1, min(want, K // 256, 64)))
 
 

@@ -61,7 +61,7 @@ def test_flash_attention_matches_reference(T, with_pos, causal, nc):
     qkv2 = qkv.view(B * T, 3 * d)
     O, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP if with_pos else None, mp)
     assert _rel(O.float().view(B, T, d), Oref.detach()) < 1.5e-2
-    lse = LSE[0] - torch.log(LSE[1])
+    lse = LSE[0] * math.log(2.0) - torch.log(LSE[1])   # LSE[0]: row max in the log2 domain
     ok = LSEref.detach() > -1e30  # fully masked rows: max + log(sum) is not representable in fp32
     assert _rel(lse[ok], LSEref.detach()[ok]) < 1e-3
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
@@ -72,3 +72,84 @@ def test_flash_attention_matches_reference(T, with_pos, causal, nc):
     assert _rel(dqkv[:, 2 * d:].float(), g[:, 2 * d:]) < 2e-2, 'dv'
     if with_pos:
         assert _rel(dQP[..., :R], grads[1][..., :R]) < 2e-2, 'dQP'
+
+
+def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward():
+    """Dropout inside the fused kernels: the mask is a pure function of (seed, offset, row, key).
+    T = 64 (one tile): with V = I the forward output IS the dropped probability matrix, which
+    exposes the mask; output and all gradients must then match a torch reference using that mask.
+    T = 150 (several tiles): keep rate, determinism, and the adjoint identity <dO, O(V)> = <dV, V>
+    (O is linear in V for a fixed mask), which ties the backward's regenerated mask to the forward's."""
+    from neural_sp_amd import ops
+    dev = torch.device('cuda:0')
+    B, H, dk, clamp, pdrop = 2, 2, 64, 10, 0.25
+    d = H * dk
+    R, Rp = clamp + 1, 16
+    scale = 1.0 / math.sqrt(dk)
+    # ---- T = 64: full check against an explicit-mask reference
+    T = 64
+    torch.manual_seed(3)
+    qk = (torch.randn(B, T, 2 * d, device=dev) * 0.5).bfloat16()
+    QP = torch.zeros(B, T, H, Rp, device=dev)
+    QP[..., :R] = torch.randn(B, T, H, R, device=dev)
+    klens = torch.tensor([T, T - 9], device=dev, dtype=torch.int32)
+    mp = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, dropout_p=pdrop, seed=1234,
+                          offset=5 << 40, r_pitch=Rp)
+    eye = torch.eye(T, dk, device=dev).repeat(1, H)[None].expand(B, T, d)            # V[j] = e_j per head
+    qkv_eye = torch.cat([qk, eye.bfloat16()], dim=-1).contiguous().view(B * T, 3 * d)
+    Pd, _ = ops.flash_attn_fwd_raw(qkv_eye, d, QP, mp)                               # [B*T, d]: Pdrop[b,i,h,j]
+    Pd = Pd.float().view(B, T, H, T).permute(0, 2, 1, 3)                             # [B,H,i,j]
+    q32 = qk.float()
+    e = torch.einsum('bihd,bjhd->bhij', q32[..., :d].reshape(B, T, H, dk), q32[..., d:].reshape(B, T, H, dk))
+    i = torch.arange(T, device=dev)[:, None]
+    j = torch.arange(T, device=dev)[None, :]
+    rel = (i - j).abs().clamp(max=clamp)
+    e = (e + torch.gather(QP.permute(0, 2, 1, 3), 3, rel[None, None].expand(B, H, T, T))) * scale
+    vis = (j[None] < klens[:, None, None])[:, None]
+    P = torch.softmax(e.masked_fill(~vis, torch.finfo(torch.float32).min), -1)
+    mask = (Pd > 0).float()
+    live = (P > 1e-4) & vis                     # where the probability cannot have rounded to zero
+    rate = 1.0 - mask[live].mean().item()
+    assert abs(rate - pdrop) < 0.03, rate
+    assert _rel(Pd[live], (P * mask / (1 - pdrop))[live]) < 2e-2
+    # gradients with that mask
+    v = (torch.randn(B, T, d, device=dev) * 0.5).bfloat16()
+    qkv = torch.cat([qk, v], dim=-1).contiguous()
+    x32 = qkv.float().requires_grad_()
+    QPr = QP.clone().requires_grad_()
+    qq, kk, vv = [t.reshape(B, T, H, dk) for t in x32.split(d, dim=-1)]
+    e2 = (torch.einsum('bihd,bjhd->bhij', qq, kk)
+          + torch.gather(QPr.permute(0, 2, 1, 3), 3, rel[None, None].expand(B, H, T, T))) * scale
+    P2 = torch.softmax(e2.masked_fill(~vis, torch.finfo(torch.float32).min), -1) * mask / (1 - pdrop)
+    Oref = torch.einsum('bhij,bjhd->bihd', P2, vv).reshape(B, T, d)
+    dO = torch.randn_like(Oref).bfloat16()
+    gx, gqp = torch.autograd.grad(Oref, [x32, QPr], dO.float())
+    O, LSE = ops.flash_attn_fwd_raw(qkv.view(B * T, 3 * d), d, QP, mp)
+    assert _rel(O.float().view(B, T, d), Oref.detach()) < 2e-2
+    dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv.view(B * T, 3 * d), d, QP, dO.view(B * T, d), O, LSE, mp, dqkv)
+    g = gx.view(B * T, 3 * d)
+    assert _rel(dq32, g[:, :d]) < 3e-2, 'dq'
+    assert _rel(dqkv[:, d:2 * d].float(), g[:, d:2 * d]) < 3e-2, 'dk'
+    assert _rel(dqkv[:, 2 * d:].float(), g[:, 2 * d:]) < 3e-2, 'dv'
+    assert _rel(dQP[..., :R], gqp[..., :R]) < 3e-2, 'dQP'
+    # ---- T = 150: several key tiles
+    T = 150
+    qkv = (torch.randn(B, T, 3 * d, device=dev) * 0.5).bfloat16().view(B * T, 3 * d)
+    QP = torch.zeros(B, T, H, Rp, device=dev)
+    QP[..., :R] = torch.randn(B, T, H, R, device=dev)
+    klens = torch.tensor([T, T - 40], device=dev, dtype=torch.int32)
+    mp = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, dropout_p=pdrop, seed=99,
+                          offset=7 << 40, r_pitch=Rp)
+    mp0 = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, r_pitch=Rp)
+    O1, LSE1 = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
+    O2, _ = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
+    O0, _ = ops.flash_attn_fwd_raw(qkv, d, QP, mp0)
+    assert torch.equal(O1, O2)
+    assert _rel(O1.float(), O0.float()) > 0.05          # dropout does something
+    dO = torch.randn(B * T, d, device=dev).bfloat16()
+    dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+    ops.flash_attn_bwd_raw(qkv, d, QP, dO, O1, LSE1, mp, dqkv)
+    lhs = (dO.float() * O1.float()).sum().item()
+    rhs = (dqkv[:, 2 * d:].float() * qkv[:, 2 * d:].float()).sum().item()
+    assert abs(lhs - rhs) / abs(lhs) < 2e-2, (lhs, rhs)
