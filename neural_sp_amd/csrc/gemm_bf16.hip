@@ -543,9 +543,12 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   if (a_kc && b_kc && p.K % BK == 0 && p.K >= BK) {
     // how many workgroups would share a CU decides how the load latency gets hidden
     static int ring_env = -1;
+    static long long ring2_max = 640;
     if (ring_env < 0) {
       const char* e = getenv("NSP_GEMM_RING");
       ring_env = e ? atoi(e) : 1;
+      const char* e2 = getenv("NSP_GEMM_RING2_MAX");
+      if (e2) ring2_max = atoll(e2);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
@@ -558,7 +561,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 2>), grid, block, 4 * 24576, st, p, tiles_m, tiles_n, c_vec);
     } else if (ring_env && wgs <= 288 && nkt >= 4)
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 4>), grid, block, 4 * 32768, st, p, tiles_m, tiles_n, c_vec);
-    else if (ring_env && wgs <= 640 && nkt >= 2)
+    else if (ring_env && wgs <= ring2_max && nkt >= 2)
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
     else
       hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);

@@ -811,7 +811,9 @@ class Conv3x3ReLUFn(torch.autograd.Function):
         _check(_lib.lib().nsp_conv2d3x3_wgrad(_p(x), _p(dz), buf.data_ptr(), buf.data_ptr() + 4 * Co * 9 * Ci,
                                               B, T, F, Ci, Co, _COMPUTE_MODE['mode'], _stream()),
                'nsp_conv2d3x3_wgrad')
-        dw = buf[:Co * 9 * Ci].view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
+        # canonical strides (C_in = 1 would otherwise keep the permuted ones and make DDP's bucket
+        # views mismatch)
+        dw = buf[:Co * 9 * Ci].view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous().view(Co, Ci, 3, 3)
         db = buf[Co * 9 * Ci:]
         return dx, dw, db
 
