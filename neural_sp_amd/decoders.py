@@ -186,14 +186,36 @@ class RNNTransducer(DecoderBase):
                 recog_params={}, idx2token=None, trigger_points=None):
         observation = {'loss': None, 'loss_transducer': None, 'loss_ctc': None, 'loss_mbr': None}
         loss = eouts.new_zeros((1,))
-        if self.ctc_weight > 0 and (task == 'all' or 'ctc' in task):
-            loss_ctc, _ = self.ctc(eouts, elens, ys)
-            observation['loss_ctc'] = loss_ctc.detach()   # device scalar; Speech2Text syncs once
-            loss = loss + (loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight)
-        if self.rnnt_weight > 0 and (task == 'all' or 'ctc' not in task):
+        do_ctc = self.ctc_weight > 0 and (task == 'all' or 'ctc' in task)
+        do_rnnt = self.rnnt_weight > 0 and (task == 'all' or 'ctc' not in task)
+        loss_ctc = None
+        ctc_stream = None
+        if do_ctc:
+            if do_rnnt and eouts.is_cuda and os.environ.get('NSP_CTC_STREAM', '1') != '0':
+                # The two loss branches are independent and each contains a long latency-bound
+                # lattice kernel on B workgroups (CTC alpha/beta ~0.4 ms, RNN-T ~0.5 ms): the CTC
+                # branch runs on its own stream beside the transducer branch, forward and backward.
+                if getattr(self, '_ctc_stream', None) is None:
+                    self._ctc_stream = torch.cuda.Stream(device=eouts.device)
+                ctc_stream = self._ctc_stream
+                cur = torch.cuda.current_stream(eouts.device)
+                ctc_stream.wait_stream(cur)
+                with torch.cuda.stream(ctc_stream):
+                    loss_ctc, _ = self.ctc(eouts, elens, ys)
+                eouts.record_stream(ctc_stream)
+            else:
+                loss_ctc, _ = self.ctc(eouts, elens, ys)
+        if do_rnnt:
             loss_transducer = self.forward_transducer(eouts, elens, ys)
             observation['loss_transducer'] = loss_transducer.detach()
             loss = loss + (loss_transducer if self.mtl_per_batch else loss_transducer * self.rnnt_weight)
+        if do_ctc:
+            if ctc_stream is not None:
+                cur = torch.cuda.current_stream(eouts.device)
+                cur.wait_stream(ctc_stream)
+                loss_ctc.record_stream(cur)
+            observation['loss_ctc'] = loss_ctc.detach()   # device scalar; Speech2Text syncs once
+            loss = loss + (loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight)
         observation['loss'] = loss.detach()
         return loss, observation
 
@@ -235,6 +257,8 @@ class RNNTransducer(DecoderBase):
             self._side_stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._side_stream):
             dec_proj = self._prediction_network(ys, dev)
+            self._pred_done = torch.cuda.Event()
+            self._pred_done.record(self._side_stream)
         self._pending_dec_proj = (dec_proj, id(ys))
 
     def forward_transducer(self, eouts, elens, ys):
@@ -246,7 +270,7 @@ class RNNTransducer(DecoderBase):
         if pending is not None and pending[1] == id(ys):
             dec_proj = pending[0]
             cur = torch.cuda.current_stream(dev)
-            cur.wait_stream(self._side_stream)
+            cur.wait_event(self._pred_done)
             dec_proj.record_stream(cur)
             if torch.is_grad_enabled() and dec_proj.requires_grad \
                     and os.environ.get('NSP_PREDNET_PRIORITY', '1') != '0':
