@@ -42,6 +42,7 @@ extern "C" {
 #define NSP_ACT_TANH 3
 #define NSP_ACT_GELU 4 /* 0.5x(1+erf(x/sqrt2)), reference modules/gelu.py gelu_accurate=tanh form is 5 */
 #define NSP_ACT_GELU_TANH 5
+#define NSP_ACT_TANH_OUT 6 /* derivative only (dact): source holds y = tanh(x), factor 1 - y^2 */
 
 int nsp_version(void);
 
@@ -335,6 +336,13 @@ int nsp_rnnt_joint_tanh_fwd(const float* e, const float* g, float* h, void* h16,
 /* dh is overwritten with dz = dh*(1-h^2); de[b,t,:] = sum_u dz, dg[b,u,:] = sum_t dz */
 int nsp_rnnt_joint_tanh_bwd(const float* h, const void* h16, float* dh, float* de, float* dg,
                             int B, int T, int U1, int J, void* stream);
+/* bf16 path: dz = dh * (1 - h^2) already formed (bf16 [B,T,U1,J]) by the data-gradient GEMM's
+ * epilogue (dact = NSP_ACT_TANH_OUT); one pass over it yields de[b,t,:] = sum_u dz (written) and
+ * `nslab` partial sums over time of dg[b,u,:] = sum_t dz (slab z = steps [z*ceil(T/nslab), ...),
+ * each [B,U1,J] fp32; nslab slabs are always written; sum them with nsp_splitk_reduce).
+ * J % 32 == 0, U1 <= 512. */
+int nsp_rnnt_joint_dz_reduce(const void* dz16, float* de, float* dg_slabs, int nslab, int B, int T,
+                             int U1, int J, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * LSTM recurrence of the RNN-T prediction network (rnn_transducer.py:101-111,  *

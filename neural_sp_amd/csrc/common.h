@@ -64,6 +64,7 @@ __device__ __forceinline__ float nsp_dact(float x, int act) {
       float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
       return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
     }
+    case NSP_ACT_TANH_OUT: return 1.f - x * x;   // x is the activation OUTPUT here
     default: return 1.f;
   }
 }

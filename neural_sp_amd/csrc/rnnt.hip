@@ -378,7 +378,83 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_dg_kernel(const float* __r
   }
 }
 
+// One pass over dz (bf16 [B,T,U1,J]) for both joint-input gradients.  grid: (J/32, B); block 256:
+// thread = (4 columns of the workgroup's 32-column slice, one of 32 u-lanes).  A thread meets the
+// same (u, columns) for every t, so sum_t lives in registers (<= 8 x 4 fp32 for U1 <= 256, LDS
+// spill beyond); sum_u is reduced across the u-lanes once per t.
+template <int KU>
+__global__ __launch_bounds__(256) void joint_dz_reduce_kernel(const __bf16* __restrict__ dz,
+                                                              float* __restrict__ de, float* __restrict__ dg,
+                                                              int B, int T, int U1, int J, int Tc) {
+  __shared__ float red[4][8][4];
+  const int cg = threadIdx.x & 7, ul = threadIdx.x >> 3;
+  const int wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 32 + cg * 4;
+  const long long b = blockIdx.y;
+  float4 accg[KU];
+#pragma unroll
+  for (int k = 0; k < KU; ++k) accg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // blockIdx.z owns the time steps [z*Tc, (z+1)*Tc): its sum_t goes to slab z of dg (summed by
+  // nsp_splitk_reduce afterwards); 8 workgroups per CU hide each other's barriers and latencies
+  const int t_end = min(T, (int)(blockIdx.z + 1) * Tc);
+  dg += (long long)blockIdx.z * B * U1 * J;
+  for (int t = blockIdx.z * Tc; t < t_end; ++t) {
+    const __bf16* base = dz + ((b * T + t) * U1) * J + c0;
+    bf16x4 v[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int u = ul + 32 * k;
+      if (u < U1) v[k] = *reinterpret_cast<const bf16x4*>(base + (long long)u * J);
+    }
+    float4 acce = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int u = ul + 32 * k;
+      if (u < U1) {
+        const float x0 = (float)v[k][0], x1 = (float)v[k][1], x2 = (float)v[k][2], x3 = (float)v[k][3];
+        accg[k].x += x0; accg[k].y += x1; accg[k].z += x2; accg[k].w += x3;
+        acce.x += x0; acce.y += x1; acce.z += x2; acce.w += x3;
+      }
+    }
+    // u-lanes of one wave: lane bits 3..5
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      acce.x += __shfl_xor(acce.x, o, 64); acce.y += __shfl_xor(acce.y, o, 64);
+      acce.z += __shfl_xor(acce.z, o, 64); acce.w += __shfl_xor(acce.w, o, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) < 8) {
+      red[wave][cg][0] = acce.x; red[wave][cg][1] = acce.y; red[wave][cg][2] = acce.z; red[wave][cg][3] = acce.w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int cc = threadIdx.x >> 2, e = threadIdx.x & 3;
+      de[(b * T + t) * J + blockIdx.x * 32 + cc * 4 + e] = red[0][cc][e] + red[1][cc][e] + red[2][cc][e] + red[3][cc][e];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KU; ++k) {
+    const int u = ul + 32 * k;
+    if (u < U1) *reinterpret_cast<float4*>(dg + (b * U1 + u) * J + c0) = accg[k];
+  }
+}
+
 }  // namespace
+
+extern "C" int nsp_rnnt_joint_dz_reduce(const void* dz16, float* de, float* dg_slabs, int nslab, int B, int T,
+                                        int U1, int J, void* stream) {
+  if (J % 32 || U1 > 512 || B <= 0 || T <= 0 || U1 <= 0 || nslab < 1) return NSP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const __bf16* z = reinterpret_cast<const __bf16*>(dz16);
+  const int Tc = nsp_cdiv(T, nslab);
+  dim3 grid(J / 32, B, nslab);
+  const int ku = nsp_cdiv(U1, 32);
+  if (ku <= 4) hipLaunchKernelGGL((joint_dz_reduce_kernel<4>), grid, dim3(256), 0, st, z, de, dg_slabs, B, T, U1, J, Tc);
+  else if (ku <= 8) hipLaunchKernelGGL((joint_dz_reduce_kernel<8>), grid, dim3(256), 0, st, z, de, dg_slabs, B, T, U1, J, Tc);
+  else hipLaunchKernelGGL((joint_dz_reduce_kernel<16>), grid, dim3(256), 0, st, z, de, dg_slabs, B, T, U1, J, Tc);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
 
 extern "C" int nsp_rnnt_logsoftmax_gather(const float* logits, const int* labels, const int* elens,
                                           const int* ylens, float* lse, float* lp_blank,

@@ -976,9 +976,22 @@ class RNNTJointLossFn(torch.autograd.Function):
             _check(L.nsp_splitk_reduce(_p(part), _p(dw), (sk), (V * J), _stream()),
                    'nsp_splitk_reduce')
             wt = _weight_t_shadow(w_out, True)                      # [J, roundup64(V)]
+            db = db_fused if Vp <= 1024 else (colsum(d16[:, :V]) if ctx.has_bias else None)
+            de = torch.empty((B, T, J), device=h.device, dtype=torch.float32)
+            dg = torch.empty((B, U1, J), device=h.device, dtype=torch.float32)
+            if J % 32 == 0 and U1 <= 512:
+                # dz = (dlogits W_out) * (1 - h^2) straight out of the GEMM epilogue as a bf16 image,
+                # then ONE pass over it for both reductions (sum_u -> de, sum_t -> dg)
+                dz = torch.empty((n, J), device=h.device, dtype=torch.bfloat16)
+                gemm_raw(n, J, Vp, d16, Vp, 1, wt, 1, wt.stride(0), dz, J, dact_src=h2d, dact=6)
+                nslab = max(1, min(16, T // 16))
+                slabs = torch.empty((nslab, B * U1 * J), device=h.device, dtype=torch.float32)
+                _check(L.nsp_rnnt_joint_dz_reduce(_p(dz), _p(de), _p(slabs), nslab, B, T, U1, J, _stream()),
+                       'nsp_rnnt_joint_dz_reduce')
+                _check(L.nsp_splitk_reduce(_p(slabs), _p(dg), nslab, B * U1 * J, _stream()), 'nsp_splitk_reduce')
+                return de, dg, dw.view(w_out.shape), db, None, None, None, None
             dh = torch.empty((n, J), device=h.device, dtype=torch.float32)
             gemm_raw(n, J, Vp, d16, Vp, 1, wt, 1, wt.stride(0), dh, J)
-            db = db_fused if Vp <= 1024 else (colsum(d16[:, :V]) if ctx.has_bias else None)
         else:
             dw = linear_wgrad(dlogits, h2d)
             db = db_fused if V <= 1024 else (colsum(dlogits) if ctx.has_bias else None)

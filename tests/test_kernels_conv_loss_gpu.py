@@ -166,6 +166,37 @@ def test_rnnt_joint_loss():
         assert _rel(a.cpu().double(), r) < 2e-4
 
 
+@pytest.mark.parametrize('U,J,V', [(6, 32, 32), (40, 64, 40), (70, 96, 1000)])
+def test_rnnt_joint_loss_bf16_fused_backward(U, J, V):
+    """bf16 mode: tanh' applied in the data-gradient GEMM epilogue (bf16 dz image) and the single
+    reduction pass for both joint-input gradients, against the fp64 oracle (bf16 tolerances)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from oracle.rnnt_ref import rnnt_loss_ref_diag
+    from neural_sp_amd import ops
+    torch.manual_seed(U)
+    B, T = 3, 17
+    e = (torch.randn(B, T, J, device=_dev()) * 0.7).requires_grad_()
+    gq = (torch.randn(B, U + 1, J, device=_dev()) * 0.7).requires_grad_()
+    w = (torch.randn(V, J, device=_dev()) * 0.2).requires_grad_()
+    bo = torch.randn(V, device=_dev(), requires_grad=True)
+    elens = torch.tensor([T, T - 4, 5], dtype=torch.int32)
+    ylens = torch.tensor([U, max(0, U - 3), 0], dtype=torch.int32)
+    lab = torch.randint(1, V, (B, U), dtype=torch.int32)
+    for b in range(B):
+        lab[b, ylens[b]:] = 0
+    with ops.compute_mode('bf16'):
+        loss, nll = ops.rnnt_joint_loss(e, gq, w, bo, lab.to(_dev()), elens.to(_dev()), ylens.to(_dev()), 0)
+        grads = torch.autograd.grad(loss, (e, gq, w, bo))
+    e64, g64, w64, b64 = [t.detach().cpu().double().requires_grad_() for t in (e, gq, w, bo)]
+    logits = torch.tanh(e64[:, :, None] + g64[:, None]) @ w64.t() + b64
+    ref = rnnt_loss_ref_diag(torch.log_softmax(logits, -1), lab.long(), elens.long(), ylens.long(), blank=0).mean()
+    rg = torch.autograd.grad(ref, (e64, g64, w64, b64))
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 5e-3, (loss.item(), ref.item())
+    for a, r in zip(grads, rg):
+        assert _rel(a.cpu().double(), r) < 3e-2
+
+
 def test_ctc_forced_align_vs_reference_golden():
     """trigger points must equal the reference CTCForcedAligner's output (fixture generated by
     oracle/gen_golden.py run_align from neural_sp/models/seq2seq/decoders/ctc.py:628-753)."""
