@@ -242,6 +242,12 @@ int nsp_dwconv1d_fwd(const float* x, const float* wt /*[k,C]*/, const float* bia
 /* dwt[k][C], dbias[C] are accumulated atomically into caller-zeroed buffers */
 int nsp_dwconv1d_wgrad(const float* x, const float* dy, float* dwt, float* dbias,
                        int B, int T, int C, int k, int pad, void* stream);
+/* k <= 15: LDS-tiled variant without atomics.  Utterance b's time axis is cut into `tsplit`
+ * ranges; workgroup (channel block, range, b) writes its partial [(k+1)][C] (taps, then the bias
+ * row) to slab b*tsplit + range of `part` (B*tsplit slabs, all written); sum them with
+ * nsp_splitk_reduce. */
+int nsp_dwconv1d_wgrad_slabs(const float* x, const float* dy, float* part, int tsplit,
+                             int B, int T, int C, int k, int pad, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * VGG-style Conv2d frontend on channels-last [B,T,F,C] (conv.py:289-396).  *

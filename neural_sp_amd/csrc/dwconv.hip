@@ -159,7 +159,77 @@ inline int ew_grid(long long n) {
   return (int)g;
 }
 
+// LDS-tiled weight gradient for k <= 15.  grid: (ceil(C4/64), tsplit, B); block 256:
+// thread = (one float4 of channels, one of 4 tap groups of 4 slots: taps 4jg..4jg+3, slot k = bias).
+// Per 24-row chunk the x rows (with their k-1 halo rows; zero outside the utterance) and the dy
+// rows are staged once; every (row, tap) product then reads LDS only.  (The register version
+// issues 1 + k global loads per row and is TA-bound: 80 us for 52 MB.)
+constexpr int DW_RC = 24;
+__global__ __launch_bounds__(256) void dwconv_wgrad_lds_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ dy,
+                                                               float* __restrict__ part, int B, int T, int C,
+                                                               int k, int pad, int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float4 dsh[];
+  float4* xs = dsh;                              // [(DW_RC + k - 1)][64]
+  float4* dys = dsh + (DW_RC + k - 1) * 64;      // [DW_RC][64]
+  const int lane = threadIdx.x & 63, jg = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  const int c4 = blockIdx.x * 64 + lane;
+  const bool active = c4 < C4;
+  const long long b = blockIdx.z;
+  const int ts = blockIdx.y * rows_per_wg;
+  const int te = min(T, ts + rows_per_wg);
+  const float4* x4 = reinterpret_cast<const float4*>(x) + b * T * C4;
+  const float4* d4 = reinterpret_cast<const float4*>(dy) + b * T * C4;
+  float4 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t0 = ts; t0 < te; t0 += DW_RC) {
+    const int nr = min(DW_RC, te - t0);
+    __syncthreads();
+    for (int i = jg; i < nr + k - 1; i += 4) {
+      const int tt = t0 - pad + i;
+      xs[i * 64 + lane] = (active && tt >= 0 && tt < T) ? x4[(long long)tt * C4 + c4] : zero;
+    }
+    for (int i = jg; i < nr; i += 4) dys[i * 64 + lane] = active ? d4[(long long)(t0 + i) * C4 + c4] : zero;
+    __syncthreads();
+    for (int i = 0; i < nr; ++i) {
+      const float4 g = dys[i * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int j = jg * 4 + s;
+        if (j < k) {
+          const float4 xv = xs[(i + j) * 64 + lane];
+          acc[s].x += g.x * xv.x; acc[s].y += g.y * xv.y; acc[s].z += g.z * xv.z; acc[s].w += g.w * xv.w;
+        } else if (j == k) {
+          acc[s].x += g.x; acc[s].y += g.y; acc[s].z += g.z; acc[s].w += g.w;
+        }
+      }
+    }
+  }
+  if (active) {
+    float* slab = part + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * (long long)(k + 1) * C;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int j = jg * 4 + s;
+      if (j <= k) *reinterpret_cast<float4*>(slab + (long long)j * C + c4 * 4) = acc[s];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int nsp_dwconv1d_wgrad_slabs(const float* x, const float* dy, float* part, int tsplit, int B,
+                                        int T, int C, int k, int pad, void* stream) {
+  if (C % 4 || k < 1 || k > 15 || tsplit < 1) return NSP_EUNSUPPORTED;
+  const int rows_per_wg = nsp_cdiv(T, tsplit);
+  const size_t shmem = sizeof(float4) * 64 * (size_t)(2 * DW_RC + k - 1);
+  hipLaunchKernelGGL(dwconv_wgrad_lds_kernel, dim3(nsp_cdiv(C / 4, 64), tsplit, B), dim3(256), shmem,
+                     (hipStream_t)stream, x, dy, part, B, T, C, k, pad, rows_per_wg);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
 
 extern "C" int nsp_dwconv1d_fwd(const float* x, const float* wt, const float* bias, float* y, int B,
                                 int T, int C, int k, int pad, int flip, void* stream) {

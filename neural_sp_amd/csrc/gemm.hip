@@ -176,7 +176,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const nsp_gemm_params p,
     int per = (nkt + p.splitk - 1) / p.splitk;
     kbeg = split * per * BK;
     kend = min(p.K, (split + 1) * per * BK);
-    if (kbeg >= kend) return;
+    if (kbeg >= kend) {
+      if (!p.c_ss) return;   // atomic accumulation: nothing to add
+      kend = kbeg;           // slab mode: an empty split still has to write its zeros
+    }
   }
 
   f32x4 acc[4][4];

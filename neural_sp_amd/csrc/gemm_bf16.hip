@@ -248,7 +248,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
     int per = (nkt + p.splitk - 1) / p.splitk;
     kbeg = split * per * BK;
     kend = min(p.K, (split + 1) * per * BK);
-    if (kbeg >= kend) return;
+    if (kbeg >= kend) {
+      if (!p.c_ss) return;   // atomic accumulation: nothing to add
+      kend = kbeg;           // slab mode: an empty split still has to write its zeros
+    }
   }
 
   f32x4 acc[4][4];
@@ -321,7 +324,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_glds_kernel(const nsp_g
     int per = (nkt + p.splitk - 1) / p.splitk;
     kbeg = split * per * BK;
     kend = min(p.K, (split + 1) * per * BK);
-    if (kbeg >= kend) return;
+    if (kbeg >= kend) {
+      if (!p.c_ss) return;   // atomic accumulation: nothing to add
+      kend = kbeg;           // slab mode: an empty split still has to write its zeros
+    }
   }
   f32x4 acc[4][4];
 #pragma unroll
@@ -414,7 +420,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
     int per = (nkt_all + p.splitk - 1) / p.splitk;
     kbeg = split * per * BK;
     kend = min(p.K, (split + 1) * per * BK);
-    if (kbeg >= kend) return;
+    if (kbeg >= kend) {
+      if (!p.c_ss) return;   // atomic accumulation: nothing to add
+      kend = kbeg;           // slab mode: an empty split still has to write its zeros
+    }
   }
   f32x4 acc[MI][4];
 #pragma unroll

@@ -195,7 +195,11 @@ def _pick_splitk(M, N, K, batch=1):
     if tiles >= 256 or K < 1024:
         return 1
     want = max(1, int(os.environ.get('NSP_SPLITK_TARGET', '512')) // tiles)
-    return int(max(1, min(want, K // 256, 64)))
+    sk = int(max(1, min(want, K // 256, 64)))
+    # no empty splits: the kernels cut the k-tiles (64 wide) into ceil(nkt / sk) per split
+    nkt = (K + 63) // 64
+    per = -(-nkt // sk)
+    return -(-nkt // per)
 
 
 def linear_fwd(x2d, weight, bias=None, act=0, res=None, alpha=1.0, pre_out=None, out=None,
@@ -704,6 +708,17 @@ class DepthwiseConv1dFn(torch.autograd.Function):
         B, T, C = x.shape
         k, pad = ctx.k, ctx.pad
         dx = _dwconv_fwd(dy, wt, None, k, k - 1 - pad, 1) if ctx.needs_input_grad[0] else None
+        if k <= 15 and ((k + 1) * C) % 4 == 0:
+            tsplit = max(1, min(16, T // 48))
+            part = torch.empty((B * tsplit, (k + 1) * C), device=x.device, dtype=torch.float32)
+            _check(_lib.lib().nsp_dwconv1d_wgrad_slabs(_p(x), _p(dy), _p(part), tsplit, B, T, C, k, pad, _stream()),
+                   'nsp_dwconv1d_wgrad_slabs')
+            buf = torch.empty((k + 1, C), device=x.device, dtype=torch.float32)
+            _check(_lib.lib().nsp_splitk_reduce(_p(part), _p(buf), B * tsplit, (k + 1) * C, _stream()),
+                   'nsp_splitk_reduce')
+            dw = buf[:k].t().contiguous().view(C, 1, k)
+            db = buf[k] if ctx.has_bias else None
+            return dx, dw, db, None
         buf = zeros_small((k + 1, C), x.device)
         _check(_lib.lib().nsp_dwconv1d_wgrad(_p(x), _p(dy), (buf.data_ptr()),
                                              (buf.data_ptr() + 4 * k * C),

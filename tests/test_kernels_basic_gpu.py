@@ -202,3 +202,23 @@ def test_gemm_bf16_operands_all_layouts(M, N, K):
             y2 = torch.empty(M, N, device=_dev())
             ops.gemm_raw(M, N, K, xt, 1, M, w, 1, K, y2, N)                         # RC x KC
             assert _rel(y2, x.float() @ w.float().t()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['bf16', 'f32'])
+def test_splitk_slabs_with_an_empty_split_are_fully_written(mode):
+    """K = 2091 rows cut into 8 splits of ceil(33/8) = 5 k-tiles leaves the last split empty: its
+    slab must still be written (zeros), or the slab reduction sums garbage left in the buffer."""
+    from neural_sp_amd import ops
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    M, N, K, sk = 40, 64, 2091, 8
+    a = torch.randn(K, M, device=dev)
+    b = torch.randn(K, N, device=dev)
+    with ops.compute_mode(mode):
+        aa, bb = (ops.to_bf16(a), ops.to_bf16(b)) if mode == 'bf16' else (a, b)
+        part = torch.full((sk, M, N), float('nan'), device=dev)
+        ops.gemm_raw(M, N, K, aa, 1, aa.stride(0), bb, bb.stride(0), 1, part, N, splitk=sk, c_ss=M * N)
+    assert torch.isfinite(part).all()
+    ref = aa.float().t() @ bb.float()
+    assert ((part.sum(0) - ref).abs().max() / ref.abs().max()).item() < (2e-3 if mode == 'bf16' else 1e-4)
