@@ -82,11 +82,32 @@ __device__ __forceinline__ uint32_t nsp_hash_u32(unsigned long long seed, unsign
   x ^= x >> 16;
   return x;
 }
+// One 32-bit mix decides TWO adjacent elements (16 bits each): element idx uses the low / high half
+// of hash(seed, idx >> 1).  The per-element hash was ~45 % of the VALU work of a dropout-carrying
+// GEMM epilogue; the drop probability is quantised to 1/65536.
 __device__ __forceinline__ float nsp_keep_scale(unsigned long long seed, unsigned long long idx,
                                                 float p) {
   // returns 0 (dropped) or 1/(1-p)
-  float u = (float)(nsp_hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
-  return u < p ? 0.f : nsp_rcp(1.f - p);
+  const uint32_t h = nsp_hash_u32(seed, idx >> 1);
+  const uint32_t bits = (idx & 1ull) ? (h >> 16) : (h & 0xFFFFu);
+  return bits < (uint32_t)(p * 65536.f) ? 0.f : nsp_rcp(1.f - p);
+}
+// the same function for 4 consecutive elements base .. base+3 (two mixes when base is even)
+__device__ __forceinline__ void nsp_keep_scale4(unsigned long long seed, unsigned long long base, float p,
+                                                float (&k)[4]) {
+  if ((base & 1ull) == 0ull) {
+    const uint32_t thr = (uint32_t)(p * 65536.f);
+    const float inv = nsp_rcp(1.f - p);
+    const uint32_t h0 = nsp_hash_u32(seed, base >> 1);
+    const uint32_t h1 = nsp_hash_u32(seed, (base >> 1) + 1ull);
+    k[0] = (h0 & 0xFFFFu) < thr ? 0.f : inv;
+    k[1] = (h0 >> 16) < thr ? 0.f : inv;
+    k[2] = (h1 & 0xFFFFu) < thr ? 0.f : inv;
+    k[3] = (h1 >> 16) < thr ? 0.f : inv;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k[e] = nsp_keep_scale(seed, base + (unsigned long long)e, p);
+  }
 }
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {

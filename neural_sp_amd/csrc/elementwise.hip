@@ -79,8 +79,10 @@ __global__ void grad_prep_kernel(const float* __restrict__ dy, const void* __res
     const float4 g4 = reinterpret_cast<const float4*>(dy)[i];
     float g[4] = {g4.x * alpha, g4.y * alpha, g4.z * alpha, g4.w * alpha};
     if (p > 0.f) {
+      float kp[4];
+      nsp_keep_scale4(seed, offset + (unsigned long long)(i * 4), p, kp);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] *= nsp_keep_scale(seed, offset + (unsigned long long)(i * 4 + e), p);
+      for (int e = 0; e < 4; ++e) g[e] *= kp[e];
     }
     if (pre) {
       float q[4];

@@ -1,8 +1,10 @@
 #!/usr/bin/env python
-"""Count python-initiated zero fills of one training step by call site (monkeypatched torch.zeros*)."""
-import collections, os, sys, traceback
+"""Which ops issue the small fill kernels of a training step?  (torch.profiler event tree:
+every aten::fill_/zero_ is attributed to its chain of parent ops, across threads.)"""
+import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from torch.profiler import profile, ProfilerActivity
 from neural_sp_amd import ops, parallel
 from neural_sp_amd.configs import conformer_rnnt_args, synthetic_batch
 from neural_sp_amd.speech2text import Speech2Text
@@ -17,20 +19,15 @@ def step():
     parallel.clip_grad_norm_(params, 5.0); opt.step(); opt.zero_grad(set_to_none=True)
 for _ in range(3): step()
 torch.cuda.synchronize()
-cnt = collections.Counter()
-def wrap(mod, name):
-    orig = getattr(mod, name)
-    def f(*a, **k):
-        fr = [x for x in traceback.extract_stack()[:-1] if 'neural_sp_amd' in x.filename or 'tools' in x.filename]
-        cnt[(name, '%s:%d' % (os.path.basename(fr[-1].filename), fr[-1].lineno) if fr else '?')] += 1
-        return orig(*a, **k)
-    setattr(mod, name, f)
-for n in ('zeros', 'zeros_like', 'ones', 'full'):
-    wrap(torch, n)
-for n in ('new_zeros', 'zero_', 'fill_'):
-    wrap(torch.Tensor, n)
-step()
+with profile(activities=[ProfilerActivity.CPU]) as prof:
+    step()
 torch.cuda.synchronize()
-print('python-initiated fills:', sum(cnt.values()))
-for (n, s), k in cnt.most_common(40):
-    print('%4d %-12s %s' % (k, n, s))
+cnt = collections.Counter()
+for ev in prof.events():
+    if ev.name in ('aten::fill_', 'aten::zero_'):
+        chain, p = [], ev.cpu_parent
+        while p is not None and len(chain) < 4:
+            chain.append(p.name); p = p.cpu_parent
+        cnt[(ev.name, ' <- '.join(chain))] += 1
+for (n, s), k in cnt.most_common(25):
+    print('%4d %-12s %s' % (k, n, s[:150]))

@@ -26,9 +26,9 @@ bench('plain bf16 out', M, N, K, odt=torch.bfloat16)
 bench('bias', M, N, K, bias=True, odt=torch.bfloat16)
 bench('bias+swish', M, N, K, bias=True, act=2, odt=torch.bfloat16)
 bench('bias+swish+pre', M, N, K, bias=True, act=2, pre=True, odt=torch.bfloat16)
-bench('bias+swish+pre+dropout', M, N, K, bias=True, act=2, pre=True, dropout_p=0.1, seed=1, offset=5, odt=torch.bfloat16)
-bench('bias+dropout', M, N, K, bias=True, dropout_p=0.1, seed=1, offset=5, odt=torch.bfloat16)
-bench('FFN2: bias+dropout+res fp32 (N=512,K=2048)', M, 512, 2048, bias=True, dropout_p=0.1, seed=1, offset=5, res=True)
+bench('bias+swish+pre+dropout', M, N, K, bias=True, act=2, pre=True, dropout_p=0.1, seed=1, offset=8, odt=torch.bfloat16)
+bench('bias+dropout', M, N, K, bias=True, dropout_p=0.1, seed=1, offset=8, odt=torch.bfloat16)
+bench('FFN2: bias+dropout+res fp32 (N=512,K=2048)', M, 512, 2048, bias=True, dropout_p=0.1, seed=1, offset=8, res=True)
 bench('FFN2 plain', M, 512, 2048)
 bench('square 4096', 4096, 4096, 4096)
 bench('square 8192', 8192, 8192, 8192, odt=torch.bfloat16)
