@@ -204,9 +204,10 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
       if (p.dropout_p > 0.f) {
+        float kp[4];
+        nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] *= nsp_keep_scale(p.seed, p.offset + (unsigned long long)(off + e), p.dropout_p);
+        for (int e = 0; e < 4; ++e) v[e] *= kp[e];
       }
       if (p.res) {
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
