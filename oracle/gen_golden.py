@@ -72,6 +72,31 @@ CASES = {
                                                          lc_chunk_size_left='16', lc_chunk_size_current='8',
                                                          lc_chunk_size_right='0', lc_type='mask'),
                              dict(B=2, t_range=(40, 61), u_range=(2, 5), vocab=40, seed=5)),
+    # Conformer v2 block ordering (conformer_block_v2.py)
+    'conformer_v2_ctc_xs': (lambda: conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=1.0,
+                                                        ctc_fc_list='', ctc_lsm_prob=0.0,
+                                                        enc_type='conv_conformer_v2', conformer_kernel_size=7),
+                            dict(B=2, t_range=(40, 61), u_range=(2, 5), vocab=40, seed=7)),
+    # latency-controlled encoder, lc_type = reshape (chunks become batch rows)
+    'lc_conformer_reshape_xs': (lambda: conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=1.0,
+                                                            ctc_fc_list='', ctc_lsm_prob=0.0,
+                                                            conformer_kernel_size=7,
+                                                            lc_chunk_size_left='16', lc_chunk_size_current='8',
+                                                            lc_chunk_size_right='8', lc_type='reshape'),
+                                dict(B=2, t_range=(40, 61), u_range=(2, 5), vocab=40, seed=8)),
+    # Transformer with additive sinusoidal positions
+    'transformer_ctc_peadd_xs': (lambda: transformer_ctc_args(n_layers=2, d_model=32, d_ff=64, n_heads=4, vocab=40,
+                                                              transformer_enc_pe_type='add'),
+                                 dict(B=3, t_range=(50, 90), u_range=(2, 8), vocab=40, seed=9)),
+    # d_k = 64 + 256-unit 2-layer prediction network + 32-dim joint: in bf16 mode this one runs the
+    # flash-attention kernels, the persistent LSTM stack and the fused joint backward end to end
+    'conformer_rnnt_dk64_xs': (lambda: conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=0.3,
+                                                           ctc_fc_list='', ctc_lsm_prob=0.0,
+                                                           transformer_enc_d_model=128, transformer_enc_n_heads=2,
+                                                           transformer_enc_d_ff=256, conformer_kernel_size=7,
+                                                           dec_n_units=256, dec_n_layers=2, emb_dim=64,
+                                                           dec_bottleneck_dim=32),
+                               dict(B=3, t_range=(90, 140), u_range=(4, 12), vocab=40, seed=10)),
 }
 
 
