@@ -122,10 +122,13 @@ int nsp_layernorm_fwd(const float* x, const float* gamma, const float* beta,
                       int rows, int d, float eps, int act, float* y_pre,
                       void* y16, void* stream);
 /* dx (may alias dy), dgamma/dbeta accumulated via atomics into zeroed buffers.
- * If act != NONE, y_pre is the pre-activation LN output saved by fwd. */
+ * If act != NONE, y_pre is the pre-activation LN output saved by fwd.
+ * dres (optional, [rows,d]) is added to dx: the gradient that reaches x through the residual
+ * connection around the normalised branch (x feeds both LN and "+ x"), so that the two are summed
+ * in this pass instead of by a separate elementwise kernel. */
 int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                       const float* mean, const float* rstd, const float* y_pre,
-                      float* dx, float* dgamma, float* dbeta,
+                      const float* dres, float* dx, float* dgamma, float* dbeta,
                       int rows, int d, int act, void* stream);
 
 /* ------------------------------------------------------------------------ *

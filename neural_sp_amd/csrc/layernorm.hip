@@ -74,8 +74,8 @@ template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ y_pre,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int d,
-    int act) {
+    const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int rows, int d, int act) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][4][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int d4 = d >> 2;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   // store, ~3.4 TB/s with 6 waves per CU)
   const long long rstride = (long long)gridDim.x * 4;
   long long row = (long long)blockIdx.x * 4 + w;
-  float4 nx[VPL], ng[VPL], np[VPL];
+  float4 nx[VPL], ng[VPL], np[VPL], nr[VPL];
   float nmu = 0.f, nrs = 0.f;
   auto fetch = [&](long long r) {
     nmu = mean[r];
@@ -108,15 +108,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         nx[i] = xr[c];
         ng[i] = gr[c];
         if (pr) np[i] = pr[c];
+        if (dres) nr[i] = reinterpret_cast<const float4*>(dres + r * d)[c];
       }
     }
   };
   if (row < rows) fetch(row);
   for (; row < rows; row += rstride) {
     const float mu = nmu, rs = nrs;
-    float4 xv_[VPL], gv_[VPL], pv_[VPL];
+    float4 xv_[VPL], gv_[VPL], pv_[VPL], rv_[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { xv_[i] = nx[i]; gv_[i] = ng[i]; pv_[i] = np[i]; }
+    for (int i = 0; i < VPL; ++i) { xv_[i] = nx[i]; gv_[i] = ng[i]; pv_[i] = np[i]; rv_[i] = nr[i]; }
     if (row + rstride < rows) fetch(row + rstride);
     float4 xh[VPL], g[VPL];
     float s1 = 0.f, s2 = 0.f;
@@ -149,9 +150,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       int c = lane + i * 64;
-      if (c < d4)
-        dxr[c] = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
-                             rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
+      if (c < d4) {
+        float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
+                               rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
+        if (dres) { o.x += rv_[i].x; o.y += rv_[i].y; o.z += rv_[i].z; o.w += rv_[i].w; }
+        dxr[c] = o;
+      }
     }
   }
   // combine the 4 waves' partial dgamma/dbeta through LDS, one atomic per column
@@ -202,8 +206,8 @@ extern "C" int nsp_layernorm_fwd(const float* x, const float* gamma, const float
 
 extern "C" int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, const float* y_pre,
-                                 float* dx, float* dgamma, float* dbeta, int rows, int d, int act,
-                                 void* stream) {
+                                 const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
+                                 int d, int act, void* stream) {
   if (d % 4 || d > 2048 || rows <= 0) return NSP_EUNSUPPORTED;
   if (act != NSP_ACT_NONE && !y_pre) return NSP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -212,7 +216,7 @@ extern "C" int nsp_layernorm_bwd(const float* dy, const float* x, const float* g
   if (grid < 1) grid = 1;
   const size_t shmem = sizeof(float) * 8 * d;
   const int vpl = nsp_cdiv(d, 256);
-#define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), shmem, st, dy, x, gamma, mean, rstd, y_pre, dx, dgamma, dbeta, rows, d, act)
+#define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), shmem, st, dy, x, gamma, mean, rstd, y_pre, dres, dx, dgamma, dbeta, rows, d, act)
   if (vpl <= 1) LN_BWD(1);
   else if (vpl <= 2) LN_BWD(2);
   else if (vpl <= 4) LN_BWD(4);

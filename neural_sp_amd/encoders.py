@@ -262,16 +262,16 @@ class TransformerEncoderBlock(nn.Module):
                 return xs, {}
             else:
                 xs = ops.scale(xs, 1.0 / (1 - self.dropout_layer))
+        xn, xs = ops.layer_norm_split(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         residual = xs
-        xn = ops.layer_norm(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         if self.rel_attn:
             xs, self._xx_aws = self.self_attn(xn, xn, pos_embs, xx_mask, u_bias, v_bias,
                                               residual=residual, out_dropout=self.dropout_p)
         else:
             xs, self._xx_aws = self.self_attn(xn, xn, xn, mask=xx_mask, residual=residual,
                                               out_dropout=self.dropout_p)[:2]
+        xn, xs = ops.layer_norm_split(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         residual = xs
-        xn = ops.layer_norm(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         xs = self.feed_forward(xn, residual=residual, alpha=1.0, out_dropout=self.dropout_p)
         return xs, {}
 
@@ -318,14 +318,14 @@ class ConformerEncoderBlock(nn.Module):
             else:
                 xs = ops.scale(xs, 1.0 / (1 - self.dropout_layer))
         p = self.dropout_p
-        xn = ops.layer_norm(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        xn, xs = ops.layer_norm_split(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         xs = self.feed_forward_macaron(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
-        xn = ops.layer_norm(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        xn, xs = ops.layer_norm_split(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         xs, self._xx_aws = self.self_attn(xn, xn, pos_embs, xx_mask, u_bias, v_bias,
                                           residual=xs, out_dropout=p)
-        xn = ops.layer_norm(xs, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        xn, xs = ops.layer_norm_split(xs, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         xs = self.conv(xn, residual=xs, out_dropout=p)
-        xn = ops.layer_norm(xs, self.norm4.weight, self.norm4.bias, self.norm4.eps)
+        xn, xs = ops.layer_norm_split(xs, self.norm4.weight, self.norm4.bias, self.norm4.eps)
         xs = self.feed_forward(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
         xs = ops.layer_norm(xs, self.norm5.weight, self.norm5.bias, self.norm5.eps)
         return xs, {}
@@ -370,13 +370,13 @@ class ConformerEncoderBlock_v2(nn.Module):
             else:
                 xs = ops.scale(xs, 1.0 / (1 - self.dropout_layer))
         p = self.dropout_p
-        xn = ops.layer_norm(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        xn, xs = ops.layer_norm_split(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         xs = self.feed_forward_macaron(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
-        xn = ops.layer_norm(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        xn, xs = ops.layer_norm_split(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         xs = self.conv(xn, residual=xs, out_dropout=p)
-        xn = ops.layer_norm(xs, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        xn, xs = ops.layer_norm_split(xs, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         xs, self._xx_aws = self.self_attn(xn, xn, xn, mask=xx_mask, residual=xs, out_dropout=p)[:2]
-        xn = ops.layer_norm(xs, self.norm4.weight, self.norm4.bias, self.norm4.eps)
+        xn, xs = ops.layer_norm_split(xs, self.norm4.weight, self.norm4.bias, self.norm4.eps)
         xs = self.feed_forward(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
         xs = ops.layer_norm(xs, self.norm5.weight, self.norm5.bias, self.norm5.eps)
         return xs, {}

@@ -471,11 +471,11 @@ def layernorm_fwd_raw(x2d, gamma, beta, eps, act=0, want_pre=False, want16=False
     return y, mean, rstd, y_pre, y16
 
 
-def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0):
+def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0, dres=None):
     rows, d = x2d.shape
     dx = torch.empty_like(x2d)
     dgb = zeros_small((2, d), x2d.device)
-    _check(_lib.lib().nsp_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(y_pre),
+    _check(_lib.lib().nsp_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(y_pre), _p(dres),
                                         _p(dx), (dgb.data_ptr()),
                                         (dgb.data_ptr() + 4 * d),
                                         (rows), (d), (act),
@@ -506,6 +506,39 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, eps=1e-12, act='none'):
     return LayerNormFn.apply(x, gamma, beta, eps, ACT[act] if not isinstance(act, int) else act)
+
+
+class LayerNormSplitFn(torch.autograd.Function):
+    """(LN(x), x) for the pre-norm residual pattern  x + branch(LN(x)):  the second output is x
+    itself, to be used as the residual operand.  x then has ONE consumer in the autograd graph, and
+    backward receives the branch gradient and the residual gradient together: their sum is formed
+    inside the LayerNorm backward kernel instead of by a separate accumulation kernel per sub-block."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2d = _f32c(x).reshape(-1, x.shape[-1])
+        want16 = bf16_mode() and x2d.shape[1] % 8 == 0
+        y, mean, rstd, _, y16 = layernorm_fwd_raw(x2d, gamma, beta, eps, 0, want_pre=False, want16=want16)
+        ctx.save_for_backward(x2d, gamma, mean, rstd)
+        out = y.view(x.shape)
+        if y16 is not None:
+            out._nsp16 = y16
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x2d, gamma, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dy2d = _f32c(dy).reshape(x2d.shape)
+        r2d = _f32c(dres).reshape(x2d.shape) if dres is not None else None
+        dx, dg, db = layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, None, 0, dres=r2d)
+        return dx.view(dy.shape), dg, db, None
+
+
+def layer_norm_split(x, gamma, beta, eps=1e-12):
+    """-> (LN(x), x_residual); see LayerNormSplitFn."""
+    return LayerNormSplitFn.apply(x, gamma, beta, eps)
 
 
 # --------------------------------------------------------------------------
