@@ -23,8 +23,9 @@ with profile(activities=[ProfilerActivity.CPU]) as prof:
     step()
 torch.cuda.synchronize()
 cnt = collections.Counter()
+WANT = tuple(sys.argv[1:]) or ('aten::fill_', 'aten::zero_')
 for ev in prof.events():
-    if ev.name in ('aten::fill_', 'aten::zero_'):
+    if ev.name in WANT:
         chain, p = [], ev.cpu_parent
         while p is not None and len(chain) < 4:
             chain.append(p.name); p = p.cpu_parent
