@@ -415,7 +415,8 @@ int nsp_lstm_stack_bwd(const nsp_lstm_stack_params* p, void* stream);
  * weights in registers for all stages (the per-stage launches above re-read 8-16 MB of weights *
  * from beyond L2 after every launch boundary), stages are separated by a grid barrier (one      *
  * monotonic device counter; h / dgates handed over with write-through stores + agent acquire). *
- * Requires B <= 16, H % 256 == 0, H <= 1024, nl * H/16 co-resident workgroups (<= 256).        *
+ * Requires B <= 64 (batch blocks of 16 are looped inside a stage), H % 256 == 0, H <= 1024,     *
+ * nl * H/16 co-resident workgroups (<= 256).                                                   *
  * `sync` = 2 zero-initialised 32-bit words owned by this call (barrier counter, abort flag):   *
  * spins are bounded; on expiry the flag is set and y_top[0] / dg16[0][0] become NaN instead of *
  * the call hanging.  Returns NSP_EUNSUPPORTED when the shape does not qualify.                 */

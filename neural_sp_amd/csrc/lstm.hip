@@ -376,6 +376,9 @@ __device__ __forceinline__ bool grid_wait(unsigned int* sync, unsigned int targe
 // forward.  grid: (H/16, nl); block 512.  Workgroup (ub, l) owns hidden units 16*ub.. of layer l:
 // wave w holds, for each of the 4 gates, the 16 W rows of those units restricted to its 1/8 of the
 // reduction (layer 0: K = H; layers >= 1: K = 2H over [W_ih | W_hh]) as MFMA B-fragments.
+// NB = ceil(B/16) batch blocks are processed one after the other inside a stage (same register-
+// resident weights, one grid barrier per stage whatever the batch).
+template <int NB>
 __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const nsp_lstm_stack_params p,
                                                                         unsigned int* sync) {
   __shared__ float part[8][4][16][17];
@@ -401,8 +404,6 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
         if (f < nf)
           bfrag[j][f] = *reinterpret_cast<const bf16x8*>(W + (long long)(j * H + u0 + r) * Ktot + kbeg + f * 32 + g * 8);
   }
-  const bool a_valid = r < B;
-  const long long arow0 = (long long)min(r, B - 1) * L;
   const __bf16* abase0;
   bool a_rec;  // the wave's k-slice lies in the recurrent half
   if (l == 0 || kbeg >= H) {
@@ -412,102 +413,111 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
     abase0 = reinterpret_cast<const __bf16*>(p.yd16[l - 1]) + kbeg;
     a_rec = false;
   }
-  // cell-update thread (b, unit): threads 0..255
+  // cell-update thread (b within block, unit): threads 0..255
   const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
   const int u = u0 + uu;
-  const bool upd = threadIdx.x < 256 && bb < B;
-  float c_reg = 0.f;
-  float gin[4] = {0.f, 0.f, 0.f, 0.f};
-  if (upd && l > 0) {
+  float c_reg[NB];
+  float gin[NB][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gin[q] = p.bias[l][q * H + u];
-  }
-  if (upd && l == 0) {
+  for (int bk = 0; bk < NB; ++bk) {
+    c_reg[bk] = 0.f;
+    const bool upd = threadIdx.x < 256 && bk * 16 + bb < B;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gin[q] = p.gi0[((long long)bb * L) * 4 * H + q * H + u];
+    for (int q = 0; q < 4; ++q) {
+      gin[bk][q] = 0.f;
+      if (upd) gin[bk][q] = l > 0 ? p.bias[l][q * H + u] : p.gi0[((long long)(bk * 16 + bb) * L) * 4 * H + q * H + u];
+    }
   }
   const int nstage = L + p.nl - 1;
   bool alive = true;
   for (int s = 0; s < nstage; ++s) {
     const int t = s - l;
     if (t >= 0 && t < L) {
-      f32x4 acc[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!a_rec || t > 0) {
-        const __bf16* ap = abase0 + (arow0 + t) * H + g * 8;
-        bf16x8 af[8];
+      for (int bk = 0; bk < NB; ++bk) {
+        const int b0 = bk * 16;
+        const bool a_valid = b0 + r < B;
+        const long long arow0 = (long long)min(b0 + r, B - 1) * L;
+        const bool upd = threadIdx.x < 256 && b0 + bb < B;
+        f32x4 acc[4];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-          bf16x8 z;
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!a_rec || t > 0) {
+          const __bf16* ap = abase0 + (arow0 + t) * H + g * 8;
+          bf16x8 af[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-          af[f] = (f < nf && a_valid) ? *reinterpret_cast<const bf16x8*>(ap + f * 32) : z;
-        }
+          for (int f = 0; f < 8; ++f) {
+            bf16x8 z;
 #pragma unroll
-        for (int f = 0; f < 8; ++f)
-          if (f < nf) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfrag[j][f], acc[j], 0, 0, 0);
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            af[f] = (f < nf && a_valid) ? *reinterpret_cast<const bf16x8*>(ap + f * 32) : z;
           }
-      }
-      // D[i = batch][j = unit]: lane holds unit r, batches 4g..4g+3
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+          for (int f = 0; f < 8; ++f)
+            if (f < nf) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) part[w][j][g * 4 + e][r] = acc[j][e];
-      __syncthreads();
-      const long long row = (long long)bb * L + t;
-      if (upd) {
-        float pre[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = gin[q];
-#pragma unroll
-          for (int ww = 0; ww < 8; ++ww) v += part[ww][q][bb][uu];
-          pre[q] = v;
+              for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfrag[j][f], acc[j], 0, 0, 0);
+            }
         }
-        const float ig = nsp_sigmoid(pre[0]);
-        const float fg = nsp_sigmoid(pre[1]);
-        const float gg = nsp_tanh(pre[2]);
-        const float og = nsp_sigmoid(pre[3]);
-        c_reg = fg * c_reg + ig * gg;
-        const float h = og * nsp_tanh(c_reg);
-        p.c_all[l][row * H + u] = c_reg;
-        float* gs = p.gates[l] + row * 4 * H;
-        gs[u] = ig; gs[H + u] = fg; gs[2 * H + u] = gg; gs[3 * H + u] = og;
-        hs[0][bb][uu] = (__bf16)h;
-        if (l == top) {
-          p.y_top[row * H + u] = h;
-        } else {
-          float hd = h;
-          if (p.dropout_p > 0.f)
-            hd *= nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
-          hs[1][bb][uu] = (__bf16)hd;
-        }
-        if (l == 0 && t + 1 < L) {   // next step's input projection (plain data from an earlier kernel)
-          const float* gnext = p.gi0 + (row + 1) * 4 * H;
+        if (bk > 0) __syncthreads();   // the previous block's readers of part / hs are done
+        // D[i = batch][j = unit]: lane holds unit r, batches 4g..4g+3
 #pragma unroll
-          for (int q = 0; q < 4; ++q) gin[q] = gnext[q * H + u];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part[w][j][g * 4 + e][r] = acc[j][e];
+        __syncthreads();
+        const long long row = (long long)(b0 + bb) * L + t;
+        if (upd) {
+          float pre[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = gin[bk][q];
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) v += part[ww][q][bb][uu];
+            pre[q] = v;
+          }
+          const float ig = nsp_sigmoid(pre[0]);
+          const float fg = nsp_sigmoid(pre[1]);
+          const float gg = nsp_tanh(pre[2]);
+          const float og = nsp_sigmoid(pre[3]);
+          c_reg[bk] = fg * c_reg[bk] + ig * gg;
+          const float h = og * nsp_tanh(c_reg[bk]);
+          p.c_all[l][row * H + u] = c_reg[bk];
+          float* gs = p.gates[l] + row * 4 * H;
+          gs[u] = ig; gs[H + u] = fg; gs[2 * H + u] = gg; gs[3 * H + u] = og;
+          hs[0][bb][uu] = (__bf16)h;
+          if (l == top) {
+            p.y_top[row * H + u] = h;
+          } else {
+            float hd = h;
+            if (p.dropout_p > 0.f)
+              hd *= nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
+            hs[1][bb][uu] = (__bf16)hd;
+          }
+          if (l == 0 && t + 1 < L) {   // next step's input projection (plain data from an earlier kernel)
+            const float* gnext = p.gi0 + (row + 1) * 4 * H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gin[bk][q] = gnext[q * H + u];
+          }
         }
-      }
-      __syncthreads();
-      // publish h (shifted by one step) and dropout(h) with 8-byte write-through stores
-      if (threadIdx.x < 64) {
-        const int pb = threadIdx.x >> 2, pq = threadIdx.x & 3;
-        if (pb < B) {
-          const long long prow = (long long)pb * L + t;
-          if (t + 1 < L)
-            __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.hp16[l]) + (prow + 1) * H + u0 + pq * 4),
-                               *reinterpret_cast<const unsigned long long*>(&hs[0][pb][pq * 4]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-          if (t == 0)
-            *reinterpret_cast<unsigned long long*>(reinterpret_cast<__bf16*>(p.hp16[l]) + prow * H + u0 + pq * 4) = 0ull;
-          if (l < top)
-            __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.yd16[l]) + prow * H + u0 + pq * 4),
-                               *reinterpret_cast<const unsigned long long*>(&hs[1][pb][pq * 4]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        // publish h (shifted by one step) and dropout(h) with 8-byte write-through stores
+        if (threadIdx.x < 64) {
+          const int pb = threadIdx.x >> 2, pq = threadIdx.x & 3;
+          if (b0 + pb < B) {
+            const long long prow = (long long)(b0 + pb) * L + t;
+            if (t + 1 < L)
+              __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.hp16[l]) + (prow + 1) * H + u0 + pq * 4),
+                                 *reinterpret_cast<const unsigned long long*>(&hs[0][pb][pq * 4]), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0)
+              *reinterpret_cast<unsigned long long*>(reinterpret_cast<__bf16*>(p.hp16[l]) + prow * H + u0 + pq * 4) = 0ull;
+            if (l < top)
+              __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.yd16[l]) + prow * H + u0 + pq * 4),
+                                 *reinterpret_cast<const unsigned long long*>(&hs[1][pb][pq * 4]), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
@@ -521,6 +531,10 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
 
 // backward.  grid: (H/16, nl); block 1024 = 16 waves, each holding its 1/16 of the reduction of the
 // workgroup's 16 rows of W_hh^T (top layer, K = 4H) or [W_ih_{l+1}^T | W_hh_l^T] (K = 8H).
+// NB batch blocks per stage as in the forward kernel.  With one block the cell-update inputs of the
+// next stage are fetched before the grid barrier; with several they are loaded per block (the
+// register budget at 4 waves per SIMD is 128, 64 of them hold weights).
+template <int NB>
 __global__ __launch_bounds__(1024) void lstm_stack_bwd_persistent_kernel(const nsp_lstm_stack_params p,
                                                                          unsigned int* sync) {
   __shared__ float part[16][16][17];
@@ -546,84 +560,95 @@ __global__ __launch_bounds__(1024) void lstm_stack_bwd_persistent_kernel(const n
     for (int f = 0; f < 16; ++f)
       if (f < nf) bfrag[f] = *reinterpret_cast<const bf16x8*>(W + f * 32);
   }
-  const bool a_valid = r < B;
-  const long long arow0 = (long long)min(r, B - 1) * L;
   const bool a_ext = has_ext && kbeg < K4;
   const __bf16* abase0 = a_ext ? reinterpret_cast<const __bf16*>(p.dg16[l + 1]) + kbeg
                                : reinterpret_cast<const __bf16*>(p.dg16[l]) + (has_ext ? kbeg - K4 : kbeg);
   const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
   const int u = u0 + uu;
-  const bool upd = threadIdx.x < 256 && bb < B;
-  float dc_reg = 0.f;
+  float dc_reg[NB];
+#pragma unroll
+  for (int bk = 0; bk < NB; ++bk) dc_reg[bk] = 0.f;
   const int nstage = L + p.nl - 1;
   bool alive = true;
-  // the cell-update inputs of the NEXT stage (saved by the forward pass: plain data) are fetched
-  // before the grid barrier, so their latency hides behind it
   float n_dy = 0.f, n_ig = 0.f, n_fg = 0.f, n_gg = 0.f, n_og = 0.f, n_cp = 0.f, n_c = 0.f;
-  auto fetch = [&](int tn) {
-    if (!upd || tn < 0) return;
-    const long long rown = (long long)bb * L + tn;
+  auto fetch = [&](int bk, int tn) {
+    if (!(threadIdx.x < 256 && bk * 16 + bb < B) || tn < 0) return;
+    const long long rown = (long long)(bk * 16 + bb) * L + tn;
     const float* gs = p.gates[l] + rown * K4;
     if (!has_ext) n_dy = p.dy_top[rown * H + u];
     n_ig = gs[u]; n_fg = gs[H + u]; n_gg = gs[2 * H + u]; n_og = gs[3 * H + u];
     n_cp = tn > 0 ? p.c_all[l][(rown - 1) * H + u] : 0.f;
+    if (NB > 1) n_c = p.c_all[l][rown * H + u];
   };
-  if (upd) n_c = p.c_all[l][((long long)bb * L + L - 1) * H + u];
-  fetch(L - 1);
+  if (NB == 1) {
+    if (threadIdx.x < 256 && bb < B) n_c = p.c_all[l][((long long)bb * L + L - 1) * H + u];
+    fetch(0, L - 1);
+  }
   for (int s = 0; s < nstage; ++s) {
     const int t = L - 1 - (s - (top - l));
     if (t >= 0 && t < L) {
-      const long long row = (long long)bb * L + t;
-      const float dyv = n_dy, ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, cp = n_cp, c = n_c;
-      float keep = 1.f;
-      if (upd && has_ext && p.dropout_p > 0.f)
-        keep = nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
-      n_c = cp;          // c_{t-1} is this step's c_prev
-      fetch(t - 1);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (a_ext || t + 1 < L) {
-        const __bf16* ap = abase0 + (arow0 + t + (a_ext ? 0 : 1)) * K4 + g * 8;
-        // four rounds of 4 fragments: 4 waves per SIMD leave 128 VGPRs per wave, 64 hold weights
 #pragma unroll
-        for (int h2 = 0; h2 < 4; ++h2) {
-          bf16x8 af[4];
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            bf16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-            af[f] = (h2 * 4 + f < nf && a_valid) ? *reinterpret_cast<const bf16x8*>(ap + (h2 * 4 + f) * 32) : z;
-          }
-#pragma unroll
-          for (int f = 0; f < 4; ++f)
-            if (h2 * 4 + f < nf) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfrag[h2 * 4 + f], acc, 0, 0, 0);
+      for (int bk = 0; bk < NB; ++bk) {
+        const int b0 = bk * 16;
+        const bool upd = threadIdx.x < 256 && b0 + bb < B;
+        const bool a_valid = b0 + r < B;
+        const long long arow0 = (long long)min(b0 + r, B - 1) * L;
+        const long long row = (long long)(b0 + bb) * L + t;
+        if (NB > 1) fetch(bk, t);
+        const float dyv = n_dy, ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, cp = n_cp, c = n_c;
+        float keep = 1.f;
+        if (upd && has_ext && p.dropout_p > 0.f)
+          keep = nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
+        if (NB == 1) {
+          n_c = cp;          // c_{t-1} is this step's c_prev
+          fetch(0, t - 1);
         }
-      }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (a_ext || t + 1 < L) {
+          const __bf16* ap = abase0 + (arow0 + t + (a_ext ? 0 : 1)) * K4 + g * 8;
+          // four rounds of 4 fragments: 4 waves per SIMD leave 128 VGPRs per wave, 64 hold weights
 #pragma unroll
-      for (int e = 0; e < 4; ++e) part[w][g * 4 + e][r] = acc[e];
-      __syncthreads();
-      if (upd) {
-        float ext = 0.f, rec = 0.f;
+          for (int h2 = 0; h2 < 4; ++h2) {
+            bf16x8 af[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ext += part[q][bb][uu];
+            for (int f = 0; f < 4; ++f) {
+              bf16x8 z;
 #pragma unroll
-        for (int q = 8; q < 16; ++q) rec += part[q][bb][uu];
-        const float dh = has_ext ? keep * ext + rec : dyv + ext + rec;
-        const float tc = nsp_tanh(c);
-        const float dct = dc_reg + dh * og * (1.f - tc * tc);
-        dss[3][bb][uu] = (__bf16)(dh * tc * og * (1.f - og));
-        dss[0][bb][uu] = (__bf16)(dct * gg * ig * (1.f - ig));
-        dss[1][bb][uu] = (__bf16)(dct * cp * fg * (1.f - fg));
-        dss[2][bb][uu] = (__bf16)(dct * ig * (1.f - gg * gg));
-        dc_reg = dct * fg;
-      }
-      __syncthreads();
-      if (threadIdx.x < 256) {   // (gate q, batch pb, 4-unit group pq): one 8-byte write-through store
-        const int q = threadIdx.x >> 6, pb = (threadIdx.x >> 2) & 15, pq = threadIdx.x & 3;
-        if (pb < B)
-          __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.dg16[l]) + ((long long)pb * L + t) * K4 + q * H + u0 + pq * 4),
-                             *reinterpret_cast<const unsigned long long*>(&dss[q][pb][pq * 4]), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+              for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+              af[f] = (h2 * 4 + f < nf && a_valid) ? *reinterpret_cast<const bf16x8*>(ap + (h2 * 4 + f) * 32) : z;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+              if (h2 * 4 + f < nf) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfrag[h2 * 4 + f], acc, 0, 0, 0);
+          }
+        }
+        if (bk > 0) __syncthreads();   // the previous block's readers of part / dss are done
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[w][g * 4 + e][r] = acc[e];
+        __syncthreads();
+        if (upd) {
+          float ext = 0.f, rec = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) ext += part[q][bb][uu];
+#pragma unroll
+          for (int q = 8; q < 16; ++q) rec += part[q][bb][uu];
+          const float dh = has_ext ? keep * ext + rec : dyv + ext + rec;
+          const float tc = nsp_tanh(c);
+          const float dct = dc_reg[bk] + dh * og * (1.f - tc * tc);
+          dss[3][bb][uu] = (__bf16)(dh * tc * og * (1.f - og));
+          dss[0][bb][uu] = (__bf16)(dct * gg * ig * (1.f - ig));
+          dss[1][bb][uu] = (__bf16)(dct * cp * fg * (1.f - fg));
+          dss[2][bb][uu] = (__bf16)(dct * ig * (1.f - gg * gg));
+          dc_reg[bk] = dct * fg;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {   // (gate q, batch pb, 4-unit group pq): one 8-byte write-through store
+          const int q = threadIdx.x >> 6, pb = (threadIdx.x >> 2) & 15, pq = threadIdx.x & 3;
+          if (b0 + pb < B)
+            __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.dg16[l]) + ((long long)(b0 + pb) * L + t) * K4 + q * H + u0 + pq * 4),
+                               *reinterpret_cast<const unsigned long long*>(&dss[q][pb][pq * 4]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     if (s + 1 < nstage) {
@@ -706,7 +731,7 @@ extern "C" int nsp_lstm_stack_bwd(const nsp_lstm_stack_params* p, void* stream) 
 static int lstm_persistent_check(const nsp_lstm_stack_params* p) {
   int rc = lstm_stack_check(p);
   if (rc != NSP_OK) return rc;
-  if (p->B > 16 || p->H % 256 || p->H > 1024 || p->nl * (p->H / 16) > 256) return NSP_EUNSUPPORTED;
+  if (p->B > 64 || p->H % 256 || p->H > 1024 || p->nl * (p->H / 16) > 256) return NSP_EUNSUPPORTED;
   return NSP_OK;
 }
 
@@ -715,7 +740,13 @@ extern "C" int nsp_lstm_stack_fwd_persistent(const nsp_lstm_stack_params* p, uns
   if (rc != NSP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(sync, 0, 2 * sizeof(unsigned int), st);
-  hipLaunchKernelGGL(lstm_stack_fwd_persistent_kernel, dim3(p->H / 16, p->nl), dim3(512), 0, st, *p, sync);
+  const dim3 grid(p->H / 16, p->nl);
+  switch (nsp_cdiv(p->B, 16)) {
+    case 1: hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<1>), grid, dim3(512), 0, st, *p, sync); break;
+    case 2: hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<2>), grid, dim3(512), 0, st, *p, sync); break;
+    case 3: hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<3>), grid, dim3(512), 0, st, *p, sync); break;
+    default: hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<4>), grid, dim3(512), 0, st, *p, sync); break;
+  }
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
@@ -725,7 +756,13 @@ extern "C" int nsp_lstm_stack_bwd_persistent(const nsp_lstm_stack_params* p, uns
   if (rc != NSP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(sync, 0, 2 * sizeof(unsigned int), st);
-  hipLaunchKernelGGL(lstm_stack_bwd_persistent_kernel, dim3(p->H / 16, p->nl), dim3(1024), 0, st, *p, sync);
+  const dim3 grid(p->H / 16, p->nl);
+  switch (nsp_cdiv(p->B, 16)) {
+    case 1: hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<1>), grid, dim3(1024), 0, st, *p, sync); break;
+    case 2: hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<2>), grid, dim3(1024), 0, st, *p, sync); break;
+    case 3: hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<3>), grid, dim3(1024), 0, st, *p, sync); break;
+    default: hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<4>), grid, dim3(1024), 0, st, *p, sync); break;
+  }
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -1256,10 +1256,10 @@ def _cat_cached(owner, name, parts, build):
 
 
 def _lstm_stack_launch(which, P, dev):
-    """Persistent single-launch recurrence when the shape qualifies (B <= 16, H % 256 == 0,
+    """Persistent single-launch recurrence when the shape qualifies (B <= 64, H % 256 == 0,
     H <= 1024; NSP_LSTM_PERSISTENT=0 disables), else one launch per wavefront stage."""
     lib = _lib.lib()
-    if os.environ.get('NSP_LSTM_PERSISTENT', '1') != '0' and P.B <= 16 and P.H % 256 == 0 and P.H <= 1024 \
+    if os.environ.get('NSP_LSTM_PERSISTENT', '1') != '0' and P.B <= 64 and P.H % 256 == 0 and P.H <= 1024 \
             and P.nl * (P.H // 16) <= 256:
         sync = torch.empty((2,), device=dev, dtype=torch.int32)   # zeroed by the call itself
         fn = lib.nsp_lstm_stack_fwd_persistent if which == 'fwd' else lib.nsp_lstm_stack_bwd_persistent
