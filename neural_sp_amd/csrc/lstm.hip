@@ -376,14 +376,19 @@ __device__ __forceinline__ bool grid_wait(unsigned int* sync, unsigned int targe
 // forward.  grid: (H/16, nl); block 512.  Workgroup (ub, l) owns hidden units 16*ub.. of layer l:
 // wave w holds, for each of the 4 gates, the 16 W rows of those units restricted to its 1/8 of the
 // reduction (layer 0: K = H; layers >= 1: K = 2H over [W_ih | W_hh]) as MFMA B-fragments.
-// NB = ceil(B/16) batch blocks are processed one after the other inside a stage (same register-
-// resident weights, one grid barrier per stage whatever the batch).
+// NB = ceil(B/16) batch blocks share a stage: all their partial products go to LDS first (their
+// operand loads are independent, so the latencies overlap), ONE workgroup barrier, then the two
+// halves of the workgroup run the cell updates of alternating blocks, one barrier, publish.
 template <int NB>
 __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const nsp_lstm_stack_params p,
                                                                         unsigned int* sync) {
-  __shared__ float part[8][4][16][17];
-  __shared__ __attribute__((aligned(16))) __bf16 hs[2][16][16];
+  extern __shared__ __attribute__((aligned(16))) float fdyn[];
+  typedef float part_t[8][4][16][17];
+  part_t* part = reinterpret_cast<part_t*>(fdyn);                                   // [NB]
+  typedef __bf16 hs_t[2][16][16];
+  hs_t* hs = reinterpret_cast<hs_t*>(fdyn + NB * (8 * 4 * 16 * 17));                // [NB]
   __shared__ int dead_sh;
+  constexpr int NU = (NB + 1) / 2;   // blocks per cell-update thread (thread group tg: blocks tg, tg+2)
   const int l = blockIdx.y;
   const int H = p.H, L = p.L, B = p.B, top = p.nl - 1;
   const int nwg = gridDim.x * gridDim.y;
@@ -413,19 +418,20 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
     abase0 = reinterpret_cast<const __bf16*>(p.yd16[l - 1]) + kbeg;
     a_rec = false;
   }
-  // cell-update thread (b within block, unit): threads 0..255
-  const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
+  // cell-update thread (block group tg, b within block, unit)
+  const int tg = threadIdx.x >> 8, bb = (threadIdx.x >> 4) & 15, uu = threadIdx.x & 15;
   const int u = u0 + uu;
-  float c_reg[NB];
-  float gin[NB][4];
+  float c_reg[NU];
+  float gin[NU][4];
 #pragma unroll
-  for (int bk = 0; bk < NB; ++bk) {
-    c_reg[bk] = 0.f;
-    const bool upd = threadIdx.x < 256 && bk * 16 + bb < B;
+  for (int i = 0; i < NU; ++i) {
+    c_reg[i] = 0.f;
+    const int bk = tg + 2 * i;
+    const bool upd = bk < NB && bk * 16 + bb < B;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      gin[bk][q] = 0.f;
-      if (upd) gin[bk][q] = l > 0 ? p.bias[l][q * H + u] : p.gi0[((long long)(bk * 16 + bb) * L) * 4 * H + q * H + u];
+      gin[i][q] = 0.f;
+      if (upd) gin[i][q] = l > 0 ? p.bias[l][q * H + u] : p.gi0[((long long)(bk * 16 + bb) * L) * 4 * H + q * H + u];
     }
   }
   const int nstage = L + p.nl - 1;
@@ -438,7 +444,6 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
         const int b0 = bk * 16;
         const bool a_valid = b0 + r < B;
         const long long arow0 = (long long)min(b0 + r, B - 1) * L;
-        const bool upd = threadIdx.x < 256 && b0 + bb < B;
         f32x4 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -460,64 +465,67 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfrag[j][f], acc[j], 0, 0, 0);
             }
         }
-        if (bk > 0) __syncthreads();   // the previous block's readers of part / hs are done
         // D[i = batch][j = unit]: lane holds unit r, batches 4g..4g+3
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) part[w][j][g * 4 + e][r] = acc[j][e];
-        __syncthreads();
-        const long long row = (long long)(b0 + bb) * L + t;
-        if (upd) {
+          for (int e = 0; e < 4; ++e) part[bk][w][j][g * 4 + e][r] = acc[j][e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int bk = tg + 2 * i;
+        if (bk < NB && bk * 16 + bb < B) {
+          const long long row = (long long)(bk * 16 + bb) * L + t;
           float pre[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float v = gin[bk][q];
+            float v = gin[i][q];
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) v += part[ww][q][bb][uu];
+            for (int ww = 0; ww < 8; ++ww) v += part[bk][ww][q][bb][uu];
             pre[q] = v;
           }
           const float ig = nsp_sigmoid(pre[0]);
           const float fg = nsp_sigmoid(pre[1]);
           const float gg = nsp_tanh(pre[2]);
           const float og = nsp_sigmoid(pre[3]);
-          c_reg[bk] = fg * c_reg[bk] + ig * gg;
-          const float h = og * nsp_tanh(c_reg[bk]);
-          p.c_all[l][row * H + u] = c_reg[bk];
+          c_reg[i] = fg * c_reg[i] + ig * gg;
+          const float h = og * nsp_tanh(c_reg[i]);
+          p.c_all[l][row * H + u] = c_reg[i];
           float* gs = p.gates[l] + row * 4 * H;
           gs[u] = ig; gs[H + u] = fg; gs[2 * H + u] = gg; gs[3 * H + u] = og;
-          hs[0][bb][uu] = (__bf16)h;
+          hs[bk][0][bb][uu] = (__bf16)h;
           if (l == top) {
             p.y_top[row * H + u] = h;
           } else {
             float hd = h;
             if (p.dropout_p > 0.f)
               hd *= nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
-            hs[1][bb][uu] = (__bf16)hd;
+            hs[bk][1][bb][uu] = (__bf16)hd;
           }
           if (l == 0 && t + 1 < L) {   // next step's input projection (plain data from an earlier kernel)
             const float* gnext = p.gi0 + (row + 1) * 4 * H;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gin[bk][q] = gnext[q * H + u];
+            for (int q = 0; q < 4; ++q) gin[i][q] = gnext[q * H + u];
           }
         }
-        __syncthreads();
-        // publish h (shifted by one step) and dropout(h) with 8-byte write-through stores
-        if (threadIdx.x < 64) {
-          const int pb = threadIdx.x >> 2, pq = threadIdx.x & 3;
-          if (b0 + pb < B) {
-            const long long prow = (long long)(b0 + pb) * L + t;
-            if (t + 1 < L)
-              __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.hp16[l]) + (prow + 1) * H + u0 + pq * 4),
-                                 *reinterpret_cast<const unsigned long long*>(&hs[0][pb][pq * 4]), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-            if (t == 0)
-              *reinterpret_cast<unsigned long long*>(reinterpret_cast<__bf16*>(p.hp16[l]) + prow * H + u0 + pq * 4) = 0ull;
-            if (l < top)
-              __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.yd16[l]) + prow * H + u0 + pq * 4),
-                                 *reinterpret_cast<const unsigned long long*>(&hs[1][pb][pq * 4]), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-          }
+      }
+      __syncthreads();
+      // publish h (shifted by one step) and dropout(h) with 8-byte write-through stores
+      if (threadIdx.x < 64 * NB) {
+        const int bk = threadIdx.x >> 6, pb = (threadIdx.x >> 2) & 15, pq = threadIdx.x & 3;
+        if (bk * 16 + pb < B) {
+          const long long prow = (long long)(bk * 16 + pb) * L + t;
+          if (t + 1 < L)
+            __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.hp16[l]) + (prow + 1) * H + u0 + pq * 4),
+                               *reinterpret_cast<const unsigned long long*>(&hs[bk][0][pb][pq * 4]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          if (t == 0)
+            *reinterpret_cast<unsigned long long*>(reinterpret_cast<__bf16*>(p.hp16[l]) + prow * H + u0 + pq * 4) = 0ull;
+          if (l < top)
+            __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.yd16[l]) + prow * H + u0 + pq * 4),
+                               *reinterpret_cast<const unsigned long long*>(&hs[bk][1][pb][pq * 4]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
@@ -531,14 +539,17 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
 
 // backward.  grid: (H/16, nl); block 1024 = 16 waves, each holding its 1/16 of the reduction of the
 // workgroup's 16 rows of W_hh^T (top layer, K = 4H) or [W_ih_{l+1}^T | W_hh_l^T] (K = 8H).
-// NB batch blocks per stage as in the forward kernel.  With one block the cell-update inputs of the
-// next stage are fetched before the grid barrier; with several they are loaded per block (the
-// register budget at 4 waves per SIMD is 128, 64 of them hold weights).
+// NB <= 4 batch blocks per stage: the dot products of all blocks go to LDS, then thread group
+// tg = tid/256 runs the cell update of block tg (so every update thread owns ONE (block, b, unit)
+// for the whole sequence: dc and the prefetched inputs of the next stage stay in registers).
 template <int NB>
 __global__ __launch_bounds__(1024) void lstm_stack_bwd_persistent_kernel(const nsp_lstm_stack_params p,
                                                                          unsigned int* sync) {
-  __shared__ float part[16][16][17];
-  __shared__ __attribute__((aligned(16))) __bf16 dss[4][16][16];
+  extern __shared__ __attribute__((aligned(16))) float bdyn[];
+  typedef float part_t[16][16][17];
+  part_t* part = reinterpret_cast<part_t*>(bdyn);                                  // [NB]
+  typedef __bf16 dss_t[4][16][16];
+  dss_t* dss = reinterpret_cast<dss_t*>(bdyn + NB * (16 * 16 * 17));               // [NB]
   __shared__ int dead_sh;
   const int top = p.nl - 1;
   const int l = blockIdx.y;
@@ -563,46 +574,40 @@ __global__ __launch_bounds__(1024) void lstm_stack_bwd_persistent_kernel(const n
   const bool a_ext = has_ext && kbeg < K4;
   const __bf16* abase0 = a_ext ? reinterpret_cast<const __bf16*>(p.dg16[l + 1]) + kbeg
                                : reinterpret_cast<const __bf16*>(p.dg16[l]) + (has_ext ? kbeg - K4 : kbeg);
-  const int bb = threadIdx.x >> 4, uu = threadIdx.x & 15;
+  const int tg = threadIdx.x >> 8, bb = (threadIdx.x >> 4) & 15, uu = threadIdx.x & 15;
   const int u = u0 + uu;
-  float dc_reg[NB];
-#pragma unroll
-  for (int bk = 0; bk < NB; ++bk) dc_reg[bk] = 0.f;
+  const bool upd = tg < NB && tg * 16 + bb < B;
+  const long long brow = (long long)(tg * 16 + bb) * L;
+  float dc_reg = 0.f;
   const int nstage = L + p.nl - 1;
   bool alive = true;
+  // the cell-update inputs of the NEXT stage (saved by the forward pass: plain data) are fetched
+  // before the grid barrier, so their latency hides behind it
   float n_dy = 0.f, n_ig = 0.f, n_fg = 0.f, n_gg = 0.f, n_og = 0.f, n_cp = 0.f, n_c = 0.f;
-  auto fetch = [&](int bk, int tn) {
-    if (!(threadIdx.x < 256 && bk * 16 + bb < B) || tn < 0) return;
-    const long long rown = (long long)(bk * 16 + bb) * L + tn;
+  auto fetch = [&](int tn) {
+    if (!upd || tn < 0) return;
+    const long long rown = brow + tn;
     const float* gs = p.gates[l] + rown * K4;
     if (!has_ext) n_dy = p.dy_top[rown * H + u];
     n_ig = gs[u]; n_fg = gs[H + u]; n_gg = gs[2 * H + u]; n_og = gs[3 * H + u];
     n_cp = tn > 0 ? p.c_all[l][(rown - 1) * H + u] : 0.f;
-    if (NB > 1) n_c = p.c_all[l][rown * H + u];
   };
-  if (NB == 1) {
-    if (threadIdx.x < 256 && bb < B) n_c = p.c_all[l][((long long)bb * L + L - 1) * H + u];
-    fetch(0, L - 1);
-  }
+  if (upd) n_c = p.c_all[l][(brow + L - 1) * H + u];
+  fetch(L - 1);
   for (int s = 0; s < nstage; ++s) {
     const int t = L - 1 - (s - (top - l));
     if (t >= 0 && t < L) {
+      const long long row = brow + t;
+      const float dyv = n_dy, ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, cp = n_cp, c = n_c;
+      float keep = 1.f;
+      if (upd && has_ext && p.dropout_p > 0.f)
+        keep = nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
+      n_c = cp;          // c_{t-1} is this step's c_prev
+      fetch(t - 1);
 #pragma unroll
       for (int bk = 0; bk < NB; ++bk) {
-        const int b0 = bk * 16;
-        const bool upd = threadIdx.x < 256 && b0 + bb < B;
-        const bool a_valid = b0 + r < B;
-        const long long arow0 = (long long)min(b0 + r, B - 1) * L;
-        const long long row = (long long)(b0 + bb) * L + t;
-        if (NB > 1) fetch(bk, t);
-        const float dyv = n_dy, ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, cp = n_cp, c = n_c;
-        float keep = 1.f;
-        if (upd && has_ext && p.dropout_p > 0.f)
-          keep = nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
-        if (NB == 1) {
-          n_c = cp;          // c_{t-1} is this step's c_prev
-          fetch(0, t - 1);
-        }
+        const bool a_valid = bk * 16 + r < B;
+        const long long arow0 = (long long)min(bk * 16 + r, B - 1) * L;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (a_ext || t + 1 < L) {
           const __bf16* ap = abase0 + (arow0 + t + (a_ext ? 0 : 1)) * K4 + g * 8;
@@ -622,33 +627,32 @@ __global__ __launch_bounds__(1024) void lstm_stack_bwd_persistent_kernel(const n
               if (h2 * 4 + f < nf) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfrag[h2 * 4 + f], acc, 0, 0, 0);
           }
         }
-        if (bk > 0) __syncthreads();   // the previous block's readers of part / dss are done
 #pragma unroll
-        for (int e = 0; e < 4; ++e) part[w][g * 4 + e][r] = acc[e];
-        __syncthreads();
-        if (upd) {
-          float ext = 0.f, rec = 0.f;
+        for (int e = 0; e < 4; ++e) part[bk][w][g * 4 + e][r] = acc[e];
+      }
+      __syncthreads();
+      if (upd) {
+        float ext = 0.f, rec = 0.f;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) ext += part[q][bb][uu];
+        for (int q = 0; q < 8; ++q) ext += part[tg][q][bb][uu];
 #pragma unroll
-          for (int q = 8; q < 16; ++q) rec += part[q][bb][uu];
-          const float dh = has_ext ? keep * ext + rec : dyv + ext + rec;
-          const float tc = nsp_tanh(c);
-          const float dct = dc_reg[bk] + dh * og * (1.f - tc * tc);
-          dss[3][bb][uu] = (__bf16)(dh * tc * og * (1.f - og));
-          dss[0][bb][uu] = (__bf16)(dct * gg * ig * (1.f - ig));
-          dss[1][bb][uu] = (__bf16)(dct * cp * fg * (1.f - fg));
-          dss[2][bb][uu] = (__bf16)(dct * ig * (1.f - gg * gg));
-          dc_reg[bk] = dct * fg;
-        }
-        __syncthreads();
-        if (threadIdx.x < 256) {   // (gate q, batch pb, 4-unit group pq): one 8-byte write-through store
-          const int q = threadIdx.x >> 6, pb = (threadIdx.x >> 2) & 15, pq = threadIdx.x & 3;
-          if (b0 + pb < B)
-            __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.dg16[l]) + ((long long)(b0 + pb) * L + t) * K4 + q * H + u0 + pq * 4),
-                               *reinterpret_cast<const unsigned long long*>(&dss[q][pb][pq * 4]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (int q = 8; q < 16; ++q) rec += part[tg][q][bb][uu];
+        const float dh = has_ext ? keep * ext + rec : dyv + ext + rec;
+        const float tc = nsp_tanh(c);
+        const float dct = dc_reg + dh * og * (1.f - tc * tc);
+        dss[tg][3][bb][uu] = (__bf16)(dh * tc * og * (1.f - og));
+        dss[tg][0][bb][uu] = (__bf16)(dct * gg * ig * (1.f - ig));
+        dss[tg][1][bb][uu] = (__bf16)(dct * cp * fg * (1.f - fg));
+        dss[tg][2][bb][uu] = (__bf16)(dct * ig * (1.f - gg * gg));
+        dc_reg = dct * fg;
+      }
+      __syncthreads();
+      {   // (block tg, gate q, batch pb, 4-unit group pq): one 8-byte write-through store
+        const int q = (threadIdx.x >> 6) & 3, pb = (threadIdx.x >> 2) & 15, pq = threadIdx.x & 3;
+        if (tg < NB && tg * 16 + pb < B)
+          __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.dg16[l]) + ((long long)(tg * 16 + pb) * L + t) * K4 + q * H + u0 + pq * 4),
+                             *reinterpret_cast<const unsigned long long*>(&dss[tg][q][pb][pq * 4]), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (s + 1 < nstage) {
@@ -741,12 +745,21 @@ extern "C" int nsp_lstm_stack_fwd_persistent(const nsp_lstm_stack_params* p, uns
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(sync, 0, 2 * sizeof(unsigned int), st);
   const dim3 grid(p->H / 16, p->nl);
-  switch (nsp_cdiv(p->B, 16)) {
-    case 1: hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<1>), grid, dim3(512), 0, st, *p, sync); break;
-    case 2: hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<2>), grid, dim3(512), 0, st, *p, sync); break;
-    case 3: hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<3>), grid, dim3(512), 0, st, *p, sync); break;
-    default: hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<4>), grid, dim3(512), 0, st, *p, sync); break;
+  const int nb = nsp_cdiv(p->B, 16);
+  const size_t shmem = (size_t)nb * (sizeof(float) * 8 * 4 * 16 * 17 + 2 * 16 * 16 * 2);
+#define LSTM_FWD_P(N)                                                                                         \
+  do {                                                                                                        \
+    (void)hipFuncSetAttribute((const void*)lstm_stack_fwd_persistent_kernel<N>,                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                        \
+    hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<N>), grid, dim3(512), shmem, st, *p, sync);          \
+  } while (0)
+  switch (nb) {
+    case 1: LSTM_FWD_P(1); break;
+    case 2: LSTM_FWD_P(2); break;
+    case 3: LSTM_FWD_P(3); break;
+    default: LSTM_FWD_P(4); break;
   }
+#undef LSTM_FWD_P
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
@@ -757,12 +770,21 @@ extern "C" int nsp_lstm_stack_bwd_persistent(const nsp_lstm_stack_params* p, uns
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(sync, 0, 2 * sizeof(unsigned int), st);
   const dim3 grid(p->H / 16, p->nl);
-  switch (nsp_cdiv(p->B, 16)) {
-    case 1: hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<1>), grid, dim3(1024), 0, st, *p, sync); break;
-    case 2: hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<2>), grid, dim3(1024), 0, st, *p, sync); break;
-    case 3: hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<3>), grid, dim3(1024), 0, st, *p, sync); break;
-    default: hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<4>), grid, dim3(1024), 0, st, *p, sync); break;
+  const int nb = nsp_cdiv(p->B, 16);
+  const size_t shmem = (size_t)nb * (sizeof(float) * 16 * 16 * 17 + 4 * 16 * 16 * 2);
+#define LSTM_BWD_P(N)                                                                                         \
+  do {                                                                                                        \
+    (void)hipFuncSetAttribute((const void*)lstm_stack_bwd_persistent_kernel<N>,                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                        \
+    hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<N>), grid, dim3(1024), shmem, st, *p, sync);         \
+  } while (0)
+  switch (nb) {
+    case 1: LSTM_BWD_P(1); break;
+    case 2: LSTM_BWD_P(2); break;
+    case 3: LSTM_BWD_P(3); break;
+    default: LSTM_BWD_P(4); break;
   }
+#undef LSTM_BWD_P
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

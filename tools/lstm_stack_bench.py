@@ -6,7 +6,7 @@ import torch
 from neural_sp_amd import ops
 ops.set_compute_mode('bf16')
 dev = torch.device('cuda:0')
-B, L, I, H, nl = 16, 200, 1024, 1024, 2
+B, L, I, H, nl = int(os.environ.get("LB", "16")), 200, 1024, 1024, 2
 refs = [torch.nn.LSTM(I if l == 0 else H, H, 1, batch_first=True).to(dev) for l in range(nl)]
 layers = [(r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0) for r in refs]
 x = torch.randn(B, L, I, device=dev, requires_grad=True)
