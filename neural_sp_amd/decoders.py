@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from neural_sp_amd import ops
-from neural_sp_amd.torch_utils import np2tensor, pad_list, tensor2scalar, repeat
+from neural_sp_amd.torch_utils import repeat
 
 logger = logging.getLogger(__name__)
 

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from neural_sp_amd import _lib
-from neural_sp_amd._lib import GemmParams, AttnMaskParams
+from neural_sp_amd._lib import AttnMaskParams
 
 ACT = {'none': 0, None: 0, '': 0, 'relu': 1, 'swish': 2, 'tanh': 3, 'gelu_accurate': 4, 'gelu': 5}
 # NOTE: reference modules/gelu.py: gelu() is the tanh approximation, gelu_accurate() the erf form.

@@ -1,7 +1,6 @@
 """Host glue mirrored from the reference (neural_sp/models/torch_utils.py:15-94).
 
 These are list/array <-> tensor conversions on the host; no model arithmetic."""
-import numpy as np
 import torch
 
 
