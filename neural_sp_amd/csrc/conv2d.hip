@@ -66,29 +66,68 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
     }
   }
   const long long ntiles = (long long)B * tiles_t * tiles_f;
+  // bf16 mode: the halo of the NEXT tile is fetched into registers before the MFMAs of the current
+  // one and written to the other LDS buffer after its epilogue: one barrier per tile and the
+  // global-load latency hides behind the tile's compute + stores (the single-buffered version
+  // ran load -> barrier -> 36 MFMAs -> store -> barrier: 2.6 TB/s, neither HBM- nor MFMA-bound)
+  constexpr int NST = (HT * HF * 8 + 255) / 256;   // float4 per thread per halo tile
+  float4 pre[NST];
+  auto halo_fetch = [&](long long tl) {
+    const int tf = (int)(tl % tiles_f);
+    const int tt = (int)((tl / tiles_f) % tiles_t);
+    const long long b = tl / ((long long)tiles_f * tiles_t);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = tid + i * 256;
+      const int c4 = idx & 7, pix = idx >> 3;
+      const int ht = pix / HF, hf = pix % HF;
+      const int t = tt * TT + ht - 1, f = tf * TF + hf - 1;
+      pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < HT * HF * 8 && t >= 0 && t < T && f >= 0 && f < F)
+        pre[i] = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
+    }
+  };
+  auto halo_commit = [&](unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < HT * HF * 8) {
+        const int c4 = idx & 7, pix = idx >> 3;
+        bf16x4 h;
+        h[0] = (__bf16)pre[i].x; h[1] = (__bf16)pre[i].y; h[2] = (__bf16)pre[i].z; h[3] = (__bf16)pre[i].w;
+        *reinterpret_cast<bf16x4*>(dst + pix * PP + c4 * 8) = h;
+      }
+    }
+  };
+  int cur = 0;
+  if (MODE == 0 && (long long)blockIdx.x < ntiles) {
+    halo_fetch(blockIdx.x);
+    halo_commit(smem);
+    __syncthreads();
+  }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tf = (int)(tile % tiles_f);
     const int tt = (int)((tile / tiles_f) % tiles_t);
     const long long b = tile / ((long long)tiles_f * tiles_t);
     const int f0 = tf * TF, t0 = tt * TT;
-    __syncthreads();  // previous tile's fragment reads are done
-    // ---- stage the halo tile: HT*HF pixels x 8 float4
-    for (int idx = tid; idx < HT * HF * 8; idx += 256) {
-      const int c4 = idx & 7, pix = idx >> 3;
-      const int ht = pix / HF, hf = pix % HF;
-      const int t = t0 + ht - 1, f = f0 + hf - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t >= 0 && t < T && f >= 0 && f < F)
-        v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
-      if (MODE == 0) {
-        bf16x4 h;
-        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(xs + pix * PP + c4 * 8) = h;
-      } else {
+    const bool has_next = tile + gridDim.x < ntiles;
+    if (MODE == 0) {
+      xs = smem + cur * (HT * HF * PP);
+      if (has_next) halo_fetch(tile + gridDim.x);
+    } else {
+      __syncthreads();  // previous tile's fragment reads are done
+      // ---- stage the halo tile: HT*HF pixels x 8 float4
+      for (int idx = tid; idx < HT * HF * 8; idx += 256) {
+        const int c4 = idx & 7, pix = idx >> 3;
+        const int ht = pix / HF, hf = pix % HF;
+        const int t = t0 + ht - 1, f = f0 + hf - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T && f >= 0 && f < F)
+          v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
         *reinterpret_cast<float4*>(xs + pix * PP + c4 * 16) = v;
       }
+      __syncthreads();
     }
-    __syncthreads();
     f32x4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -153,6 +192,11 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
         }
         *reinterpret_cast<float4*>(y + off) = v;
       }
+    }
+    if (MODE == 0) {
+      if (has_next) halo_commit(smem + (cur ^ 1) * (HT * HF * PP));
+      __syncthreads();  // next buffer complete, every wave done reading the current one
+      cur ^= 1;
     }
   }
 }
@@ -525,7 +569,7 @@ extern "C" int nsp_conv2d3x3_fwd(const float* x, const float* w, const float* bi
     const long long ntiles = (long long)B * tiles_f * tiles_t;
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // 4 persistent workgroups per CU
     if (mode == NSP_COMPUTE_BF16) {
-      const size_t sh = HT * HF * ConvCfg<0>::PIX_PITCH;
+      const size_t sh = 2 * HT * HF * ConvCfg<0>::PIX_PITCH;   // double-buffered halo
       hipLaunchKernelGGL((conv3x3_c32_kernel<0>), dim3(grid), dim3(256), sh, st, x, w, bias, y, B, T, F,
                          relu, mask_src, tiles_f, tiles_t);
     } else {
