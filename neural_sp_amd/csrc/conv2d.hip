@@ -370,9 +370,12 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
     float* __restrict__ dbias, int B, int T, int F, int tiles_f, int tiles_t) {
   constexpr int PP = 80;  // bytes per pixel: 32 bf16 + 16 B pad
-  __shared__ __attribute__((aligned(16))) unsigned char xs[HT * HF * PP];
-  __shared__ __attribute__((aligned(16))) unsigned char ds[TT * TF * PP];
-  __shared__ float red[4][16][68];
+  constexpr int XS_B = HT * HF * PP, DS_B = TT * TF * PP;
+  // two (x halo, dy tile) buffer pairs: the next tile is fetched into registers before the MFMAs
+  // of the current one and committed to the other pair afterwards (one barrier per tile); the
+  // final cross-wave reduction reuses the same memory
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (XS_B + DS_B)];
+  float (*red)[16][68] = reinterpret_cast<float (*)[16][68]>(smem);   // [4][16][68] after the tile loop
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4, a4 = r >> 2, b4 = r & 3;
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -385,33 +388,61 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
       for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread always stages channel quad tid&7
   const long long ntiles = (long long)B * tiles_t * tiles_f;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int tf = (int)(tile % tiles_f);
-    const int tt = (int)((tile / tiles_f) % tiles_t);
-    const long long b = tile / ((long long)tiles_f * tiles_t);
+  constexpr int NX = (HT * HF * 8 + 255) / 256, ND = (TT * TF * 8) / 256;
+  float4 px[NX], pd[ND];
+  auto fetch = [&](long long tl) {
+    const int tf = (int)(tl % tiles_f);
+    const int tt = (int)((tl / tiles_f) % tiles_t);
+    const long long b = tl / ((long long)tiles_f * tiles_t);
     const int f0 = tf * TF, t0 = tt * TT;
-    __syncthreads();
-    for (int idx = tid; idx < HT * HF * 8; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = tid + i * 256;
       const int c4 = idx & 7, pix = idx >> 3;
       const int t = t0 + pix / HF - 1, f = f0 + pix % HF - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t >= 0 && t < T && f >= 0 && f < F)
-        v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
-      bf16x4 h;
-      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-      *reinterpret_cast<bf16x4*>(xs + pix * PP + c4 * 8) = h;
+      px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < HT * HF * 8 && t >= 0 && t < T && f >= 0 && f < F)
+        px[i] = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
     }
-    for (int idx = tid; idx < TT * TF * 8; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int idx = tid + i * 256;
       const int c4 = idx & 7, pix = idx >> 3;
       const int t = t0 + pix / TF, f = f0 + pix % TF;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < T && f < F) v = reinterpret_cast<const float4*>(dy + ((b * T + t) * F + f) * CH)[c4];
-      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-      bf16x4 h;
-      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-      *reinterpret_cast<bf16x4*>(ds + pix * PP + c4 * 8) = h;
+      pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T && f < F) pd[i] = reinterpret_cast<const float4*>(dy + ((b * T + t) * F + f) * CH)[c4];
     }
-    __syncthreads();
+  };
+  auto commit = [&](unsigned char* xs_, unsigned char* ds_) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < HT * HF * 8) {
+        bf16x4 h;
+        h[0] = (__bf16)px[i].x; h[1] = (__bf16)px[i].y; h[2] = (__bf16)px[i].z; h[3] = (__bf16)px[i].w;
+        *reinterpret_cast<bf16x4*>(xs_ + (idx >> 3) * PP + (idx & 7) * 8) = h;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int idx = tid + i * 256;
+      bsum.x += pd[i].x; bsum.y += pd[i].y; bsum.z += pd[i].z; bsum.w += pd[i].w;
+      bf16x4 h;
+      h[0] = (__bf16)pd[i].x; h[1] = (__bf16)pd[i].y; h[2] = (__bf16)pd[i].z; h[3] = (__bf16)pd[i].w;
+      *reinterpret_cast<bf16x4*>(ds_ + (idx >> 3) * PP + (idx & 7) * 8) = h;
+    }
+  };
+  int cur = 0;
+  if ((long long)blockIdx.x < ntiles) {
+    fetch(blockIdx.x);
+    commit(smem, smem + XS_B);
+  }
+  __syncthreads();
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const unsigned char* xs = smem + cur * (XS_B + DS_B);
+    const unsigned char* ds = xs + XS_B;
+    const bool has_next = tile + gridDim.x < ntiles;
+    if (has_next) fetch(tile + gridDim.x);
     // this wave's 32 pixels: tile-local pixel k = 32*wave + 8g + a4 (+4)
     const int kloc = 8 * g + a4;                 // 0..31 within the wave's two tile rows
     const int trow = 2 * wave + (kloc >> 4), fcol = kloc & 15;
@@ -442,6 +473,12 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
           acc[tap][cf][cif] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfrag[cf], xf, acc[tap][cf][cif], 0, 0, 0);
       }
     }
+    if (has_next) {
+      unsigned char* nx = smem + (cur ^ 1) * (XS_B + DS_B);
+      commit(nx, nx + XS_B);
+    }
+    __syncthreads();  // next pair complete, every wave done with the current one
+    cur ^= 1;
   }
   // ---- reduce the 4 waves' fragments and flush: lane holds D[co = cf*16 + 4g + e][ci = cif*16 + r]
   for (int tap = 0; tap < 9; ++tap) {
