@@ -201,36 +201,57 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
   }
 }
 
-// ---- first layer: C_in = 1 -> 32, direct; thread = (pixel, co-quad)
+// ---- first layer: C_in = 1 -> 32, direct.  A workgroup owns `rows_per_block` consecutive (b,t)
+// rows: their input rows (+1 halo row each side, zero halo columns) are staged in LDS once; thread =
+// (4 output channels with their 9x4 filter taps in registers, one of 32 pixel lanes); the only
+// global stream is the 128 B/pixel output, written as float4.  (The first version re-derived
+// (b,t,f) with 64-bit divisions per element and issued 9 predicated global loads: 1.4 TB/s.)
 __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ y, int B, int T, int F,
-                                                         int relu) {
-  __shared__ float wt[9][CH];  // tap-major copy of w[co][tap]
-  for (int i = threadIdx.x; i < 9 * CH; i += blockDim.x) wt[i % 9][i / 9] = w[i];
+                                                         int relu, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float xs1[];  // [(rows_per_block + 2)][F + 2]
+  const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int BT = B * T, FP = F + 2;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int nr = min(BT, r0 + rows_per_block) - r0;
+  for (int idx = threadIdx.x; idx < (nr + 2) * FP; idx += blockDim.x) {
+    const int gr = r0 + idx / FP - 1, fc = idx % FP - 1;
+    xs1[idx] = (gr >= 0 && gr < BT && fc >= 0 && fc < F) ? x[(long long)gr * F + fc] : 0.f;
+  }
+  float wr[9][4];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wr[tap][e] = w[(cg * 4 + e) * 9 + tap];
+  const float4 b4 = bias ? reinterpret_cast<const float4*>(bias)[cg] : make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  const long long total = (long long)B * T * F * 8;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    const int c4 = (int)(idx & 7);
-    const long long pix = idx >> 3;
-    const int f = (int)(pix % F);
-    const int t = (int)((pix / F) % T);
-    const long long b = pix / ((long long)F * T);
-    float4 acc = bias ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int t0 = r0 % T;
+  int lr = pl / F, f = pl % F;
+  float* yb = y + (long long)r0 * F * CH + cg * 4;
+#pragma unroll 2
+  for (int q = pl; q < nr * F; q += 32) {
+    int t = t0 + lr;
+    if (t >= T) t -= T;
+    // a halo row that belongs to the neighbouring utterance (or lies outside) counts as zero
+    const float m_up = t > 0 ? 1.f : 0.f, m_dn = t < T - 1 ? 1.f : 0.f;
+    const float* xc = xs1 + (lr + 1) * FP + (f + 1);
+    float4 acc = b4;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int tt = t + tap / 3 - 1, ff = f + tap % 3 - 1;
-      if (tt < 0 || tt >= T || ff < 0 || ff >= F) continue;
-      const float xv = x[(b * T + tt) * F + ff];
-      const float4 wv = *reinterpret_cast<const float4*>(&wt[tap][c4 * 4]);
-      acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
+      const int dt = tap / 3 - 1, df = tap % 3 - 1;
+      float xv = xc[dt * FP + df];
+      if (dt < 0) xv *= m_up;
+      if (dt > 0) xv *= m_dn;
+      acc.x += xv * wr[tap][0]; acc.y += xv * wr[tap][1]; acc.z += xv * wr[tap][2]; acc.w += xv * wr[tap][3];
     }
     if (relu) {
       acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
-    reinterpret_cast<float4*>(y)[idx] = acc;
+    *reinterpret_cast<float4*>(yb + (long long)q * CH) = acc;
+    f += 32;
+    while (f >= F) { f -= F; ++lr; }
   }
 }
 
@@ -599,8 +620,15 @@ extern "C" int nsp_conv2d3x3_fwd(const float* x, const float* w, const float* bi
   if (Co != CH) return NSP_EUNSUPPORTED;
   if (Ci == 1) {
     if (mask_src) return NSP_EUNSUPPORTED;
-    hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(ew_grid((long long)B * T * F * 8)), dim3(256), 0, st, x,
-                       w, bias, y, B, T, F, relu);
+    const int BT = B * T;
+    int rpb = (BT + 2047) / 2048;                        // ~2048 workgroups ...
+    const int cap = (int)((20 * 1024) / (sizeof(float) * (F + 2))) - 2;  // ... within 20 KB of staged rows
+    if (rpb > cap) rpb = cap;
+    if (rpb > T) rpb = T;
+    if (rpb < 1) return NSP_EUNSUPPORTED;
+    const size_t shmem = sizeof(float) * (size_t)(rpb + 2) * (F + 2);
+    hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(nsp_cdiv(BT, rpb)), dim3(256), shmem, st, x, w, bias, y, B, T,
+                       F, relu, rpb);
   } else if (Ci == CH) {
     const int tiles_f = nsp_cdiv(F, TF), tiles_t = nsp_cdiv(T, TT);
     const long long ntiles = (long long)B * tiles_f * tiles_t;
