@@ -274,7 +274,8 @@ class RNNTransducer(DecoderBase):
             dec_proj.record_stream(cur)
             if torch.is_grad_enabled() and dec_proj.requires_grad \
                     and os.environ.get('NSP_PREDNET_PRIORITY', '1') != '0':
-                dec_proj = ops.replay_graph_first(dec_proj)
+                dec_proj = ops.replay_graph_first(
+                    dec_proj, self._side_stream if os.environ.get('NSP_REPLAY_SIDE', '1') != '0' else None)
         else:
             dec_proj = self._prediction_network(ys, dev)                        # `[B,L+1,J]`
         enc_proj = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias)       # `[B,T,J]`
