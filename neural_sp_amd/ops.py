@@ -1256,14 +1256,39 @@ def _cat_cached(owner, name, parts, build):
 
 
 def _lstm_stack_launch(which, P, dev):
-    """Persistent single-launch recurrence when the shape qualifies (B <= 64, H % 256 == 0,
-    H <= 1024; NSP_LSTM_PERSISTENT=0 disables), else one launch per wavefront stage."""
+    """Persistent single-launch recurrence when the shape qualifies (H % 256 == 0, H <= 1024;
+    NSP_LSTM_PERSISTENT=0 disables), else one launch per wavefront stage.  The persistent kernels
+    take at most 64 utterances (4 batch blocks); a larger batch is cut into slabs of 64 --
+    utterances are independent and [B, L, .] tensors are contiguous per utterance -- launched one
+    after the other (the dropout counters are offset so that the masks do not depend on the cut)."""
     lib = _lib.lib()
-    if os.environ.get('NSP_LSTM_PERSISTENT', '1') != '0' and P.B <= 64 and P.H % 256 == 0 and P.H <= 1024 \
+    if os.environ.get('NSP_LSTM_PERSISTENT', '1') != '0' and P.H % 256 == 0 and P.H <= 1024 \
             and P.nl * (P.H // 16) <= 256:
-        sync = torch.empty((2,), device=dev, dtype=torch.int32)   # zeroed by the call itself
         fn = lib.nsp_lstm_stack_fwd_persistent if which == 'fwd' else lib.nsp_lstm_stack_bwd_persistent
-        _check(fn(ctypes.byref(P), sync.data_ptr(), _stream()), 'nsp_lstm_stack_%s_persistent' % which)
+        B, L, H, nl = P.B, P.L, P.H, P.nl
+        for b0 in range(0, B, 64):
+            Q = P
+            if B > 64:
+                Q = _lib.LstmStackParams()
+                ctypes.memmove(ctypes.byref(Q), ctypes.byref(P), ctypes.sizeof(P))
+                Q.B = min(64, B - b0)
+                rows = b0 * L
+
+                def off(ptr, per_row_bytes):
+                    return ptr + rows * per_row_bytes if ptr else ptr
+                Q.gi0 = off(P.gi0, 4 * H * 4)
+                Q.dy_top = off(P.dy_top, H * 4)
+                Q.y_top = off(P.y_top, H * 4)
+                for l in range(nl):
+                    Q.hp16[l] = off(P.hp16[l], H * 2)
+                    Q.yd16[l] = off(P.yd16[l], H * 2)
+                    Q.c_all[l] = off(P.c_all[l], H * 4)
+                    Q.gates[l] = off(P.gates[l], 4 * H * 4)
+                    Q.dg16[l] = off(P.dg16[l], 4 * H * 2)
+                    Q.dc[l] = (P.dc[l] + b0 * H * 4) if P.dc[l] else P.dc[l]
+                    Q.offset[l] = P.offset[l] + rows * H
+            sync = torch.empty((2,), device=dev, dtype=torch.int32)   # zeroed by the call itself
+            _check(fn(ctypes.byref(Q), sync.data_ptr(), _stream()), 'nsp_lstm_stack_%s_persistent' % which)
         return
     fn = lib.nsp_lstm_stack_fwd if which == 'fwd' else lib.nsp_lstm_stack_bwd
     _check(fn(ctypes.byref(P), _stream()), 'nsp_lstm_stack_' + which)

@@ -67,3 +67,40 @@ def test_unsupported_configurations_fail_loudly():
         Speech2Text(conformer_rnnt_args('XS', n_layers=2, enc_type='blstm'))
     with pytest.raises(NotImplementedError):
         Speech2Text(conformer_rnnt_args('XS', n_layers=2, conformer_normalization='batch_norm'))
+
+
+def test_lazy_observation_behaves_like_the_reference_dict_of_floats():
+    """speech2text.py:262-293 returns python floats; LazyObservation defers their transfer but
+    must read like that dict in every access pattern train.py / Reporter use."""
+    import pickle
+    import torch
+    from neural_sp_amd.speech2text import LazyObservation, Speech2Text
+    vals = torch.tensor([1.5, 2.25])
+    obs = LazyObservation({'loss.ctc': None, 'loss.transducer': None, 'acc.att': None}, ['loss.ctc', 'loss.transducer'], vals)
+    assert obs['loss.ctc'] == 1.5 and isinstance(obs['loss.ctc'], float)
+    assert obs.get('loss.transducer') == 2.25 and obs.get('missing', 7) == 7
+    assert dict(obs.items()) == {'loss.ctc': 1.5, 'loss.transducer': 2.25, 'acc.att': None}
+    assert obs == {'loss.ctc': 1.5, 'loss.transducer': 2.25, 'acc.att': None}
+    assert pickle.loads(pickle.dumps(obs)) == dict(obs)
+    assert 'loss.ctc' in obs and len(obs) == 3
+    # _finalize_observation: tensors become lazily fetched floats, everything else passes through
+    out = Speech2Text._finalize_observation({'loss.ctc': torch.tensor(3.0), 'loss.mbr': None})
+    assert out['loss.ctc'] == 3.0 and out['loss.mbr'] is None
+    assert Speech2Text._finalize_observation({'a': None}) == {'a': None}
+
+
+def test_bench_cpu_core_detection_and_h2d_on_cpu():
+    """bench._usable_cpus never exceeds the affinity mask; ops.h2d is a plain conversion when the
+    target is the CPU (no pinned staging, no device)."""
+    import importlib.util
+    import os
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(__file__), '..', 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench._usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    from neural_sp_amd import ops
+    t = ops.h2d(np.arange(6, dtype=np.int64).reshape(2, 3), 'cpu', torch.int32)
+    assert t.dtype == torch.int32 and t.tolist() == [[0, 1, 2], [3, 4, 5]]
