@@ -44,6 +44,7 @@ def parse():
     p.add_argument('--mode', default='bf16', choices=['bf16', 'f32'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-kernel-events', action='store_true')
+    p.add_argument('--no-b16', action='store_true', help='skip the secondary batch-16 measurement')
     p.add_argument('--event-stride', type=int, default=4,
                    help='HIP events around every GEMM launch of every k-th timed step (roofline line)')
     p.add_argument('--cpu-batch', type=int, default=1, help='utterances in the CPU-baseline sample')
@@ -181,7 +182,7 @@ def main():
         parallel.clip_grad_norm_(params, 5.0)
         opt.step()
         opt.zero_grad(set_to_none=True)
-        return sum(batch['xlens'])
+        return sum(batch['xlens']), len(batch['xlens']) * max(batch['xlens'])
 
     def sync():
         if distributed:
@@ -196,24 +197,52 @@ def main():
         ops.kernel_events_start()
     t0 = time.perf_counter()
     frames = 0
+    padded = 0
     for i in range(a.steps):
         if not a.no_kernel_events:
             # HIP events around every GEMM launch of every `event_stride`-th timed step
             ops.kernel_events_enable(i % a.event_stride == 0)
-        frames += step(a.warmup + i)
+        v, pd = step(a.warmup + i)
+        frames += v
+        padded += pd
     report_pending()     # the last step's values are fetched inside the timed region too
     sync()
     dt = time.perf_counter() - t0
     assert len(reported) == a.warmup + a.steps and all(np.isfinite(list(r.values())).all() for r in reported)
     kev = ops.kernel_events_stop() if not a.no_kernel_events else None
 
-    tot = torch.tensor([dt, float(frames)], device=dev, dtype=torch.float64)
+    # Secondary measurement (single GPU only, outside the timed region above): the same step at 16
+    # utterances per GPU, the upper end of the per-GPU batch SURVEY.md section 8(d) wrote down for
+    # this config, so that both operating points are on record in one line.
+    also = None
+    if not distributed and a.batch != 16 and not a.no_b16:
+        batches = [synthetic_batch(B=16, t_range=(a.tmin, a.tmax), u_range=(a.umin, a.umax),
+                                   vocab=1000, seed=7000 + i) for i in range(4)]
+        for i in range(4):
+            step(i)
+        report_pending()
+        sync()
+        t1 = time.perf_counter()
+        f16 = 0
+        for i in range(12):
+            f16 += step(4 + i)[0]
+        report_pending()
+        sync()
+        dt16 = time.perf_counter() - t1
+        also = {'per_gpu_batch': 16, 'value': round(f16 / dt16, 1), 'unit': 'frames/s', 'steps': 12,
+                'ms_per_step': round(dt16 / 12 * 1e3, 2)}
+
+    tot = torch.tensor([dt, float(frames), float(padded)], device=dev, dtype=torch.float64)
+    padded_all = float(padded)
     if distributed:
         tmax = tot[0:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         fsum = tot[1:2].clone()
         dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
         dt, frames = tmax.item(), fsum.item()
+        psum = tot[2:3].clone()
+        dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+        padded_all = psum.item()
 
     if rank == 0:
         peak_tf = 2500.0 if a.mode == 'bf16' else 157.3
@@ -245,9 +274,12 @@ def main():
                                    'T~U[%d,%d], U~U[%d,%d], dropout %.2f; full train step (fwd+loss+bwd+clip+Adam)'
                                    % (a.size, a.tmin, a.tmax, a.umin, a.umax, a.dropout),
                        'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'params': n_params,
+                       'padded_frames_per_s': round(padded_all / dt, 1),
                        'parallelism': 'dp%d' % world},
             'roofline': roof,
         }
+        if also is not None:
+            out['also'] = also
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(a, margs, _usable_cpus())
         print(json.dumps(out))
