@@ -497,6 +497,121 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
   gemm_epilogue(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
+// ---- RC x RC (both operands contiguous along their OUTPUT index, reduction index strided: the
+// weight gradients dW = dY^T X) on the same LDS-DMA ring.  A stage holds the k-major images
+// [64 k][128 m] and [64 k][128 n] (256-B rows, unpadded: the DMA writes lane-linear); MFMA operands
+// are formed with ds_read_b64_tr_b16 (4 k-rows x 16 columns -> 4 k-values per lane).  The 32-B
+// column pair a transposed read touches in row k is XOR-swizzled with (k & 3) | ((k >> 3) & 1) << 2
+// (on the source address of the DMA and on the read), which spreads the 4 rows of one 16-lane group
+// and the two row groups of a 32-lane pass over all 64 banks.  Requires K % 64 == 0.
+__device__ __forceinline__ int rr_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+
+__device__ __forceinline__ bf16x8 rr_frag(const unsigned char* tile, int cbase, int s, int r, int g) {
+  const int a = r >> 2, b = r & 3;
+  const int k0 = s * 32 + g * 8 + a;          // rows k0 and k0 + 4 share (k & 3) and bit 3
+  const int col = cbase + b * 4;
+  const int off = (((col >> 3) ^ rr_swz(k0)) << 4) + ((col & 7) << 1);
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + k0 * 256 + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + (k0 + 4) * 256 + off));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+
+template <int NS>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_rr_ring_kernel(const nsp_gemm_params p, int tiles_m,
+                                                                     int tiles_n, int c_vec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // NS x (A image 16 KB | B image 16 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  int z = blockIdx.z;
+  const int split = z % p.splitk;
+  z /= p.splitk;
+  const int z2 = z % p.batch2, z1 = z / p.batch2;
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
+  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
+  const long long lda = p.a_cs, ldb = p.b_ks;   // row pitch of the k-major operands
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    int nkt_all = p.K / BK;
+    int per = (nkt_all + p.splitk - 1) / p.splitk;
+    kbeg = split * per * BK;
+    kend = min(p.K, (split + 1) * per * BK);
+    if (kbeg >= kend) {
+      if (!p.c_ss) return;
+      kend = kbeg;
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // DMA instruction i of wave w covers k-rows 16w + 4i .. +3 of a tile: lane = (k-row & 3, chunk)
+  const int lk = lane >> 4, lp = lane & 15;
+  const __bf16* asrc[4];
+  const __bf16* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int krow = wave * 16 + i * 4 + lk;
+    const int csrc = lp ^ rr_swz(krow);
+    // chunks beyond M / N re-read chunk 0 of the row: they only feed outputs that are never stored
+    const int ma = (m0 + csrc * 8 < p.M) ? m0 + csrc * 8 : m0;
+    const int nb = (n0 + csrc * 8 < p.N) ? n0 + csrc * 8 : n0;
+    asrc[i] = A + (long long)(kbeg + krow) * lda + ma;
+    bsrc[i] = B + (long long)(kbeg + krow) * ldb + nb;
+  }
+  const int fr = lane & 15, fg = lane >> 4;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int nkt = (kend - kbeg) / BK;
+  auto issue = [&](int kt) {
+    unsigned char* sa = ring + (kt % NS) * 32768 + wave * 4096;
+    const long long ka = (long long)kt * BK * lda, kb = (long long)kt * BK * ldb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + ka), (lds_void*)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + kb), (lds_void*)(sa + 16384 + i * 1024), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) issue(s);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int ahead = min(NS - 2, nkt - 1 - kt);
+    if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NS >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nkt) issue(kt + NS - 1);
+    const unsigned char* smA = ring + (kt % NS) * 32768;
+    const unsigned char* smB = smA + 16384;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = rr_frag(smA, wm * 64 + i * 16, s, fr, fg);
+        bf[i] = rr_frag(smB, wn * 64 + i * 16, s, fr, fg);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // the epilogue reuses the ring as its staging area
+  gemm_epilogue<4>(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
+}
+
 // fp32 [rows, cols] (row stride ld_in) -> bf16 [rows, ld_out] with zero fill; 8 elements per lane
 __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long long rows,
                                  int cols, long long ld_in, long long ld_out, int vec_in) {
@@ -523,6 +638,13 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// NSP_GEMM_RR_RING = 2 / 3 selects the LDS-DMA weight-gradient kernel with that many ring stages
+// (default 0 = register-staged kernel; read on every call so that tests can switch it)
+inline int rr_ring_stages() {
+  const char* e = getenv("NSP_GEMM_RR_RING");
+  return e ? atoi(e) : 0;
+}
 
 }  // namespace
 
@@ -575,6 +697,21 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
     else
       hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+  }
+  else if (!a_kc && !b_kc && p.K % BK == 0 && p.K >= 2 * BK && p.M % 8 == 0 && p.N % 8 == 0 &&
+           tiles_m * tiles_n >= 24 && rr_ring_stages() > 0) {
+    // weight gradients on the LDS-DMA ring with swizzled transposed reads.  OPT-IN: back to back it
+    // beats the register-staged kernel (2 stages: 545 -> 660 TFLOP/s on dW[2048,512] over 51200
+    // rows; 3 stages = 1 workgroup per CU is slower), but inside the training step it measured 1 %
+    // SLOWER (97.5 vs 96.0 ms): its 64 KB of LDS per workgroup leave room for one instead of two
+    // workgroups beside the persistent LSTM kernel that runs concurrently on half of the CUs.
+    if (rr_ring_stages() >= 3) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_rr_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
+      hipLaunchKernelGGL((gemm_bf16_rr_ring_kernel<3>), grid, block, 3 * 32768, st, p, tiles_m, tiles_n, c_vec);
+    } else {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_rr_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
+      hipLaunchKernelGGL((gemm_bf16_rr_ring_kernel<2>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
+    }
   }
   else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);

@@ -222,3 +222,25 @@ def test_splitk_slabs_with_an_empty_split_are_fully_written(mode):
     assert torch.isfinite(part).all()
     ref = aa.float().t() @ bb.float()
     assert ((part.sum(0) - ref).abs().max() / ref.abs().max()).item() < (2e-3 if mode == 'bf16' else 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('stages', ['2', '3'])
+def test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch):
+    """Opt-in RC x RC kernel (NSP_GEMM_RR_RING): unpadded k-major LDS images written by LDS-DMA,
+    operands formed by swizzled transposed reads; split-K slabs; ragged M/N edges."""
+    from neural_sp_amd import ops
+    torch.manual_seed(1)
+    dev = torch.device('cuda:0')
+    for rows, N, K in [(2048, 640, 512), (1280, 1000, 264), (4096, 512, 2048)]:
+        dy = torch.randn(rows, N, device=dev).bfloat16()
+        x = torch.randn(rows, K, device=dev).bfloat16()
+        ref = dy.float().t() @ x.float()
+        with ops.compute_mode('bf16'):
+            monkeypatch.setenv('NSP_GEMM_RR_RING', '0')
+            base = ops.linear_wgrad(dy, x)
+            monkeypatch.setenv('NSP_GEMM_RR_RING', stages)
+            dw = ops.linear_wgrad(dy, x)
+        scale = ref.abs().max()
+        assert ((base - ref).abs().max() / scale).item() < 1e-4
+        assert ((dw - ref).abs().max() / scale).item() < 1e-4
