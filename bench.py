@@ -122,9 +122,32 @@ def cpu_baseline(args, margs, cores):
                       % (what, args.size, dt, threads, t_cal)}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _spawn_ranks(a):
+    """`python bench.py --gpus N` with no launcher in the environment: re-run this file as N ranks
+    (one per GPU) through torch.distributed.run on 127.0.0.1; rank 0 prints the JSON line."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '4'))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(_spawn_ranks(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if a.gpus != world:
+        print('bench.py: --gpus %d but the launcher started %d rank(s); using the launcher\'s world size'
+              % (a.gpus, world), file=sys.stderr)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1

@@ -438,6 +438,22 @@ int nsp_pad_batch(const float* packed, const long long* offsets /*device [B]*/,
                   const int* lens /*device [B]*/, float* out, int B, int Tmax, int F,
                   float pad_value, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Greedy decoding helpers (validate(): train.py:341 -> evaluators ->        *
+ * Speech2Text.decode, speech2text.py:709-800).                             *
+ * nsp_argmax_rows: out[r] = argmax_c x[r*ld + c] (first index on ties) --   *
+ *   the best path of ctc.py:229-230 and the per-frame 1-best of             *
+ *   rnn_transducer.py:363-364, without a host sync per frame.               *
+ * nsp_lstm_cell_step: one LSTM cell update from pre-activation gates        *
+ *   [B,4H] (i,f,g,o) and the previous state; rows with update[b] == 0 keep   *
+ *   their state (rnn_transducer.py:367-370: the prediction network advances *
+ *   only where a non-blank label was emitted).  update may be NULL.         *
+ * ------------------------------------------------------------------------ */
+int nsp_argmax_rows(const float* x, int* out, long long rows, int cols, long long ld, void* stream);
+int nsp_lstm_cell_step(const float* gates, const float* h_prev, const float* c_prev,
+                       const int* update /*device [B] or NULL*/, float* h_out, float* c_out,
+                       int B, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

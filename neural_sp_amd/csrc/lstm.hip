@@ -739,6 +739,26 @@ static int lstm_persistent_check(const nsp_lstm_stack_params* p) {
   return NSP_OK;
 }
 
+// The grid barrier needs every workgroup of the launch co-resident: refuse (NSP_EUNSUPPORTED, the
+// caller falls back to one launch per stage) unless the device could hold the whole grid even if
+// nothing else were running -- a CU-masked / partitioned device or an oversized grid fails here
+// instead of timing out inside the kernel.  (Transient crowding by co-running kernels only delays
+// residency; a genuine timeout raises the `dead` word sync[1], which the host checks.)
+static bool lstm_grid_fits(const void* kernel, int block, size_t shmem, int nwg) {
+  // capacity (workgroups the idle device holds) cached per (kernel, dynamic LDS size)
+  static struct { const void* k; size_t sh; long long cap; } cache[16];
+  static int ncache = 0;
+  for (int i = 0; i < ncache; ++i)
+    if (cache[i].k == kernel && cache[i].sh == shmem) return cache[i].cap >= nwg;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, shmem) != hipSuccess) return false;
+  const long long cap = (long long)per_cu * cus;
+  if (ncache < 16) { cache[ncache].k = kernel; cache[ncache].sh = shmem; cache[ncache].cap = cap; ++ncache; }
+  return cap >= nwg;
+}
+
 extern "C" int nsp_lstm_stack_fwd_persistent(const nsp_lstm_stack_params* p, unsigned int* sync, void* stream) {
   int rc = lstm_persistent_check(p);
   if (rc != NSP_OK) return rc;
@@ -751,6 +771,8 @@ extern "C" int nsp_lstm_stack_fwd_persistent(const nsp_lstm_stack_params* p, uns
   do {                                                                                                        \
     (void)hipFuncSetAttribute((const void*)lstm_stack_fwd_persistent_kernel<N>,                               \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                        \
+    if (!lstm_grid_fits((const void*)lstm_stack_fwd_persistent_kernel<N>, 512, shmem, grid.x * grid.y))       \
+      return NSP_EUNSUPPORTED;                                                                                \
     hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<N>), grid, dim3(512), shmem, st, *p, sync);          \
   } while (0)
   switch (nb) {
@@ -776,6 +798,8 @@ extern "C" int nsp_lstm_stack_bwd_persistent(const nsp_lstm_stack_params* p, uns
   do {                                                                                                        \
     (void)hipFuncSetAttribute((const void*)lstm_stack_bwd_persistent_kernel<N>,                               \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                        \
+    if (!lstm_grid_fits((const void*)lstm_stack_bwd_persistent_kernel<N>, 1024, shmem, grid.x * grid.y))      \
+      return NSP_EUNSUPPORTED;                                                                                \
     hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<N>), grid, dim3(1024), shmem, st, *p, sync);         \
   } while (0)
   switch (nb) {

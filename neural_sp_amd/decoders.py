@@ -14,8 +14,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import copy
+from itertools import groupby
+
 from neural_sp_amd import ops
-from neural_sp_amd.torch_utils import repeat
 
 logger = logging.getLogger(__name__)
 
@@ -110,6 +112,26 @@ class CTC(DecoderBase):
             self.data_dict['elens'] = elens.numpy()
         return loss, trigger_points
 
+    def greedy(self, eouts, elens):
+        """ctc.py:219-243: best path -> collapse repeats -> drop blanks.  The per-frame arg-max
+        runs on the device (nsp_argmax_rows) and comes back in ONE transfer; the reference reads
+        every frame with .item().  Returns `[B]` lists holding one hypothesis (n-best format)."""
+        B, T = eouts.shape[:2]
+        logits = self.logits(eouts)
+        best = ops.argmax_rows(logits.reshape(B * T, -1)).view(B, T).cpu().numpy()
+        hyps = []
+        for b in range(B):
+            collapsed = [k for k, _ in groupby(best[b, :int(elens[b])].tolist())]
+            hyps.append([[x for x in collapsed if x != self.blank]])
+        return hyps
+
+    def beam_search(self, *a, **k):
+        raise NotImplementedError('CTC prefix beam search is inference-side and not built: decode with '
+                                  'recog_beam_width=1 (greedy), or load the state_dict into the reference')
+
+    def _plot_ctc(self, save_path=None, topk=10):
+        pass  # plotting needs matplotlib figures of self.prob_dict; the training loop only needs it not to raise
+
     def probs(self, eouts, temperature=1.):
         return torch.softmax(self.logits(eouts) / temperature, dim=-1)
 
@@ -160,7 +182,8 @@ class RNNTransducer(DecoderBase):
         if self.rnnt_weight > 0:
             self.rnn = nn.ModuleList()
             dec_odim = emb_dim
-            self.proj = repeat(nn.Linear(n_units, n_projs), n_layers) if n_projs > 0 else None
+            self.proj = nn.ModuleList([copy.deepcopy(nn.Linear(n_units, n_projs))
+                                       for _ in range(n_layers)]) if n_projs > 0 else None
             self.dropout = nn.Dropout(p=dropout)
             for _ in range(n_layers):
                 self.rnn += [nn.LSTM(dec_odim, n_units, 1, batch_first=True)]
@@ -195,9 +218,7 @@ class RNNTransducer(DecoderBase):
                 # The two loss branches are independent and each contains a long latency-bound
                 # lattice kernel on B workgroups (CTC alpha/beta ~0.4 ms, RNN-T ~0.5 ms): the CTC
                 # branch runs on its own stream beside the transducer branch, forward and backward.
-                if getattr(self, '_ctc_stream', None) is None:
-                    self._ctc_stream = torch.cuda.Stream(device=eouts.device)
-                ctc_stream = self._ctc_stream
+                ctc_stream = self.ensure_streams()[1]
                 cur = torch.cuda.current_stream(eouts.device)
                 ctc_stream.wait_stream(cur)
                 with torch.cuda.stream(ctc_stream):
@@ -230,6 +251,31 @@ class RNNTransducer(DecoderBase):
         dout, _ = self.recurrency(self.embed_token_id(ys_in), None, need_state=False)
         return ops.linear(dout, self.w_dec.weight, None)
 
+    def ensure_streams(self):
+        """(prediction-network side stream, CTC-branch stream) of the training step, created on
+        first use; None where the corresponding overlap is disabled / not applicable."""
+        if not torch.cuda.is_available() or not next(self.parameters()).is_cuda:
+            return None, None
+        dev = self.device
+        side = ctc = None
+        if self.rnnt_weight > 0 and os.environ.get('NSP_PREDNET_STREAM', '1') != '0':
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream(
+                    device=dev, priority=int(os.environ.get('NSP_PREDNET_STREAM_PRIORITY', '-1')))
+            side = self._side_stream
+        if self.ctc_weight > 0 and self.rnnt_weight > 0 and os.environ.get('NSP_CTC_STREAM', '1') != '0':
+            if getattr(self, '_ctc_stream', None) is None:
+                self._ctc_stream = torch.cuda.Stream(device=dev)
+            ctc = self._ctc_stream
+        return side, ctc
+
+    def prediction_network_parameters(self):
+        """Parameters whose gradients are produced on the side stream (embed, LSTM stack, proj, w_dec)."""
+        if self.rnnt_weight <= 0:
+            return []
+        mods = [self.embed, self.rnn, self.w_dec] + ([self.proj] if self.proj is not None else [])
+        return [p for m in mods for p in m.parameters()]
+
     def mark_step_start(self):
         """Record the point on the current stream the prediction network has to wait for
         (the previous step's optimizer update); everything enqueued later is independent of it."""
@@ -247,8 +293,7 @@ class RNNTransducer(DecoderBase):
         if self.rnnt_weight <= 0 or not torch.cuda.is_available() or os.environ.get('NSP_PREDNET_STREAM', '1') == '0':
             return
         dev = self.device
-        if getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('NSP_PREDNET_STREAM_PRIORITY', '-1')))
+        self.ensure_streams()
         ev = getattr(self, '_step_start_event', None)
         self._step_start_event = None
         if ev is not None:
@@ -282,6 +327,75 @@ class RNNTransducer(DecoderBase):
         loss, _ = ops.rnnt_joint_loss(enc_proj, dec_proj, self.output.weight, self.output.bias,
                                       lab, elens_dev, ylens_dev, self.blank)
         return loss
+
+    # ---- greedy decoding (validate() -> evaluators -> Speech2Text.decode)
+    def joint(self, eouts, douts):
+        """rnn_transducer.py:262-276: `[B,T,enc]` x `[B,L,dec]` -> logits `[B,T,L,V]` (inference sizes)."""
+        e = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias).unsqueeze(2)
+        g = ops.linear(douts, self.w_dec.weight, None).unsqueeze(1)
+        h = ops.act_fwd((e + g).contiguous(), ops.ACT['tanh'])
+        return ops.linear(h, self.output.weight, self.output.bias)
+
+    def _step_state(self, y, state, update):
+        """One prediction-network step for a batch of states: embed -> per layer
+        (x W_ih^T + b_ih + h W_hh^T + b_hh -> cell) [-> proj+ReLU]; rows with update == 0 keep
+        their state and output (rnn_transducer.py:278-311 with dstate, eval mode)."""
+        x = self.embed(y)
+        new_state = []
+        for lth in range(self.n_layers):
+            rnn = self.rnn[lth]
+            h_prev, c_prev = state[lth]
+            gi = ops.linear(x, rnn.weight_ih_l0, rnn.bias_ih_l0)
+            gates = ops.linear(h_prev, rnn.weight_hh_l0, rnn.bias_hh_l0, res=gi)
+            h, c = ops.lstm_cell_step(gates, h_prev, c_prev, update)
+            new_state.append((h, c))
+            x = h
+            if self.proj is not None:
+                x = ops.linear(x, self.proj[lth].weight, self.proj[lth].bias, act='relu')
+        return x, new_state
+
+    @torch.no_grad()
+    def greedy(self, eouts, elens, max_len_ratio=None, idx2token=None, exclude_eos=False,
+               refs_id=None, utt_ids=None, speakers=None, trigger_points=None, teacher_force=False):
+        """rnn_transducer.py:330-382 for the whole batch in lock-step over frames: per frame every
+        utterance takes the 1-best of joint(e_t, d); the prediction network advances only in the
+        rows that emitted a non-blank label (at most one label per frame, as in the reference).
+        No host sync inside the loop: labels are collected on the device and read once."""
+        B, T = eouts.shape[:2]
+        dev = eouts.device
+        H = self.dec_n_units
+        enc_proj = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias)            # [B,T,J]
+        state = [(eouts.new_zeros(B, H), eouts.new_zeros(B, H)) for _ in range(self.n_layers)]
+        y = torch.full((B,), self.eos, dtype=torch.int64, device=dev)
+        dout, state = self._step_state(y, state, None)
+        elens_dev = ops.h2d(elens, dev, torch.int32)
+        labels = torch.empty((T, B), device=dev, dtype=torch.int32)
+        for t in range(T):
+            g = ops.linear(dout, self.w_dec.weight, None)
+            h = ops.act_fwd(ops.axpby(enc_proj[:, t].contiguous(), g, 1.0, 1.0), ops.ACT['tanh'])
+            yt = ops.argmax_rows(ops.linear(h, self.output.weight, self.output.bias))
+            labels[t] = yt
+            update = ((yt != self.blank) & (elens_dev > t)).to(torch.int32)
+            dout, state = self._step_state(yt.long(), state, update)
+        lab = labels.cpu().numpy()
+        hyps = [[int(v) for v in lab[:int(elens[b]), b] if v != self.blank] for b in range(B)]
+        if idx2token is not None:
+            for b in range(B):
+                if utt_ids is not None:
+                    logger.debug('Utt-id: %s' % utt_ids[b])
+                logger.debug('Hyp: %s' % idx2token(hyps[b]))
+        return hyps, None
+
+    def beam_search(self, *a, **k):
+        raise NotImplementedError('RNN-T beam search is inference-side and not built: decode with '
+                                  'recog_beam_width=1 (greedy), or load the state_dict into the reference')
+
+    def _plot_attention(self, save_path=None, n_cols=1):
+        pass
+
+    def _plot_ctc(self, save_path=None, topk=10):
+        if self.ctc_weight > 0:
+            self.ctc._plot_ctc(save_path, topk)
 
     def embed_token_id(self, indices):
         # embedding lookup = row gather of a [V, emb] table (host-side indexing glue)
@@ -346,6 +460,12 @@ class CTCOnlyDecoder(DecoderBase):
         loss = loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight
         observation['loss'] = loss.detach()
         return loss, observation
+
+    def _plot_attention(self, save_path=None, n_cols=1):
+        pass
+
+    def _plot_ctc(self, save_path=None, topk=10):
+        self.ctc._plot_ctc(save_path, topk)
 
 
 def build_decoder(args, special_symbols, enc_n_units, vocab, ctc_weight, global_weight, external_lm=None):

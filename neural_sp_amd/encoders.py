@@ -65,7 +65,7 @@ class EncoderBase(nn.Module):
         raise NotImplementedError
 
     def _plot_attention(self, save_path=None, n_cols=2):
-        raise NotImplementedError('plotting is out of scope (SURVEY.md section 8)')
+        pass  # train.py:484-487 calls it through Speech2Text.plot_attention(); nothing is drawn here
 
 
 # --------------------------------------------------------------------------- CNN frontend

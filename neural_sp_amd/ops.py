@@ -227,7 +227,9 @@ def linear_dgrad(dy2d, weight, dact_src=None, dact=0, alpha=1.0, res=None, out=N
     """dx[M,K] = res + alpha*(dy2d[M,N] @ weight[N,K]) * act'(dact_src)."""
     M = dy2d.shape[0]
     N, K = weight.shape[0], weight[0].numel()
-    use16 = bf16_mode() and K % 8 == 0 and N % 8 == 0
+    # a bf16 dy whose width is not a multiple of 8 arrives zero-padded to roundup8(N) (grad_prep /
+    # to_bf16); the W^T shadow is zero-padded to roundup64(N), so reducing over the padded width is exact
+    use16 = bf16_mode() and K % 8 == 0 and (N % 8 == 0 or dy2d.dtype == torch.bfloat16)
     if use16:
         ga = to_bf16(dy2d)
     else:
@@ -239,7 +241,7 @@ def linear_dgrad(dy2d, weight, dact_src=None, dact=0, alpha=1.0, res=None, out=N
     if use16:
         # W^T shadow [K, roundup64(N)] makes the data gradient a KC x KC product
         wt = _weight_t_shadow(weight, True)
-        gemm_raw(M, K, N, ga, ga.stride(0), 1, wt, 1, wt.stride(0), out, out.stride(0),
+        gemm_raw(M, K, _r8(N), ga, ga.stride(0), 1, wt, 1, wt.stride(0), out, out.stride(0),
                  dact_src=dact_src, dact=dact, alpha=alpha, res=res)
     else:
         wb = weight.reshape(N, K)
@@ -347,17 +349,20 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xa, weight, pre = ctx.saved_tensors
-        dy2d = _f32c(dy).reshape(-1, weight.shape[0])
+        N = weight.shape[0]
+        dy2d = _f32c(dy).reshape(-1, N)
         dres = dy if ctx.has_res else None
         p, seed, offset = ctx.drop
+        # bf16 image of the gradient; for N % 8 != 0 (e.g. a 10001-word CTC head) it is zero-padded to
+        # roundup8(N) columns and the padded rows / entries of dW / db are dropped below
         g = grad_prep(dy2d, pre, ctx.act, ctx.alpha, p, seed, offset, xa.dtype == torch.bfloat16)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(g, weight)[:, :ctx.xshape[-1]].reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = linear_wgrad(g, xa).view(weight.shape)
+            dw = linear_wgrad(g, xa)[:N].view(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(g)
+            db = colsum(g)[:N]
         return dx, dw, db, None, dres, None, None
 
 
@@ -666,18 +671,65 @@ class AttentionFn(torch.autograd.Function):
         return dQ, dQbd, dK, dV, dpos, None, None
 
 
-_DROPOUT_STATE = {'seed': 0x5EED, 'counter': 0}
+_DROPOUT_STATE = {'seed': None, 'counter': 0}
+_M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    """splitmix64 finaliser (host side, once per dropout site)."""
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
 
 
 def manual_dropout_seed(seed):
-    _DROPOUT_STATE['seed'] = int(seed)
+    """Fix the base seed of the dropout masks explicitly (and restart the site counter)."""
+    _DROPOUT_STATE['seed'] = int(seed) & _M64
     _DROPOUT_STATE['counter'] = 0
 
 
+def _dropout_base_seed():
+    """Base seed of this process: taken ONCE, at the first dropout site, from torch's seed (what
+    train.py:57-58 sets with torch.manual_seed(args.seed)) and the data-parallel rank, so that runs
+    are reproducible from the training seed and replicas draw different masks."""
+    s = _DROPOUT_STATE['seed']
+    if s is None:
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+            else:
+                rank = int(os.environ.get('RANK', '0'))
+        except Exception:
+            rank = 0
+        s = _mix64((int(torch.initial_seed()) & _M64) ^ _mix64(0x5EED + rank))
+        _DROPOUT_STATE['seed'] = s
+    return s
+
+
 def next_dropout_seed():
-    """(seed, offset) for one dropout site; offsets advance by 2^40 so sites never overlap."""
+    """(seed, offset) for one dropout site.  Every site gets its own 64-bit stream seed =
+    mix(base seed, site counter); the offset (element index base) stays 0, so no number of sites
+    or elements can make two sites' counters collide or overflow the 64-bit index."""
     _DROPOUT_STATE['counter'] += 1
-    return _DROPOUT_STATE['seed'], _DROPOUT_STATE['counter'] << 40
+    return _mix64(_dropout_base_seed() ^ ((_DROPOUT_STATE['counter'] * 0xD1342543DE82EF95) & _M64)), 0
+
+
+def invalidate_weight_shadows(module):
+    """Drop every cached bf16 / transposed / stacked weight shadow of `module`'s parameters.  The
+    caches are keyed by Parameter._version, which optimizers bump -- but in-place writes through
+    `.data` (p.data.add_, EMA / weight-noise code, manual checkpoint surgery) do NOT; call this
+    after such an update (load_state_dict and torch.optim steps need no call)."""
+    for p in module.parameters():
+        for name in ('_nsp_bf16', '_nsp_t16', '_nsp_t32', '_nsp_stack16', '_nsp_stackt16',
+                     '_nsp_lstm_cat', '_nsp_lstm_catT'):
+            if hasattr(p, name):
+                try:
+                    delattr(p, name)
+                except AttributeError:
+                    pass
 
 
 # --------------------------------------------------------------------------
@@ -1127,6 +1179,26 @@ def ctc_forced_align(logits, labels, elens, ylens, blank=0):
     return tp
 
 
+def argmax_rows(x2d):
+    """int32 [rows] arg-max over the last dim of a contiguous fp32 [rows, V] matrix (first index on ties)."""
+    x2d = _f32c(x2d)
+    rows, V = x2d.shape
+    out = torch.empty((rows,), device=x2d.device, dtype=torch.int32)
+    _check(_lib.lib().nsp_argmax_rows(_p(x2d), _p(out), rows, V, x2d.stride(0), _stream()), 'nsp_argmax_rows')
+    return out
+
+
+def lstm_cell_step(gates, h_prev, c_prev, update=None):
+    """One LSTM cell update (gate order i,f,g,o) from pre-activations [B,4H]; rows whose int32
+    `update` flag is 0 keep (h_prev, c_prev).  Inference-side (greedy decoding), no autograd."""
+    gates, h_prev, c_prev = _f32c(gates), _f32c(h_prev), _f32c(c_prev)
+    B, H = h_prev.shape
+    h, c = torch.empty_like(h_prev), torch.empty_like(c_prev)
+    _check(_lib.lib().nsp_lstm_cell_step(_p(gates), _p(h_prev), _p(c_prev), _p(update), _p(h), _p(c), B, H,
+                                         _stream()), 'nsp_lstm_cell_step')
+    return h, c
+
+
 # --------------------------------------------------------------------------
 # per-launch timing of the GEMM kernel with HIP events (bench.py roofline)
 # --------------------------------------------------------------------------
@@ -1255,17 +1327,42 @@ def _cat_cached(owner, name, parts, build):
     return t
 
 
+_LSTM_DEAD_CHECKS = []   # (pinned flag, event, which) of persistent launches whose `dead` word is still in flight
+
+
+def _lstm_poll_dead(block=False):
+    """Raise if a finished persistent launch reported a grid-barrier timeout (sync[1] != 0): its
+    outputs are garbage (forward additionally poisons y_top[0], backward dg16[0] with NaN)."""
+    keep = []
+    for flag, ev, which in _LSTM_DEAD_CHECKS:
+        if block:
+            ev.synchronize()
+        if ev.query():
+            if int(flag[0]) != 0:
+                del _LSTM_DEAD_CHECKS[:]
+                raise RuntimeError('nsp_lstm_stack_%s_persistent: grid barrier timed out (workgroups were not '
+                                   'co-resident); set NSP_LSTM_PERSISTENT=0 to use one launch per stage' % which)
+        else:
+            keep.append((flag, ev, which))
+    _LSTM_DEAD_CHECKS[:] = keep
+
+
 def _lstm_stack_launch(which, P, dev):
     """Persistent single-launch recurrence when the shape qualifies (H % 256 == 0, H <= 1024;
-    NSP_LSTM_PERSISTENT=0 disables), else one launch per wavefront stage.  The persistent kernels
-    take at most 64 utterances (4 batch blocks); a larger batch is cut into slabs of 64 --
-    utterances are independent and [B, L, .] tensors are contiguous per utterance -- launched one
-    after the other (the dropout counters are offset so that the masks do not depend on the cut)."""
+    NSP_LSTM_PERSISTENT=0 disables) AND the device can hold the whole grid (the C side checks
+    occupancy x CU count and answers NSP_EUNSUPPORTED otherwise), else one launch per wavefront
+    stage.  The persistent kernels take at most 64 utterances (4 batch blocks); a larger batch is
+    cut into slabs of 64 -- utterances are independent and [B, L, .] tensors are contiguous per
+    utterance -- launched one after the other (the dropout counters are offset so that the masks do
+    not depend on the cut).  Each launch's `dead` word is copied to pinned memory behind the kernel
+    and checked (without a sync) at the next launch / by ops.lstm_check()."""
     lib = _lib.lib()
     if os.environ.get('NSP_LSTM_PERSISTENT', '1') != '0' and P.H % 256 == 0 and P.H <= 1024 \
             and P.nl * (P.H // 16) <= 256:
+        _lstm_poll_dead()
         fn = lib.nsp_lstm_stack_fwd_persistent if which == 'fwd' else lib.nsp_lstm_stack_bwd_persistent
         B, L, H, nl = P.B, P.L, P.H, P.nl
+        fell_back = False
         for b0 in range(0, B, 64):
             Q = P
             if B > 64:
@@ -1288,10 +1385,25 @@ def _lstm_stack_launch(which, P, dev):
                     Q.dc[l] = (P.dc[l] + b0 * H * 4) if P.dc[l] else P.dc[l]
                     Q.offset[l] = P.offset[l] + rows * H
             sync = torch.empty((2,), device=dev, dtype=torch.int32)   # zeroed by the call itself
-            _check(fn(ctypes.byref(Q), sync.data_ptr(), _stream()), 'nsp_lstm_stack_%s_persistent' % which)
-        return
+            rc = fn(ctypes.byref(Q), sync.data_ptr(), _stream())
+            if rc == -2 and b0 == 0:        # NSP_EUNSUPPORTED: the grid does not fit this device
+                fell_back = True
+                break
+            _check(rc, 'nsp_lstm_stack_%s_persistent' % which)
+            flag = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+            flag.copy_(sync[1:2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            _LSTM_DEAD_CHECKS.append((flag, ev, which))
+        if not fell_back:
+            return
     fn = lib.nsp_lstm_stack_fwd if which == 'fwd' else lib.nsp_lstm_stack_bwd
     _check(fn(ctypes.byref(P), _stream()), 'nsp_lstm_stack_' + which)
+
+
+def lstm_check():
+    """Wait for the outstanding persistent-LSTM launches and raise if one of them timed out."""
+    _lstm_poll_dead(block=True)
 
 
 class LSTMStackFn(torch.autograd.Function):

@@ -2,12 +2,33 @@
 
 The reference's only parallelism is DistributedDataParallel(Speech2Text)
 (neural_sp/bin/asr/train.py:263) plus the `.module` wrappers of models/data_parallel.py.
-Utterances are independent, so the path shards with no data-path collective other than
-the gradient reduction.  `wrap_ddp` keeps torch's DDP (so train.py runs unchanged) but
-(a) drops the per-forward buffer broadcast (the only buffers are constant tables) and
-(b) uses large buckets: xGMI is 7 point-to-point links per GPU, few large collectives
-beat many 25 MB ones.
+Utterances are independent, so the path shards with no data-path collective other than the
+gradient reduction.  `wrap_ddp` keeps torch's DDP (so train.py runs unchanged) and adapts it to
+this step's shape:
+
+* **multi-stream backward.**  The step runs three streams (main; prediction network on a side
+  stream; CTC branch on its own stream).  DDP's reducer launches a bucket's all-reduce from
+  whichever gradient hook completes the bucket and orders it only after THAT hook's current
+  stream -- gradients written into the same bucket from another stream would race.  The comm hook
+  below launches every bucket from a small "gather" stream that first waits for all streams of the
+  step, so the collective sees every write and no compute stream is ever blocked by it.
+* **gradient accumulators pinned to their streams.**  DDP keeps every parameter's AccumulateGrad
+  node alive from construction on, and a node runs on the stream that was current when it was
+  created.  Created on the main stream, the prediction-network accumulators would make the main
+  stream wait for the whole LSTM backward (the stall ops.replay_graph_first exists to avoid);
+  `pin_grad_streams` creates them under the stream their gradients are produced on.
+* **buckets sized for xGMI.**  7 point-to-point links per GPU: few large collectives beat many
+  25 MB ones, but the LAST bucket (conv front-end + first blocks, ready only when backward ends)
+  cannot overlap with anything, so the cap is 48 MB (362 MB of fp32 gradients -> 8 buckets, DDP
+  re-orders them by gradient arrival after the first step); optional bf16 compression halves the
+  bytes on the links (NSP_DDP_COMPRESS=bf16 or compress='bf16').
+* no per-forward buffer broadcast (the only buffers are constant tables); `no_sync()` on
+  accumulation micro-steps is torch DDP's own context manager (train.py reduces every micro-step,
+  train.py:414-452; `accumulate(model, is_boundary)` below skips the collective until the boundary).
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 
@@ -23,13 +44,96 @@ class CPUWrapperASR(nn.Module):
         return self.module(*args, **kwargs)
 
 
-def wrap_ddp(model, local_rank=None, bucket_cap_mb=128):
+def step_streams(model):
+    """The non-default streams the training step of `model` uses (created on demand)."""
+    dec = getattr(model, 'dec_fwd', None)
+    out = []
+    if dec is not None and hasattr(dec, 'ensure_streams'):
+        out = [s for s in dec.ensure_streams() if s is not None]
+    return out
+
+
+def pin_grad_streams(model):
+    """Create (and keep alive on the model) the AccumulateGrad nodes of the parameters whose
+    gradients are produced on a side stream, with that stream current.  Must run before DDP is
+    constructed: DDP then adopts these nodes instead of creating its own on the main stream."""
+    dec = getattr(model, 'dec_fwd', None)
+    if dec is None or not hasattr(dec, 'ensure_streams') or not next(model.parameters()).is_cuda:
+        return []
+    side, ctc = dec.ensure_streams()
+    keep = []
+
+    def pin(params, stream):
+        if stream is None:
+            return
+        with torch.cuda.stream(stream):
+            for p in params:
+                if p.requires_grad:
+                    keep.append(p.view_as(p).grad_fn.next_functions[0][0])
+    if side is not None:
+        pin(dec.prediction_network_parameters(), side)
+    if ctc is not None and getattr(dec, 'ctc', None) is not None and side is not None:
+        pin(dec.ctc.parameters(), ctc)
+    model._nsp_grad_accumulators = keep
+    return keep
+
+
+def make_comm_hook(streams, compress=None):
+    """DDP communication hook: all-reduce(mean) of one bucket, launched from a gather stream that
+    waits for every stream of the step (see the module docstring); `compress='bf16'` sends bf16."""
+    import torch.distributed as dist
+    gather = {}
+
+    def hook(state, bucket):
+        buf = bucket.buffer()
+        group = state if state is not None else dist.group.WORLD
+        world = dist.get_world_size(group)
+        if not buf.is_cuda:
+            return dist.all_reduce(buf.div_(world), group=group, async_op=True).get_future().then(lambda f: f.value()[0])
+        dev = buf.device
+        g = gather.get(dev)
+        if g is None:
+            g = gather[dev] = torch.cuda.Stream(device=dev)
+        g.wait_stream(torch.cuda.current_stream(dev))
+        for s in streams:
+            g.wait_stream(s)
+        buf.record_stream(g)
+        with torch.cuda.stream(g):
+            if compress == 'bf16':
+                send = buf.to(torch.bfloat16).div_(world)
+                fut = dist.all_reduce(send, group=group, async_op=True).get_future()
+
+                def decompress(f):
+                    buf.copy_(f.value()[0])
+                    return buf
+                return fut.then(decompress)
+            buf.div_(world)
+            fut = dist.all_reduce(buf, group=group, async_op=True).get_future()
+        return fut.then(lambda f: f.value()[0])
+    return hook
+
+
+def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
     """DDP(model) with the settings above; local_rank=None wraps a CPU module (gloo tests)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     kw = dict(broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
     if local_rank is None:
         return DDP(model, **kw)
-    return DDP(model, device_ids=[local_rank], **kw)
+    pin_grad_streams(model)
+    ddp = DDP(model, device_ids=[local_rank], **kw)
+    compress = compress if compress is not None else (os.environ.get('NSP_DDP_COMPRESS') or None)
+    ddp.register_comm_hook(None, make_comm_hook(step_streams(model), compress))
+    return ddp
+
+
+@contextlib.contextmanager
+def accumulate(ddp_model, is_boundary):
+    """Gradient accumulation: skip the collective on non-boundary micro-steps (DDP.no_sync)."""
+    if is_boundary or not hasattr(ddp_model, 'no_sync'):
+        yield
+    else:
+        with ddp_model.no_sync():
+            yield
 
 
 def shard_batch(indices, rank, world):

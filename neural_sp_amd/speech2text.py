@@ -5,8 +5,8 @@ Mirrors neural_sp/models/seq2seq/speech2text.py: `__init__(args, save_path, idx2
 (:239-269), `_forward` (:271-345), `encode` (:369-431), with the same submodule /
 parameter names (`enc.*`, `dec_fwd.*`) so `state_dict`s are interchangeable and
 neural_sp/bin/asr/train.py drives it unchanged.  Everything below `encode()` runs on the
-HIP kernels (neural_sp_amd.ops); there is no CPU path.  Decoding / streaming / plotting
-members are inference-side and raise NotImplementedError.
+HIP kernels (neural_sp_amd.ops); there is no CPU path.  Greedy decoding (what validate() runs)
+is built; beam search / streaming raise NotImplementedError; the plot hooks are no-ops.
 """
 import logging
 import random
@@ -106,6 +106,21 @@ class LazyObservation(dict):
 
     def items(self):
         return dict.items(self.materialize())
+
+    def keys(self):
+        return dict.keys(self.materialize())
+
+    def __iter__(self):
+        # overriding __iter__ also takes dict(obs) / {**obs} / dict.update(obs) off CPython's
+        # raw-storage fast path (it is only used when tp_iter is dict's own), so every way of
+        # reading the mapping goes through materialize()
+        return dict.__iter__(self.materialize())
+
+    def setdefault(self, k, default=None):
+        return dict.setdefault(self.materialize(), k, default)
+
+    def popitem(self):
+        return dict.popitem(self.materialize())
 
     def values(self):
         return dict.values(self.materialize())
@@ -246,14 +261,67 @@ class Speech2Text(nn.Module):
         pass
 
     def plot_attention(self):
-        raise NotImplementedError('plotting is out of scope')
+        """speech2text.py:494-503, called by train.py:484-487 every 10*print_step steps on rank 0.
+        Drawing the attention maps needs the probabilities the fused kernels never materialise (and
+        matplotlib); the training loop only needs the call to succeed: warn once, do nothing."""
+        self._warn_once('plot_attention')
 
     def plot_ctc(self):
-        raise NotImplementedError('plotting is out of scope')
+        """speech2text.py:505-511 (same call site)."""
+        self._warn_once('plot_ctc')
 
-    def decode(self, *a, **k):
-        raise NotImplementedError('decoding is inference-side and out of scope; load the '
-                                  'state_dict into the reference model to decode')
+    def _warn_once(self, what):
+        done = self.__dict__.setdefault('_warned', set())
+        if what not in done:
+            done.add(what)
+            logger.warning('%s() is a no-op in neural_sp_amd (attention / CTC posteriors are not '
+                           'kept on the HIP path); training continues' % what)
+
+    @staticmethod
+    def _param(params, key, default=None):
+        """recog_* hyper-parameters arrive as a dict, an argparse.Namespace or an OmegaConf DictConfig."""
+        if isinstance(params, dict):
+            return params.get(key, default)
+        if hasattr(params, 'get') and not isinstance(params, dict):
+            try:
+                v = params.get(key)
+                return default if v is None else v
+            except Exception:
+                pass
+        return getattr(params, key, default)
+
+    @torch.no_grad()
+    def decode(self, xs, params, idx2token=None, exclude_eos=False, refs_id=None, refs=None,
+               utt_ids=None, speakers=None, task='ys', ensemble_models=[], trigger_points=None,
+               teacher_force=False):
+        """speech2text.py:709-800 for GREEDY decoding (recog_beam_width == 1), which is what
+        validate() (train.py:341,513-557 -> evaluators/*.py) runs during training with the default
+        recog_* arguments: CTC best path (ctc.py:219-243) when the model is CTC-only or
+        recog_ctc_weight == 1, else the RNN-T frame-synchronous 1-best (rnn_transducer.py:330-382).
+        Returns (nbest_hyps_id `[B][1][L]`, aws None).  Beam search / LM fusion / streaming /
+        ensembles are inference-side and raise NotImplementedError."""
+        self.eval()
+        if task.split('.')[0] != 'ys':
+            raise NotImplementedError('decode(task=%s): sub-task decoders are not built' % task)
+        P = self._param
+        if P(params, 'recog_streaming_encoding', False) or P(params, 'recog_block_sync', False):
+            raise NotImplementedError('streaming encoding / block-synchronous decoding')
+        if len(ensemble_models) > 0:
+            raise NotImplementedError('ensemble decoding')
+        beam = P(params, 'recog_beam_width', 1)
+        eout_dict = self.encode(xs, task)
+        eouts, elens = eout_dict[task]['xs'], eout_dict[task]['xlens']
+        dec = self.dec_fwd
+        if (self.fwd_weight == 0 and self.bwd_weight == 0) or \
+                (self.ctc_weight > 0 and P(params, 'recog_ctc_weight', 0) == 1):
+            if beam != 1:
+                dec.ctc.beam_search()
+            return dec.ctc.greedy(eouts, elens), None
+        if beam != 1 or P(params, 'recog_fwd_bwd_attention', False):
+            dec.beam_search()
+        best_hyps_id, aws = dec.greedy(eouts, elens, P(params, 'recog_max_len_ratio', 1.0), idx2token,
+                                       exclude_eos, refs_id, utt_ids, speakers)
+        return [[hyp] for hyp in best_hyps_id], aws
 
     # ---- hot path
     def forward(self, batch, task, is_eval=False, teacher=None, teacher_lm=None):

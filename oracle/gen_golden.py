@@ -97,7 +97,22 @@ CASES = {
                                                            dec_n_units=256, dec_n_layers=2, emb_dim=64,
                                                            dec_bottleneck_dim=32),
                                dict(B=3, t_range=(90, 140), u_range=(4, 12), vocab=40, seed=10)),
+    # Transformer-XL style relative attention: separate w_pos projection + global u/v biases
+    # (relative_multihead_attention.py:176-190, transformer.py:283-286)
+    'conformer_relxl_ctc_xs': (lambda: conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=1.0,
+                                                           ctc_fc_list='', ctc_lsm_prob=0.0,
+                                                           transformer_enc_pe_type='relative_xl',
+                                                           conformer_kernel_size=7),
+                               dict(B=3, t_range=(40, 71), u_range=(2, 6), vocab=40, seed=11)),
+    # the reference's own initialisation (all biases zero): zero-padded frames stay EXACT zero rows
+    # through the first block's LayerNorms (eps = 1e-12 -> rstd = 1e6), so the
+    # gradients that flow through those rows are amplified by 1e6 -- pinned here, vocab 43 (% 8 != 0)
+    'conformer_rnnt_zero_bias_xs': (lambda: conformer_rnnt_args('XS', n_layers=2, vocab=43, ctc_weight=0.3,
+                                                                ctc_fc_list='', ctc_lsm_prob=0.1,
+                                                                conformer_kernel_size=7),
+                                    dict(B=4, t_range=(30, 83), u_range=(2, 7), vocab=43, seed=12)),
 }
+KEEP_REFERENCE_INIT = {'conformer_rnnt_zero_bias_xs'}
 
 
 def run_case(name):
@@ -113,6 +128,8 @@ def run_case(name):
     # make every parameter non-degenerate (biases are zero-initialised in the reference)
     with torch.no_grad():
         for n, p in model.named_parameters():
+            if name in KEEP_REFERENCE_INIT:
+                break
             if p.dim() == 1 and 'norm' not in n:
                 p.uniform_(-0.1, 0.1)
             elif p.dim() == 1:
@@ -167,10 +184,39 @@ def run_align():
     print('ctc_align -> %s' % path, tp.tolist())
 
 
+def run_decode():
+    """Greedy hypotheses of the reference's Speech2Text.decode (speech2text.py:709-800 ->
+    ctc.py:219-243 / rnn_transducer.py:330-382) on the weights and batches of existing fixtures."""
+    import argparse
+    import_reference()
+    install_rnnt_stub()
+    from neural_sp.models.seq2seq.speech2text import Speech2Text
+    params = {'recog_beam_width': 1, 'recog_ctc_weight': 0.0, 'recog_streaming_encoding': False,
+              'recog_fwd_bwd_attention': False, 'recog_max_len_ratio': 1.0, 'recog_bwd_attention': False,
+              'recog_batch_size': 1, 'recog_block_sync': False}
+    out = {'params': params, 'cases': {}}
+    for name in ('conformer_ctc_xs', 'conformer_rnnt_xs', 'conformer_rnnt_dk64_xs', 'transformer_ctc_xs'):
+        fix = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+        args = argparse.Namespace(**fix['args'])
+        model = Speech2Text(args)
+        model.load_state_dict(fix['state_dict'])
+        hyps, _ = model.decode(fix['batch']['xs'], dict(params), None, exclude_eos=True)
+        entry = {'default': [[[int(v) for v in h] for h in nb] for nb in hyps]}
+        if args.ctc_weight > 0 and args.ctc_weight < 1:
+            p2 = dict(params, recog_ctc_weight=1.0)     # CTC best path of a joint CTC/RNN-T model
+            hyps2, _ = model.decode(fix['batch']['xs'], p2, None, exclude_eos=True)
+            entry['ctc'] = [[[int(v) for v in h] for h in nb] for nb in hyps2]
+        out['cases'][name] = entry
+        print('%-28s %s' % (name, {k: [len(nb[0]) for nb in v] for k, v in entry.items()}))
+    torch.save(out, os.path.join(GOLDEN, 'decode_greedy.pt'))
+
+
 if __name__ == '__main__':
-    names = sys.argv[1:] or (list(CASES.keys()) + ['ctc_align'])
+    names = sys.argv[1:] or (list(CASES.keys()) + ['ctc_align', 'decode'])
     for name in names:
         if name == 'ctc_align':
             run_align()
+        elif name == 'decode':
+            run_decode()
         else:
             run_case(name)

@@ -4,8 +4,13 @@ loss, encoder output and every parameter gradient.
 
 Tolerances (stated, fp32): loss 1e-4 relative (north-star bar is 1e-3), encoder output
 2e-4 of its max magnitude, gradients 2e-3 of each tensor's max magnitude in the exact
-fp32-MFMA mode.  In bf16-MFMA mode (the throughput mode): loss 1e-2 relative, gradients
-compared by cosine similarity >= 0.99."""
+fp32-MFMA mode.  In bf16-MFMA mode (the throughput mode): loss 1e-3 relative (the north-star
+bar; full-size bf16 parity incl. gradient norms is in tests/test_fullsize_parity_gpu.py), gradients
+compared by cosine similarity >= 0.99 on these XS models (tensors of a few dozen elements).
+
+The floor of the per-tensor gradient scale is taken from the 90th percentile of the per-tensor
+maxima, not from the largest one: the zero-bias fixture has ONE tensor (enc.conv.bridge.bias)
+whose gradient is amplified 1e6x by the eps=1e-12 zero-variance LayerNorm rows."""
 import argparse
 import glob
 import os
@@ -43,6 +48,11 @@ def _run(fix, mode):
     return loss.item(), obs, eout['ys']['xs'].cpu(), eout['ys']['xlens'], grads, loss_eval.item()
 
 
+def _robust_gmax(grads):
+    m = sorted(g.abs().max().item() for g in grads.values())
+    return m[int(0.9 * (len(m) - 1))]
+
+
 @pytest.mark.parametrize('name', CASES)
 def test_golden_fp32(name):
     fix = _load(name)
@@ -59,7 +69,7 @@ def test_golden_fp32(name):
     assert set(grads) == set(fix['grads'])
     # tensors whose true gradient is zero (e.g. w_key.bias: softmax is shift-invariant) hold
     # only rounding noise in the reference, so the floor of the scale is 1e-5 of the largest grad
-    gmax = max(g.abs().max().item() for g in fix['grads'].values())
+    gmax = _robust_gmax(fix['grads'])
     err = {n: ((grads[n] - g).abs().max() / max(g.abs().max().item(), 1e-5 * gmax)).item()
            for n, g in fix['grads'].items()}
     bad = {n: e for n, e in err.items() if e > 2e-3}
@@ -71,12 +81,14 @@ def test_golden_bf16(name):
     fix = _load(name)
     loss, obs, eout, elens, grads, _ = _run(fix, 'bf16')
     ref = fix['loss'].item()
-    assert abs(loss - ref) / abs(ref) < 1e-2, (loss, ref)
+    assert abs(loss - ref) / abs(ref) < 1e-3, (loss, ref)
     cos = {}
-    gmax = max(g.abs().max().item() for g in fix['grads'].values())
+    gmax = _robust_gmax(fix['grads'])
     for n, g in fix['grads'].items():
         if g.numel() < 16 or g.abs().max() < 1e-5 * gmax:
             continue
         cos[n] = torch.nn.functional.cosine_similarity(grads[n].flatten(), g.flatten(), dim=0).item()
     bad = {n: c for n, c in cos.items() if c < 0.99}
+    print('[golden bf16 %s] loss rel %.2e, min cosine %.5f over %d tensors' % (
+        name, abs(loss - ref) / abs(ref), min(cos.values()), len(cos)))
     assert not bad, bad
