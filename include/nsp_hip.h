@@ -221,14 +221,19 @@ int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
  *   qkv  bf16 [B*T, 3d]: q | k | v column blocks, head h at +h*64           *
  *   QP   fp32 [B,T,H,r_pitch] position scores (NULL for plain MHA); needs    *
  *        clamp > 0 and R <= 16                                              *
- *   O    bf16 [B*T, d] context; LSE fp32 [2,B,H,T]: row max and 1/row-sum    *
+ *   O    bf16 [B*T, d] context (operand of the output projection);          *
+ *   O32  fp32 [B*T, d] the same context un-rounded (may be NULL in inference): *
+ *        backward forms D_i = dO_i . O_i from it -- the probabilities enter   *
+ *        P V as a bf16 hi+lo pair so that D matches sum_j P_ij dP_ij of the   *
+ *        recomputed P to ~2^-17 (softmax shift invariance, see flash_attn.hip) *
+ *   LSE  fp32 [2,B,H,T]: row max (log2 domain) and 1/row-sum                  *
  * Backward: dqkv bf16 [B*T,3d] receives dK (block d) and dV (block 2d);      *
  * dq32 fp32 [B*T,d] and dQP [B,T,H,r_pitch] are written (no zero-init);      *
  * D is scratch [B,H,T].  Masks / dropout as in nsp_attn_softmax_*.          *
  * ------------------------------------------------------------------------ */
-int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* LSE,
+int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* O32, float* LSE,
                        const nsp_attn_mask_params* p, void* stream);
-int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const void* O,
+int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const float* O32,
                        const float* LSE, float* D, void* dqkv, float* dq32, float* dQP,
                        const nsp_attn_mask_params* p, void* stream);
 

@@ -144,7 +144,8 @@ __device__ __forceinline__ unsigned fa_rowhash(const nsp_attn_mask_params& p, in
 
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict__ qkv, int d,
                                                         const float* __restrict__ QP,
-                                                        __bf16* __restrict__ O, float* __restrict__ LSE,
+                                                        __bf16* __restrict__ O, float* __restrict__ O32,
+                                                        float* __restrict__ LSE,
                                                         const nsp_attn_mask_params p) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * KP];
@@ -214,7 +215,13 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
     float rs = 0.f;
-    bf16x8 Pf[2];
+    // The probabilities enter P V as a bf16 PAIR hi + lo (two MFMAs): O then carries P to ~2^-17
+    // instead of 2^-9.  Backward's D_i = dO_i . O_i must equal sum_j P_ij dP_ij of the RECOMPUTED fp32
+    // P to far better than bf16 precision: dS = P (dP - D) sums to zero over keys only then, and any
+    // residue multiplies the component common to all keys / queries (large once biases are non-zero),
+    // which the softmax's shift invariance removes from the true gradient (measured: w_query / w_key
+    // gradients of the upper Conformer-L blocks at cosine 0.45 with a single bf16 P).
+    bf16x8 Pf[2], Pl[2];
     float kp[4][4];
     if (drop) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
 #pragma unroll
@@ -224,7 +231,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
         float pr = __builtin_amdgcn_exp2f(ev[kf][e] - m_new);
         rs += pr;
         if (drop) pr *= kp[kf][e];
-        Pf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)pr;
+        const __bf16 hi = (__bf16)pr;
+        Pf[kf >> 1][(kf & 1) * 4 + e] = hi;
+        Pl[kf >> 1][(kf & 1) * 4 + e] = (__bf16)(pr - (float)hi);
       }
     rs += __shfl_xor(rs, 16, 64);
     rs += __shfl_xor(rs, 32, 64);
@@ -238,19 +247,23 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
 #pragma unroll
     for (int ddf = 0; ddf < 4; ++ddf)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        o_acc[ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            frag_tr(Vs, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), Pf[s], o_acc[ddf], 0, 0, 0);
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 vT = frag_tr(Vs, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r);
+        o_acc[ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pf[s], o_acc[ddf], 0, 0, 0);
+        o_acc[ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pl[s], o_acc[ddf], 0, 0, 0);
+      }
   }
   if (qi < T) {
     const float inv = nsp_rcp(l_run);
     __bf16* op = O + (brow0 + qi) * d + h * DK;
+    float* op32 = O32 ? O32 + (brow0 + qi) * d + h * DK : nullptr;
 #pragma unroll
     for (int ddf = 0; ddf < 4; ++ddf) {
+      const float4 o = make_float4(o_acc[ddf][0] * inv, o_acc[ddf][1] * inv, o_acc[ddf][2] * inv, o_acc[ddf][3] * inv);
       bf16x4 o4;
-      o4[0] = (__bf16)(o_acc[ddf][0] * inv); o4[1] = (__bf16)(o_acc[ddf][1] * inv);
-      o4[2] = (__bf16)(o_acc[ddf][2] * inv); o4[3] = (__bf16)(o_acc[ddf][3] * inv);
+      o4[0] = (__bf16)o.x; o4[1] = (__bf16)o.y; o4[2] = (__bf16)o.z; o4[3] = (__bf16)o.w;
       *reinterpret_cast<bf16x4*>(op + ddf * 16 + 4 * g) = o4;
+      if (op32) *reinterpret_cast<float4*>(op32 + ddf * 16 + 4 * g) = o;   // backward's D reads this one
     }
     if (g == 0) {
       // row max and 1/sum are kept SEPARATELY: for a fully masked row max = -FLT_MAX and
@@ -263,16 +276,17 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
   }
 }
 
-// D[b,h,i] = sum_dd dO[i,dd] * O[i,dd]   (one wave per (b,i,h) row of 64)
+// D[b,h,i] = sum_dd dO[i,dd] * O[i,dd]   (one wave per (b,i,h) row of 64); O is the forward's
+// fp32 output (see the hi/lo note there), dO the bf16 image the dP MFMAs consume
 __global__ __launch_bounds__(256) void flash_dot_kernel(const __bf16* __restrict__ dO,
-                                                        const __bf16* __restrict__ O, float* __restrict__ D,
+                                                        const float* __restrict__ O, float* __restrict__ D,
                                                         int B, int T, int H, int d) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long n = (long long)B * T * H;
   for (long long row = (long long)blockIdx.x * 4 + w; row < n; row += (long long)gridDim.x * 4) {
     const int hh = (int)(row % H);
     const long long bt = row / H;
-    const float v = (float)dO[bt * d + hh * DK + lane] * (float)O[bt * d + hh * DK + lane];
+    const float v = (float)dO[bt * d + hh * DK + lane] * O[bt * d + hh * DK + lane];
     const float s = wave_reduce_sum(v);
     if (lane == 0) {
       const long long b = bt / T, i = bt % T;
@@ -521,7 +535,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
 
 }  // namespace
 
-extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* LSE,
+extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* O32, float* LSE,
                                   const nsp_attn_mask_params* pp, void* stream) {
   if (!pp || !qkv || !O || !LSE) return NSP_EINVAL;
   nsp_attn_mask_params p = *pp;
@@ -531,17 +545,17 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
   if (p.r_pitch < p.R) p.r_pitch = p.R;
   dim3 grid((p.Tq + 63) / 64, p.H, p.B);
   hipLaunchKernelGGL(flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), LSE, p);
+                     reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE, p);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
 
 // dq32 [B*T, d] fp32 and dQP are plainly written (no zero-init needed); dqkv receives dK at
 // column block d and dV at 2d (bf16); D is scratch [B,H,T].
-extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const void* O,
+extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const float* O32,
                                   const float* LSE, float* D, void* dqkv, float* dq32, float* dQP,
                                   const nsp_attn_mask_params* pp, void* stream) {
-  if (!pp || !qkv || !dO || !O || !LSE || !D || !dqkv || !dq32) return NSP_EINVAL;
+  if (!pp || !qkv || !dO || !O32 || !LSE || !D || !dqkv || !dq32) return NSP_EINVAL;
   nsp_attn_mask_params p = *pp;
   if (p.Tq != p.Tk || d != p.H * DK) return NSP_EUNSUPPORTED;
   if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16)) return NSP_EUNSUPPORTED;
@@ -552,7 +566,7 @@ extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const
   int g1 = nsp_cdiv(n, 4);
   if (g1 > 8192) g1 = 8192;
   hipLaunchKernelGGL(flash_dot_kernel, dim3(g1), dim3(256), 0, st, reinterpret_cast<const __bf16*>(dO),
-                     reinterpret_cast<const __bf16*>(O), D, p.B, p.Tq, p.H, d);
+                     O32, D, p.B, p.Tq, p.H, d);
   dim3 grid((p.Tq + 63) / 64, p.H, p.B);
   hipLaunchKernelGGL(flash_bwd_dkv_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
                      QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);

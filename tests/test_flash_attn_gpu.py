@@ -59,13 +59,14 @@ def test_flash_attention_matches_reference(T, with_pos, causal, nc):
     mp = ops._mask_params(B, H, T, T, R if with_pos else 0, clamp if with_pos else -1, scale, klens, causal, 1,
                           nl, nc, r_pitch=Rp if with_pos else 0)
     qkv2 = qkv.view(B * T, 3 * d)
-    O, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP if with_pos else None, mp)
+    O, O32, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP if with_pos else None, mp)
+    assert _rel(O32.view(B, T, d), Oref.detach()) < 1e-4      # hi+lo P: fp32-grade context
     assert _rel(O.float().view(B, T, d), Oref.detach()) < 1.5e-2
     lse = LSE[0] * math.log(2.0) - torch.log(LSE[1])   # LSE[0]: row max in the log2 domain
     ok = LSEref.detach() > -1e30  # fully masked rows: max + log(sum) is not representable in fp32
     assert _rel(lse[ok], LSEref.detach()[ok]) < 1e-3
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
-    dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP if with_pos else None, dO.view(B * T, d), O, LSE, mp, dqkv)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP if with_pos else None, dO.view(B * T, d), O32, LSE, mp, dqkv)
     g = grads[0].view(B * T, 3 * d)
     assert _rel(dq32, g[:, :d]) < 2e-2, 'dq'
     assert _rel(dqkv[:, d:2 * d].float(), g[:, d:2 * d]) < 2e-2, 'dk'
@@ -97,7 +98,7 @@ def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward
                           offset=5 << 40, r_pitch=Rp)
     eye = torch.eye(T, dk, device=dev).repeat(1, H)[None].expand(B, T, d)            # V[j] = e_j per head
     qkv_eye = torch.cat([qk, eye.bfloat16()], dim=-1).contiguous().view(B * T, 3 * d)
-    Pd, _ = ops.flash_attn_fwd_raw(qkv_eye, d, QP, mp)                               # [B*T, d]: Pdrop[b,i,h,j]
+    Pd, _, _ = ops.flash_attn_fwd_raw(qkv_eye, d, QP, mp)                               # [B*T, d]: Pdrop[b,i,h,j]
     Pd = Pd.float().view(B, T, H, T).permute(0, 2, 1, 3)                             # [B,H,i,j]
     q32 = qk.float()
     e = torch.einsum('bihd,bjhd->bhij', q32[..., :d].reshape(B, T, H, dk), q32[..., d:].reshape(B, T, H, dk))
@@ -124,10 +125,10 @@ def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward
     Oref = torch.einsum('bhij,bjhd->bihd', P2, vv).reshape(B, T, d)
     dO = torch.randn_like(Oref).bfloat16()
     gx, gqp = torch.autograd.grad(Oref, [x32, QPr], dO.float())
-    O, LSE = ops.flash_attn_fwd_raw(qkv.view(B * T, 3 * d), d, QP, mp)
+    O, O32, LSE = ops.flash_attn_fwd_raw(qkv.view(B * T, 3 * d), d, QP, mp)
     assert _rel(O.float().view(B, T, d), Oref.detach()) < 2e-2
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
-    dq32, dQP = ops.flash_attn_bwd_raw(qkv.view(B * T, 3 * d), d, QP, dO.view(B * T, d), O, LSE, mp, dqkv)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv.view(B * T, 3 * d), d, QP, dO.view(B * T, d), O32, LSE, mp, dqkv)
     g = gx.view(B * T, 3 * d)
     assert _rel(dq32, g[:, :d]) < 3e-2, 'dq'
     assert _rel(dqkv[:, d:2 * d].float(), g[:, d:2 * d]) < 3e-2, 'dk'
@@ -142,14 +143,60 @@ def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward
     mp = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, dropout_p=pdrop, seed=99,
                           offset=7 << 40, r_pitch=Rp)
     mp0 = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, r_pitch=Rp)
-    O1, LSE1 = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
-    O2, _ = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
-    O0, _ = ops.flash_attn_fwd_raw(qkv, d, QP, mp0)
+    O1, O1_32, LSE1 = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
+    O2, _, _ = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
+    O0, _, _ = ops.flash_attn_fwd_raw(qkv, d, QP, mp0)
     assert torch.equal(O1, O2)
     assert _rel(O1.float(), O0.float()) > 0.05          # dropout does something
     dO = torch.randn(B * T, d, device=dev).bfloat16()
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
-    ops.flash_attn_bwd_raw(qkv, d, QP, dO, O1, LSE1, mp, dqkv)
+    ops.flash_attn_bwd_raw(qkv, d, QP, dO, O1_32, LSE1, mp, dqkv)
     lhs = (dO.float() * O1.float()).sum().item()
     rhs = (dqkv[:, 2 * d:].float() * qkv[:, 2 * d:].float()).sum().item()
     assert abs(lhs - rhs) / abs(lhs) < 2e-2, (lhs, rhs)
+
+
+@pytest.mark.parametrize('T,H,B', [(200, 2, 3), (800, 8, 2)])
+def test_flash_attention_backward_keeps_softmax_shift_invariance(T, H, B):
+    """q and k with a LARGE component common to all positions (what non-zero LayerNorm / projection
+    biases produce).  softmax(q.(k+c)) = softmax(q.k): the true dq is orthogonal to the common key,
+    sum_j dk_j = 0 -- any inconsistency between D_i = dO_i.O_i and sum_j P_ij dP_ij leaks D-error x
+    common component into dq / dk.  With a single bf16 P in the forward this test sees cosines of
+    ~0.5 against the fp32 reference; with the hi+lo pair (fp32-grade O) they are >= 0.999.
+    (T=800, H=8 is the first-stage shape of Conformer-L.)"""
+    from neural_sp_amd import ops
+    torch.manual_seed(T + H)
+    dev = torch.device('cuda:0')
+    dk, clamp = 64, 10
+    d = H * dk
+    R, Rp = clamp + 1, 16
+    qkv = torch.randn(B, T, 3 * d, device=dev) * 0.4
+    qkv[..., :d] += torch.randn(1, 1, d, device=dev) * 1.5          # common query component
+    qkv[..., d:2 * d] += torch.randn(1, 1, d, device=dev) * 1.5     # common key component
+    qkv = qkv.bfloat16()
+    QP = torch.zeros(B, T, H, Rp, device=dev)
+    QP[..., :R] = torch.randn(B, T, H, R, device=dev)
+    klens = torch.tensor([T, max(1, T - 37), max(1, T // 3)][:B], device=dev, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(dk)
+    q32 = qkv.float().requires_grad_()
+    QPr = QP.clone().requires_grad_()
+    Oref, _ = _reference(q32, QPr, klens, H, clamp, scale, False, 0, 0, 0)
+    dO = torch.randn_like(Oref).bfloat16()
+    g, gqp = torch.autograd.grad(Oref, [q32, QPr], dO.float())
+    g = g.view(B * T, 3 * d)
+    mp = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, r_pitch=Rp)
+    qkv2 = qkv.view(B * T, 3 * d)
+    O, O32, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP, mp)
+    dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP, dO.view(B * T, d), O32, LSE, mp, dqkv)
+
+    def cos(a, b):
+        return torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+    c = {'dq': cos(dq32, g[:, :d]), 'dk': cos(dqkv[:, d:2 * d].float(), g[:, d:2 * d]),
+         'dv': cos(dqkv[:, 2 * d:].float(), g[:, 2 * d:]), 'dQP': cos(dQP[..., :R], gqp[..., :R])}
+    # what the weight gradients see: dq / dk contracted with an input that ALSO has a common component
+    x = torch.randn(B * T, 96, device=dev) + 2.0
+    c['x^T dq'] = cos(x.t() @ dq32, x.t() @ g[:, :d])
+    c['x^T dk'] = cos(x.t() @ dqkv[:, d:2 * d].float(), x.t() @ g[:, d:2 * d])
+    print('[flash shift-invariance T=%d H=%d] cosines %s' % (T, H, {k: round(v, 5) for k, v in c.items()}))
+    assert min(c.values()) > 0.999, c
