@@ -1716,7 +1716,7 @@ class SelfAttnFn(torch.autograd.Function):
         P16 = Pd16 = LSE = cv32 = None
         if fused:
             # flash-style kernel: scores / probabilities never leave the CU
-            cv16, cv32, LSE = flash_attn_fwd_raw(qkv, d, QP, mp, want_o32=torch.is_grad_enabled())
+            cv16, cv32, LSE = flash_attn_fwd_raw(qkv, d, QP, mp, want_o32=any(ctx.needs_input_grad))
             aw = None
         else:
             S = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)
