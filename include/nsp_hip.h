@@ -91,7 +91,25 @@ typedef struct {
   /* split-K without atomics: if c_ss != 0 split s stores its alpha-scaled partial tile at
    * C + s*c_ss (fp32); the caller sums the splitk slabs with nsp_splitk_reduce. */
   long long c_ss;
+  /* RNN-T joint epilogues: set only by nsp_rnnt_joint_gemm (NSP_EPI_NONE = the epilogue above).
+   * N is the PADDED vocabulary width (multiple of 64), epi_ncols the real one.
+   *   NSP_EPI_RNNT_LSE    : nothing is stored to C.  Per row and 64-column block: (max, sum exp(.-max))
+   *                         -> epi_f0 [M, N/64, 2]; logit at column epi_blank -> epi_f1 [M]; logit at
+   *                         column epi_lab[m] (>= 0) -> epi_f2 [M].
+   *   NSP_EPI_RNNT_DLOGITS: C (bf16 [M, ldc = N]) <- scale * (-(gb+gl) exp(logit - lse) + gb [n=blank]
+   *                         + gl [n=lab]) with lse = epi_f0 [M], gb = epi_f1 [M], gl = epi_f2 [M], zeros
+   *                         in the pad columns; column sums of every 64-row block -> epi_f3
+   *                         [ceil(M/128)*2, N] (output-bias gradient slabs, no atomics).
+   *   scale = epi_scale * (epi_scale_dev ? *epi_scale_dev : 1).                                  */
+  int epi_mode, epi_ncols, epi_blank;
+  const int* epi_lab;
+  float* epi_f0; float* epi_f1; float* epi_f2; float* epi_f3;
+  const float* epi_scale_dev;
+  float epi_scale;
 } nsp_gemm_params;
+#define NSP_EPI_NONE 0
+#define NSP_EPI_RNNT_LSE 1
+#define NSP_EPI_RNNT_DLOGITS 2
 
 /* out[i] = sum_s part[s*n + i] (i < n): the deterministic reduction of split-K slabs */
 int nsp_splitk_reduce(const float* part, float* out, int splits, long long n, void* stream);
@@ -355,6 +373,35 @@ int nsp_rnnt_joint_tanh_bwd(const float* h, const void* h16, float* dh, float* d
  * `nslab` partial sums over time of dg[b,u,:] = sum_t dz (slab z = steps [z*ceil(T/nslab), ...),
  * each [B,U1,J] fp32; nslab slabs are always written; sum them with nsp_splitk_reduce).
  * J % 32 == 0, U1 <= 512. */
+/* ---- fused / compacted RNN-T joint (bf16 throughput mode): the [B,T,U+1,V] logit tensor is never  *
+ * written (rnn_transducer.py:239-242,262-276 materialise it twice: logits and log_softmax).         *
+ * Lattice nodes are stored COMPACTED: utterance b owns rows roff[b] .. roff[b+1] laid out           *
+ * [T_b][U_b+1] (t-major); padded nodes do not exist.  M = roff[B].                                   *
+ *   nsp_rnnt_joint_tanh_compact: h16[row] = bf16 tanh(e[b,t,:] + g[b,u,:]) (J % 8 == 0);             *
+ *        lab[row] = labels[b,u] for u < U_b, -1 at u = U_b.  e [B,T,J], g [B,U1,J] fp32.             *
+ *   nsp_rnnt_joint_gemm: logits = h16 W^T + b on the bf16 MFMA GEMM with the NSP_EPI_RNNT_* epilogues *
+ *        (mode LSE in forward; mode DLOGITS recomputes the logit tiles in backward and emits the     *
+ *        bf16 gradient image d16 [M,Vp] + bias-gradient slabs).  w16 bf16 [Vp,J] zero-padded rows,   *
+ *        bias [Vp] fp32; f0..f3 as documented at nsp_gemm_params.                                    *
+ *   nsp_rnnt_lse_merge: partials -> lse [M], lp_blank = raw_b - lse, lp_label = raw_l - lse (-inf at  *
+ *        lab < 0), in place over raw_b / raw_l.                                                      *
+ *   nsp_rnnt_lattice_compact: alpha / beta / nll / occupancies on the compact layout.                *
+ *   nsp_rnnt_joint_dz_reduce_compact: de[b,t,:] = sum_u dz, dg slabs [nslab][B,U1,J] = sum_t dz      *
+ *        (zeros at padded t / u), dz bf16 [M,J].                                                     */
+int nsp_rnnt_joint_tanh_compact(const float* e, const float* g, const int* labels /*[B,U1-1]*/,
+                                const int* elens, const int* ylens, const long long* roff /*[B+1]*/,
+                                void* h16, int* lab, int B, int T, int U1, int J, void* stream);
+int nsp_rnnt_joint_gemm(int epi_mode, const void* h16, const void* w16, const float* bias, long long M,
+                        int V, int Vp, int J, int blank, const int* lab, float* f0, float* f1, float* f2,
+                        float* f3, void* d16, float scale, const float* scale_dev, void* stream);
+int nsp_rnnt_lse_merge(const float* part, int npart, float* lse, float* raw_b_to_lpb, float* raw_l_to_lpl,
+                       const int* lab, long long M, void* stream);
+int nsp_rnnt_lattice_compact(const float* lp_blank, const float* lp_label, const int* elens, const int* ylens,
+                             const long long* roff, float* alpha, float* beta, float* nll, float* g_blank,
+                             float* g_label, int B, int U1max, void* stream);
+int nsp_rnnt_joint_dz_reduce_compact(const void* dz16, const int* elens, const int* ylens, const long long* roff,
+                                     float* de, float* dg_slabs, int nslab, int B, int T, int U1, int J,
+                                     void* stream);
 int nsp_rnnt_joint_dz_reduce(const void* dz16, float* de, float* dg_slabs, int nslab, int B, int T,
                              int U1, int J, void* stream);
 

@@ -93,6 +93,11 @@ class GemmParams(ctypes.Structure):
         ('a_dtype', ctypes.c_int), ('b_dtype', ctypes.c_int), ('c_dtype', ctypes.c_int),
         ('pre_dtype', ctypes.c_int), ('dact_dtype', ctypes.c_int),
         ('c_ss', ctypes.c_longlong),
+        ('epi_mode', ctypes.c_int), ('epi_ncols', ctypes.c_int), ('epi_blank', ctypes.c_int),
+        ('epi_lab', ctypes.c_void_p),
+        ('epi_f0', ctypes.c_void_p), ('epi_f1', ctypes.c_void_p), ('epi_f2', ctypes.c_void_p),
+        ('epi_f3', ctypes.c_void_p),
+        ('epi_scale_dev', ctypes.c_void_p), ('epi_scale', ctypes.c_float),
     ]
 
 

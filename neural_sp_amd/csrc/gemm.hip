@@ -388,5 +388,7 @@ extern "C" int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs,
   p.seed = seed; p.offset = offset;
   p.a_dtype = a_dtype; p.b_dtype = b_dtype; p.c_dtype = c_dtype; p.pre_dtype = pre_dtype;
   p.dact_dtype = dact_dtype; p.c_ss = c_ss;
+  p.epi_mode = NSP_EPI_NONE; p.epi_ncols = 0; p.epi_blank = 0; p.epi_lab = nullptr;
+  p.epi_f0 = p.epi_f1 = p.epi_f2 = p.epi_f3 = nullptr; p.epi_scale_dev = nullptr; p.epi_scale = 1.f;
   return nsp_gemm(&p, stream);
 }

@@ -144,11 +144,115 @@ __device__ __forceinline__ void load4(const void* base, int dtype, long long off
   }
 }
 
+// ---- RNN-T joint epilogues (nsp_gemm_params::epi_mode, nsp_rnnt_joint_gemm): the tile holds logits
+// of 16*MI x 64 (rows = compacted lattice nodes, cols = vocabulary) per wave.  Same LDS staging as
+// the standard epilogue: after the read-back the 16 lanes (lane & 15) of one row group hold the 64
+// columns of one row, so row statistics are 4 xor-shuffles.
+//   LSE     : per row (max, sum exp) of this 64-column block + the raw logits at the blank / label
+//             columns.  Nothing of the [M, V] logit matrix reaches HBM (128 B of partials per row
+//             instead of 4 KB of fp32 logits).
+//   DLOGITS : d loss / d logits from the recomputed tile, written as the bf16 operand image of the
+//             two gradient GEMMs; column sums (output-bias gradient) per 64-row block, no atomics.
+template <int MI>
+__device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], unsigned char* smem,
+                                              int m0, int n0, int wm, int wn, int lane, int wave) {
+  const int fr = lane & 15, fg = lane >> 4;
+  constexpr int SP = 68;
+  float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
+  const int er = lane >> 4, ec = (lane & 15) * 4;
+  const int n = n0 + wn * 64 + ec;                   // first of this lane's 4 columns (n + 3 < N: N % 64 == 0)
+  const bool lse_mode = p.epi_mode == NSP_EPI_RNNT_LSE;
+  const int npart = p.N >> 6, pidx = (n0 >> 6) + wn;
+  float b4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && n < p.N) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
+  }
+  const float sc = lse_mode ? 1.f : p.epi_scale * (p.epi_scale_dev ? p.epi_scale_dev[0] : 1.f);
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      *reinterpret_cast<float4*>(stage + fr * SP + ni * 16 + fg * 4) =
+          make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = er + 4 * j;
+      const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
+      const int m = m0 + wm * (16 * MI) + mi * 16 + row;
+      const bool rowok = m < p.M && n < p.N;
+      float v[4] = {a4.x + b4[0], a4.y + b4[1], a4.z + b4[2], a4.w + b4[3]};
+      if (lse_mode) {
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < p.epi_ncols) mx = fmaxf(mx, v[e]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n + e < p.epi_ncols) sm += __expf(v[e] - mx);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
+        if (rowok) {
+          if ((lane & 15) == 0)
+            *reinterpret_cast<float2*>(p.epi_f0 + ((long long)m * npart + pidx) * 2) = make_float2(mx, sm);
+          const int lab = p.epi_lab[m];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e == p.epi_blank) p.epi_f1[m] = v[e];
+            if (n + e == lab) p.epi_f2[m] = v[e];
+          }
+        }
+      } else {
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rowok) {
+          const float ls = p.epi_f0[m];
+          const float gb = p.epi_f1[m] * sc, gl = p.epi_f2[m] * sc;
+          const int lab = p.epi_lab[m];
+          const float gs = gb + gl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < p.epi_ncols) {
+              float t = -gs * __expf(v[e] - ls);
+              if (n + e == p.epi_blank) t += gb;
+              if (n + e == lab) t += gl;
+              g[e] = t;
+            }
+          }
+          bf16x4 o;
+          o[0] = (__bf16)g[0]; o[1] = (__bf16)g[1]; o[2] = (__bf16)g[2]; o[3] = (__bf16)g[3];
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C) + (long long)m * p.ldc + n) = o;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] += g[e];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!lse_mode && p.epi_f3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      csum[e] += __shfl_xor(csum[e], 16, 64);
+      csum[e] += __shfl_xor(csum[e], 32, 64);
+    }
+    if (lane < 16 && n < p.N) {
+      const long long slab = (long long)(m0 / (32 * MI)) * 2 + wm;
+      *reinterpret_cast<float4*>(p.epi_f3 + slab * p.N + n) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+    }
+  }
+}
+
 // ---- shared epilogue (see the comment inside): acc[mi][ni] -> global with full-line accesses
 template <int MI>  // MI 16-row fragments per wave along M (wave tile = 16*MI x 64)
 __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4],
                                               unsigned char* smem, int m0, int n0, int wm, int wn,
                                               int lane, int wave, long long coff, int c_vec) {
+  if (p.epi_mode != NSP_EPI_NONE) {
+    rnnt_epilogue<MI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+    return;
+  }
   const int fr = lane & 15, fg = lane >> 4;
   // ---- epilogue.  The MFMA leaves lane (fr, fg) with C[m0+..+fr][n .. n+3]: storing that
   // directly makes every store instruction touch 16 different rows with 16..64 B each
@@ -687,7 +791,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     }
     const long long wgs = (long long)grid.x * grid.z;
     const int nkt = p.K / BK / p.splitk;
-    if (ring_env && wgs < 192 && p.M > 64 && nkt >= 4) {
+    if (ring_env && wgs < 192 && p.M > 64 && nkt >= 4 && p.epi_mode == NSP_EPI_NONE) {
       tiles_m = nsp_cdiv(p.M, 64);
       grid.x = tiles_m * tiles_n;
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 2>), grid, block, 4 * 24576, st, p, tiles_m, tiles_n, c_vec);

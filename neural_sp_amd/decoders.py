@@ -308,7 +308,7 @@ class RNNTransducer(DecoderBase):
 
     def forward_transducer(self, eouts, elens, ys):
         dev = eouts.device
-        lab, ylens_dev, _ = _labels_to_device(ys, dev, pad=self.blank)         # ys_out, blank-padded
+        lab, ylens_dev, ylens = _labels_to_device(ys, dev, pad=self.blank)     # ys_out, blank-padded
         elens_dev = ops.h2d(elens, dev, torch.int32)
         pending = getattr(self, '_pending_dec_proj', None)
         self._pending_dec_proj = None
@@ -325,7 +325,8 @@ class RNNTransducer(DecoderBase):
             dec_proj = self._prediction_network(ys, dev)                        # `[B,L+1,J]`
         enc_proj = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias)       # `[B,T,J]`
         loss, _ = ops.rnnt_joint_loss(enc_proj, dec_proj, self.output.weight, self.output.bias,
-                                      lab, elens_dev, ylens_dev, self.blank)
+                                      lab, elens_dev, ylens_dev, self.blank,
+                                      elens_host=elens.tolist(), ylens_host=ylens)
         return loss
 
     # ---- greedy decoding (validate() -> evaluators -> Speech2Text.decode)

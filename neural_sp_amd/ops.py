@@ -1104,7 +1104,149 @@ class RNNTJointLossFn(torch.autograd.Function):
         return de, dg, dw.view(w_out.shape), db, None, None, None, None
 
 
-def rnnt_joint_loss(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blank=0):
+def _rows_padded_bf16(w, mult):
+    """bf16 shadow of a [N,K] parameter with N zero-padded to a multiple of `mult` (cached like weight_bf16)."""
+    wb = weight_bf16(w)
+    N = wb.shape[0]
+    Np = (N + mult - 1) // mult * mult
+    if Np == N:
+        return wb
+    ent = getattr(w, '_nsp_rowpad16', None)
+    if ent is not None and ent[0] == w._version and ent[1].device == w.device and ent[1].shape[0] == Np:
+        return ent[1]
+    out = torch.zeros((Np, wb.shape[1]), device=wb.device, dtype=torch.bfloat16)
+    out[:N] = wb
+    try:
+        w._nsp_rowpad16 = (w._version, out)
+    except Exception:
+        pass
+    return out
+
+
+def _vec_padded(b, n, device):
+    """fp32 [n] copy of a 1-D parameter (zeros beyond its length / if None), cached on the parameter."""
+    if b is None:
+        return torch.zeros((n,), device=device, dtype=torch.float32)
+    ent = getattr(b, '_nsp_vecpad', None)
+    if ent is not None and ent[0] == b._version and ent[1].device == b.device and ent[1].numel() == n:
+        return ent[1]
+    out = torch.zeros((n,), device=b.device, dtype=torch.float32)
+    out[:b.numel()] = b.detach()
+    try:
+        b._nsp_vecpad = (b._version, out)
+    except Exception:
+        pass
+    return out
+
+
+class RNNTJointLossFusedFn(torch.autograd.Function):
+    """mean_b -log P(y_b | x_b) of the RNN-Transducer WITHOUT the [B,T,U+1,V] logit tensor
+    (rnn_transducer.py:239-256,262-276), bf16 throughput mode (csrc/rnnt_fused.hip):
+
+      h = tanh(enc_proj[b,t] + dec_proj[b,u]) for the VALID lattice nodes only, stored compacted as
+      bf16 [M, J] (utterance b: rows roff[b].., dense [T_b][U_b+1]);  the logit GEMM h W_out^T + b
+      keeps per-row (max, sum exp) partials + the blank / label logits in its epilogue; lattice;
+      backward runs the same GEMM again and its epilogue emits d loss/d logits as the bf16 operand of
+      the weight-gradient / data-gradient GEMMs (tanh' fused in the latter's epilogue), then one pass
+      over dz gives both joint-input gradients."""
+
+    @staticmethod
+    def forward(ctx, enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blank, elens_host, ylens_host):
+        enc_proj, dec_proj = _f32c(enc_proj), _f32c(dec_proj)
+        B, T, J = enc_proj.shape
+        U1 = dec_proj.shape[1]
+        V = w_out.shape[0]
+        Vp = (V + 63) // 64 * 64
+        dev = enc_proj.device
+        L = _lib.lib()
+        Tb = [min(int(t), T) for t in elens_host]
+        Ub = [min(int(u), U1 - 1) for u in ylens_host]
+        roff_h = np.zeros((B + 1,), dtype=np.int64)
+        np.cumsum([t * (u + 1) for t, u in zip(Tb, Ub)], out=roff_h[1:])
+        M = int(roff_h[-1])
+        roff = h2d(roff_h, dev)
+        if labels.shape[1] != U1 - 1:
+            # labels arrive as [B, max(1, Umax)]; the kernels index them with pitch U1 - 1
+            lab2 = torch.zeros((B, max(1, U1 - 1)), device=dev, dtype=torch.int32)
+            w = min(lab2.shape[1], labels.shape[1])
+            lab2[:, :w] = labels[:, :w]
+            labels = lab2
+        h16 = torch.empty((max(M, 1), J), device=dev, dtype=torch.bfloat16)
+        lab = torch.empty((max(M, 1),), device=dev, dtype=torch.int32)
+        _check(L.nsp_rnnt_joint_tanh_compact(_p(enc_proj), _p(dec_proj), _p(labels), _p(elens), _p(ylens), _p(roff),
+                                             _p(h16), _p(lab), B, T, U1, J, _stream()), 'nsp_rnnt_joint_tanh_compact')
+        w16 = _rows_padded_bf16(w_out, 64)                                   # [Vp, J]
+        bias = _vec_padded(b_out, Vp, dev)
+        npart = Vp // 64
+        part = torch.empty((max(M, 1), npart, 2), device=dev, dtype=torch.float32)
+        aux = torch.empty((7, max(M, 1)), device=dev, dtype=torch.float32)   # lse, lpb, lpl, alpha, beta, gb, gl
+        nll = torch.empty((B,), device=dev, dtype=torch.float32)
+        _check(L.nsp_rnnt_joint_gemm(1, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(part),
+                                     _p(aux[1]), _p(aux[2]), None, None, 1.0, None, _stream()),
+               'nsp_rnnt_joint_gemm(lse)')
+        _check(L.nsp_rnnt_lse_merge(_p(part), npart, _p(aux[0]), _p(aux[1]), _p(aux[2]), _p(lab), M, _stream()),
+               'nsp_rnnt_lse_merge')
+        del part
+        _check(L.nsp_rnnt_lattice_compact(_p(aux[1]), _p(aux[2]), _p(elens), _p(ylens), _p(roff), _p(aux[3]),
+                                          _p(aux[4]), _p(nll), _p(aux[5]), _p(aux[6]), B, U1, _stream()),
+               'nsp_rnnt_lattice_compact')
+        ctx.save_for_backward(h16, lab, aux, w_out, bias, roff, elens, ylens)
+        ctx.dims = (B, T, U1, J, V, Vp, blank, M)
+        ctx.has_bias = b_out is not None
+        ctx.mark_non_differentiable(nll)
+        return nll.mean().view(1), nll
+
+    @staticmethod
+    def backward(ctx, dloss, _dnll):
+        h16, lab, aux, w_out, bias, roff, elens, ylens = ctx.saved_tensors
+        B, T, U1, J, V, Vp, blank, M = ctx.dims
+        L = _lib.lib()
+        dev = h16.device
+        dl = _f32c(dloss).reshape(-1)                    # upstream gradient stays on the device
+        w16 = _rows_padded_bf16(w_out, 64)
+        d16 = torch.empty((max(M, 1), Vp), device=dev, dtype=torch.bfloat16)
+        nslab = (M + 127) // 128 * 2
+        dbpart = torch.empty((max(nslab, 1), Vp), device=dev, dtype=torch.float32) if ctx.has_bias else None
+        _check(L.nsp_rnnt_joint_gemm(2, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
+                                     _p(aux[5]), _p(aux[6]), _p(dbpart), _p(d16), 1.0 / B, _p(dl), _stream()),
+               'nsp_rnnt_joint_gemm(dlogits)')
+        db = colsum(dbpart)[:V] if ctx.has_bias else None
+        # dW = dlogits^T h  (split over the M rows, deterministic slab reduction)
+        sk = _pick_splitk(V, J, M)
+        part = torch.empty((sk, V, J), device=dev, dtype=torch.float32)
+        gemm_raw(V, J, M, d16, 1, Vp, h16, J, 1, part, J, splitk=sk, c_ss=V * J)
+        dw = torch.empty((V, J), device=dev, dtype=torch.float32)
+        _check(L.nsp_splitk_reduce(_p(part), _p(dw), sk, V * J, _stream()), 'nsp_splitk_reduce')
+        # dz = (dlogits W_out) * (1 - h^2): tanh' is the epilogue of the data-gradient GEMM
+        wt = _weight_t_shadow(w_out, True)                                   # [J, roundup64(V)]
+        dz = torch.empty((max(M, 1), J), device=dev, dtype=torch.bfloat16)
+        gemm_raw(M, J, Vp, d16, Vp, 1, wt, 1, wt.stride(0), dz, J, dact_src=h16, dact=6)
+        del d16
+        de = torch.empty((B, T, J), device=dev, dtype=torch.float32)
+        nsl = max(1, min(16, T // 16))
+        slabs = torch.empty((nsl, B * U1 * J), device=dev, dtype=torch.float32)
+        _check(L.nsp_rnnt_joint_dz_reduce_compact(_p(dz), _p(elens), _p(ylens), _p(roff), _p(de), _p(slabs), nsl,
+                                                  B, T, U1, J, _stream()), 'nsp_rnnt_joint_dz_reduce_compact')
+        dg = torch.empty((B, U1, J), device=dev, dtype=torch.float32)
+        _check(L.nsp_splitk_reduce(_p(slabs), _p(dg), nsl, B * U1 * J, _stream()), 'nsp_splitk_reduce')
+        return de, dg, dw.view(w_out.shape), db, None, None, None, None, None, None
+
+
+def rnnt_joint_fused_supported(J, U1, M):
+    return bf16_mode() and J % 32 == 0 and U1 <= 512 and M > 0 and os.environ.get('NSP_RNNT_FUSED', '1') != '0'
+
+
+def rnnt_joint_loss(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, blank=0, elens_host=None,
+                    ylens_host=None):
+    """elens_host / ylens_host (python ints) select the fused, compacted path in bf16 mode (the row
+    offsets of the compact lattice are computed on the host); without them, or in fp32 parity mode, the
+    materialising path runs."""
+    if elens_host is not None and ylens_host is not None:
+        T, J, U1 = enc_proj.shape[1], enc_proj.shape[2], dec_proj.shape[1]
+        M = sum(min(int(t), T) * (min(int(u), U1 - 1) + 1) for t, u in zip(elens_host, ylens_host))
+        if rnnt_joint_fused_supported(J, U1, M):
+            return RNNTJointLossFusedFn.apply(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, int(blank),
+                                              [int(t) for t in elens_host], [int(u) for u in ylens_host])
     return RNNTJointLossFn.apply(enc_proj, dec_proj, w_out, b_out, labels, elens, ylens, int(blank))
 
 

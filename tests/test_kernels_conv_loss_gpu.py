@@ -296,3 +296,52 @@ def test_lstm_stack_persistent_matches_wavefront(nl, p_drop, B, L, H, monkeypatc
     for a, b in zip(outs['1'], outs['0']):
         assert torch.isfinite(a).all()
         assert _rel(a, b) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,T,U,J,V', [(3, 21, 6, 32, 29), (4, 37, 40, 64, 43), (3, 50, 70, 96, 1000),
+                                       (5, 120, 33, 512, 1000), (2, 9, 0, 64, 130)])
+def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V):
+    """The fused / compacted RNN-T joint (csrc/rnnt_fused.hip + the NSP_EPI_RNNT_* GEMM epilogues):
+    loss and all four gradients against the fp64 lattice oracle on the materialised joint, ragged
+    lengths incl. an empty label sequence and T_b = 1, V % 64 != 0, and the peak allocation of the
+    op must stay far below ONE [B,T,U+1,V] fp32 tensor."""
+    from oracle.rnnt_ref import rnnt_loss_ref_diag
+    from neural_sp_amd import ops
+    torch.manual_seed(B * 1000 + T)
+    e = (torch.randn(B, T, J, device=_dev()) * 0.7).requires_grad_()
+    gq = (torch.randn(B, U + 1, J, device=_dev()) * 0.7).requires_grad_()
+    w = (torch.randn(V, J, device=_dev()) * (2.0 / J ** 0.5)).requires_grad_()
+    bo = torch.randn(V, device=_dev(), requires_grad=True)
+    el = [T, max(1, T - 4), 1, max(1, T // 2), T][:B]
+    yl = [U, max(0, U - 3), 0, U // 2, U][:B]
+    elens, ylens = torch.tensor(el, dtype=torch.int32), torch.tensor(yl, dtype=torch.int32)
+    lab = torch.randint(1, V, (B, max(U, 1)), dtype=torch.int32)
+    for b in range(B):
+        lab[b, yl[b]:] = 0
+    with ops.compute_mode('bf16'):
+        M = sum(t * (u + 1) for t, u in zip(el, yl))
+        assert ops.rnnt_joint_fused_supported(J, U + 1, M)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loss, nll = ops.rnnt_joint_loss(e, gq, w, bo, lab.to(_dev()), elens.to(_dev()), ylens.to(_dev()), 0,
+                                        elens_host=el, ylens_host=yl)
+        assert loss.grad_fn.__class__.__name__.startswith('RNNTJointLossFusedFn')
+        grads = torch.autograd.grad(loss, (e, gq, w, bo))
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+    if B * T * (U + 1) * V * 4 > (64 << 20):
+        assert peak < 0.8 * B * T * (U + 1) * V * 4, (peak, B * T * (U + 1) * V * 4)
+    e64, g64, w64, b64 = [t.detach().cpu().double().requires_grad_() for t in (e, gq, w, bo)]
+    logits = torch.tanh(e64[:, :, None] + g64[:, None]) @ w64.t() + b64
+    refs = rnnt_loss_ref_diag(torch.log_softmax(logits, -1), lab.long(), elens.long(), ylens.long(), blank=0)
+    ref = refs.mean()
+    rg = torch.autograd.grad(ref, (e64, g64, w64, b64))
+    assert torch.allclose(nll.cpu().double(), refs.detach(), rtol=5e-3, atol=1e-2), (nll, refs)
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 5e-3, (loss.item(), ref.item())
+    for a, r, name in zip(grads, rg, ('d enc_proj', 'd dec_proj', 'd W_out', 'd b_out')):
+        assert a.shape == r.shape
+        assert _rel(a.cpu().double(), r) < 3e-2, name
+        cos = torch.nn.functional.cosine_similarity(a.cpu().double().flatten(), r.flatten(), dim=0).item()
+        assert cos > 0.9995, (name, cos)
