@@ -304,8 +304,11 @@ def test_lstm_stack_persistent_matches_wavefront(nl, p_drop, B, L, H, monkeypatc
 def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V):
     """The fused / compacted RNN-T joint (csrc/rnnt_fused.hip + the NSP_EPI_RNNT_* GEMM epilogues):
     loss and all four gradients against the fp64 lattice oracle on the materialised joint, ragged
-    lengths incl. an empty label sequence and T_b = 1, V % 64 != 0, and the peak allocation of the
-    op must stay far below ONE [B,T,U+1,V] fp32 tensor."""
+    lengths incl. an empty label sequence and T_b = 1, V % 64 != 0.  Memory: no fp32 [.,V] tensor exists;
+    the only V-wide buffer is the bf16 gradient image over the M COMPACTED nodes that the weight-gradient
+    GEMM reduces over (2 Vp bytes per node), next to h and dz (2 J bytes each): the peak must fit that
+    budget, which is less than half of what logits(fp32) + log-softmax gradient(bf16) + h + dz cost on
+    the padded [B,T,U+1] grid."""
     from oracle.rnnt_ref import rnnt_loss_ref_diag
     from neural_sp_amd import ops
     torch.manual_seed(B * 1000 + T)
@@ -331,8 +334,12 @@ def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V):
         grads = torch.autograd.grad(loss, (e, gq, w, bo))
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated() - base
-    if B * T * (U + 1) * V * 4 > (64 << 20):
-        assert peak < 0.8 * B * T * (U + 1) * V * 4, (peak, B * T * (U + 1) * V * 4)
+    Vp = (V + 63) // 64 * 64
+    budget = M * (2 * Vp + 4 * J + 256) + 20 * V * J * 4 + (8 << 20)      # d16 + h + dz + per-node scalars; dW slabs
+    padded_old = B * T * (U + 1) * (4 * V + 2 * Vp + 4 * J)
+    assert peak < budget, (peak, budget)
+    if padded_old > (64 << 20):
+        assert peak < 0.6 * padded_old, (peak, padded_old)
     e64, g64, w64, b64 = [t.detach().cpu().double().requires_grad_() for t in (e, gq, w, bo)]
     logits = torch.tanh(e64[:, :, None] + g64[:, None]) @ w64.t() + b64
     refs = rnnt_loss_ref_diag(torch.log_softmax(logits, -1), lab.long(), elens.long(), ylens.long(), blank=0)
