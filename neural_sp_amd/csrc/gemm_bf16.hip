@@ -238,7 +238,7 @@ __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&
       csum[e] += __shfl_xor(csum[e], 32, 64);
     }
     if (lane < 16 && n < p.N) {
-      const long long slab = (long long)(m0 / (32 * MI)) * 2 + wm;
+      const long long slab = (long long)(m0 + wm * (16 * MI)) / (16 * MI);   // one slab per 16*MI-row block
       *reinterpret_cast<float4*>(p.epi_f3 + slab * p.N + n) = make_float4(csum[0], csum[1], csum[2], csum[3]);
     }
   }
@@ -601,6 +601,123 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
   gemm_epilogue(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
+// ---- KC x KC, 256 x 256 x 64 tile, 8 waves (2 x 4; wave tile 128 x 64 = 8 x 4 MFMA fragments, 128
+// accumulator registers), PERSISTENT over output tiles.  Why: the 128 x 128 kernels above read
+// (64 + 64) rows x 128 B of fragments per wave per k-tile for 32 MFMAs; here a wave reads
+// (128 + 64) rows for 64 MFMAs, and a k-tile moves 64 KB global -> LDS for 4x the flops -- per
+// flop: 0.75x the LDS fragment traffic, 0.5x the DMA / L2 traffic.  One workgroup per CU (128 KB
+// of LDS: two 64-KB stages {A 256 x 128 B | B 256 x 128 B}), two waves per SIMD covering each
+// other's LDS reads and waits.  With a single workgroup per CU nobody else hides a tile's
+// prologue (first DMA latency) or epilogue, so the workgroup walks a list of tiles and the DMA
+// ring runs CONTINUOUSLY across tile boundaries: the first k-tile of tile i+1 lands while tile
+// i's last k-tile is multiplied and its epilogue (staged through the just-consumed LDS stage) runs.
+// Tile order: workgroup w (XCD w % 8, dispatch is round-robin) takes, at step s, tile
+// 32 (8 s + w % 8) + w / 8 of the n-fastest tile list: the 32 workgroups of one XCD work on 32
+// consecutive tiles = a few A panels x all their N tiles at the same time (A read once per XCD L2).
+// Requires K % 64 == 0, batch == 1, splitk == 1.
+__global__ __launch_bounds__(512) void gemm_bf16_kk256_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
+                                                              int c_vec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 32 KB | B 32 KB)
+  constexpr int STAGE = 65536, A_BYTES = 32768;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntiles = tiles_m * tiles_n;
+  const int nkt = p.K / BK;
+  const int G = gridDim.x;
+  const int xq = blockIdx.x >> 3, xx = blockIdx.x & 7, per_xcd = G >> 3;
+  auto tile_of = [&](int step) { return per_xcd * (8 * step + xx) + xq; };   // G % 8 == 0 (launcher)
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A);
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B);
+  const int lrow = lane >> 3, lpos = lane & 7;
+  const int fr = lane & 15, fg = lane >> 4;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  // per-lane DMA sources of the CURRENT load tile: wave w, instruction i covers tile rows (w*4+i)*8 .. +7
+  const __bf16* asrc[4];
+  const __bf16* bsrc[4];
+  auto set_src = [&](int tile) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + lrow;
+      const int sw = (lpos ^ (row & 7)) * 8;
+      asrc[i] = A + (long long)min(tm * 256 + row, p.M - 1) * p.a_rs + sw;
+      bsrc[i] = B + (long long)min(tn * 256 + row, p.N - 1) * p.b_ns + sw;
+    }
+  };
+  auto issue = [&](int stage, int kt) {
+    unsigned char* sa = ring + stage * STAGE;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + k0), (lds_void*)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + k0), (lds_void*)(sa + A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+  int step = 0;
+  int tile = tile_of(0);
+  if (tile >= ntiles) return;
+  set_src(tile);
+  issue(0, 0);
+  int seq = 0;                       // k-tiles consumed so far by this workgroup (ring position)
+  while (tile < ntiles) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int next_tile = tile_of(step + 1);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nkt; ++kt, ++seq) {
+      const int st = seq & 1;
+      // this wave's loads of k-tile `seq` have landed; after the barrier everybody's have, and every
+      // wave has finished reading stage st^1 (k-tile seq-1 / the previous tile's epilogue staging)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 1 < nkt) {
+        issue(st ^ 1, kt + 1);
+      } else if (next_tile < ntiles) {
+        set_src(next_tile);          // the ring keeps running across the tile boundary
+        issue(st ^ 1, 0);
+      }
+      const unsigned char* smA = ring + st * STAGE;
+      const unsigned char* smB = smA + A_BYTES;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[8], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rb = wn * 64 + i * 16 + fr;
+          bf[i] = *reinterpret_cast<const bf16x8*>(smB + rb * 128 + (((s * 4 + fg) ^ (rb & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ra = wm * 128 + i * 16 + fr;
+          af[i] = *reinterpret_cast<const bf16x8*>(smA + ra * 128 + (((s * 4 + fg) ^ (ra & 7)) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    // all waves are done with the last stage they multiplied from: it becomes the epilogue's staging
+    // area (the other stage may be receiving the next tile's first k-tile right now)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // two 64-row halves through the MI = 4 epilogue (an 8-fragment instantiation is not fully unrolled by
+    // hipcc: the accumulators would round-trip through scratch); row = m0 + wm*128 + half*64 + ...
+    unsigned char* stg = ring + ((seq - 1) & 1) * STAGE;
+    gemm_epilogue<4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stg, m0 + wm * 64, n0, wm, wn, lane, wave, 0, c_vec);
+    gemm_epilogue<4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stg, m0 + wm * 64 + 64, n0, wm, wn, lane, wave, 0, c_vec);
+    ++step;
+    tile = next_tile;
+  }
+}
+
 // ---- RC x RC (both operands contiguous along their OUTPUT index, reduction index strided: the
 // weight gradients dW = dY^T X) on the same LDS-DMA ring.  A stage holds the k-major images
 // [64 k][128 m] and [64 k][128 n] (256-B rows, unpadded: the DMA writes lane-linear); MFMA operands
@@ -791,6 +908,23 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     }
     const long long wgs = (long long)grid.x * grid.z;
     const int nkt = p.K / BK / p.splitk;
+    // 256 x 256 persistent kernel: one problem, enough 256-tiles to keep 256 CUs busy for >= 2 rounds
+    // (or an exact multiple of a round), and at least 4 k-tiles per output tile
+    static int k256_env = -1, k256_min = 448;
+    if (k256_env < 0) {
+      const char* e = getenv("NSP_GEMM_256");
+      k256_env = e ? atoi(e) : 1;
+      const char* e2 = getenv("NSP_GEMM_256_MIN_TILES");
+      if (e2) k256_min = atoi(e2);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_kk256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    }
+    const long long t256 = (long long)nsp_cdiv(p.M, 256) * nsp_cdiv(p.N, 256);
+    if (k256_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 4 && t256 >= k256_min && p.N >= 256) {
+      const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
+      hipLaunchKernelGGL(gemm_bf16_kk256_kernel, dim3(256), dim3(512), 131072, st, p, tm256, tn256, c_vec);
+      NSP_LAUNCH_CHECK();
+      return NSP_OK;
+    }
     if (ring_env && wgs < 192 && p.M > 64 && nkt >= 4 && p.epi_mode == NSP_EPI_NONE) {
       tiles_m = nsp_cdiv(p.M, 64);
       grid.x = tiles_m * tiles_n;
