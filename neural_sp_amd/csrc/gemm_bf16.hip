@@ -601,6 +601,282 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
   gemm_epilogue(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
+// ---- KC x KC, 128 x 128 x 64, PERSISTENT with a DEFERRED epilogue.
+// Measured on the kernels above (tools/gemm_epilogue_probe.py, M = 51200, N = 2048, fp32 out):
+// t(K) = 121 us + 0.183 us * K, i.e. the main loop alone runs at 1145 TFLOP/s but every launch pays
+// "all of C at ~3.5 TB/s" on top: workgroups start together, share the CU's matrix pipe evenly and so
+// reach their epilogues together -- the chip alternates between a compute phase with idle HBM and a
+// store phase with idle MFMA (the fused bias/activation/dropout epilogues add their VALU time to
+// that second phase: y = swish(x W^T + b) with K = 512 ran at 376 TFLOP/s).
+// Here a workgroup owns a list of tiles and the epilogue of tile i is executed in 8 slices INSIDE the
+// k-loop of tile i+1 (the finished accumulators stay in registers): stores, epilogue VALU and loads
+// (bias, residual, act' source) overlap with MFMA work, on every CU, all the time.
+//   * 4 waves (2 x 2), wave tile 64 x 64; 2-stage LDS-DMA ring (64 KB) running continuously across
+//     tile boundaries + 8 KB of staging (8 rows x 64 cols per wave, XOR-swizzled) = 72 KB -> two
+//     workgroups per CU, ~190 VGPRs;
+//   * slice c = (mi = c/2, rows 8*(c%2)..+7 of that fragment row): staged through LDS so that 16 lanes
+//     store 256 contiguous bytes of one output row (same reason as gemm_epilogue);
+//   * tile order: n-fastest, grid-stride -> the tiles in flight at any time are a contiguous range of
+//     the tile list (A panels shared through L2), remapped so that a range lands on one XCD.
+// Handles the standard epilogue (no split-K, single problem) and the two RNN-T joint epilogues.
+struct EpiCarry { float csum[4]; };
+
+__device__ __forceinline__ void kkp_epi_vec(const nsp_gemm_params& p, int m, int n, float (&v)[4], int c_vec,
+                                            float sc, EpiCarry& cy, int lane) {
+  // one float4 (row m, cols n..n+3) of the finished tile; all 16 lanes of a row group are in here together
+  if (p.epi_mode == NSP_EPI_NONE) {
+    if (m >= p.M || n >= p.N) return;
+    const long long off = (long long)m * p.ldc + n;
+    const int nv = min(4, p.N - n);
+    const bool vec = c_vec && nv == 4;
+    if (p.bias) {
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      load4(p.bias, NSP_DT_F32, n, b4, nv, vec);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += b4[e];
+    }
+    if (p.pre_out) store4(p.pre_out, p.pre_dtype, off, v, nv, vec);
+    if (p.act != NSP_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], p.act);
+    }
+    if (p.dact_src) {
+      float d[4] = {0.f, 0.f, 0.f, 0.f};
+      load4(p.dact_src, p.dact_dtype, off, d, nv, vec);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], p.dact);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    if (p.dropout_p > 0.f) {
+      float kp[4];
+      nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= kp[e];
+    }
+    if (p.res) {
+      float r4[4] = {0.f, 0.f, 0.f, 0.f};
+      load4(p.res, NSP_DT_F32, off, r4, nv, vec);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += r4[e];
+    }
+    store4(p.C, p.c_dtype, off, v, nv, vec);
+    return;
+  }
+  // RNN-T joint epilogues (N % 64 == 0; bias padded to N)
+  const bool rowok = m < p.M && n < p.N;
+  if (p.bias && n < p.N) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.epi_mode == NSP_EPI_RNNT_LSE) {
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (n + e < p.epi_ncols) mx = fmaxf(mx, v[e]);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (n + e < p.epi_ncols) sm += __expf(v[e] - mx);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    if (rowok) {
+      if ((lane & 15) == 0)
+        *reinterpret_cast<float2*>(p.epi_f0 + ((long long)m * (p.N >> 6) + (n >> 6)) * 2) = make_float2(mx, sm);
+      const int lab = p.epi_lab[m];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e == p.epi_blank) p.epi_f1[m] = v[e];
+        if (n + e == lab) p.epi_f2[m] = v[e];
+      }
+    }
+  } else {
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rowok) {
+      const float ls = p.epi_f0[m];
+      const float gb = p.epi_f1[m] * sc, gl = p.epi_f2[m] * sc;
+      const int lab = p.epi_lab[m];
+      const float gs = gb + gl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e < p.epi_ncols) {
+          float t = -gs * __expf(v[e] - ls);
+          if (n + e == p.epi_blank) t += gb;
+          if (n + e == lab) t += gl;
+          g[e] = t;
+        }
+      }
+      bf16x4 o;
+      o[0] = (__bf16)g[0]; o[1] = (__bf16)g[1]; o[2] = (__bf16)g[2]; o[3] = (__bf16)g[3];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C) + (long long)m * p.ldc + n) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cy.csum[e] += g[e];
+  }
+}
+
+// slice c (0..7, wave-uniform runtime value) of a finished wave tile: fragment row mi = c/2, rows
+// 8*(c%2) .. +7 of it.  The fragment row is picked with selects (48 v_cndmask), NOT by indexing the
+// register array (that would send the accumulators through scratch) and NOT by instantiating the
+// epilogue per slice (8 x 3 call sites of it made a 110k-line kernel that spilled).
+__device__ __forceinline__ void kkp_epi_slice(int c, const nsp_gemm_params& p, const f32x4 (&acc)[4][4], float* stage,
+                                              int mbase, int nbase, int lane, int c_vec, float sc, EpiCarry& cy) {
+  const int mi = c >> 1, half = c & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  f32x4 t[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) t[ni] = acc[0][ni];
+#pragma unroll
+  for (int m2 = 1; m2 < 4; ++m2)
+    if (m2 == mi) {               // wave-uniform scalar branch; constant register indices inside
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) t[ni] = acc[m2][ni];
+    }
+  if ((fr >> 3) == half) {
+    const int row = fr & 7;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      *reinterpret_cast<float4*>(stage + row * 64 + (((ni * 4 + fg) ^ row) << 2)) =
+          make_float4(t[ni][0], t[ni][1], t[ni][2], t[ni][3]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int c4 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (lane >> 4) + 4 * j;
+    const float4 a4 = *reinterpret_cast<const float4*>(stage + row * 64 + ((c4 ^ row) << 2));
+    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+    kkp_epi_vec(p, mbase + mi * 16 + half * 8 + row, nbase + c4 * 4, v, c_vec, sc, cy, lane);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (c == 7 && p.epi_mode == NSP_EPI_RNNT_DLOGITS && p.epi_f3) {
+    // column sums of this wave's 64 rows x 64 cols -> one slab row per 64-row block
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cy.csum[e] += __shfl_xor(cy.csum[e], 16, 64);
+      cy.csum[e] += __shfl_xor(cy.csum[e], 32, 64);
+    }
+    const int n = nbase + c4 * 4;
+    if (lane < 16 && n < p.N)
+      *reinterpret_cast<float4*>(p.epi_f3 + (long long)(mbase >> 6) * p.N + n) =
+          make_float4(cy.csum[0], cy.csum[1], cy.csum[2], cy.csum[3]);
+  }
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kkp_kernel(const nsp_gemm_params p, int tiles_m,
+                                                                    int tiles_n, int c_vec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 16 KB | B 16 KB) | staging 8 KB
+  constexpr int STAGE = 32768;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* stage = reinterpret_cast<float*>(ring + 2 * STAGE) + wave * 512;
+  const int ntiles = tiles_m * tiles_n;
+  const int nkt = p.K / BK;
+  const int G = gridDim.x;
+  // grid-stride over the XCD-remapped tile list: workgroup g takes tiles xcd_remap(g + i*G)
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A);
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B);
+  const int lrow = lane >> 3, lpos = lane & 7;
+  const int fr = lane & 15, fg = lane >> 4;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const __bf16* asrc[4];
+  const __bf16* bsrc[4];
+  auto tile_at = [&](int i) {
+    const long long lin = (long long)blockIdx.x + (long long)i * G;
+    return lin < ntiles ? xcd_remap((int)lin, ntiles) : ntiles;
+  };
+  auto set_src = [&](int tile) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + lrow;
+      const int sw = (lpos ^ (row & 7)) * 8;
+      asrc[i] = A + (long long)min(tm * BM + row, p.M - 1) * p.a_rs + sw;
+      bsrc[i] = B + (long long)min(tn * BN + row, p.N - 1) * p.b_ns + sw;
+    }
+  };
+  auto issue = [&](int st, int kt) {
+    unsigned char* sa = ring + st * STAGE;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + k0), (lds_void*)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + k0), (lds_void*)(sa + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+  const float sc = p.epi_scale * (p.epi_scale_dev ? p.epi_scale_dev[0] : 1.f);
+  int it = 0;
+  int tile = tile_at(0);
+  if (tile >= ntiles) return;
+  set_src(tile);
+  issue(0, 0);
+  int seq = 0;
+  f32x4 prev[4][4];
+  int pm = 0, pn = 0;
+  bool have_prev = false;
+  EpiCarry cy;
+  while (tile < ntiles) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int next_tile = tile_at(it + 1);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (have_prev) { cy.csum[0] = cy.csum[1] = cy.csum[2] = cy.csum[3] = 0.f; }
+    auto ktile = [&](int kt) {
+      const int st = seq & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 1 < nkt) {
+        issue(st ^ 1, kt + 1);
+      } else if (next_tile < ntiles) {
+        set_src(next_tile);
+        issue(st ^ 1, 0);
+      }
+      const unsigned char* smA = ring + st * STAGE;
+      const unsigned char* smB = smA + 16384;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ra = wm * 64 + i * 16 + fr, rb = wn * 64 + i * 16 + fr;
+          af[i] = *reinterpret_cast<const bf16x8*>(smA + ra * 128 + (((s2 * 4 + fg) ^ (ra & 7)) << 4));
+          bf[i] = *reinterpret_cast<const bf16x8*>(smB + rb * 128 + (((s2 * 4 + fg) ^ (rb & 7)) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+      ++seq;
+    };
+    // k-tile kt < 8 carries slice kt of the PREVIOUS tile's epilogue behind its MFMAs
+    for (int kt = 0; kt < nkt; ++kt) {
+      ktile(kt);
+      if (have_prev && kt < 8) kkp_epi_slice(kt, p, prev, stage, pm, pn, lane, c_vec, sc, cy);
+    }
+    if (have_prev)
+      for (int c = nkt; c < 8; ++c) kkp_epi_slice(c, p, prev, stage, pm, pn, lane, c_vec, sc, cy);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) prev[i][j] = acc[i][j];
+    pm = tm * BM + wm * 64;
+    pn = tn * BN + wn * 64;
+    have_prev = true;
+    ++it;
+    tile = next_tile;
+  }
+  // the last tile of this workgroup: nothing left to hide it behind
+  cy.csum[0] = cy.csum[1] = cy.csum[2] = cy.csum[3] = 0.f;
+  for (int c = 0; c < 8; ++c) kkp_epi_slice(c, p, prev, stage, pm, pn, lane, c_vec, sc, cy);
+}
+
 // ---- KC x KC, 256 x 256 x 64 tile, 8 waves (2 x 4; wave tile 128 x 64 = 8 x 4 MFMA fragments, 128
 // accumulator registers), PERSISTENT over output tiles.  Why: the 128 x 128 kernels above read
 // (64 + 64) rows x 128 B of fragments per wave per k-tile for 32 MFMAs; here a wave reads
@@ -913,10 +1189,26 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     static int k256_env = -1, k256_min = 448;
     if (k256_env < 0) {
       const char* e = getenv("NSP_GEMM_256");
-      k256_env = e ? atoi(e) : 1;
+      k256_env = e ? atoi(e) : 0;
       const char* e2 = getenv("NSP_GEMM_256_MIN_TILES");
       if (e2) k256_min = atoi(e2);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_kk256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    }
+    // persistent 128 x 128 kernel with the deferred epilogue: single problem, >= 3 tiles per workgroup slot
+    // (the two switches are read on every call so that tests can flip them inside one process)
+    static bool kkp_attr = false;
+    if (!kkp_attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_kkp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768 + 8192);
+      kkp_attr = true;
+    }
+    const char* kkp_e = getenv("NSP_GEMM_PERSIST");
+    const char* kkp_e2 = getenv("NSP_GEMM_PERSIST_MIN_TILES");
+    const int kkp_env = kkp_e ? atoi(kkp_e) : 1;
+    const long long kkp_min = kkp_e2 ? atoll(kkp_e2) : 1536;
+    if (kkp_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 2 && wgs >= kkp_min) {
+      hipLaunchKernelGGL(gemm_bf16_kkp_kernel, dim3(512), block, 2 * 32768 + 8192, st, p, tiles_m, tiles_n, c_vec);
+      NSP_LAUNCH_CHECK();
+      return NSP_OK;
     }
     const long long t256 = (long long)nsp_cdiv(p.M, 256) * nsp_cdiv(p.N, 256);
     if (k256_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 4 && t256 >= k256_min && p.N >= 256) {

@@ -244,3 +244,42 @@ def test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch):
         scale = ref.abs().max()
         assert ((base - ref).abs().max() / scale).item() < 1e-4
         assert ((dw - ref).abs().max() / scale).item() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K', [(1000, 384, 128), (2051, 1000, 512), (4096, 512, 2048), (700, 2048, 64)])
+def test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch):
+    """gemm_bf16_kkp_kernel (persistent tiles, the epilogue of tile i sliced into the k-loop of tile i+1)
+    forced onto small problems: every epilogue feature against torch, ragged M / N, nkt < 8 and > 8,
+    workgroups with 0, 1 and several tiles."""
+    from neural_sp_amd import ops
+    monkeypatch.setenv('NSP_GEMM_PERSIST_MIN_TILES', '1')
+    torch.manual_seed(M + N)
+    dev = _dev()
+    a = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.5).bfloat16()
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    src = torch.randn(M, N, device=dev)
+    ref = a.float() @ w.float().t()
+    with ops.compute_mode('bf16'):
+        c = torch.empty(M, N, device=dev)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N)
+        assert _rel(c, ref) < 1e-5
+        c16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c16, N, bias=bias, act=2, pre_out=pre)
+        z = ref + bias
+        assert _rel(pre.float(), z) < 1e-2 and _rel(c16.float(), z * torch.sigmoid(z)) < 1e-2
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, bias=bias, res=res, alpha=0.5)
+        assert _rel(c, 0.5 * (ref + bias) + res) < 1e-5
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, dact_src=src, dact=2)
+        s = torch.sigmoid(src)
+        assert _rel(c, ref * (s * (1 + src * (1 - s)))) < 1e-4
+        # dropout: same mask as the non-persistent kernel (pure function of seed / element offset)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, dropout_p=0.3, seed=11, offset=0)
+        monkeypatch.setenv('NSP_GEMM_PERSIST', '0')
+        c2 = torch.empty(M, N, device=dev)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c2, N, dropout_p=0.3, seed=11, offset=0)
+        assert torch.equal(c == 0, c2 == 0) and _rel(c, c2) < 1e-6
+        assert 0.2 < (c == 0).float().mean().item() < 0.4

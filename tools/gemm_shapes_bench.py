@@ -21,15 +21,19 @@ for M, N, K in shapes:
     bias = torch.randn(N, device='cuda')
     def run():
         ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, bias=bias)
-    for _ in range(3): run()
-    torch.cuda.synchronize()
-    iters = 5 if big else 30
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters): run()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1000 / iters
-    rows = slice(0, M) if M <= 60000 else slice(M - 70000, M)
-    ref = a[rows].float() @ w.float().t() + bias
-    err = ((c[rows].float() - ref).abs().max() / ref.abs().max()).item()
-    print('M %8d N %5d K %5d: %9.1f us %7.1f TFLOP/s  relerr %.1e' % (M, N, K, us, 2.0 * M * N * K / us / 1e6, err), flush=True)
+    out = []
+    for persist in ('0', '1'):
+        os.environ['NSP_GEMM_PERSIST'] = persist
+        for _ in range(3): run()
+        torch.cuda.synchronize()
+        iters = 5 if big else 30
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): run()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000 / iters
+        rows = slice(0, M) if M <= 60000 else slice(M - 70000, M)
+        ref = a[rows].float() @ w.float().t() + bias
+        err = ((c[rows].float() - ref).abs().max() / ref.abs().max()).item()
+        out.append('%9.1f us %7.1f TFLOP/s err %.0e' % (us, 2.0 * M * N * K / us / 1e6, err))
+    print('M %8d N %5d K %5d | classic %s | persistent %s' % (M, N, K, out[0], out[1]), flush=True)
