@@ -619,6 +619,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
 //   * tile order: n-fastest, grid-stride -> the tiles in flight at any time are a contiguous range of
 //     the tile list (A panels shared through L2), remapped so that a range lands on one XCD.
 // Handles the standard epilogue (no split-K, single problem) and the two RNN-T joint epilogues.
+// MEASURED (round 2, tools/gemm_epilogue_probe.py / gemm_shapes_bench.py): correct, but 20-45 % SLOWER
+// than the classic kernels at every shape of the step (e.g. 51200 x 2048 x 512 fp32 out: 270 vs 211 us),
+// so it is opt-in (NSP_GEMM_PERSIST=1).  Why: (1) vmcnt on gfx9 retires loads and stores in issue order,
+// so the `s_waitcnt vmcnt(0)` that proves the next k-tile's LDS-DMA has landed also waits for the
+// previous slice's global stores to be acknowledged (1.6 us per slice measured); (2) two workgroups
+// per CU hide less DMA latency than the classic kernel's four; and the premise was wrong: starting the
+// classic kernel's workgroups 3-17 us apart (stagger experiment) changed nothing, i.e. its
+// t(K) = a + b K is not a lockstep artefact -- the main loop is bound by the L2 -> LDS fill rate of
+// 128 x 128 tiles (~26 B/clk/CU at 1.15 PFLOP/s) and the epilogue by the ~4.5 TB/s HBM write ceiling.
 struct EpiCarry { float csum[4]; };
 
 __device__ __forceinline__ void kkp_epi_vec(const nsp_gemm_params& p, int m, int n, float (&v)[4], int c_vec,
@@ -891,6 +900,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kkp_kernel(const nsp_ge
 // 32 (8 s + w % 8) + w / 8 of the n-fastest tile list: the 32 workgroups of one XCD work on 32
 // consecutive tiles = a few A panels x all their N tiles at the same time (A read once per XCD L2).
 // Requires K % 64 == 0, batch == 1, splitk == 1.
+// MEASURED (round 2): 968 vs 846 TFLOP/s at 8192^3, equal at 4096^3, but 0.6-0.7x the classic kernels at
+// the step's K = 512 shapes (one workgroup per CU: nothing hides the 256 KB-per-tile epilogue), so it is
+// opt-in (NSP_GEMM_256=1); the next step would be the phase-interleaved schedule of the CDNA guide.
 __global__ __launch_bounds__(512) void gemm_bf16_kk256_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
                                                               int c_vec) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 32 KB | B 32 KB)
@@ -1203,7 +1215,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     }
     const char* kkp_e = getenv("NSP_GEMM_PERSIST");
     const char* kkp_e2 = getenv("NSP_GEMM_PERSIST_MIN_TILES");
-    const int kkp_env = kkp_e ? atoi(kkp_e) : 1;
+    const int kkp_env = kkp_e ? atoi(kkp_e) : 0;   // OPT-IN: measured slower than the classic kernels (below)
     const long long kkp_min = kkp_e2 ? atoll(kkp_e2) : 1536;
     if (kkp_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 2 && wgs >= kkp_min) {
       hipLaunchKernelGGL(gemm_bf16_kkp_kernel, dim3(512), block, 2 * 32768 + 8192, st, p, tiles_m, tiles_n, c_vec);

@@ -253,6 +253,7 @@ def test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch):
     forced onto small problems: every epilogue feature against torch, ragged M / N, nkt < 8 and > 8,
     workgroups with 0, 1 and several tiles."""
     from neural_sp_amd import ops
+    monkeypatch.setenv('NSP_GEMM_PERSIST', '1')
     monkeypatch.setenv('NSP_GEMM_PERSIST_MIN_TILES', '1')
     torch.manual_seed(M + N)
     dev = _dev()
