@@ -27,6 +27,7 @@ namespace {
 constexpr int DK = 64;
 constexpr int KP = 144;  // LDS row pitch in bytes for [rows][64] bf16 tiles (128 + 16 pad)
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ bool fa_visible(const nsp_attn_mask_params& p, int klen, int i, int j) {
   bool ok = j < klen;
@@ -60,7 +61,6 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int cbase, 
 // stage 64 rows x 64 bf16 (rows row0.., clipped to T -> zero rows) of a [B*T, ld] matrix column block
 __device__ __forceinline__ void stage_tile(unsigned char* tile, const __bf16* __restrict__ src, long long ld,
                                            long long brow0, int row0, int T) {
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = threadIdx.x + i * 256;
@@ -84,10 +84,12 @@ __device__ __forceinline__ void stage_tile(unsigned char* tile, const __bf16* __
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct FaTile { bool plain, far; };
-__device__ __forceinline__ FaTile fa_tile(const nsp_attn_mask_params& p, bool has_qp, int q0, int k0, int T, int klen) {
+__device__ __forceinline__ FaTile fa_tile(const nsp_attn_mask_params& p, bool has_qp, int q0, int k0, int T, int klen,
+                                          int nq = 64) {
+  // queries q0 .. q0 + nq - 1 against keys k0 .. k0 + 63
   FaTile t;
   t.plain = !p.causal && p.chunk_nc == 0 && (k0 + 63 < min(klen, T));
-  t.far = has_qp && p.clamp > 0 && (k0 - (q0 + 63) >= p.clamp || q0 - (k0 + 63) >= p.clamp);
+  t.far = has_qp && p.clamp > 0 && (k0 - (q0 + nq - 1) >= p.clamp || q0 - (k0 + 63) >= p.clamp);
   return t;
 }
 
@@ -142,136 +144,200 @@ __device__ __forceinline__ unsigned fa_rowhash(const nsp_attn_mask_params& p, in
   return nsp_hash_u32(p.seed, p.offset + (unsigned long long)(((long long)b * p.H + h) * T + qi));
 }
 
+// 16 B per thread, 2 per tile: global -> registers now, registers -> LDS later (the loads are issued
+// before a tile's arithmetic and written after it, so their latency hides behind the MFMA / softmax
+// work of the current tile: the CDNA guide's "async-STAGE split")
+struct TileRegs { u32x4 v[2]; };
+__device__ __forceinline__ void tile_load(TileRegs& t, const __bf16* __restrict__ src, long long ld, long long brow0,
+                                          int row0, int T) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int j = idx >> 3, c = idx & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + j < T) v = *reinterpret_cast<const u32x4*>(src + (brow0 + row0 + j) * ld + c * 8);
+    t.v[i] = v;
+  }
+}
+__device__ __forceinline__ void tile_store(unsigned char* tile, const TileRegs& t) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int j = idx >> 3, c = idx & 7;
+    *reinterpret_cast<u32x4*>(tile + j * KP + c * 16) = t.v[i];
+  }
+}
+
+// forward: one workgroup per (128-query tile, head, utterance); 4 waves x 32 queries (two 16-query
+// fragments share every K / V fragment read); K / V tiles double-buffered in LDS with the next tile's
+// global loads in flight during the current tile's arithmetic -> ONE barrier per key tile.
+// grid.x = 8-way interleave of heads and query tiles (id % H = head): with H = 8 every head lives on one
+// XCD, so the q-tiles of one (utterance, head) re-read its K / V from that XCD's L2.
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict__ qkv, int d,
                                                         const float* __restrict__ QP,
                                                         __bf16* __restrict__ O, float* __restrict__ O32,
                                                         float* __restrict__ LSE,
                                                         const nsp_attn_mask_params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * KP];
-  __shared__ float QPs[64][17];
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[2][64 * KP];
+  __shared__ float QPs[128][17];
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.x % p.H, q0 = (blockIdx.x / p.H) * 128, b = blockIdx.y;
   const long long ld3 = 3LL * d;
   const long long brow0 = (long long)b * T;
   const int klen = p.klens ? p.klens[b] : T;
-  const int qi = q0 + wave * 16 + r;            // this lane's query
-  const int qrow = min(qi, T - 1);
-  const __bf16* qp_ = qkv + (brow0 + qrow) * ld3 + h * DK;
-  bf16x8 Qf[2];
-  Qf[0] = *reinterpret_cast<const bf16x8*>(qp_ + g * 8);
-  Qf[1] = *reinterpret_cast<const bf16x8*>(qp_ + 32 + g * 8);
   const float sl2 = p.scale * LOG2E;
+  const __bf16* kbase = qkv + d + h * DK;
+  const __bf16* vbase = qkv + 2 * d + h * DK;
+  TileRegs kr, vr;
+  tile_load(kr, kbase, ld3, brow0, 0, T);
+  tile_load(vr, vbase, ld3, brow0, 0, T);
+  int qi[2];
+  bf16x8 Qf[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    qi[f] = q0 + wave * 32 + f * 16 + r;
+    const __bf16* qp_ = qkv + (brow0 + min(qi[f], T - 1)) * ld3 + h * DK;
+    Qf[f][0] = *reinterpret_cast<const bf16x8*>(qp_ + g * 8);
+    Qf[f][1] = *reinterpret_cast<const bf16x8*>(qp_ + 32 + g * 8);
+  }
   if (QP) {
-    for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
+    for (int idx = threadIdx.x; idx < 128 * p.r_pitch; idx += 256) {
       const int ql = idx / p.r_pitch, rr = idx % p.r_pitch;
       const int q = min(q0 + ql, T - 1);
       QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr] * sl2;
     }
   }
-  const float* qprow = QP ? QPs[wave * 16 + r] : nullptr;
   const bool drop = p.dropout_p > 0.f;
   const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
-  const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
-  f32x4 o_acc[4];
+  unsigned rowhash[2] = {0u, 0u};
+  if (drop) { rowhash[0] = fa_rowhash(p, b, h, T, qi[0]); rowhash[1] = fa_rowhash(p, b, h, T, qi[1]); }
+  f32x4 o_acc[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o_acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  tile_store(Ks[0], kr);
+  tile_store(Vs[0], vr);
+  __syncthreads();
   const int nkt = (T + 63) / 64;
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    stage_tile(Ks, qkv + d + h * DK, ld3, brow0, kt * 64, T);
-    stage_tile(Vs, qkv + 2 * d + h * DK, ld3, brow0, kt * 64, T);
-    __syncthreads();
-    f32x4 s_acc[4];
+    const unsigned char* Kc = Ks[kt & 1];
+    const unsigned char* Vc = Vs[kt & 1];
+    if (kt + 1 < nkt) {
+      tile_load(kr, kbase, ld3, brow0, (kt + 1) * 64, T);
+      tile_load(vr, vbase, ld3, brow0, (kt + 1) * 64, T);
+    }
+    f32x4 s_acc[2][4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
-      s_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s_acc[0][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s_acc[1][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Ks, kf * 16, s, r, g), Qf[s], s_acc[kf], 0, 0, 0);
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 kfrag = frag_kc(Kc, kf * 16, s, r, g);
+        s_acc[0][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, Qf[0][s], s_acc[0][kf], 0, 0, 0);
+        s_acc[1][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, Qf[1][s], s_acc[1][kf], 0, 0, 0);
+      }
     }
-    // lane: query qi, keys kt*64 + kf*16 + 4g + e
-    const FaTile tl = fa_tile(p, QP != nullptr, q0, kt * 64, T, klen);
-    float ev[4][4];
-    fa_logits(s_acc, ev, p, qprow, sl2, qi, kt * 64, g, klen, tl);
-    if (!tl.plain && kt * 64 + 63 >= T) {
+    bf16x8 Pf[2][2], Pl[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      // lane: query qi[f], keys kt*64 + kf*16 + 4g + e
+      const int q0f = q0 + wave * 32 + f * 16;
+      const FaTile tl = fa_tile(p, QP != nullptr, q0f, kt * 64, T, klen, 16);
+      float ev[4][4];
+      fa_logits(s_acc[f], ev, p, QP ? QPs[wave * 32 + f * 16 + r] : nullptr, sl2, qi[f], kt * 64, g, klen, tl);
+      if (!tl.plain && kt * 64 + 63 >= T) {
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (kt * 64 + kf * 16 + 4 * g + e >= T) ev[kf][e] = -INFINITY;   // tile padding: not in the softmax
+      }
+      float mx = -INFINITY;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (kt * 64 + kf * 16 + 4 * g + e >= T) ev[kf][e] = -INFINITY;   // tile padding: not in the softmax
-    }
-    float mx = -INFINITY;
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, ev[kf][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[f], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // m_run = -inf on the first tile -> 0
+      float rs = 0.f;
+      // The probabilities enter P V as a bf16 PAIR hi + lo (two MFMAs): O then carries P to ~2^-17
+      // instead of 2^-9.  Backward's D_i = dO_i . O_i must equal sum_j P_ij dP_ij of the RECOMPUTED fp32
+      // P to far better than bf16 precision: dS = P (dP - D) sums to zero over keys only then, and any
+      // residue multiplies the component common to all keys / queries (large once biases are non-zero),
+      // which the softmax's shift invariance removes from the true gradient (measured: w_query / w_key
+      // gradients of the upper Conformer-L blocks at cosine 0.45 with a single bf16 P).
+      float kp[4][4];
+      if (drop) fa_keep(kp, rowhash[f], kt * 64, g, thr16, inv_keep);
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+      for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, ev[kf][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf on the first tile -> 0
-    float rs = 0.f;
-    // The probabilities enter P V as a bf16 PAIR hi + lo (two MFMAs): O then carries P to ~2^-17
-    // instead of 2^-9.  Backward's D_i = dO_i . O_i must equal sum_j P_ij dP_ij of the RECOMPUTED fp32
-    // P to far better than bf16 precision: dS = P (dP - D) sums to zero over keys only then, and any
-    // residue multiplies the component common to all keys / queries (large once biases are non-zero),
-    // which the softmax's shift invariance removes from the true gradient (measured: w_query / w_key
-    // gradients of the upper Conformer-L blocks at cosine 0.45 with a single bf16 P).
-    bf16x8 Pf[2], Pl[2];
-    float kp[4][4];
-    if (drop) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
+        for (int e = 0; e < 4; ++e) {
+          float pr = __builtin_amdgcn_exp2f(ev[kf][e] - m_new);
+          rs += pr;
+          if (drop) pr *= kp[kf][e];
+          const __bf16 hi = (__bf16)pr;
+          Pf[f][kf >> 1][(kf & 1) * 4 + e] = hi;
+          Pl[f][kf >> 1][(kf & 1) * 4 + e] = (__bf16)(pr - (float)hi);
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l_run[f] = l_run[f] * alpha + rs;
+      m_run[f] = m_new;
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float pr = __builtin_amdgcn_exp2f(ev[kf][e] - m_new);
-        rs += pr;
-        if (drop) pr *= kp[kf][e];
-        const __bf16 hi = (__bf16)pr;
-        Pf[kf >> 1][(kf & 1) * 4 + e] = hi;
-        Pl[kf >> 1][(kf & 1) * 4 + e] = (__bf16)(pr - (float)hi);
+      for (int i = 0; i < 4; ++i) {
+        o_acc[f][i][0] *= alpha; o_acc[f][i][1] *= alpha; o_acc[f][i][2] *= alpha; o_acc[f][i][3] *= alpha;
       }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      o_acc[i][0] *= alpha; o_acc[i][1] *= alpha; o_acc[i][2] *= alpha; o_acc[i][3] *= alpha;
     }
     // O^T[dd][query] += V^T P^T : X = V^T fragment (rows dd), Y = P fragment (rows queries)
 #pragma unroll
     for (int ddf = 0; ddf < 4; ++ddf)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 vT = frag_tr(Vs, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r);
-        o_acc[ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pf[s], o_acc[ddf], 0, 0, 0);
-        o_acc[ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pl[s], o_acc[ddf], 0, 0, 0);
-      }
-  }
-  if (qi < T) {
-    const float inv = nsp_rcp(l_run);
-    __bf16* op = O + (brow0 + qi) * d + h * DK;
-    float* op32 = O32 ? O32 + (brow0 + qi) * d + h * DK : nullptr;
+        const bf16x8 vT = frag_tr(Vc, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r);
 #pragma unroll
-    for (int ddf = 0; ddf < 4; ++ddf) {
-      const float4 o = make_float4(o_acc[ddf][0] * inv, o_acc[ddf][1] * inv, o_acc[ddf][2] * inv, o_acc[ddf][3] * inv);
-      bf16x4 o4;
-      o4[0] = (__bf16)o.x; o4[1] = (__bf16)o.y; o4[2] = (__bf16)o.z; o4[3] = (__bf16)o.w;
-      *reinterpret_cast<bf16x4*>(op + ddf * 16 + 4 * g) = o4;
-      if (op32) *reinterpret_cast<float4*>(op32 + ddf * 16 + 4 * g) = o;   // backward's D reads this one
+        for (int f = 0; f < 2; ++f) {
+          o_acc[f][ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pf[f][s], o_acc[f][ddf], 0, 0, 0);
+          o_acc[f][ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pl[f][s], o_acc[f][ddf], 0, 0, 0);
+        }
+      }
+    if (kt + 1 < nkt) {
+      tile_store(Ks[(kt + 1) & 1], kr);
+      tile_store(Vs[(kt + 1) & 1], vr);
     }
-    if (g == 0) {
-      // row max and 1/sum are kept SEPARATELY: for a fully masked row max = -FLT_MAX and
-      // max + log(sum) is not representable (the log is absorbed), which would turn the
-      // reference's uniform 1/T probabilities into 1 in the backward recomputation
-      const long long ri = ((long long)b * p.H + h) * T + qi;
-      LSE[ri] = m_run;
-      LSE[(long long)p.B * p.H * T + ri] = inv;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    if (qi[f] < T) {
+      const float inv = nsp_rcp(l_run[f]);
+      __bf16* op = O + (brow0 + qi[f]) * d + h * DK;
+      float* op32 = O32 ? O32 + (brow0 + qi[f]) * d + h * DK : nullptr;
+#pragma unroll
+      for (int ddf = 0; ddf < 4; ++ddf) {
+        const float4 o = make_float4(o_acc[f][ddf][0] * inv, o_acc[f][ddf][1] * inv, o_acc[f][ddf][2] * inv,
+                                     o_acc[f][ddf][3] * inv);
+        bf16x4 o4;
+        o4[0] = (__bf16)o.x; o4[1] = (__bf16)o.y; o4[2] = (__bf16)o.z; o4[3] = (__bf16)o.w;
+        *reinterpret_cast<bf16x4*>(op + ddf * 16 + 4 * g) = o4;
+        if (op32) *reinterpret_cast<float4*>(op32 + ddf * 16 + 4 * g) = o;   // backward's D reads this one
+      }
+      if (g == 0) {
+        // row max and 1/sum are kept SEPARATELY: for a fully masked row max = -FLT_MAX and
+        // max + log(sum) is not representable (the log is absorbed), which would turn the
+        // reference's uniform 1/T probabilities into 1 in the backward recomputation
+        const long long ri = ((long long)b * p.H + h) * T + qi[f];
+        LSE[ri] = m_run[f];
+        LSE[(long long)p.B * p.H * T + ri] = inv;
+      }
     }
   }
 }
@@ -543,7 +609,7 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
   if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16 && p.R >= (p.clamp + 1 < p.Tk ? p.clamp + 1 : p.Tk)))
     return NSP_EUNSUPPORTED;
   if (p.r_pitch < p.R) p.r_pitch = p.R;
-  dim3 grid((p.Tq + 63) / 64, p.H, p.B);
+  dim3 grid(((p.Tq + 127) / 128) * p.H, p.B);
   hipLaunchKernelGGL(flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE, p);
   NSP_LAUNCH_CHECK();
