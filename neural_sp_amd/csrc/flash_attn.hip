@@ -127,17 +127,20 @@ __device__ __forceinline__ unsigned fa_logits(const f32x4 (&s_acc)[4], float (&e
 }
 
 __device__ __forceinline__ void fa_keep(float (&kp)[4][4], unsigned rowhash, int k0, int g, unsigned thr16, float inv_keep) {
+  // one 32-bit value per PAIR of adjacent keys (16 bits per decision), from full-rate integer ops only:
+  // a 24-bit multiply-add of the pair index folded into the per-row hash, one xorshift round and a
+  // second 24-bit multiply-add (v_mul_lo_u32 is quarter rate; two of them per pair were ~40 % of this
+  // kernel's VALU cycles with dropout on).  Forward and both backward kernels call this same function.
 #pragma unroll
   for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
-      const unsigned key = (unsigned)(k0 + kf * 16 + 4 * g + 2 * pr);
-      unsigned x = rowhash ^ ((key >> 1) * 0x9E3779B9u);
-      x ^= x >> 16; x *= 0x85EBCA6Bu;
-      x ^= x >> 13; x *= 0xC2B2AE35u;
-      x ^= x >> 16;
-      kp[kf][2 * pr] = (x & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
-      kp[kf][2 * pr + 1] = (x >> 16) >= thr16 ? inv_keep : 0.f;
+      const unsigned pair = (unsigned)(k0 + kf * 16 + 4 * g + 2 * pr) >> 1;
+      unsigned y = rowhash + __umul24(pair, 0x9E3779u) + (pair << 11);
+      y ^= y << 13; y ^= y >> 17; y ^= y << 5;
+      y = __umul24(y >> 8, 0x85EBCBu) ^ y;
+      kp[kf][2 * pr] = (y & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
+      kp[kf][2 * pr + 1] = (y >> 16) >= thr16 ? inv_keep : 0.f;
     }
 }
 __device__ __forceinline__ unsigned fa_rowhash(const nsp_attn_mask_params& p, int b, int h, int T, int qi) {
@@ -173,18 +176,19 @@ __device__ __forceinline__ void tile_store(unsigned char* tile, const TileRegs& 
 // global loads in flight during the current tile's arithmetic -> ONE barrier per key tile.
 // grid.x = 8-way interleave of heads and query tiles (id % H = head): with H = 8 every head lives on one
 // XCD, so the q-tiles of one (utterance, head) re-read its K / V from that XCD's L2.
-__global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict__ qkv, int d,
+template <int NQ>   // 16-query fragments per wave: workgroup tile = 64 * NQ queries
+__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restrict__ qkv, int d,
                                                         const float* __restrict__ QP,
                                                         __bf16* __restrict__ O, float* __restrict__ O32,
                                                         float* __restrict__ LSE,
                                                         const nsp_attn_mask_params p) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[2][64 * KP];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[2][64 * KP];
-  __shared__ float QPs[128][17];
+  __shared__ float QPs[64 * NQ][17];
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int h = blockIdx.x % p.H, q0 = (blockIdx.x / p.H) * 128, b = blockIdx.y;
+  const int h = blockIdx.x % p.H, q0 = (blockIdx.x / p.H) * (64 * NQ), b = blockIdx.y;
   const long long ld3 = 3LL * d;
   const long long brow0 = (long long)b * T;
   const int klen = p.klens ? p.klens[b] : T;
@@ -192,19 +196,21 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
   const __bf16* kbase = qkv + d + h * DK;
   const __bf16* vbase = qkv + 2 * d + h * DK;
   TileRegs kr, vr;
-  tile_load(kr, kbase, ld3, brow0, 0, T);
-  tile_load(vr, vbase, ld3, brow0, 0, T);
-  int qi[2];
-  bf16x8 Qf[2][2];
+  // NOTE the order: Q / QP loads are issued BEFORE tile 0's loads.  vmcnt retires in issue order, so
+  // the wait in front of the first tile_store then covers them too and the k-loop is entered with
+  // nothing pending; issued after, hipcc has to keep a vmcnt(0) in front of the loop's first MFMA
+  // (Q is its operand), which drains every iteration's prefetch as soon as it is issued.
+  int qi[NQ];
+  bf16x8 Qf[NQ][2];
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    qi[f] = q0 + wave * 32 + f * 16 + r;
+  for (int f = 0; f < NQ; ++f) {
+    qi[f] = q0 + wave * (16 * NQ) + f * 16 + r;
     const __bf16* qp_ = qkv + (brow0 + min(qi[f], T - 1)) * ld3 + h * DK;
     Qf[f][0] = *reinterpret_cast<const bf16x8*>(qp_ + g * 8);
     Qf[f][1] = *reinterpret_cast<const bf16x8*>(qp_ + 32 + g * 8);
   }
   if (QP) {
-    for (int idx = threadIdx.x; idx < 128 * p.r_pitch; idx += 256) {
+    for (int idx = threadIdx.x; idx < 64 * NQ * p.r_pitch; idx += 256) {
       const int ql = idx / p.r_pitch, rr = idx % p.r_pitch;
       const int q = min(q0 + ql, T - 1);
       QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr] * sl2;
@@ -213,14 +219,19 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
   const bool drop = p.dropout_p > 0.f;
   const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
-  unsigned rowhash[2] = {0u, 0u};
-  if (drop) { rowhash[0] = fa_rowhash(p, b, h, T, qi[0]); rowhash[1] = fa_rowhash(p, b, h, T, qi[1]); }
-  f32x4 o_acc[2][4];
+  unsigned rowhash[NQ];
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
+  for (int f = 0; f < NQ; ++f) rowhash[f] = drop ? fa_rowhash(p, b, h, T, qi[f]) : 0u;
+  f32x4 o_acc[NQ][4];
+#pragma unroll
+  for (int f = 0; f < NQ; ++f)
 #pragma unroll
     for (int i = 0; i < 4; ++i) o_acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  float m_run[NQ], l_run[NQ];
+#pragma unroll
+  for (int f = 0; f < NQ; ++f) { m_run[f] = -INFINITY; l_run[f] = 0.f; }
+  tile_load(kr, kbase, ld3, brow0, 0, T);
+  tile_load(vr, vbase, ld3, brow0, 0, T);
   tile_store(Ks[0], kr);
   tile_store(Vs[0], vr);
   __syncthreads();
@@ -232,26 +243,27 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
       tile_load(kr, kbase, ld3, brow0, (kt + 1) * 64, T);
       tile_load(vr, vbase, ld3, brow0, (kt + 1) * 64, T);
     }
-    f32x4 s_acc[2][4];
+    f32x4 s_acc[NQ][4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
-      s_acc[0][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-      s_acc[1][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < NQ; ++f) s_acc[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 kfrag = frag_kc(Kc, kf * 16, s, r, g);
-        s_acc[0][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, Qf[0][s], s_acc[0][kf], 0, 0, 0);
-        s_acc[1][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, Qf[1][s], s_acc[1][kf], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < NQ; ++f)
+          s_acc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, Qf[f][s], s_acc[f][kf], 0, 0, 0);
       }
     }
-    bf16x8 Pf[2][2], Pl[2][2];
+    bf16x8 Pf[NQ][2], Pl[NQ][2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < NQ; ++f) {
       // lane: query qi[f], keys kt*64 + kf*16 + 4g + e
-      const int q0f = q0 + wave * 32 + f * 16;
+      const int q0f = q0 + wave * (16 * NQ) + f * 16;
       const FaTile tl = fa_tile(p, QP != nullptr, q0f, kt * 64, T, klen, 16);
       float ev[4][4];
-      fa_logits(s_acc[f], ev, p, QP ? QPs[wave * 32 + f * 16 + r] : nullptr, sl2, qi[f], kt * 64, g, klen, tl);
+      fa_logits(s_acc[f], ev, p, QP ? QPs[wave * (16 * NQ) + f * 16 + r] : nullptr, sl2, qi[f], kt * 64, g, klen, tl);
       if (!tl.plain && kt * 64 + 63 >= T) {
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
@@ -304,7 +316,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
       for (int s = 0; s < 2; ++s) {
         const bf16x8 vT = frag_tr(Vc, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r);
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < NQ; ++f) {
           o_acc[f][ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pf[f][s], o_acc[f][ddf], 0, 0, 0);
           o_acc[f][ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pl[f][s], o_acc[f][ddf], 0, 0, 0);
         }
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const __bf16* __restrict
     __syncthreads();
   }
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
+  for (int f = 0; f < NQ; ++f) {
     if (qi[f] < T) {
       const float inv = nsp_rcp(l_run[f]);
       __bf16* op = O + (brow0 + qi[f]) * d + h * DK;
@@ -362,48 +374,89 @@ __global__ __launch_bounds__(256) void flash_dot_kernel(const __bf16* __restrict
 }
 
 // ---- backward, part 1: dK / dV.  One workgroup per 64-key tile, looping over query tiles.
-__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
+// The workgroup's K and V fragments are loop invariant and live in REGISTERS (64 VGPRs); Q / dO (and the
+// position-score table) of the NEXT query tile are fetched into registers while the current tile is
+// processed and committed to the other LDS buffer afterwards: two barriers per query tile (P / dS
+// visible; buffers swapped) instead of three, and no exposed global-load latency.
+__global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, __bf16* __restrict__ dqkv,
     const nsp_attn_mask_params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char dOs[64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[2][64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char dOs[2][64 * KP];
   __shared__ __attribute__((aligned(16))) unsigned char Ps[64 * KP];   // dropped probabilities [query][key]
   __shared__ __attribute__((aligned(16))) unsigned char dSs[64 * KP];  // dS                    [query][key]
-  __shared__ float QPs[64][17];
+  __shared__ __attribute__((aligned(16))) float QPs[2][64][16];
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.x % p.H, k0 = (blockIdx.x / p.H) * 64, b = blockIdx.y;
   const long long ld3 = 3LL * d;
   const long long brow0 = (long long)b * T;
   const long long nrow = (long long)p.B * p.H * T;
   const int klen = p.klens ? p.klens[b] : T;
-  stage_tile(Ks, qkv + d + h * DK, ld3, brow0, k0, T);
-  stage_tile(Vs, qkv + 2 * d + h * DK, ld3, brow0, k0, T);
   const float sl2 = p.scale * LOG2E;
   const bool drop = p.dropout_p > 0.f;
   const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
+  const int rp = p.r_pitch;
+  // K / V MFMA fragments of this workgroup's 64 keys: rows kf*16 + r, k-chunk (s, g)
+  bf16x8 Kf[4][2], Vf[4][2];
+#pragma unroll
+  for (int kf = 0; kf < 4; ++kf) {
+    const int key = k0 + kf * 16 + r;
+    const __bf16* kp_ = qkv + (brow0 + min(key, T - 1)) * ld3 + d + h * DK;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 kv = *reinterpret_cast<const bf16x8*>(kp_ + s2 * 32 + g * 8);
+      bf16x8 vv = *reinterpret_cast<const bf16x8*>(kp_ + d + s2 * 32 + g * 8);
+      if (key >= T) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kv[e] = (__bf16)0.f; vv[e] = (__bf16)0.f; }
+      }
+      Kf[kf][s2] = kv;
+      Vf[kf][s2] = vv;
+    }
+  }
+  const __bf16* qbase = qkv + h * DK;
+  const __bf16* dobase = dO + h * DK;
+  auto qp_load = [&](int q0) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (QP) {
+      // 64 queries x 16 table slots = 256 float4: thread t -> query t/4, slots 4*(t%4)..
+      const int ql = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
+      const int q = min(q0 + ql, T - 1);
+      const float* src = QP + ((brow0 + q) * p.H + h) * rp;
+      v.x = c4 + 0 < rp ? src[c4 + 0] * sl2 : 0.f;
+      v.y = c4 + 1 < rp ? src[c4 + 1] * sl2 : 0.f;
+      v.z = c4 + 2 < rp ? src[c4 + 2] * sl2 : 0.f;
+      v.w = c4 + 3 < rp ? src[c4 + 3] * sl2 : 0.f;
+    }
+    return v;
+  };
+  auto qp_store = [&](int buf, const float4& v) {
+    *reinterpret_cast<float4*>(&QPs[buf][threadIdx.x >> 2][(threadIdx.x & 3) * 4]) = v;
+  };
+  TileRegs qr, dor;
+  tile_load(qr, qbase, ld3, brow0, 0, T);
+  tile_load(dor, dobase, d, brow0, 0, T);
+  float4 qpr = qp_load(0);
   f32x4 dk_acc[4], dv_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  tile_store(Qs[0], qr);
+  tile_store(dOs[0], dor);
+  qp_store(0, qpr);
+  __syncthreads();
   const int nqt = (T + 63) / 64;
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 64;
-    __syncthreads();
-    stage_tile(Qs, qkv + h * DK, ld3, brow0, q0, T);
-    stage_tile(dOs, dO + h * DK, d, brow0, q0, T);
-    if (QP) {
-      for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
-        const int ql = idx / p.r_pitch, rr = idx % p.r_pitch;
-        const int q = min(q0 + ql, T - 1);
-        QPs[ql][rr] = QP[((brow0 + q) * p.H + h) * p.r_pitch + rr] * sl2;
-      }
+    const int cur = qt & 1;
+    if (qt + 1 < nqt) {
+      tile_load(qr, qbase, ld3, brow0, q0 + 64, T);
+      tile_load(dor, dobase, d, brow0, q0 + 64, T);
+      qpr = qp_load(q0 + 64);
     }
-    __syncthreads();
     const int ql = wave * 16 + r;
     const int qi = q0 + ql;
     const int qc = min(qi, T - 1);
@@ -413,21 +466,27 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
     const float dsum = Drow[ri];
     const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
     f32x4 s_acc[4], dp_acc[4];
+    {
+      bf16x8 qf[2], dof[2];
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
-      s_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s2 = 0; s2 < 2; ++s2) {
+        qf[s2] = frag_kc(Qs[cur], wave * 16, s2, r, g);
+        dof[s2] = frag_kc(dOs[cur], wave * 16, s2, r, g);
+      }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Ks, kf * 16, s, r, g),
-                                                            frag_kc(Qs, wave * 16, s, r, g), s_acc[kf], 0, 0, 0);
-        dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Vs, kf * 16, s, r, g),
-                                                             frag_kc(dOs, wave * 16, s, r, g), dp_acc[kf], 0, 0, 0);
+      for (int kf = 0; kf < 4; ++kf) {
+        s_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kf][s2], qf[s2], s_acc[kf], 0, 0, 0);
+          dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kf][s2], dof[s2], dp_acc[kf], 0, 0, 0);
+        }
       }
     }
     const FaTile tl = fa_tile(p, QP != nullptr, q0, k0, T, klen);
     float ev[4][4], kp[4][4];
-    const unsigned vis = fa_logits(s_acc, ev, p, QP ? QPs[ql] : nullptr, sl2, qi, k0, g, klen, tl);
+    const unsigned vis = fa_logits(s_acc, ev, p, QP ? QPs[cur][ql] : nullptr, sl2, qi, k0, g, klen, tl);
     if (drop) fa_keep(kp, rowhash, k0, g, thr16, inv_keep);
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
@@ -449,17 +508,23 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
     // dV[key][dd] += sum_q Pd[q][key] dO[q][dd] ; dK[key][dk'] += sum_q dS[q][key] Q[q][dk']
     // wave owns keys 16*wave..; X = P^T / dS^T fragments (rows = keys, k = queries) via transpose reads
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 pT = frag_tr(Ps, wave * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
-      const bf16x8 dsT = frag_tr(dSs, wave * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pT = frag_tr(Ps, wave * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, r);
+      const bf16x8 dsT = frag_tr(dSs, wave * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, r);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        const bf16x8 doT = frag_tr(dOs, df * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
-        const bf16x8 qT = frag_tr(Qs, df * 16, 32 * s + 8 * g, 32 * s + 8 * g + 4, r);
+        const bf16x8 doT = frag_tr(dOs[cur], df * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, r);
+        const bf16x8 qT = frag_tr(Qs[cur], df * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, r);
         dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pT, doT, dv_acc[df], 0, 0, 0);
         dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsT, qT, dk_acc[df], 0, 0, 0);
       }
     }
+    if (qt + 1 < nqt) {
+      tile_store(Qs[cur ^ 1], qr);
+      tile_store(dOs[cur ^ 1], dor);
+      qp_store(cur ^ 1, qpr);
+    }
+    __syncthreads();  // next tile's Q / dO / QP visible; P / dS / this tile's buffers free
   }
   // D[i = key (4g+e)][j = lane&15 = channel within fragment df]
 #pragma unroll
@@ -476,21 +541,22 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(
 }
 
 // ---- backward, part 2: dQ and the relative-table gradient dQP.  One workgroup per 64-query
-// tile looping over key tiles (the forward's structure): every output element is owned by exactly
+// tile looping over key tiles (the forward's structure: double-buffered K / V tiles, next tile's loads
+// in flight during the current tile, one barrier per tile): every output element is owned by exactly
 // one lane, so there is not a single global atomic (the first version accumulated dQ with fp32
 // atomics from the key-parallel kernel: 88 M atomics per call at T = 800 made it 4x slower).
-__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
+__global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, float* __restrict__ dq32,
     float* __restrict__ dQP, const nsp_attn_mask_params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][64 * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[2][64 * KP];
   __shared__ float QPs[64][17];
   __shared__ float dQPs[64][17];
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.x % p.H, q0 = (blockIdx.x / p.H) * 64, b = blockIdx.y;
   const long long ld3 = 3LL * d;
   const long long brow0 = (long long)b * T;
   const long long nrow = (long long)p.B * p.H * T;
@@ -498,6 +564,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
   const int ql = wave * 16 + r;
   const int qi = q0 + ql;
   const int qc = min(qi, T - 1);
+  // everything the loop reads from global memory besides the K / V tiles is fetched BEFORE tile 0
+  // (see the forward kernel's note on vmcnt order)
   const __bf16* qp_ = qkv + (brow0 + qc) * ld3 + h * DK;
   const __bf16* dop = dO + (brow0 + qc) * d + h * DK;
   bf16x8 Qf[2], dOf[2];
@@ -522,16 +590,26 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
   const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
   const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
+  const __bf16* kbase = qkv + d + h * DK;
+  const __bf16* vbase = qkv + 2 * d + h * DK;
+  TileRegs kr, vr;
+  tile_load(kr, kbase, ld3, brow0, 0, T);
+  tile_load(vr, vbase, ld3, brow0, 0, T);
   f32x4 dq_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) dq_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float far = 0.f;
+  tile_store(Ks[0], kr);
+  tile_store(Vs[0], vr);
+  __syncthreads();
   const int nkt = (T + 63) / 64;
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    stage_tile(Ks, qkv + d + h * DK, ld3, brow0, kt * 64, T);
-    stage_tile(Vs, qkv + 2 * d + h * DK, ld3, brow0, kt * 64, T);
-    __syncthreads();
+    const unsigned char* Kc = Ks[kt & 1];
+    const unsigned char* Vc = Vs[kt & 1];
+    if (kt + 1 < nkt) {
+      tile_load(kr, kbase, ld3, brow0, (kt + 1) * 64, T);
+      tile_load(vr, vbase, ld3, brow0, (kt + 1) * 64, T);
+    }
     f32x4 s_acc[4], dp_acc[4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
@@ -539,8 +617,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
       dp_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Ks, kf * 16, s, r, g), Qf[s], s_acc[kf], 0, 0, 0);
-        dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Vs, kf * 16, s, r, g), dOf[s], dp_acc[kf], 0, 0, 0);
+        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Kc, kf * 16, s, r, g), Qf[s], s_acc[kf], 0, 0, 0);
+        dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Vc, kf * 16, s, r, g), dOf[s], dp_acc[kf], 0, 0, 0);
       }
     }
     bf16x8 dSf[2];
@@ -576,7 +654,12 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(
 #pragma unroll
       for (int s = 0; s < 2; ++s)
         dq_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            frag_tr(Ks, df * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), dSf[s], dq_acc[df], 0, 0, 0);
+            frag_tr(Kc, df * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), dSf[s], dq_acc[df], 0, 0, 0);
+    if (kt + 1 < nkt) {
+      tile_store(Ks[(kt + 1) & 1], kr);
+      tile_store(Vs[(kt + 1) & 1], vr);
+    }
+    __syncthreads();
   }
   if (qi < T) {
     float* dqp = dq32 + (brow0 + qi) * d + h * DK;
@@ -609,9 +692,17 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
   if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16 && p.R >= (p.clamp + 1 < p.Tk ? p.clamp + 1 : p.Tk)))
     return NSP_EUNSUPPORTED;
   if (p.r_pitch < p.R) p.r_pitch = p.R;
-  dim3 grid(((p.Tq + 127) / 128) * p.H, p.B);
-  hipLaunchKernelGGL(flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE, p);
+  const char* e = getenv("NSP_FLASH_NQ");
+  const int nq = e ? atoi(e) : 1;   // 16 queries per wave measured faster than 32 (occupancy 3 vs 2)
+  if (nq == 1) {
+    dim3 grid(((p.Tq + 63) / 64) * p.H, p.B);
+    hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE, p);
+  } else {
+    dim3 grid(((p.Tq + 127) / 128) * p.H, p.B);
+    hipLaunchKernelGGL(flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE, p);
+  }
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
@@ -633,7 +724,7 @@ extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const
   if (g1 > 8192) g1 = 8192;
   hipLaunchKernelGGL(flash_dot_kernel, dim3(g1), dim3(256), 0, st, reinterpret_cast<const __bf16*>(dO),
                      O32, D, p.B, p.Tq, p.H, d);
-  dim3 grid((p.Tq + 63) / 64, p.H, p.B);
+  dim3 grid(((p.Tq + 63) / 64) * p.H, p.B);
   hipLaunchKernelGGL(flash_bwd_dkv_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
                      QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
   hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
