@@ -28,6 +28,8 @@ constexpr int DK = 64;
 constexpr int KP = 144;  // LDS row pitch in bytes for [rows][64] bf16 tiles (128 + 16 pad)
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 __device__ __forceinline__ bool fa_visible(const nsp_attn_mask_params& p, int klen, int i, int j) {
   bool ok = j < klen;
@@ -262,24 +264,37 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
       // lane: query qi[f], keys kt*64 + kf*16 + 4g + e
       const int q0f = q0 + wave * (16 * NQ) + f * 16;
       const FaTile tl = fa_tile(p, QP != nullptr, q0f, kt * 64, T, klen, 16);
+      const float* qrow = QP ? QPs[wave * (16 * NQ) + f * 16 + r] : nullptr;
+      // uniform tile (no mask predicate, relative term = the per-query constant QP[i][clamp]): the logit is
+      // fma(s, sl2, addc), so max / exp2 work on the raw MFMA output and addc - m folds into ONE fma per score
+      const bool uni = tl.plain && (qrow == nullptr || tl.far);
+      const float addc = (uni && qrow) ? qrow[p.clamp] : 0.f;
       float ev[4][4];
-      fa_logits(s_acc[f], ev, p, QP ? QPs[wave * (16 * NQ) + f * 16 + r] : nullptr, sl2, qi[f], kt * 64, g, klen, tl);
-      if (!tl.plain && kt * 64 + 63 >= T) {
+      float mx = -INFINITY;
+      if (uni) {
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+          mx = fmaxf(mx, fmaxf(fmaxf(s_acc[f][kf][0], s_acc[f][kf][1]), fmaxf(s_acc[f][kf][2], s_acc[f][kf][3])));
+        mx = fmaf(mx, sl2, addc);           // sl2 > 0: max commutes with the affine map
+      } else {
+        fa_logits(s_acc[f], ev, p, qrow, sl2, qi[f], kt * 64, g, klen, tl);
+        if (!tl.plain && kt * 64 + 63 >= T) {
+#pragma unroll
+          for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (kt * 64 + kf * 16 + 4 * g + e >= T) ev[kf][e] = -INFINITY;   // tile padding: not in the softmax
+        }
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (kt * 64 + kf * 16 + 4 * g + e >= T) ev[kf][e] = -INFINITY;   // tile padding: not in the softmax
+          for (int e = 0; e < 4; ++e) mx = fmaxf(mx, ev[kf][e]);
       }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, ev[kf][e]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[f], mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // m_run = -inf on the first tile -> 0
+      const float c0 = addc - m_new;
       float rs = 0.f;
       // The probabilities enter P V as a bf16 PAIR hi + lo (two MFMAs): O then carries P to ~2^-17
       // instead of 2^-9.  Backward's D_i = dO_i . O_i must equal sum_j P_ij dP_ij of the RECOMPUTED fp32
@@ -292,13 +307,23 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float pr = __builtin_amdgcn_exp2f(ev[kf][e] - m_new);
-          rs += pr;
-          if (drop) pr *= kp[kf][e];
-          const __bf16 hi = (__bf16)pr;
-          Pf[f][kf >> 1][(kf & 1) * 4 + e] = hi;
-          Pl[f][kf >> 1][(kf & 1) * 4 + e] = (__bf16)(pr - (float)hi);
+        for (int e2 = 0; e2 < 4; e2 += 2) {
+          f32x2 pr;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int e = e2 + q;
+            float v = uni ? __builtin_amdgcn_exp2f(fmaf(s_acc[f][kf][e], sl2, c0))
+                          : __builtin_amdgcn_exp2f(ev[kf][e] - m_new);
+            rs += v;
+            if (drop) v *= kp[kf][e];
+            pr[q] = v;
+          }
+          const bf16x2 hi = __builtin_convertvector(pr, bf16x2);
+          const bf16x2 lo = __builtin_convertvector(pr - __builtin_convertvector(hi, f32x2), bf16x2);
+          Pf[f][kf >> 1][(kf & 1) * 4 + e2] = hi[0];
+          Pf[f][kf >> 1][(kf & 1) * 4 + e2 + 1] = hi[1];
+          Pl[f][kf >> 1][(kf & 1) * 4 + e2] = lo[0];
+          Pl[f][kf >> 1][(kf & 1) * 4 + e2 + 1] = lo[1];
         }
       rs += __shfl_xor(rs, 16, 64);
       rs += __shfl_xor(rs, 32, 64);
@@ -485,20 +510,25 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
       }
     }
     const FaTile tl = fa_tile(p, QP != nullptr, q0, k0, T, klen);
+    const float* qrow = QP ? QPs[cur][ql] : nullptr;
+    const bool uni = tl.plain && (qrow == nullptr || tl.far);   // see the forward kernel
+    const float c0 = ((uni && qrow) ? qrow[p.clamp] : 0.f) - rmax;
+    const float rs_ = rinv * p.scale;
     float ev[4][4], kp[4][4];
-    const unsigned vis = fa_logits(s_acc, ev, p, QP ? QPs[cur][ql] : nullptr, sl2, qi, k0, g, klen, tl);
+    unsigned vis = 0xFFFFu;
+    if (!uni) vis = fa_logits(s_acc, ev, p, qrow, sl2, qi, k0, g, klen, tl);
     if (drop) fa_keep(kp, rowhash, k0, g, thr16, inv_keep);
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
       bf16x4 p4, ds4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float pr = __builtin_amdgcn_exp2f(ev[kf][e] - rmax) * rinv;
-        if (!tl.plain && k0 + kf * 16 + 4 * g + e >= T) pr = 0.f;
+        float ex = uni ? __builtin_amdgcn_exp2f(fmaf(s_acc[kf][e], sl2, c0)) : __builtin_amdgcn_exp2f(ev[kf][e] - rmax);
+        if (!tl.plain && k0 + kf * 16 + 4 * g + e >= T) ex = 0.f;
         const float keep = drop ? kp[kf][e] : 1.f;
-        float ds = pr * (dp_acc[kf][e] * keep - dsum) * p.scale;
+        float ds = ex * rs_ * fmaf(dp_acc[kf][e], keep, -dsum);
         if (!tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
-        p4[e] = (__bf16)(pr * keep);
+        p4[e] = (__bf16)(ex * rinv * keep);
         ds4[e] = (__bf16)ds;
       }
       *reinterpret_cast<bf16x4*>(Ps + ql * KP + (kf * 16 + 4 * g) * 2) = p4;
@@ -545,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
 // in flight during the current tile, one barrier per tile): every output element is owned by exactly
 // one lane, so there is not a single global atomic (the first version accumulated dQ with fp32
 // atomics from the key-parallel kernel: 88 M atomics per call at T = 800 made it 4x slower).
-__global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(
+__global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, float* __restrict__ dq32,
     float* __restrict__ dQP, const nsp_attn_mask_params p) {
@@ -623,18 +653,23 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(
     }
     bf16x8 dSf[2];
     const FaTile tl = fa_tile(p, QP != nullptr, q0, kt * 64, T, klen);
+    const float* qrow = QP ? QPs[ql] : nullptr;
+    const bool uni = tl.plain && (qrow == nullptr || tl.far);   // see the forward kernel
+    const float c0 = ((uni && qrow) ? qrow[p.clamp] : 0.f) - rmax;
+    const float rs_ = rinv * p.scale;
     float ev[4][4], kp[4][4];
-    const unsigned vis = fa_logits(s_acc, ev, p, QP ? QPs[ql] : nullptr, sl2, qi, kt * 64, g, klen, tl);
+    unsigned vis = 0xFFFFu;
+    if (!uni) vis = fa_logits(s_acc, ev, p, qrow, sl2, qi, kt * 64, g, klen, tl);
     if (drop) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int key = kt * 64 + kf * 16 + 4 * g + e;
-        float pr = __builtin_amdgcn_exp2f(ev[kf][e] - rmax) * rinv;
-        if (!tl.plain && key >= T) pr = 0.f;
+        float ex = uni ? __builtin_amdgcn_exp2f(fmaf(s_acc[kf][e], sl2, c0)) : __builtin_amdgcn_exp2f(ev[kf][e] - rmax);
+        if (!tl.plain && key >= T) ex = 0.f;
         const float keep = drop ? kp[kf][e] : 1.f;
-        float ds = pr * (dp_acc[kf][e] * keep - dsum) * p.scale;
+        float ds = ex * rs_ * fmaf(dp_acc[kf][e], keep, -dsum);
         if (!tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
         dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
         if (QP) {

@@ -153,7 +153,10 @@ def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward
     ops.flash_attn_bwd_raw(qkv, d, QP, dO, O1_32, LSE1, mp, dqkv)
     lhs = (dO.float() * O1.float()).sum().item()
     rhs = (dqkv[:, 2 * d:].float() * qkv[:, 2 * d:].float()).sum().item()
-    assert abs(lhs - rhs) / abs(lhs) < 2e-2, (lhs, rhs)
+    # <dO, O> is a sum of random-sign terms: normalise by the norms, not by the (possibly tiny) sum
+    scale_ = (dO.float().norm() * O1.float().norm()).item()
+    print('[flash dropout adjoint] <dO,O> %.4f  <dV,V> %.4f  |diff| / (|dO||O|) %.2e' % (lhs, rhs, abs(lhs - rhs) / scale_))
+    assert abs(lhs - rhs) / scale_ < 2e-3, (lhs, rhs, scale_)
 
 
 @pytest.mark.parametrize('T,H,B', [(200, 2, 3), (800, 8, 2)])

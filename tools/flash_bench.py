@@ -22,7 +22,7 @@ for T in (800, 400, 200):
         def fwd(): ops.flash_attn_fwd_raw(qkv, d, QP, mp)
         def bwd(): ops.flash_attn_bwd_raw(qkv, d, QP, dO, O32, LSE, mp, dqkv)
         res = []
-        for nq in ('1', '2'):
+        for nq in ('2', '1'):
             os.environ['NSP_FLASH_NQ'] = nq
             for _ in range(2): fwd()
             torch.cuda.synchronize()
