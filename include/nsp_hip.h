@@ -101,6 +101,7 @@ typedef struct {
    *                         in the pad columns; column sums of every 64-row block -> epi_f3
    *                         [ceil(M/128)*2, N] (output-bias gradient slabs, no atomics).
    *   scale = epi_scale * (epi_scale_dev ? *epi_scale_dev : 1).                                  */
+  /* epi_mode == NSP_EPI_NONE and epi_f3 != NULL: column-sum slabs of the stored values (see nsp_gemm_flat) */
   int epi_mode, epi_ncols, epi_blank;
   const int* epi_lab;
   float* epi_f0; float* epi_f1; float* epi_f2; float* epi_f3;
@@ -124,7 +125,11 @@ int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs, long long 
                   float alpha, int splitk, int mode, float dropout_p,
                   unsigned long long seed, unsigned long long offset, int a_dtype,
                   int b_dtype, int c_dtype, int pre_dtype, int dact_dtype, long long c_ss,
-                  void* stream);
+                  float* colsum_slabs, void* stream);
+/* colsum_slabs (bf16 operands, splitk == 1; may be NULL): fp32 [ceil(M/32), N], ZERO-INITIALISED by the caller.
+ * Row (m / R) receives the column sums of the stored values of rows m .. m+R-1 for every R-row block a wave
+ * owns (R = 64, or 32 on the 64-row-tile variant; untouched rows stay zero): summing the rows gives
+ * sum_m C(m, n) -- the bias gradient when C is a d(pre-activation) -- without a separate pass over C. */
 
 /* ------------------------------------------------------------------------ *
  * LayerNorm over the last dim (eps inside sqrt, biased variance).          *
@@ -188,7 +193,7 @@ int nsp_colsum_bf16(const void* x /*bf16*/, float* out, int rows, int cols, long
  * (pre may be NULL; pre/out are fp32 or bf16; n % 4 == 0) */
 int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, void* out, int out_bf16,
                   int act, float alpha, float p, unsigned long long seed,
-                  unsigned long long offset, long long n, void* stream);
+                  unsigned long long offset, long long n, int cols, float* colsum, void* stream);
 /* GLU over the channel dim of [rows, 2C] -> [rows, C]: a*sigmoid(b)
  * (conformer_convolution.py:109, F.glu(dim=1) on [B,2C,T]) */
 int nsp_glu_fwd(const float* x, float* y, long long rows, int C, void* stream);

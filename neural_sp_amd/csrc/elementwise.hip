@@ -106,6 +106,85 @@ __global__ void grad_prep_kernel(const float* __restrict__ dy, const void* __res
   }
 }
 
+// grad_prep with the column sums of its OUTPUT (the bias gradient of the Linear whose gradient this is)
+// accumulated on the way: a block owns a band of rows; thread t owns the float4 column groups
+// t % C4, (+256, ...) for rows r0 + t / C4 (+ 256 / C4, ...), keeps their sums in registers and flushes
+// them once (LDS reduce over the row lanes, then one atomic per column per block).  cols % 4 == 0,
+// cols <= 4096.  Replaces a separate colsum pass over the [rows, cols] bf16 image.
+template <int NG>   // column groups per thread = ceil(C4 / 256)
+__global__ __launch_bounds__(256) void grad_prep_colsum_kernel(
+    const float* __restrict__ dy, const void* __restrict__ pre, int pre_bf16, void* __restrict__ out, int out_bf16,
+    int act, float alpha, float p, unsigned long long seed, unsigned long long offset, int rows, int cols,
+    int rows_per_block, float* __restrict__ colsum) {
+  __shared__ float red[256][4];
+  const int C4 = cols >> 2;
+  const int lanes_c = C4 < 256 ? C4 : 256;             // threads across the columns
+  const int rl = threadIdx.x / lanes_c, nrl = 256 / lanes_c;   // row lane, row lanes per block
+  const int tc = threadIdx.x % lanes_c;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc[NG][4];
+#pragma unroll
+  for (int k = 0; k < NG; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f;
+  if (rl < nrl) {
+    for (int r = r0 + rl; r < r1; r += nrl) {
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const int c4 = tc + k * 256;
+        if (c4 < C4) {
+          const long long i = (long long)r * C4 + c4;
+          const float4 g4 = reinterpret_cast<const float4*>(dy)[i];
+          float g[4] = {g4.x * alpha, g4.y * alpha, g4.z * alpha, g4.w * alpha};
+          if (p > 0.f) {
+            float kp[4];
+            nsp_keep_scale4(seed, offset + (unsigned long long)(i * 4), p, kp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] *= kp[e];
+          }
+          if (pre) {
+            float q[4];
+            if (pre_bf16) {
+              const bf16x4 h = reinterpret_cast<const bf16x4*>(pre)[i];
+              q[0] = (float)h[0]; q[1] = (float)h[1]; q[2] = (float)h[2]; q[3] = (float)h[3];
+            } else {
+              const float4 f = reinterpret_cast<const float4*>(pre)[i];
+              q[0] = f.x; q[1] = f.y; q[2] = f.z; q[3] = f.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] *= nsp_dact(q[e], act);
+          }
+          if (out_bf16) {
+            bf16x4 h;
+            h[0] = (__bf16)g[0]; h[1] = (__bf16)g[1]; h[2] = (__bf16)g[2]; h[3] = (__bf16)g[3];
+            reinterpret_cast<bf16x4*>(out)[i] = h;
+          } else {
+            reinterpret_cast<float4*>(out)[i] = make_float4(g[0], g[1], g[2], g[3]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[k][e] += g[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[threadIdx.x][e] = acc[k][e];
+    __syncthreads();
+    if (rl == 0) {
+      const int c4 = tc + k * 256;
+      if (c4 < C4) {
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < nrl; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum[e] += red[j * lanes_c + tc][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(colsum + c4 * 4 + e, sum[e]);
+      }
+    }
+  }
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                      int splits, long long n) {
   const long long n4 = n >> 2;
@@ -330,12 +409,29 @@ extern "C" int nsp_colsum_bf16(const void* x, float* out, int rows, int cols, lo
   return NSP_OK;
 }
 
-extern "C" int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, void* out, int out_bf16,
-                             int act, float alpha, float p, unsigned long long seed,
-                             unsigned long long offset, long long n, void* stream) {
+extern "C" int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, void* out, int out_bf16, int act,
+                             float alpha, float p, unsigned long long seed, unsigned long long offset,
+                             long long n, int cols, float* colsum, void* stream) {
   if (n <= 0) return NSP_OK;
   if (n % 4) return NSP_EUNSUPPORTED;
-  hipLaunchKernelGGL(grad_prep_kernel, dim3(ew_grid(n / 4)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+  hipStream_t st = (hipStream_t)stream;
+  if (colsum) {
+    // fused bias gradient: colsum [cols] fp32 must be ZERO on entry (accumulated with atomics)
+    if (cols <= 0 || cols % 4 || cols > 4096 || n % cols) return NSP_EUNSUPPORTED;
+    const int rows = (int)(n / cols);
+    int rpb = nsp_cdiv(rows, 1024);
+    if (rpb < 8) rpb = 8;
+    const int grid = nsp_cdiv(rows, rpb);
+    const int ng = nsp_cdiv(cols / 4, 256);
+#define GPCS(NG)                                                                                                  \
+    hipLaunchKernelGGL((grad_prep_colsum_kernel<NG>), dim3(grid), dim3(256), 0, st, dy, pre, pre_bf16, out, out_bf16, \
+                       act, alpha, p, seed, offset, rows, cols, rpb, colsum)
+    if (ng <= 1) GPCS(1); else if (ng == 2) GPCS(2); else GPCS(4);
+#undef GPCS
+    NSP_LAUNCH_CHECK();
+    return NSP_OK;
+  }
+  hipLaunchKernelGGL(grad_prep_kernel, dim3(ew_grid(n / 4)), dim3(EW_THREADS), 0, st,
                      dy, pre, pre_bf16, out, out_bf16, act, alpha, p, seed, offset, n);
   NSP_LAUNCH_CHECK();
   return NSP_OK;

@@ -375,7 +375,7 @@ extern "C" int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs,
                              float alpha, int splitk, int mode, float dropout_p,
                              unsigned long long seed, unsigned long long offset, int a_dtype,
                              int b_dtype, int c_dtype, int pre_dtype, int dact_dtype, long long c_ss,
-                             void* stream) {
+                             float* colsum_slabs, void* stream) {
   nsp_gemm_params p;
   p.M = M; p.N = N; p.K = K;
   p.A = A; p.a_rs = a_rs; p.a_cs = a_cs;
@@ -389,6 +389,7 @@ extern "C" int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs,
   p.a_dtype = a_dtype; p.b_dtype = b_dtype; p.c_dtype = c_dtype; p.pre_dtype = pre_dtype;
   p.dact_dtype = dact_dtype; p.c_ss = c_ss;
   p.epi_mode = NSP_EPI_NONE; p.epi_ncols = 0; p.epi_blank = 0; p.epi_lab = nullptr;
-  p.epi_f0 = p.epi_f1 = p.epi_f2 = p.epi_f3 = nullptr; p.epi_scale_dev = nullptr; p.epi_scale = 1.f;
+  p.epi_f0 = p.epi_f1 = p.epi_f2 = nullptr; p.epi_f3 = colsum_slabs; p.epi_scale_dev = nullptr; p.epi_scale = 1.f;
+  if (colsum_slabs && (a_dtype != NSP_DT_BF16 || splitk > 1)) return NSP_EUNSUPPORTED;
   return nsp_gemm(&p, stream);
 }

@@ -264,6 +264,9 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
   constexpr int SP = 68;  // floats per staged row (64 + 4 pad)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   const int er = lane >> 4, ec = (lane & 15) * 4;  // read-back: row er + 4*j, cols ec..ec+3
+  // optional: column sums of the STORED values (the bias gradient of the layer below, when C is that
+  // layer's d(pre-activation)): per wave 16*MI rows x 64 cols -> one slab row, no atomics
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -320,8 +323,23 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
         for (int e = 0; e < 4; ++e) v[e] += r4[e];
       }
       store4(p.C, p.c_dtype, off, v, nv, vec);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) csum[e] += v[e];
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (p.epi_f3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      csum[e] += __shfl_xor(csum[e], 16, 64);
+      csum[e] += __shfl_xor(csum[e], 32, 64);
+    }
+    const int n = n0 + wn * 64 + ec;
+    if (lane < 16 && n < p.N) {
+      float* dst = p.epi_f3 + (long long)((m0 + wm * (16 * MI)) / (16 * MI)) * p.N + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) dst[e] = csum[e];
+    }
   }
 }
 
@@ -1217,7 +1235,8 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     const char* kkp_e2 = getenv("NSP_GEMM_PERSIST_MIN_TILES");
     const int kkp_env = kkp_e ? atoi(kkp_e) : 0;   // OPT-IN: measured slower than the classic kernels (below)
     const long long kkp_min = kkp_e2 ? atoll(kkp_e2) : 1536;
-    if (kkp_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 2 && wgs >= kkp_min) {
+    if (kkp_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 2 && wgs >= kkp_min &&
+        !(p.epi_mode == NSP_EPI_NONE && p.epi_f3)) {   // (its standard epilogue has no column-sum slabs)
       hipLaunchKernelGGL(gemm_bf16_kkp_kernel, dim3(512), block, 2 * 32768 + 8192, st, p, tiles_m, tiles_n, c_vec);
       NSP_LAUNCH_CHECK();
       return NSP_OK;

@@ -136,7 +136,7 @@ def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
              batch=(1, 1), a_b=(0, 0), b_b=(0, 0), c_b=(0, 0),
              bias=None, act=0, pre_out=None, dact_src=None, dact=0, res=None,
              alpha=1.0, splitk=1, mode=None, a_off=0, b_off=0, c_off=0,
-             dropout_p=0.0, seed=0, offset=0, c_ss=0):
+             dropout_p=0.0, seed=0, offset=0, c_ss=0, colsum_slabs=None):
     """C = epi(A @ B) with arbitrary strides (element offsets *_off into the tensors).
     A/B are both fp32 or both bf16; C / pre_out / dact_src may be fp32 or bf16 with bf16 operands."""
     for t in (A, B, C, pre_out, dact_src, bias, res):
@@ -151,7 +151,8 @@ def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
         dact_src.data_ptr() + dact_src.element_size() * c_off if dact_src is not None else None, dact,
         res.data_ptr() + 4 * c_off if res is not None else None, alpha, splitk,
         _COMPUTE_MODE['mode'] if mode is None else mode, dropout_p, seed, offset,
-        _dt(A), _dt(B), _dt(C), _dt(pre_out), _dt(dact_src), c_ss, _stream()), 'nsp_gemm')
+        _dt(A), _dt(B), _dt(C), _dt(pre_out), _dt(dact_src), c_ss,
+        colsum_slabs.data_ptr() if colsum_slabs is not None else None, _stream()), 'nsp_gemm')
 
 
 def bf16_mode():
@@ -276,12 +277,15 @@ def linear_wgrad(dy2d, x2d, alpha=1.0):
     return dw
 
 
-def grad_prep(dy2d, pre, act, alpha, p, seed, offset, out_bf16):
-    """alpha * dy * dropout_mask * act'(pre) in one pass; bf16 output feeds the MFMA GEMMs."""
+def grad_prep(dy2d, pre, act, alpha, p, seed, offset, out_bf16, want_colsum=False):
+    """alpha * dy * dropout_mask * act'(pre) in one pass; bf16 output feeds the MFMA GEMMs.
+    want_colsum: also return the column sums of the result (the Linear's bias gradient), accumulated
+    inside the same kernel -> (g, db) instead of g."""
+    N = dy2d.shape[1]
     if pre is None and p <= 0 and alpha == 1.0 and not out_bf16:
-        return dy2d
+        return (dy2d, colsum(dy2d)) if want_colsum else dy2d
     n = dy2d.numel()
-    if n % 4 or (out_bf16 and dy2d.shape[1] % 8):
+    if n % 4 or (out_bf16 and N % 8):
         # rare odd widths: unfused path
         g = dy2d
         if p > 0:
@@ -291,13 +295,18 @@ def grad_prep(dy2d, pre, act, alpha, p, seed, offset, out_bf16):
             g = dact_mul(g, pre if pre.dtype == torch.float32 else pre.float(), act, alpha)
         elif alpha != 1.0:
             g = axpby(g, None, alpha, 0.0)
-        return to_bf16(g) if out_bf16 else g
+        g = to_bf16(g) if out_bf16 else g
+        return (g, colsum(g)[:N]) if want_colsum else g
     out = torch.empty(dy2d.shape, device=dy2d.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    fuse = want_colsum and N % 4 == 0 and N <= 4096
+    db = zeros_small((N,), dy2d.device) if fuse else None
     _check(_lib.lib().nsp_grad_prep(_p(dy2d), _p(pre), (_dt(pre)), _p(out),
                                     (int(out_bf16)), (act if pre is not None else 0),
                                     (alpha), (p), (seed),
-                                    (offset), (n), _stream()),
+                                    (offset), (n), N, _p(db), _stream()),
            'nsp_grad_prep')
+    if want_colsum:
+        return out, (db if fuse else colsum(out))
     return out
 
 
@@ -355,14 +364,16 @@ class LinearFn(torch.autograd.Function):
         p, seed, offset = ctx.drop
         # bf16 image of the gradient; for N % 8 != 0 (e.g. a 10001-word CTC head) it is zero-padded to
         # roundup8(N) columns and the padded rows / entries of dW / db are dropped below
-        g = grad_prep(dy2d, pre, ctx.act, ctx.alpha, p, seed, offset, xa.dtype == torch.bfloat16)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        g = grad_prep(dy2d, pre, ctx.act, ctx.alpha, p, seed, offset, xa.dtype == torch.bfloat16, want_colsum=want_db)
         dx = dw = db = None
+        if want_db:
+            g, db = g
+            db = db[:N]
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(g, weight)[:, :ctx.xshape[-1]].reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dw = linear_wgrad(g, xa)[:N].view(weight.shape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(g)[:N]
         return dx, dw, db, None, dres, None, None
 
 
@@ -1748,21 +1759,24 @@ class FFNFn(torch.autograd.Function):
         act, p_h, s1, alpha, p_o, s2, has_res, xshape, use16 = ctx.cfg
         N = w2.shape[0]
         dy2d = _f32c(dy).reshape(-1, N)
-        g2 = grad_prep(dy2d, None, 0, alpha, p_o, s2[0], s2[1], use16)
+        # both bias gradients ride in the kernels that produce their operands: db2 inside grad_prep,
+        # db1 as column-sum slabs of the data-gradient GEMM's epilogue (no pass over g2 / d(pre))
+        g2, db2 = grad_prep(dy2d, None, 0, alpha, p_o, s2[0], s2[1], use16, want_colsum=True)
         dw2 = linear_wgrad(g2, h).view(w2.shape)
-        db2 = colsum(g2)
         # d(pre) = (g2 W2) * dropout_h mask * act'(pre): all in the data-gradient epilogue
         M, dff = pre.shape
         dpre = torch.empty((M, dff), device=dy.device, dtype=pre.dtype)
         if use16:
             wt = _weight_t_shadow(w2, True)   # [dff, roundup64(N)]
+            slabs = torch.zeros(((M + 31) // 32, dff), device=dy.device, dtype=torch.float32)
             gemm_raw(M, dff, N, g2, g2.stride(0), 1, wt, 1, wt.stride(0), dpre, dff,
-                     dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1])
+                     dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1], colsum_slabs=slabs)
+            db1 = colsum(slabs)
         else:
             gemm_raw(M, dff, N, g2, g2.stride(0), 1, w2, w2.stride(0), 1, dpre, dff,
                      dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1])
+            db1 = colsum(dpre)
         dw1 = linear_wgrad(dpre, xa).view(w1.shape)
-        db1 = colsum(dpre)
         dx = linear_dgrad(dpre, w1)[:, :xshape[-1]].reshape(xshape) if ctx.needs_input_grad[0] else None
         return dx, dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None
 
@@ -1894,9 +1908,11 @@ class SelfAttnFn(torch.autograd.Function):
         dev = dy.device
         M, d3 = B * T, 3 * d
         dy2d = _f32c(dy).reshape(M, d)
-        g = grad_prep(dy2d, None, 0, 1.0, p_o, s_o[0], s_o[1], True)
+        g = grad_prep(dy2d, None, 0, 1.0, p_o, s_o[0], s_o[1], True, want_colsum=has_o_bias)
+        dbo = None
+        if has_o_bias:
+            g, dbo = g
         dwo = linear_wgrad(g, cv16).view(wo.shape)
-        dbo = colsum(g) if has_o_bias else None
         dO = linear_dgrad(g, wo, out_bf16=True)                                   # [M, d] bf16
         dqkv = torch.empty((M, d3), device=dev, dtype=torch.bfloat16)
         mp = _mask_params(B, H, T, T, R, clamp, scale, klens, *mask_args, p_bf16=1, tk_pitch=Tkp, r_pitch=Rp)
