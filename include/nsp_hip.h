@@ -191,6 +191,10 @@ int nsp_colsum_bf16(const void* x /*bf16*/, float* out, int rows, int cols, long
 /* out = alpha * dy * dropout_keep(seed, offset+i)/(1-p) * act'(pre): turns the gradient that
  * arrives at a Linear's fused epilogue into the dgrad/wgrad operand in ONE pass
  * (pre may be NULL; pre/out are fp32 or bf16; n % 4 == 0) */
+/* colsum (may be NULL; needs cols % 4 == 0, cols <= 4096): slabs fp32 [nsp_grad_prep_slabs(n / cols), cols];
+ * slab row k receives the column sums of `out` over the k-th band of rows, so the bias gradient is the sum
+ * of the slab rows -- no second pass over the [rows, cols] image, no atomics. */
+int nsp_grad_prep_slabs(int rows);
 int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, void* out, int out_bf16,
                   int act, float alpha, float p, unsigned long long seed,
                   unsigned long long offset, long long n, int cols, float* colsum, void* stream);

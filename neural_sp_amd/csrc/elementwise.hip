@@ -109,8 +109,10 @@ __global__ void grad_prep_kernel(const float* __restrict__ dy, const void* __res
 // grad_prep with the column sums of its OUTPUT (the bias gradient of the Linear whose gradient this is)
 // accumulated on the way: a block owns a band of rows; thread t owns the float4 column groups
 // t % C4, (+256, ...) for rows r0 + t / C4 (+ 256 / C4, ...), keeps their sums in registers and flushes
-// them once (LDS reduce over the row lanes, then one atomic per column per block).  cols % 4 == 0,
-// cols <= 4096.  Replaces a separate colsum pass over the [rows, cols] bf16 image.
+// them once (LDS reduce over the row lanes, then ONE slab row per block: colsum [gridDim.x, cols] -- with
+// one atomic per column per block, 1024 blocks x 512 columns of contended L2 atomics made the fused
+// kernel slower than grad_prep + colsum).  cols % 4 == 0, cols <= 4096.  The caller sums the slab rows
+// (a [<=1024, cols] fp32 matrix) instead of passing over the [rows, cols] bf16 image again.
 template <int NG>   // column groups per thread = ceil(C4 / 256)
 __global__ __launch_bounds__(256) void grad_prep_colsum_kernel(
     const float* __restrict__ dy, const void* __restrict__ pre, int pre_bf16, void* __restrict__ out, int out_bf16,
@@ -178,8 +180,8 @@ __global__ __launch_bounds__(256) void grad_prep_colsum_kernel(
         for (int j = 0; j < nrl; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) sum[e] += red[j * lanes_c + tc][e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(colsum + c4 * 4 + e, sum[e]);
+        *reinterpret_cast<float4*>(colsum + (long long)blockIdx.x * cols + c4 * 4) =
+            make_float4(sum[0], sum[1], sum[2], sum[3]);
       }
     }
   }
@@ -416,12 +418,12 @@ extern "C" int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, voi
   if (n % 4) return NSP_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (colsum) {
-    // fused bias gradient: colsum [cols] fp32 must be ZERO on entry (accumulated with atomics)
+    // fused bias gradient: colsum = slabs [nsp_grad_prep_slabs(rows), cols] fp32, every row written
     if (cols <= 0 || cols % 4 || cols > 4096 || n % cols) return NSP_EUNSUPPORTED;
     const int rows = (int)(n / cols);
     int rpb = nsp_cdiv(rows, 1024);
     if (rpb < 8) rpb = 8;
-    const int grid = nsp_cdiv(rows, rpb);
+    const int grid = nsp_cdiv(rows, rpb);   // == nsp_grad_prep_slabs(rows)
     const int ng = nsp_cdiv(cols / 4, 256);
 #define GPCS(NG)                                                                                                  \
     hipLaunchKernelGGL((grad_prep_colsum_kernel<NG>), dim3(grid), dim3(256), 0, st, dy, pre, pre_bf16, out, out_bf16, \
@@ -435,6 +437,12 @@ extern "C" int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, voi
                      dy, pre, pre_bf16, out, out_bf16, act, alpha, p, seed, offset, n);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
+}
+
+extern "C" int nsp_grad_prep_slabs(int rows) {
+  int rpb = nsp_cdiv(rows, 1024);
+  if (rpb < 8) rpb = 8;
+  return nsp_cdiv(rows, rpb);
 }
 
 extern "C" int nsp_glu_fwd(const float* x, float* y, long long rows, int C, void* stream) {

@@ -298,15 +298,17 @@ def grad_prep(dy2d, pre, act, alpha, p, seed, offset, out_bf16, want_colsum=Fals
         g = to_bf16(g) if out_bf16 else g
         return (g, colsum(g)[:N]) if want_colsum else g
     out = torch.empty(dy2d.shape, device=dy2d.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-    fuse = want_colsum and N % 4 == 0 and N <= 4096
-    db = zeros_small((N,), dy2d.device) if fuse else None
+    fuse = want_colsum and N % 4 == 0 and N <= 4096 and os.environ.get('NSP_FUSED_COLSUM', '1') != '0'
+    slabs = None
+    if fuse:
+        slabs = torch.empty((_lib.lib().nsp_grad_prep_slabs(n // N), N), device=dy2d.device, dtype=torch.float32)
     _check(_lib.lib().nsp_grad_prep(_p(dy2d), _p(pre), (_dt(pre)), _p(out),
                                     (int(out_bf16)), (act if pre is not None else 0),
                                     (alpha), (p), (seed),
-                                    (offset), (n), N, _p(db), _stream()),
+                                    (offset), (n), N, _p(slabs), _stream()),
            'nsp_grad_prep')
     if want_colsum:
-        return out, (db if fuse else colsum(out))
+        return out, (colsum(slabs) if fuse else colsum(out)[:N])
     return out
 
 
@@ -1766,12 +1768,17 @@ class FFNFn(torch.autograd.Function):
         # d(pre) = (g2 W2) * dropout_h mask * act'(pre): all in the data-gradient epilogue
         M, dff = pre.shape
         dpre = torch.empty((M, dff), device=dy.device, dtype=pre.dtype)
-        if use16:
+        if use16 and os.environ.get('NSP_FUSED_COLSUM', '1') != '0':
             wt = _weight_t_shadow(w2, True)   # [dff, roundup64(N)]
             slabs = torch.zeros(((M + 31) // 32, dff), device=dy.device, dtype=torch.float32)
             gemm_raw(M, dff, N, g2, g2.stride(0), 1, wt, 1, wt.stride(0), dpre, dff,
                      dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1], colsum_slabs=slabs)
             db1 = colsum(slabs)
+        elif use16:
+            wt = _weight_t_shadow(w2, True)
+            gemm_raw(M, dff, N, g2, g2.stride(0), 1, wt, 1, wt.stride(0), dpre, dff,
+                     dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1])
+            db1 = colsum(dpre)
         else:
             gemm_raw(M, dff, N, g2, g2.stride(0), 1, w2, w2.stride(0), 1, dpre, dff,
                      dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1])
