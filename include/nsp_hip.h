@@ -290,25 +290,30 @@ int nsp_dwconv1d_wgrad_slabs(const float* x, const float* dy, float* part, int t
  * ------------------------------------------------------------------------ */
 /* mask_src (optional, layout of y): y = mask_src > 0 ? y : 0 -- lets the data-gradient call
  * apply the ReLU backward of the layer below in its epilogue. */
-int nsp_conv2d3x3_fwd(const float* x, const float* w /*[Co,3,3,Ci]*/, const float* bias,
-                      float* y, int B, int T, int F, int Ci, int Co, int relu,
-                      const float* mask_src, int mode, void* stream);
+/* io_dtype (NSP_DT_F32 / NSP_DT_BF16): storage type of the 32-channel feature maps (x when Ci = 32, y,
+ * mask_src); bf16 maps need NSP_COMPUTE_BF16 (every consumer rounds them to bf16 for its MFMA anyway, so
+ * the stored rounding is free and halves the front-end's HBM traffic).  The Ci = 1 input is always fp32. */
+int nsp_conv2d3x3_fwd(const void* x, const float* w /*[Co,3,3,Ci]*/, const float* bias,
+                      void* y, int B, int T, int F, int Ci, int Co, int relu,
+                      const void* mask_src, int mode, int io_dtype, void* stream);
 /* dw [Co,3,3,Ci] and dbias [Co] accumulated atomically into caller-zeroed
  * buffers; dy must already be masked by the ReLU (nsp_relu_bwd).  The data
  * gradient is nsp_conv2d3x3_fwd on dy with the tap-flipped, channel-transposed
  * filter bank (built by the host, 9K floats). */
-int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, float* dbias,
-                        int B, int T, int F, int Ci, int Co, int mode, void* stream);
+int nsp_conv2d3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias,
+                        int B, int T, int F, int Ci, int Co, int mode, int io_dtype, void* stream);
 int nsp_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);
 /* MaxPool2d(kernel=stride=(pt,pf), ceil_mode=True) on [B,T,F,C]; if
  * to_btcf != 0 the output is written as [B,T',C,F'] (= the reference's
  * transpose(2,1).view(B,T',C*F'), conv.py:189) */
-int nsp_maxpool2d_fwd(const float* x, float* y, int* argmax, int B, int T, int F, int C,
-                      int pt, int pf, int to_btcf, void* stream);
+int nsp_maxpool2d_fwd(const void* x, void* y, int* argmax, int B, int T, int F, int C,
+                      int pt, int pf, int to_btcf, int x_dtype, int y_dtype, void* stream);
 /* relu_src (optional, layout of dx): dx = relu_src > 0 ? dx : 0 (ReLU backward of the conv that
  * fed the pool, fused) */
-int nsp_maxpool2d_bwd(const float* dy, const int* argmax, float* dx, int B, int T, int F,
-                      int C, int pt, int pf, int from_btcf, const float* relu_src, void* stream);
+/* dy_dtype: type of dy; dx_dtype: type of dx and relu_src */
+int nsp_maxpool2d_bwd(const void* dy, const int* argmax, void* dx, int B, int T, int F,
+                      int C, int pt, int pf, int from_btcf, const void* relu_src,
+                      int dy_dtype, int dx_dtype, void* stream);
 /* MaxPool1d(k=s=factor, ceil_mode=True) over time of [B,T,C]
  * (subsampling.py:188-209) */
 int nsp_maxpool1d_fwd(const float* x, float* y, int* argmax, int B, int T, int C, int factor,

@@ -25,12 +25,29 @@ template <> struct ConvCfg<0> { static constexpr int PIX_PITCH = 80; };    // 32
 template <> struct ConvCfg<1> { static constexpr int PIX_PITCH = 144; };   // 32 fp32 + 16 B pad
 constexpr int W_PITCH = 292;  // floats per co row of the fp32 LDS filter bank (288 + 4 pad)
 
-template <int MODE>
-__global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restrict__ x,
+// Feature maps [B,T,F,32] are stored as bf16 in the throughput mode (TIO = __bf16): every consumer rounds
+// them to bf16 for its MFMA anyway, so the stored rounding is numerically free, and the four
+// full-resolution maps of the front-end (0.9 GB each in fp32 at batch 64) are what its kernels stream.
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<__bf16>(const __bf16* p) {
+  const bf16x4 h = *reinterpret_cast<const bf16x4*>(p);
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float4& v);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, const float4& v) {
+  bf16x4 h;
+  h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+  *reinterpret_cast<bf16x4*>(p) = h;
+}
+
+template <int MODE, typename TIO>
+__global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict__ x,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
-                                                          float* __restrict__ y, int B, int T, int F,
-                                                          int relu, const float* __restrict__ mask_src,
+                                                          TIO* __restrict__ y, int B, int T, int F,
+                                                          int relu, const TIO* __restrict__ mask_src,
                                                           int tiles_f, int tiles_t) {
   // Persistent workgroups: the 32x288 filter bank (36 x 16 B per lane) is fetched ONCE per
   // workgroup and kept in registers (bf16 mode) / LDS (fp32 mode) while the workgroup walks
@@ -84,7 +101,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
       const int t = tt * TT + ht - 1, f = tf * TF + hf - 1;
       pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < HT * HF * 8 && t >= 0 && t < T && f >= 0 && f < F)
-        pre[i] = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
+        pre[i] = ld4<TIO>(x + ((b * T + t) * F + f) * CH + c4 * 4);
     }
   };
   auto halo_commit = [&](unsigned char* dst) {
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
         const int t = t0 + ht - 1, f = f0 + hf - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t >= 0 && t < T && f >= 0 && f < F)
-          v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
+          v = ld4<TIO>(x + ((b * T + t) * F + f) * CH + c4 * 4);
         *reinterpret_cast<float4*>(xs + pix * PP + c4 * 16) = v;
       }
       __syncthreads();
@@ -186,11 +203,11 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         if (mask_src) {
-          const float4 m = *reinterpret_cast<const float4*>(mask_src + off);
+          const float4 m = ld4<TIO>(mask_src + off);
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
           v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
-        *reinterpret_cast<float4*>(y + off) = v;
+        st4<TIO>(y + off, v);
       }
     }
     if (MODE == 0) {
@@ -206,10 +223,11 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const float* __restric
 // (4 output channels with their 9x4 filter taps in registers, one of 32 pixel lanes); the only
 // global stream is the 128 B/pixel output, written as float4.  (The first version re-derived
 // (b,t,f) with 64-bit divisions per element and issued 9 predicated global loads: 1.4 TB/s.)
+template <typename TY>
 __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
-                                                         float* __restrict__ y, int B, int T, int F,
+                                                         TY* __restrict__ y, int B, int T, int F,
                                                          int relu, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float xs1[];  // [(rows_per_block + 2)][F + 2]
   const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
   __syncthreads();
   const int t0 = r0 % T;
   int lr = pl / F, f = pl % F;
-  float* yb = y + (long long)r0 * F * CH + cg * 4;
+  TY* yb = y + (long long)r0 * F * CH + cg * 4;
 #pragma unroll 2
   for (int q = pl; q < nr * F; q += 32) {
     int t = t0 + lr;
@@ -249,7 +267,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
     if (relu) {
       acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
-    *reinterpret_cast<float4*>(yb + (long long)q * CH) = acc;
+    st4<TY>(yb + (long long)q * CH, acc);
     f += 32;
     while (f >= F) { f -= F; ++lr; }
   }
@@ -260,8 +278,9 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
 // zero halo columns) are staged in LDS once, so the only global stream is dy, read as float4 by
 // thread = (4 output channels, one of 32 pixel lanes).  (The first version re-derived (b,t,f)
 // with 64-bit divisions and issued 9 predicated global loads per pixel: 0.3 TB/s.)
+template <typename TD>
 __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x,
-                                                               const float* __restrict__ dy,
+                                                               const TD* __restrict__ dy,
                                                                float* __restrict__ dw,
                                                                float* __restrict__ dbias, int B, int T,
                                                                int F, int rows_per_block) {
@@ -283,10 +302,10 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
     for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
   const int t0 = r0 % T;
   int lr = pl / F, f = pl % F;
-  const float* dyb = dy + (long long)r0 * F * CH + cg * 4;
+  const TD* dyb = dy + (long long)r0 * F * CH + cg * 4;
 #pragma unroll 2
   for (int q = pl; q < nr * F; q += 32) {
-    const float4 g = *reinterpret_cast<const float4*>(dyb + (long long)q * CH);
+    const float4 g = ld4<TD>(dyb + (long long)q * CH);
     int t = t0 + lr;
     if (t >= T) t -= T;
     // a halo row that belongs to the neighbouring utterance (or lies outside) counts as zero
@@ -387,8 +406,9 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_kernel(const float* __r
 // pixels of tile rows 2w, 2w+1 (one MFMA k-step) for all 9 taps: 36 MFMAs per wave per tile, 36
 // accumulator fragments kept across the persistent tile loop, one cross-wave LDS reduction and
 // one atomic flush per workgroup at the end.
+template <typename TIO>
 __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+    const TIO* __restrict__ x, const TIO* __restrict__ dy, float* __restrict__ dw,
     float* __restrict__ dbias, int B, int T, int F, int tiles_f, int tiles_t) {
   constexpr int PP = 80;  // bytes per pixel: 32 bf16 + 16 B pad
   constexpr int XS_B = HT * HF * PP, DS_B = TT * TF * PP;
@@ -423,7 +443,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
       const int t = t0 + pix / HF - 1, f = f0 + pix % HF - 1;
       px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < HT * HF * 8 && t >= 0 && t < T && f >= 0 && f < F)
-        px[i] = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * CH)[c4];
+        px[i] = ld4<TIO>(x + ((b * T + t) * F + f) * CH + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
@@ -431,7 +451,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
       const int c4 = idx & 7, pix = idx >> 3;
       const int t = t0 + pix / TF, f = f0 + pix % TF;
       pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < T && f < F) pd[i] = reinterpret_cast<const float4*>(dy + ((b * T + t) * F + f) * CH)[c4];
+      if (t < T && f < F) pd[i] = ld4<TIO>(dy + ((b * T + t) * F + f) * CH + c4 * 4);
     }
   };
   auto commit = [&](unsigned char* xs_, unsigned char* ds_) {
@@ -532,7 +552,8 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
 }
 
 // ---- MaxPool2d(kernel=stride=(pt,pf), ceil_mode) on [B,T,F,C]
-__global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename TX, typename TY>
+__global__ void maxpool2d_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y,
                                      int* __restrict__ argmax, int B, int T, int F, int C, int To,
                                      int Fo, int pt, int pf, int to_btcf) {
   const int C4 = C >> 2;
@@ -552,7 +573,7 @@ __global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restr
       for (int df = 0; df < pf; ++df) {
         const int f = fo * pf + df;
         if (f >= F) break;
-        const float4 v = reinterpret_cast<const float4*>(x + ((b * T + t) * F + f) * C)[c4];
+        const float4 v = ld4<TX>(x + ((b * T + t) * F + f) * C + c4 * 4);
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -564,20 +585,21 @@ __global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restr
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const long long o = ((b * To + to) * C + c4 * 4 + e) * Fo + fo;
-        y[o] = best[e];
+        y[o] = (TY)best[e];
         argmax[o] = bi[e];
       }
     } else {
-      reinterpret_cast<float4*>(y)[idx] = make_float4(best[0], best[1], best[2], best[3]);
+      st4<TY>(y + idx * 4, make_float4(best[0], best[1], best[2], best[3]));
       reinterpret_cast<int4*>(argmax)[idx] = make_int4(bi[0], bi[1], bi[2], bi[3]);
     }
   }
 }
 
-__global__ void maxpool2d_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ argmax,
-                                     float* __restrict__ dx, int B, int T, int F, int C, int To,
+template <typename TD, typename TX>
+__global__ void maxpool2d_bwd_kernel(const TD* __restrict__ dy, const int* __restrict__ argmax,
+                                     TX* __restrict__ dx, int B, int T, int F, int C, int To,
                                      int Fo, int pt, int pf, int from_btcf,
-                                     const float* __restrict__ relu_src) {
+                                     const TX* __restrict__ relu_src) {
   const int C4 = C >> 2;
   const long long total = (long long)B * T * F * C4;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -593,14 +615,14 @@ __global__ void maxpool2d_bwd_kernel(const float* __restrict__ dy, const int* __
     for (int e = 0; e < 4; ++e) {
       const long long oi = from_btcf ? ((b * To + to) * C + c4 * 4 + e) * Fo + fo
                                      : ((b * To + to) * Fo + fo) * C + c4 * 4 + e;
-      o[e] = argmax[oi] == self ? dy[oi] : 0.f;
+      o[e] = argmax[oi] == self ? (float)dy[oi] : 0.f;
     }
     if (relu_src) {  // fused ReLU backward of the layer that fed the pool (its output is relu_src)
-      const float4 m = reinterpret_cast<const float4*>(relu_src)[idx];
+      const float4 m = ld4<TX>(relu_src + idx * 4);
       o[0] = m.x > 0.f ? o[0] : 0.f; o[1] = m.y > 0.f ? o[1] : 0.f;
       o[2] = m.z > 0.f ? o[2] : 0.f; o[3] = m.w > 0.f ? o[3] : 0.f;
     }
-    reinterpret_cast<float4*>(dx)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+    st4<TX>(dx + idx * 4, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -613,11 +635,15 @@ inline int ew_grid(long long n) {
 
 }  // namespace
 
-extern "C" int nsp_conv2d3x3_fwd(const float* x, const float* w, const float* bias, float* y, int B,
-                                 int T, int F, int Ci, int Co, int relu, const float* mask_src,
-                                 int mode, void* stream) {
+// io_dtype (NSP_DT_F32 / NSP_DT_BF16): element type of the 32-channel feature maps x (C_in = 32), y and
+// mask_src; the single-channel input of the first layer is always fp32.  bf16 maps need NSP_COMPUTE_BF16.
+extern "C" int nsp_conv2d3x3_fwd(const void* x, const float* w, const float* bias, void* y, int B,
+                                 int T, int F, int Ci, int Co, int relu, const void* mask_src,
+                                 int mode, int io_dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (Co != CH) return NSP_EUNSUPPORTED;
+  const bool io16 = io_dtype == NSP_DT_BF16;
+  if (io16 && mode != NSP_COMPUTE_BF16) return NSP_EINVAL;
   if (Ci == 1) {
     if (mask_src) return NSP_EUNSUPPORTED;
     const int BT = B * T;
@@ -627,21 +653,29 @@ extern "C" int nsp_conv2d3x3_fwd(const float* x, const float* w, const float* bi
     if (rpb > T) rpb = T;
     if (rpb < 1) return NSP_EUNSUPPORTED;
     const size_t shmem = sizeof(float) * (size_t)(rpb + 2) * (F + 2);
-    hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(nsp_cdiv(BT, rpb)), dim3(256), shmem, st, x, w, bias, y, B, T,
-                       F, relu, rpb);
+    if (io16)
+      hipLaunchKernelGGL(conv3x3_c1_kernel<__bf16>, dim3(nsp_cdiv(BT, rpb)), dim3(256), shmem, st, (const float*)x, w,
+                         bias, (__bf16*)y, B, T, F, relu, rpb);
+    else
+      hipLaunchKernelGGL(conv3x3_c1_kernel<float>, dim3(nsp_cdiv(BT, rpb)), dim3(256), shmem, st, (const float*)x, w,
+                         bias, (float*)y, B, T, F, relu, rpb);
   } else if (Ci == CH) {
     const int tiles_f = nsp_cdiv(F, TF), tiles_t = nsp_cdiv(T, TT);
     const long long ntiles = (long long)B * tiles_f * tiles_t;
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // 4 persistent workgroups per CU
     if (mode == NSP_COMPUTE_BF16) {
       const size_t sh = 2 * HT * HF * ConvCfg<0>::PIX_PITCH;   // double-buffered halo
-      hipLaunchKernelGGL((conv3x3_c32_kernel<0>), dim3(grid), dim3(256), sh, st, x, w, bias, y, B, T, F,
-                         relu, mask_src, tiles_f, tiles_t);
+      if (io16)
+        hipLaunchKernelGGL((conv3x3_c32_kernel<0, __bf16>), dim3(grid), dim3(256), sh, st, (const __bf16*)x, w, bias,
+                           (__bf16*)y, B, T, F, relu, (const __bf16*)mask_src, tiles_f, tiles_t);
+      else
+        hipLaunchKernelGGL((conv3x3_c32_kernel<0, float>), dim3(grid), dim3(256), sh, st, (const float*)x, w, bias,
+                           (float*)y, B, T, F, relu, (const float*)mask_src, tiles_f, tiles_t);
     } else {
       const size_t sh = HT * HF * ConvCfg<1>::PIX_PITCH + sizeof(float) * CH * W_PITCH;
-      hipFuncSetAttribute((const void*)conv3x3_c32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      hipLaunchKernelGGL((conv3x3_c32_kernel<1>), dim3(grid), dim3(256), sh, st, x, w, bias, y, B, T, F,
-                         relu, mask_src, tiles_f, tiles_t);
+      hipFuncSetAttribute((const void*)conv3x3_c32_kernel<1, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipLaunchKernelGGL((conv3x3_c32_kernel<1, float>), dim3(grid), dim3(256), sh, st, (const float*)x, w, bias,
+                         (float*)y, B, T, F, relu, (const float*)mask_src, tiles_f, tiles_t);
     }
   } else {
     return NSP_EUNSUPPORTED;
@@ -650,11 +684,13 @@ extern "C" int nsp_conv2d3x3_fwd(const float* x, const float* w, const float* bi
   return NSP_OK;
 }
 
-// dw / dbias must be zeroed by the caller (atomic accumulation)
-extern "C" int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B,
-                                   int T, int F, int Ci, int Co, int mode, void* stream) {
+// dw / dbias must be zeroed by the caller (atomic accumulation); io_dtype: type of dy and (C_in = 32) of x
+extern "C" int nsp_conv2d3x3_wgrad(const void* x, const void* dy, float* dw, float* dbias, int B,
+                                   int T, int F, int Ci, int Co, int mode, int io_dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (Co != CH) return NSP_EUNSUPPORTED;
+  const bool io16 = io_dtype == NSP_DT_BF16;
+  if (io16 && mode != NSP_COMPUTE_BF16) return NSP_EINVAL;
   if (Ci == 1) {
     const int BT = B * T;
     int rpb = (BT + 1023) / 1024;                       // ~1024 workgroups ...
@@ -663,19 +699,27 @@ extern "C" int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, f
     if (rpb > T) rpb = T;
     if (rpb < 1) return NSP_EUNSUPPORTED;
     const size_t shmem = sizeof(float) * (size_t)(rpb + 2) * (F + 2);
-    hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(nsp_cdiv(BT, rpb)), dim3(256), shmem, st, x, dy, dw,
-                       dbias, B, T, F, rpb);
+    if (io16)
+      hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel<__bf16>, dim3(nsp_cdiv(BT, rpb)), dim3(256), shmem, st, (const float*)x,
+                         (const __bf16*)dy, dw, dbias, B, T, F, rpb);
+    else
+      hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel<float>, dim3(nsp_cdiv(BT, rpb)), dim3(256), shmem, st, (const float*)x,
+                         (const float*)dy, dw, dbias, B, T, F, rpb);
   } else if (Ci == CH) {
     const int tiles_f = nsp_cdiv(F, TF), tiles_t = nsp_cdiv(T, TT);
     long long ntiles = (long long)B * tiles_f * tiles_t;
     if (mode == NSP_COMPUTE_BF16) {
       int blocks = ntiles < 512 ? (int)ntiles : 512;
-      hipLaunchKernelGGL(conv3x3_c32_wgrad_mfma_kernel, dim3(blocks), dim3(256), 0, st, x, dy, dw, dbias,
-                         B, T, F, tiles_f, tiles_t);
+      if (io16)
+        hipLaunchKernelGGL(conv3x3_c32_wgrad_mfma_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16*)x,
+                           (const __bf16*)dy, dw, dbias, B, T, F, tiles_f, tiles_t);
+      else
+        hipLaunchKernelGGL(conv3x3_c32_wgrad_mfma_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x,
+                           (const float*)dy, dw, dbias, B, T, F, tiles_f, tiles_t);
     } else {
       int blocks = ntiles < 1024 ? (int)ntiles : 1024;
-      hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dy, dw, dbias, B, T,
-                         F, tiles_f, tiles_t);
+      hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)dy, dw,
+                         dbias, B, T, F, tiles_f, tiles_t);
     }
   } else {
     return NSP_EUNSUPPORTED;
@@ -684,23 +728,38 @@ extern "C" int nsp_conv2d3x3_wgrad(const float* x, const float* dy, float* dw, f
   return NSP_OK;
 }
 
-extern "C" int nsp_maxpool2d_fwd(const float* x, float* y, int* argmax, int B, int T, int F, int C,
-                                 int pt, int pf, int to_btcf, void* stream) {
+extern "C" int nsp_maxpool2d_fwd(const void* x, void* y, int* argmax, int B, int T, int F, int C,
+                                 int pt, int pf, int to_btcf, int x_dtype, int y_dtype, void* stream) {
   if (C % 4) return NSP_EUNSUPPORTED;
   const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
-  hipLaunchKernelGGL(maxpool2d_fwd_kernel, dim3(ew_grid((long long)B * To * Fo * (C / 4))), dim3(256),
-                     0, (hipStream_t)stream, x, y, argmax, B, T, F, C, To, Fo, pt, pf, to_btcf);
+  const dim3 grid(ew_grid((long long)B * To * Fo * (C / 4)));
+  hipStream_t st = (hipStream_t)stream;
+#define MPF(TX, TY) hipLaunchKernelGGL((maxpool2d_fwd_kernel<TX, TY>), grid, dim3(256), 0, st, (const TX*)x, (TY*)y, \
+                                       argmax, B, T, F, C, To, Fo, pt, pf, to_btcf)
+  if (x_dtype == NSP_DT_BF16 && y_dtype == NSP_DT_BF16) MPF(__bf16, __bf16);
+  else if (x_dtype == NSP_DT_BF16) MPF(__bf16, float);
+  else if (y_dtype == NSP_DT_BF16) MPF(float, __bf16);
+  else MPF(float, float);
+#undef MPF
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
 
-extern "C" int nsp_maxpool2d_bwd(const float* dy, const int* argmax, float* dx, int B, int T, int F,
-                                 int C, int pt, int pf, int from_btcf, const float* relu_src,
-                                 void* stream) {
+// dy_dtype: type of the incoming gradient; dx_dtype: type of dx AND of relu_src
+extern "C" int nsp_maxpool2d_bwd(const void* dy, const int* argmax, void* dx, int B, int T, int F,
+                                 int C, int pt, int pf, int from_btcf, const void* relu_src,
+                                 int dy_dtype, int dx_dtype, void* stream) {
   if (C % 4) return NSP_EUNSUPPORTED;
   const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
-  hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(ew_grid((long long)B * T * F * (C / 4))), dim3(256), 0,
-                     (hipStream_t)stream, dy, argmax, dx, B, T, F, C, To, Fo, pt, pf, from_btcf, relu_src);
+  const dim3 grid(ew_grid((long long)B * T * F * (C / 4)));
+  hipStream_t st = (hipStream_t)stream;
+#define MPB(TD, TX) hipLaunchKernelGGL((maxpool2d_bwd_kernel<TD, TX>), grid, dim3(256), 0, st, (const TD*)dy, argmax, \
+                                       (TX*)dx, B, T, F, C, To, Fo, pt, pf, from_btcf, (const TX*)relu_src)
+  if (dy_dtype == NSP_DT_BF16 && dx_dtype == NSP_DT_BF16) MPB(__bf16, __bf16);
+  else if (dy_dtype == NSP_DT_BF16) MPB(__bf16, float);
+  else if (dx_dtype == NSP_DT_BF16) MPB(float, __bf16);
+  else MPB(float, float);
+#undef MPB
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

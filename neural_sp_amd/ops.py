@@ -868,19 +868,41 @@ def maxpool1d_time(x, factor):
 # --------------------------------------------------------------------------
 # Conv2d frontend (channels-last)
 # --------------------------------------------------------------------------
-def _conv3x3_fwd(x, w_cl, bias, relu, mask_src=None):
+def _maps16():
+    """bf16 storage of the [B,T,F,32] feature maps of the conv front-end (throughput mode)."""
+    return bf16_mode() and os.environ.get('NSP_CONV_BF16_MAPS', '1') != '0'
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _conv3x3_fwd(x, w_cl, bias, relu, mask_src=None, out16=False):
     B, T, F, Ci = x.shape
     Co = w_cl.shape[0]
-    y = torch.empty((B, T, F, Co), device=x.device, dtype=torch.float32)
+    io16 = out16 or (Ci != 1 and x.dtype == torch.bfloat16)
+    if io16:
+        if Ci != 1 and x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        if mask_src is not None and mask_src.dtype != torch.bfloat16:
+            mask_src = mask_src.to(torch.bfloat16)
+    else:
+        x = _f32c(x)
+        if mask_src is not None:
+            mask_src = _f32c(mask_src)
+    if Ci == 1:
+        x = _f32c(x)
+    y = torch.empty((B, T, F, Co), device=x.device, dtype=torch.bfloat16 if io16 else torch.float32)
     _check(_lib.lib().nsp_conv2d3x3_fwd(_p(x), _p(w_cl), _p(bias), _p(y), B, T, F, Ci, Co, int(relu),
-                                        _p(mask_src), _COMPUTE_MODE['mode'], _stream()),
+                                        _p(mask_src), _COMPUTE_MODE['mode'], int(io16), _stream()),
            'nsp_conv2d3x3_fwd (only 3x3, pad 1, stride 1, C_in in {1,32}, C_out=32 are built)')
     return y
 
 
 class Conv3x3ReLUFn(torch.autograd.Function):
     """relu(conv2d(x, w, b, padding=1)) on channels-last x [B,T,F,Ci]; weight in the
-    reference's nn.Conv2d layout [Co,Ci,3,3] (conv.py:303-307,317-321).
+    reference's nn.Conv2d layout [Co,Ci,3,3] (conv.py:303-307,317-321).  In bf16 mode the
+    32-channel maps (outputs, their gradients) are stored as bf16.
 
     ReLU backward is fused into whoever produces this node's incoming gradient: the output
     carries a flag object; a consumer that knows its input is a ReLU output (next conv's data
@@ -889,9 +911,11 @@ class Conv3x3ReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x_in = x
-        x = _f32c(x)
+        x = _c(x)
         w_cl = weight.permute(0, 2, 3, 1).contiguous()  # [Co,3,3,Ci]
-        y = _conv3x3_fwd(x, w_cl, bias, True)
+        y = _conv3x3_fwd(x, w_cl, bias, True, out16=_maps16())
+        if x.shape[-1] != 1 and y.dtype == torch.bfloat16 and x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
         ctx.save_for_backward(x, w_cl, y)
         ctx.flag = {'masked': False, 'consumers': 0}
         y._nsp_relu = ctx.flag
@@ -905,24 +929,30 @@ class Conv3x3ReLUFn(torch.autograd.Function):
         x, w_cl, y = ctx.saved_tensors
         B, T, F, Ci = x.shape
         Co = w_cl.shape[0]
-        dy = _f32c(dy)
+        io16 = y.dtype == torch.bfloat16
+        dy = _c(dy)
+        if io16 and dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        elif not io16:
+            dy = _f32c(dy)
         if ctx.flag['masked'] and ctx.flag['consumers'] == 1:
             dz = dy  # the single consumer already applied (y > 0)
         else:
-            dz = torch.empty_like(dy)
-            _check(_lib.lib().nsp_relu_bwd(_p(y), _p(dy), _p(dz), dy.numel(), _stream()), 'nsp_relu_bwd')
+            dz32 = torch.empty(dy.shape, device=dy.device, dtype=torch.float32)
+            _check(_lib.lib().nsp_relu_bwd(_p(_f32c(y)), _p(_f32c(dy)), _p(dz32), dy.numel(), _stream()), 'nsp_relu_bwd')
+            dz = dz32.to(torch.bfloat16) if io16 else dz32
         dx = None
         if ctx.needs_input_grad[0]:
             # data gradient = conv of dz with the tap-flipped, channel-transposed bank; if x is
             # itself a ReLU output its backward mask (x > 0) rides in this kernel's epilogue
             w_t = w_cl.flip(1, 2).permute(3, 1, 2, 0).contiguous()  # [Ci,3,3,Co]
             fuse = ctx.in_flag is not None and ctx.in_flag['consumers'] == 1
-            dx = _conv3x3_fwd(dz, w_t, None, False, mask_src=x if fuse else None)
+            dx = _conv3x3_fwd(dz, w_t, None, False, mask_src=x if fuse else None, out16=io16)
             if fuse:
                 ctx.in_flag['masked'] = True
         buf = zeros_small((Co * 9 * Ci + Co,), x.device)
         _check(_lib.lib().nsp_conv2d3x3_wgrad(_p(x), _p(dz), buf.data_ptr(), buf.data_ptr() + 4 * Co * 9 * Ci,
-                                              B, T, F, Ci, Co, _COMPUTE_MODE['mode'], _stream()),
+                                              B, T, F, Ci, Co, _COMPUTE_MODE['mode'], int(io16), _stream()),
                'nsp_conv2d3x3_wgrad')
         # canonical strides (C_in = 1 would otherwise keep the permuted ones and make DDP's bucket
         # views mismatch)
@@ -937,38 +967,44 @@ def conv3x3_relu(x_cl, weight, bias):
 
 class MaxPool2dFn(torch.autograd.Function):
     """MaxPool2d(kernel=stride=(pt,pf), ceil_mode=True) on [B,T,F,C]; optionally emits
-    [B,T',C,F'] (flattened = the reference's [B,T',C*F'] feature order)."""
+    [B,T',C,F'] (flattened = the reference's [B,T',C*F'] feature order).  bf16 in -> bf16 out."""
 
     @staticmethod
     def forward(ctx, x, pt, pf, to_btcf):
         in_flag = getattr(x, '_nsp_relu', None)
-        x = _f32c(x)
+        x = _c(x)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
         B, T, F, C = x.shape
         To, Fo = (T + pt - 1) // pt, (F + pf - 1) // pf
         shape = (B, To, C, Fo) if to_btcf else (B, To, Fo, C)
-        y = torch.empty(shape, device=x.device, dtype=torch.float32)
+        y = torch.empty(shape, device=x.device, dtype=x.dtype)
         am = torch.empty(shape, device=x.device, dtype=torch.int32)
-        _check(_lib.lib().nsp_maxpool2d_fwd(_p(x), _p(y), _p(am), B, T, F, C, pt, pf, int(to_btcf), _stream()),
-               'nsp_maxpool2d_fwd')
+        d16 = int(x.dtype == torch.bfloat16)
+        _check(_lib.lib().nsp_maxpool2d_fwd(_p(x), _p(y), _p(am), B, T, F, C, pt, pf, int(to_btcf), d16, d16,
+                                            _stream()), 'nsp_maxpool2d_fwd')
         ctx.in_flag = in_flag
         if in_flag is not None:
             in_flag['consumers'] += 1
             ctx.save_for_backward(am, x)
         else:
             ctx.save_for_backward(am)
-        ctx.dims = (B, T, F, C, pt, pf, to_btcf)
+        ctx.dims = (B, T, F, C, pt, pf, to_btcf, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         am = ctx.saved_tensors[0]
-        B, T, F, C, pt, pf, to_btcf = ctx.dims
-        dy = _f32c(dy)
-        dx = torch.empty((B, T, F, C), device=dy.device, dtype=torch.float32)
+        B, T, F, C, pt, pf, to_btcf, xdt = ctx.dims
+        dy = _c(dy)
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dx = torch.empty((B, T, F, C), device=dy.device, dtype=xdt)
         fuse = ctx.in_flag is not None and ctx.in_flag['consumers'] == 1
         relu_src = ctx.saved_tensors[1] if fuse else None
         _check(_lib.lib().nsp_maxpool2d_bwd(_p(dy), _p(am), _p(dx), B, T, F, C, pt, pf, int(to_btcf),
-                                            _p(relu_src), _stream()), 'nsp_maxpool2d_bwd')
+                                            _p(relu_src), int(dy.dtype == torch.bfloat16),
+                                            int(xdt == torch.bfloat16), _stream()), 'nsp_maxpool2d_bwd')
         if fuse:
             ctx.in_flag['masked'] = True
         return dx, None, None, None

@@ -50,12 +50,18 @@ def test_glu_dwconv_maxpool1d():
         assert _rel(torch.autograd.grad(y, xm, g)[0], torch.autograd.grad(ref, xm, g)[0]) < 1e-6
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16', 'bf16maps'])
 @pytest.mark.parametrize('Ci', [1, 32])
-def test_conv3x3(mode, Ci):
+def test_conv3x3(mode, Ci, monkeypatch):
     """bf16 mode is checked on bf16-representable inputs so that products are exact and
-    ReLU masks cannot flip: any residual error is indexing, not rounding."""
+    ReLU masks cannot flip: any residual error is indexing, not rounding.  'bf16' keeps fp32 feature
+    maps (NSP_CONV_BF16_MAPS=0: exact comparison); 'bf16maps' is the default throughput layout with the
+    [B,T,F,32] maps and their gradients stored as bf16 (one output rounding: 8e-3 of max)."""
     from neural_sp_amd import ops
+    maps16 = mode == 'bf16maps'
+    monkeypatch.setenv('NSP_CONV_BF16_MAPS', '1' if maps16 else '0')
+    mode = 'bf16' if maps16 else mode
+    tol = 8e-3 if maps16 else 1e-4
     torch.manual_seed(1)
     B, T, Fq, Co = 2, 37, 40, 32
 
@@ -71,10 +77,11 @@ def test_conv3x3(mode, Ci):
     xcl = x.detach().permute(0, 2, 3, 1).contiguous().requires_grad_(Ci > 1)
     with ops.compute_mode(mode):
         y = ops.conv3x3_relu(xcl, w, b)
-        assert _rel(y.permute(0, 3, 1, 2), ref) < 1e-4
-        grads = torch.autograd.grad(y, (xcl, w, b) if Ci > 1 else (w, b), g.permute(0, 2, 3, 1).contiguous())
+        assert y.dtype == (torch.bfloat16 if maps16 else torch.float32)
+        assert _rel(y.float().permute(0, 3, 1, 2), ref) < tol
+        grads = torch.autograd.grad(y, (xcl, w, b) if Ci > 1 else (w, b), g.permute(0, 2, 3, 1).contiguous().to(y.dtype))
     if Ci > 1:
-        assert _rel(grads[0].permute(0, 3, 1, 2), rgrads[0]) < 1e-4
+        assert _rel(grads[0].float().permute(0, 3, 1, 2), rgrads[0]) < tol
     assert _rel(grads[-2], rgrads[-2]) < 1e-3
     assert _rel(grads[-1], rgrads[-1]) < 1e-4
 
@@ -96,6 +103,14 @@ def test_maxpool2d():
             gg = g.permute(0, 2, 1, 3) if btcf else g.permute(0, 2, 3, 1)
             gx, = torch.autograd.grad(y, xcl, gg.contiguous())
             assert _rel(gx.permute(0, 3, 1, 2), rx) < 1e-6
+            # bf16 maps: values are selected, never computed -> bit-exact against the fp32 path on bf16 inputs
+            x16 = xcl.detach().bfloat16().requires_grad_()
+            y16 = ops.maxpool2d(x16, pt, pf, btcf)
+            assert y16.dtype == torch.bfloat16
+            y32 = ops.maxpool2d(x16.detach().float(), pt, pf, btcf)
+            assert torch.equal(y16.float(), y32)
+            g16, = torch.autograd.grad(y16, x16, gg.contiguous())
+            assert g16.dtype == torch.bfloat16 and _rel(g16.float().permute(0, 3, 1, 2), rx) < 8e-3
 
 
 def _ctc_ref(logits, ys, elens, lsm):

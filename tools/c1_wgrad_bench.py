@@ -10,7 +10,7 @@ dz = torch.randn(B, T, F, 32, device='cuda')
 buf = torch.zeros(32 * 9 + 32, device='cuda')
 def run():
     ops._check(_lib.lib().nsp_conv2d3x3_wgrad(x.data_ptr(), dz.data_ptr(), buf.data_ptr(), buf.data_ptr() + 4 * 288,
-                                             B, T, F, 1, 32, 0, ops._stream()), 'wgrad')
+                                             B, T, F, 1, 32, 0, 0, ops._stream()), 'wgrad')
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
