@@ -87,8 +87,14 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict_
   // one and written to the other LDS buffer after its epilogue: one barrier per tile and the
   // global-load latency hides behind the tile's compute + stores (the single-buffered version
   // ran load -> barrier -> 36 MFMAs -> store -> barrier: 2.6 TB/s, neither HBM- nor MFMA-bound)
-  constexpr int NST = (HT * HF * 8 + 255) / 256;   // float4 per thread per halo tile
-  float4 pre[NST];
+  constexpr bool IO16 = sizeof(TIO) == 2;
+  // fp32 maps: 8 float4 per pixel, converted to bf16 on commit; bf16 maps: 4 x 16-B chunks per pixel copied
+  // verbatim (the first bf16 version went through 8-byte loads + unpack + repack: 1.5x SLOWER than fp32 maps)
+  constexpr int CPP = IO16 ? 4 : 8;                        // chunks per pixel
+  constexpr int NST = (HT * HF * CPP + 255) / 256;         // chunks per thread per halo tile
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  float4 pre[IO16 ? 1 : NST];
+  u32x4_t pre16[IO16 ? NST : 1];
   auto halo_fetch = [&](long long tl) {
     const int tf = (int)(tl % tiles_f);
     const int tt = (int)((tl / tiles_f) % tiles_t);
@@ -96,23 +102,32 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict_
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int idx = tid + i * 256;
-      const int c4 = idx & 7, pix = idx >> 3;
+      const int cc = idx % CPP, pix = idx / CPP;
       const int ht = pix / HF, hf = pix % HF;
       const int t = tt * TT + ht - 1, f = tf * TF + hf - 1;
-      pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < HT * HF * 8 && t >= 0 && t < T && f >= 0 && f < F)
-        pre[i] = ld4<TIO>(x + ((b * T + t) * F + f) * CH + c4 * 4);
+      const bool ok = idx < HT * HF * CPP && t >= 0 && t < T && f >= 0 && f < F;
+      if constexpr (IO16) {
+        pre16[i] = u32x4_t{0u, 0u, 0u, 0u};
+        if (ok) pre16[i] = *reinterpret_cast<const u32x4_t*>(x + ((b * T + t) * F + f) * CH + cc * 8);
+      } else {
+        pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) pre[i] = ld4<TIO>(x + ((b * T + t) * F + f) * CH + cc * 4);
+      }
     }
   };
   auto halo_commit = [&](unsigned char* dst) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int idx = tid + i * 256;
-      if (idx < HT * HF * 8) {
-        const int c4 = idx & 7, pix = idx >> 3;
-        bf16x4 h;
-        h[0] = (__bf16)pre[i].x; h[1] = (__bf16)pre[i].y; h[2] = (__bf16)pre[i].z; h[3] = (__bf16)pre[i].w;
-        *reinterpret_cast<bf16x4*>(dst + pix * PP + c4 * 8) = h;
+      if (idx < HT * HF * CPP) {
+        const int cc = idx % CPP, pix = idx / CPP;
+        if constexpr (IO16) {
+          *reinterpret_cast<u32x4_t*>(dst + pix * PP + cc * 16) = pre16[i];
+        } else {
+          bf16x4 h;
+          h[0] = (__bf16)pre[i].x; h[1] = (__bf16)pre[i].y; h[2] = (__bf16)pre[i].z; h[3] = (__bf16)pre[i].w;
+          *reinterpret_cast<bf16x4*>(dst + pix * PP + cc * 8) = h;
+        }
       }
     }
   };
@@ -429,8 +444,12 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
       for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread always stages channel quad tid&7
   const long long ntiles = (long long)B * tiles_t * tiles_f;
-  constexpr int NX = (HT * HF * 8 + 255) / 256, ND = (TT * TF * 8) / 256;
-  float4 px[NX], pd[ND];
+  constexpr bool IO16 = sizeof(TIO) == 2;
+  constexpr int CPP = IO16 ? 4 : 8;     // chunks per pixel: 4 x 16 B (bf16 maps, copied verbatim) or 8 float4
+  constexpr int NX = (HT * HF * CPP + 255) / 256, ND = (TT * TF * CPP) / 256;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  float4 px[IO16 ? 1 : NX], pd[IO16 ? 1 : ND];
+  u32x4_t px16[IO16 ? NX : 1], pd16[IO16 ? ND : 1];
   auto fetch = [&](long long tl) {
     const int tf = (int)(tl % tiles_f);
     const int tt = (int)((tl / tiles_f) % tiles_t);
@@ -439,38 +458,65 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int idx = tid + i * 256;
-      const int c4 = idx & 7, pix = idx >> 3;
+      const int cc = idx % CPP, pix = idx / CPP;
       const int t = t0 + pix / HF - 1, f = f0 + pix % HF - 1;
-      px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < HT * HF * 8 && t >= 0 && t < T && f >= 0 && f < F)
-        px[i] = ld4<TIO>(x + ((b * T + t) * F + f) * CH + c4 * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      const int idx = tid + i * 256;
-      const int c4 = idx & 7, pix = idx >> 3;
-      const int t = t0 + pix / TF, f = f0 + pix % TF;
-      pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < T && f < F) pd[i] = ld4<TIO>(dy + ((b * T + t) * F + f) * CH + c4 * 4);
-    }
-  };
-  auto commit = [&](unsigned char* xs_, unsigned char* ds_) {
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < HT * HF * 8) {
-        bf16x4 h;
-        h[0] = (__bf16)px[i].x; h[1] = (__bf16)px[i].y; h[2] = (__bf16)px[i].z; h[3] = (__bf16)px[i].w;
-        *reinterpret_cast<bf16x4*>(xs_ + (idx >> 3) * PP + (idx & 7) * 8) = h;
+      const bool ok = idx < HT * HF * CPP && t >= 0 && t < T && f >= 0 && f < F;
+      if constexpr (IO16) {
+        px16[i] = u32x4_t{0u, 0u, 0u, 0u};
+        if (ok) px16[i] = *reinterpret_cast<const u32x4_t*>(x + ((b * T + t) * F + f) * CH + cc * 8);
+      } else {
+        px[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) px[i] = ld4<TIO>(x + ((b * T + t) * F + f) * CH + cc * 4);
       }
     }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int idx = tid + i * 256;
-      bsum.x += pd[i].x; bsum.y += pd[i].y; bsum.z += pd[i].z; bsum.w += pd[i].w;
-      bf16x4 h;
-      h[0] = (__bf16)pd[i].x; h[1] = (__bf16)pd[i].y; h[2] = (__bf16)pd[i].z; h[3] = (__bf16)pd[i].w;
-      *reinterpret_cast<bf16x4*>(ds_ + (idx >> 3) * PP + (idx & 7) * 8) = h;
+      const int cc = idx % CPP, pix = idx / CPP;
+      const int t = t0 + pix / TF, f = f0 + pix % TF;
+      const bool ok = t < T && f < F;
+      if constexpr (IO16) {
+        pd16[i] = u32x4_t{0u, 0u, 0u, 0u};
+        if (ok) pd16[i] = *reinterpret_cast<const u32x4_t*>(dy + ((b * T + t) * F + f) * CH + cc * 8);
+      } else {
+        pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) pd[i] = ld4<TIO>(dy + ((b * T + t) * F + f) * CH + cc * 4);
+      }
+    }
+  };
+  // bias sums: a thread always stages the same channel group (cc = tid % CPP): 4 channels (fp32 maps, in
+  // bsum) or 8 channels (bf16 maps, in bsum + bsum_hi)
+  float4 bsum_hi = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto commit = [&](unsigned char* xs_, unsigned char* ds_) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < HT * HF * CPP) {
+        if constexpr (IO16) {
+          *reinterpret_cast<u32x4_t*>(xs_ + (idx / CPP) * PP + (idx % CPP) * 16) = px16[i];
+        } else {
+          bf16x4 h;
+          h[0] = (__bf16)px[i].x; h[1] = (__bf16)px[i].y; h[2] = (__bf16)px[i].z; h[3] = (__bf16)px[i].w;
+          *reinterpret_cast<bf16x4*>(xs_ + (idx >> 3) * PP + (idx & 7) * 8) = h;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int idx = tid + i * 256;
+      if constexpr (IO16) {
+        const u32x4_t q = pd16[i];
+        bsum.x += __uint_as_float(q[0] << 16); bsum.y += __uint_as_float(q[0] & 0xffff0000u);
+        bsum.z += __uint_as_float(q[1] << 16); bsum.w += __uint_as_float(q[1] & 0xffff0000u);
+        bsum_hi.x += __uint_as_float(q[2] << 16); bsum_hi.y += __uint_as_float(q[2] & 0xffff0000u);
+        bsum_hi.z += __uint_as_float(q[3] << 16); bsum_hi.w += __uint_as_float(q[3] & 0xffff0000u);
+        *reinterpret_cast<u32x4_t*>(ds_ + (idx / CPP) * PP + (idx % CPP) * 16) = q;
+      } else {
+        bsum.x += pd[i].x; bsum.y += pd[i].y; bsum.z += pd[i].z; bsum.w += pd[i].w;
+        bf16x4 h;
+        h[0] = (__bf16)pd[i].x; h[1] = (__bf16)pd[i].y; h[2] = (__bf16)pd[i].z; h[3] = (__bf16)pd[i].w;
+        *reinterpret_cast<bf16x4*>(ds_ + (idx >> 3) * PP + (idx & 7) * 8) = h;
+      }
     }
   };
   int cur = 0;
@@ -539,13 +585,16 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
   }
   if (dbias) {
     __syncthreads();
-    float* rb = &red[0][0][0];  // [256][4]
-    rb[tid * 4 + 0] = bsum.x; rb[tid * 4 + 1] = bsum.y; rb[tid * 4 + 2] = bsum.z; rb[tid * 4 + 3] = bsum.w;
+    float* rb = &red[0][0][0];  // [256][8]
+    rb[tid * 8 + 0] = bsum.x; rb[tid * 8 + 1] = bsum.y; rb[tid * 8 + 2] = bsum.z; rb[tid * 8 + 3] = bsum.w;
+    rb[tid * 8 + 4] = bsum_hi.x; rb[tid * 8 + 5] = bsum_hi.y; rb[tid * 8 + 6] = bsum_hi.z; rb[tid * 8 + 7] = bsum_hi.w;
     __syncthreads();
     if (tid < 32) {
-      const int c4 = tid >> 2, e = tid & 3;
+      // channel tid: fp32 maps -> staged by threads with tid % 8 == tid / 4, element tid % 4;
+      //              bf16 maps -> threads with tid % 4 == tid / 8, element tid % 8
+      const int grp = IO16 ? (tid >> 3) : (tid >> 2), e = IO16 ? (tid & 7) : (tid & 3);
       float s2 = 0.f;
-      for (int k = c4; k < 256; k += 8) s2 += rb[k * 4 + e];
+      for (int k = grp; k < 256; k += CPP) s2 += rb[k * 8 + e];
       unsafeAtomicAdd(dbias + tid, s2);
     }
   }

@@ -938,8 +938,9 @@ class Conv3x3ReLUFn(torch.autograd.Function):
         if ctx.flag['masked'] and ctx.flag['consumers'] == 1:
             dz = dy  # the single consumer already applied (y > 0)
         else:
+            y32, dy32 = _f32c(y), _f32c(dy)      # (named: a temporary would be freed before the launch)
             dz32 = torch.empty(dy.shape, device=dy.device, dtype=torch.float32)
-            _check(_lib.lib().nsp_relu_bwd(_p(_f32c(y)), _p(_f32c(dy)), _p(dz32), dy.numel(), _stream()), 'nsp_relu_bwd')
+            _check(_lib.lib().nsp_relu_bwd(_p(y32), _p(dy32), _p(dz32), dy.numel(), _stream()), 'nsp_relu_bwd')
             dz = dz32.to(torch.bfloat16) if io16 else dz32
         dx = None
         if ctx.needs_input_grad[0]:

@@ -103,14 +103,16 @@ def test_maxpool2d():
             gg = g.permute(0, 2, 1, 3) if btcf else g.permute(0, 2, 3, 1)
             gx, = torch.autograd.grad(y, xcl, gg.contiguous())
             assert _rel(gx.permute(0, 3, 1, 2), rx) < 1e-6
-            # bf16 maps: values are selected, never computed -> bit-exact against the fp32 path on bf16 inputs
+            # bf16 maps: values are selected, never computed -> bit-exact against the fp32 path on the same
+            # (bf16-representable) input, forward and backward
             x16 = xcl.detach().bfloat16().requires_grad_()
+            x32 = x16.detach().float().requires_grad_()
             y16 = ops.maxpool2d(x16, pt, pf, btcf)
-            assert y16.dtype == torch.bfloat16
-            y32 = ops.maxpool2d(x16.detach().float(), pt, pf, btcf)
-            assert torch.equal(y16.float(), y32)
+            y32 = ops.maxpool2d(x32, pt, pf, btcf)
+            assert y16.dtype == torch.bfloat16 and torch.equal(y16.float(), y32)
             g16, = torch.autograd.grad(y16, x16, gg.contiguous())
-            assert g16.dtype == torch.bfloat16 and _rel(g16.float().permute(0, 3, 1, 2), rx) < 8e-3
+            g32, = torch.autograd.grad(y32, x32, gg.contiguous())
+            assert g16.dtype == torch.bfloat16 and torch.equal(g16, g32.bfloat16())
 
 
 def _ctc_ref(logits, ys, elens, lsm):
