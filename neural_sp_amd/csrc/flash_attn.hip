@@ -398,20 +398,30 @@ __global__ __launch_bounds__(256) void flash_dot_kernel(const __bf16* __restrict
   }
 }
 
-// ---- backward, part 1: dK / dV.  One workgroup per 64-key tile, looping over query tiles.
-// The workgroup's K and V fragments are loop invariant and live in REGISTERS (64 VGPRs); Q / dO (and the
-// position-score table) of the NEXT query tile are fetched into registers while the current tile is
-// processed and committed to the other LDS buffer afterwards: two barriers per query tile (P / dS
-// visible; buffers swapped) instead of three, and no exposed global-load latency.
+// ---- backward, part 1: dK / dV.  One workgroup per 64-key tile, looping over 64-query tiles.
+// Wave w owns keys k0 + 16 w .. + 15 for the WHOLE pipeline: it computes S and dP as
+// S[query][key] = mfma(X = Q fragment, Y = K fragment), so a lane holds ONE key (lane & 15) and four
+// queries (4 g + e) of each of the four 16-query blocks.  Two blocks side by side are exactly the
+// 8 k-values lane group g feeds into the key-major products dV += P^T dO and dK += dS^T Q -- the
+// reduction index may be enumerated in any order as long as both operands agree, and the dO^T / Q^T
+// operands are transpose-read from LDS with that same enumeration (rows 32 s + 4 g .. +3 and
+// 32 s + 16 + 4 g .. +3).  P and dS therefore never leave registers (the previous version wrote both
+// as 64 x 64 bf16 tiles to LDS and transposed them back: two extra barriers' worth of LDS traffic per
+// query tile and 36 KB of LDS).  The wave's K / V fragments are 16 registers; Q / dO tiles and the
+// per-query statistics (row max, 1/sum, D, dropout row hash, far-diagonal position score) of the NEXT
+// query tile are fetched while the current one is processed: one barrier per query tile.
 __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, __bf16* __restrict__ dqkv,
     const nsp_attn_mask_params p) {
   __shared__ __attribute__((aligned(16))) unsigned char Qs[2][64 * KP];
   __shared__ __attribute__((aligned(16))) unsigned char dOs[2][64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char Ps[64 * KP];   // dropped probabilities [query][key]
-  __shared__ __attribute__((aligned(16))) unsigned char dSs[64 * KP];  // dS                    [query][key]
   __shared__ __attribute__((aligned(16))) float QPs[2][64][16];
+  __shared__ __attribute__((aligned(16))) float st_c0[2][64];    // far score * sl2 - row max (uniform tiles)
+  __shared__ __attribute__((aligned(16))) float st_max[2][64];   // row max (log2 domain)
+  __shared__ __attribute__((aligned(16))) float st_inv[2][64];   // 1 / row sum (0 for rows >= T)
+  __shared__ __attribute__((aligned(16))) float st_d[2][64];     // D_i = dO_i . O_i
+  __shared__ __attribute__((aligned(16))) unsigned st_hash[2][64];
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -425,11 +435,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
   const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
   const int rp = p.r_pitch;
-  // K / V MFMA fragments of this workgroup's 64 keys: rows kf*16 + r, k-chunk (s, g)
-  bf16x8 Kf[4][2], Vf[4][2];
-#pragma unroll
-  for (int kf = 0; kf < 4; ++kf) {
-    const int key = k0 + kf * 16 + r;
+  const int key = k0 + wave * 16 + r;                 // this lane's key
+  // K / V fragments of the wave's 16 keys (Y operands: row = key r, k-chunk (s, g))
+  bf16x8 Kf[2], Vf[2];
+  {
     const __bf16* kp_ = qkv + (brow0 + min(key, T - 1)) * ld3 + d + h * DK;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -439,16 +448,40 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) { kv[e] = (__bf16)0.f; vv[e] = (__bf16)0.f; }
       }
-      Kf[kf][s2] = kv;
-      Vf[kf][s2] = vv;
+      Kf[s2] = kv;
+      Vf[s2] = vv;
     }
   }
   const __bf16* qbase = qkv + h * DK;
   const __bf16* dobase = dO + h * DK;
+  // per-tile staging registers: Q / dO tiles, one float4 of the position table, and (threads 0..63) the
+  // statistics of query q0 + tid
+  struct Stat { float c0, mx, inv, dd; unsigned hash; };
+  auto stat_load = [&](int q0) {
+    Stat s_;
+    s_.c0 = 0.f; s_.mx = 0.f; s_.inv = 0.f; s_.dd = 0.f; s_.hash = 0u;
+    if (threadIdx.x < 64) {
+      const int qi = q0 + threadIdx.x;
+      const int qc = min(qi, T - 1);
+      const long long ri = ((long long)b * p.H + h) * T + qc;
+      s_.mx = LSE[ri];
+      s_.inv = qi < T ? LSE[nrow + ri] : 0.f;           // rows beyond T contribute nothing
+      s_.dd = Drow[ri];
+      const float far = (QP && p.clamp > 0) ? QP[((brow0 + qc) * p.H + h) * rp + p.clamp] * sl2 : 0.f;
+      s_.c0 = far - s_.mx;
+      s_.hash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
+    }
+    return s_;
+  };
+  auto stat_store = [&](int buf, const Stat& s_) {
+    if (threadIdx.x < 64) {
+      st_c0[buf][threadIdx.x] = s_.c0; st_max[buf][threadIdx.x] = s_.mx; st_inv[buf][threadIdx.x] = s_.inv;
+      st_d[buf][threadIdx.x] = s_.dd; st_hash[buf][threadIdx.x] = s_.hash;
+    }
+  };
   auto qp_load = [&](int q0) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (QP) {
-      // 64 queries x 16 table slots = 256 float4: thread t -> query t/4, slots 4*(t%4)..
       const int ql = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
       const int q = min(q0 + ql, T - 1);
       const float* src = QP + ((brow0 + q) * p.H + h) * rp;
@@ -466,13 +499,19 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
   tile_load(qr, qbase, ld3, brow0, 0, T);
   tile_load(dor, dobase, d, brow0, 0, T);
   float4 qpr = qp_load(0);
+  Stat str = stat_load(0);
   f32x4 dk_acc[4], dv_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   tile_store(Qs[0], qr);
   tile_store(dOs[0], dor);
   qp_store(0, qpr);
+  stat_store(0, str);
   __syncthreads();
+  // dropout: the pair-of-keys part of the hash is constant for the lane (its key is fixed)
+  const unsigned pair = (unsigned)key >> 1;
+  const unsigned pair_mix = __umul24(pair, 0x9E3779u) + (pair << 11);
+  const int half_shift = (key & 1) * 16;
   const int nqt = (T + 63) / 64;
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 64;
@@ -481,89 +520,96 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
       tile_load(qr, qbase, ld3, brow0, q0 + 64, T);
       tile_load(dor, dobase, d, brow0, q0 + 64, T);
       qpr = qp_load(q0 + 64);
+      str = stat_load(q0 + 64);
     }
-    const int ql = wave * 16 + r;
-    const int qi = q0 + ql;
-    const int qc = min(qi, T - 1);
-    const long long ri = ((long long)b * p.H + h) * T + qc;
-    const float rmax = LSE[ri];
-    const float rinv = qi < T ? LSE[nrow + ri] : 0.f;   // rows beyond T contribute nothing
-    const float dsum = Drow[ri];
-    const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
+    // S[query][key], dP[query][key] for the 4 query blocks: lane = key r, queries qb*16 + 4g + e
     f32x4 s_acc[4], dp_acc[4];
-    {
-      bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      s_acc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp_acc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        qf[s2] = frag_kc(Qs[cur], wave * 16, s2, r, g);
-        dof[s2] = frag_kc(dOs[cur], wave * 16, s2, r, g);
-      }
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf) {
-        s_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kf][s2], qf[s2], s_acc[kf], 0, 0, 0);
-          dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kf][s2], dof[s2], dp_acc[kf], 0, 0, 0);
-        }
+        s_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Qs[cur], qb * 16, s2, r, g), Kf[s2], s_acc[qb], 0, 0, 0);
+        dp_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(dOs[cur], qb * 16, s2, r, g), Vf[s2], dp_acc[qb], 0, 0, 0);
       }
     }
     const FaTile tl = fa_tile(p, QP != nullptr, q0, k0, T, klen);
-    const float* qrow = QP ? QPs[cur][ql] : nullptr;
-    const bool uni = tl.plain && (qrow == nullptr || tl.far);   // see the forward kernel
-    const float c0 = ((uni && qrow) ? qrow[p.clamp] : 0.f) - rmax;
-    const float rs_ = rinv * p.scale;
-    float ev[4][4], kp[4][4];
-    unsigned vis = 0xFFFFu;
-    if (!uni) vis = fa_logits(s_acc, ev, p, qrow, sl2, qi, k0, g, klen, tl);
-    if (drop) fa_keep(kp, rowhash, k0, g, thr16, inv_keep);
+    const bool uni = tl.plain && (QP == nullptr || tl.far);
+    bf16x8 Pt[2], dSt[2];     // X operands: rows = keys, k = [block 2s: queries 4g..4g+3 | block 2s+1: same]
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
-      bf16x4 p4, ds4;
+    for (int qb = 0; qb < 4; ++qb) {
+      const float4 c0v = *reinterpret_cast<const float4*>(&st_c0[cur][qb * 16 + 4 * g]);
+      const float4 mxv = *reinterpret_cast<const float4*>(&st_max[cur][qb * 16 + 4 * g]);
+      const float4 inv = *reinterpret_cast<const float4*>(&st_inv[cur][qb * 16 + 4 * g]);
+      const float4 ddv = *reinterpret_cast<const float4*>(&st_d[cur][qb * 16 + 4 * g]);
+      const float c0a[4] = {c0v.x, c0v.y, c0v.z, c0v.w}, mxa[4] = {mxv.x, mxv.y, mxv.z, mxv.w};
+      const float ina[4] = {inv.x, inv.y, inv.z, inv.w}, dda[4] = {ddv.x, ddv.y, ddv.z, ddv.w};
+      unsigned ha[4] = {0u, 0u, 0u, 0u};
+      if (drop) {
+        const uint4 hv = *reinterpret_cast<const uint4*>(&st_hash[cur][qb * 16 + 4 * g]);
+        ha[0] = hv.x; ha[1] = hv.y; ha[2] = hv.z; ha[3] = hv.w;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float ex = uni ? __builtin_amdgcn_exp2f(fmaf(s_acc[kf][e], sl2, c0)) : __builtin_amdgcn_exp2f(ev[kf][e] - rmax);
-        if (!tl.plain && k0 + kf * 16 + 4 * g + e >= T) ex = 0.f;
-        const float keep = drop ? kp[kf][e] : 1.f;
-        float ds = ex * rs_ * fmaf(dp_acc[kf][e], keep, -dsum);
-        if (!tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
-        p4[e] = (__bf16)(ex * rinv * keep);
-        ds4[e] = (__bf16)ds;
+        const int ql = qb * 16 + 4 * g + e;
+        float ex;
+        bool vis = true;
+        if (uni) {
+          ex = __builtin_amdgcn_exp2f(fmaf(s_acc[qb][e], sl2, c0a[e]));
+        } else {
+          const int qi = q0 + ql;
+          float v = s_acc[qb][e] * sl2;
+          if (QP) {
+            int rel = qi > key ? qi - key : key - qi;
+            if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+            v += QPs[cur][ql][rel];
+          }
+          vis = tl.plain || fa_visible(p, klen, qi, key);
+          if (!vis) v = -FLT_MAX;
+          ex = __builtin_amdgcn_exp2f(v - mxa[e]);
+          if (key >= T) ex = 0.f;                          // tile padding: not in the softmax
+        }
+        float keep = 1.f;
+        if (drop) {
+          unsigned y = ha[e] + pair_mix;
+          y ^= y << 13; y ^= y >> 17; y ^= y << 5;
+          y = __umul24(y >> 8, 0x85EBCBu) ^ y;
+          keep = ((y >> half_shift) & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
+        }
+        const float pr = ex * ina[e];
+        float ds = pr * p.scale * fmaf(dp_acc[qb][e], keep, -dda[e]);
+        if (!vis) ds = 0.f;
+        Pt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)(pr * keep);
+        dSt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)ds;
       }
-      *reinterpret_cast<bf16x4*>(Ps + ql * KP + (kf * 16 + 4 * g) * 2) = p4;
-      *reinterpret_cast<bf16x4*>(dSs + ql * KP + (kf * 16 + 4 * g) * 2) = ds4;
     }
-    __syncthreads();  // P / dS tiles complete
     // dV[key][dd] += sum_q Pd[q][key] dO[q][dd] ; dK[key][dk'] += sum_q dS[q][key] Q[q][dk']
-    // wave owns keys 16*wave..; X = P^T / dS^T fragments (rows = keys, k = queries) via transpose reads
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const bf16x8 pT = frag_tr(Ps, wave * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, r);
-      const bf16x8 dsT = frag_tr(dSs, wave * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, r);
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        const bf16x8 doT = frag_tr(dOs[cur], df * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, r);
-        const bf16x8 qT = frag_tr(Qs[cur], df * 16, 32 * s2 + 8 * g, 32 * s2 + 8 * g + 4, r);
-        dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pT, doT, dv_acc[df], 0, 0, 0);
-        dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsT, qT, dk_acc[df], 0, 0, 0);
+        const bf16x8 doT = frag_tr(dOs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
+        const bf16x8 qT = frag_tr(Qs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
+        dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pt[s2], doT, dv_acc[df], 0, 0, 0);
+        dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dSt[s2], qT, dk_acc[df], 0, 0, 0);
       }
-    }
     if (qt + 1 < nqt) {
       tile_store(Qs[cur ^ 1], qr);
       tile_store(dOs[cur ^ 1], dor);
       qp_store(cur ^ 1, qpr);
+      stat_store(cur ^ 1, str);
     }
-    __syncthreads();  // next tile's Q / dO / QP visible; P / dS / this tile's buffers free
+    __syncthreads();  // next tile's buffers visible; this tile's free
   }
   // D[i = key (4g+e)][j = lane&15 = channel within fragment df]
 #pragma unroll
   for (int df = 0; df < 4; ++df)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int key = k0 + wave * 16 + 4 * g + e;
-      if (key < T) {
-        const long long rowoff = (brow0 + key) * ld3 + h * DK + df * 16 + r;
+      const int ko = k0 + wave * 16 + 4 * g + e;
+      if (ko < T) {
+        const long long rowoff = (brow0 + ko) * ld3 + h * DK + df * 16 + r;
         dqkv[rowoff + d] = (__bf16)dk_acc[df][e];
         dqkv[rowoff + 2 * d] = (__bf16)dv_acc[df][e];
       }
