@@ -1231,7 +1231,8 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         part = torch.empty((max(M, 1), npart, 2), device=dev, dtype=torch.float32)
         aux = torch.empty((7, max(M, 1)), device=dev, dtype=torch.float32)   # lse, lpb, lpl, alpha, beta, gb, gl
         nll = torch.empty((B,), device=dev, dtype=torch.float32)
-        _check(L.nsp_rnnt_joint_gemm(1, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(part),
+        _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_gemm, M, Vp, J,
+                                     1, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(part),
                                      _p(aux[1]), _p(aux[2]), None, None, 1.0, None, _stream()),
                'nsp_rnnt_joint_gemm(lse)')
         _check(L.nsp_rnnt_lse_merge(_p(part), npart, _p(aux[0]), _p(aux[1]), _p(aux[2]), _p(lab), M, _stream()),
@@ -1256,8 +1257,9 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         w16 = _rows_padded_bf16(w_out, 64)
         d16 = torch.empty((max(M, 1), Vp), device=dev, dtype=torch.bfloat16)
         nslab = (M + 127) // 128 * 2
-        dbpart = torch.empty((max(nslab, 1), Vp), device=dev, dtype=torch.float32) if ctx.has_bias else None
-        _check(L.nsp_rnnt_joint_gemm(2, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
+        dbpart = torch.zeros((max(nslab, 1), Vp), device=dev, dtype=torch.float32) if ctx.has_bias else None
+        _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_gemm, M, Vp, J,
+                                     2, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
                                      _p(aux[5]), _p(aux[6]), _p(dbpart), _p(d16), 1.0 / B, _p(dl), _stream()),
                'nsp_rnnt_joint_gemm(dlogits)')
         db = colsum(dbpart)[:V] if ctx.has_bias else None
@@ -1412,6 +1414,20 @@ def _gemm_raw_timed(M, N, K, *a, **k):
 
 
 gemm_raw = _gemm_raw_timed
+
+
+def rnnt_joint_gemm_timed(fn, M, Vp, J, *args):
+    """Call nsp_rnnt_joint_gemm and, when bench.py's per-launch events are on, record it like any other GEMM."""
+    if not _KEV['on']:
+        return fn(*args)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    _KEV['events'].append((e0, e1))
+    _KEV['flops'] += 2.0 * M * Vp * J
+    return rc
 
 
 def kernel_events_start():

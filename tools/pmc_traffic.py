@@ -3,7 +3,8 @@
 FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced
 reads (MI355X_MICROARCH.md, HBM section) -> doubled here.  WRITE_SIZE is calibrated against the
 bf16 cast kernel, whose written bytes are known from its grid (see --calib).
-usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv>"""
+usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json revision]
+With out.json: also writes the GEMM-class aggregate (all gemm_bf16_* kernels) that bench.py quotes as roofline.traffic."""
 import collections
 import csv
 import re
@@ -40,5 +41,22 @@ def main(fp, wp):
         print('%-48s %6d %12.3f %12.3f %10.1f %9.0f' % (k[:48], n, rd / 1e6, wrb / 1e6, us, (rd + wrb) / us / 1e3))
 
 
+    return rows
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    rows = main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3:
+        import json
+        g = [r for r in rows if r[1].startswith('gemm_bf16')]
+        n = sum(r[2] for r in g)
+        rd = sum(r[3] * r[2] for r in g) / n
+        wr = sum(r[4] * r[2] for r in g) / n
+        json.dump({'kernel_class': 'bf16 GEMM class (all gemm_bf16_* kernels of libnsp_hip.so, incl. the RNN-T joint GEMMs)',
+                   'workload': 'bench.py default (Conformer-L, per-GPU batch 64, bf16), 2 steps in the trace',
+                   'launches': n, 'hbm_bytes_per_launch': rd + wr, 'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
+                   'per_kernel': {r[1]: {'launches': r[2], 'read_MB_per_launch': round(r[3] / 1e6, 3),
+                                         'write_MB_per_launch': round(r[4] / 1e6, 3), 'avg_us': round(r[5], 1)} for r in g},
+                   'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (kernel trace only) over '
+                             'bench.py --steps 1 --warmup 1; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section)',
+                   'revision': sys.argv[4] if len(sys.argv) > 4 else 'unknown'}, open(sys.argv[3], 'w'), indent=1)
