@@ -505,6 +505,18 @@ int nsp_pad_batch(const float* packed, const long long* offsets /*device [B]*/,
                   float pad_value, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * Label-smoothed cross entropy of the attention decoders + gradient +      *
+ * teacher-forcing accuracy in one kernel (criterion.py:45-86                *
+ * cross_entropy_lsm, decoders/transformer.py:442; torch_utils.py:129-145).  *
+ *   logits fp32 [rows, V]; ys int32 [rows] (ignore_index rows contribute 0);*
+ *   loss_rows[r] = -sum_v target_v log_softmax(logits_r)_v with             *
+ *   target = 1 - lsm at ys[r], lsm / (V-1) elsewhere; correct[r] = argmax == *
+ *   ys[r]; grad (may be NULL) = grad_scale * (softmax - target).            *
+ * ------------------------------------------------------------------------ */
+int nsp_xe_lsm_fwd_bwd(const float* logits, const int* ys, float* loss_rows, int* correct, float* grad,
+                       long long rows, int V, int ignore_index, float lsm_prob, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * Greedy decoding helpers (validate(): train.py:341 -> evaluators ->        *
  * Speech2Text.decode, speech2text.py:709-800).                             *
  * nsp_argmax_rows: out[r] = argmax_c x[r*ld + c] (first index on ties) --   *

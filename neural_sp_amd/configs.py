@@ -95,6 +95,19 @@ def transformer_ctc_args(n_layers=12, d_model=256, d_ff=2048, n_heads=4, vocab=1
     return base_args(**a)
 
 
+def conformer_ctc_att_args(size='M', n_layers=12, vocab=10000, dropout=0.0, ctc_weight=0.3, dec_n_layers=6, **kw):
+    """BASELINE config 3 family: Conformer-M encoder + hybrid CTC / attention loss with a Transformer
+    decoder (decoders/transformer.py; LibriSpeech recipe shape: ctc_weight 0.3, lsm_prob 0.1, V = 10k)."""
+    a = vars(conformer_rnnt_args(size, n_layers=n_layers, vocab=vocab, dropout=dropout, ctc_weight=ctc_weight))
+    d = a['transformer_enc_d_model']
+    a.update(dec_type='transformer', dec_n_layers=dec_n_layers, transformer_dec_d_model=d,
+             transformer_dec_d_ff=a['transformer_enc_d_ff'], transformer_dec_n_heads=a['transformer_enc_n_heads'],
+             transformer_dec_attn_type='scaled_dot', transformer_dec_pe_type='add',
+             transformer_ffn_activation='relu', lsm_prob=0.1, dropout_dec=dropout, dropout_dec_layer=0.0)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
 def synthetic_batch(B, t_range, u_range, vocab, input_dim=80, seed=0):
     """The batch dict of datasets/asr/build.py:73-105 filled with synthetic data of the shapes in
     SURVEY.md section 8d: features ~ N(0,1), lengths uniform in the given ranges, labels ~ U[4,V)."""

@@ -469,6 +469,151 @@ class CTCOnlyDecoder(DecoderBase):
         self.ctc._plot_ctc(save_path, topk)
 
 
+class TransformerDecoderBlock(nn.Module):
+    """modules/transformer.py:21-260 (training path: scaled-dot source attention, no cache, no LM
+    fusion): x += drop(SelfMHA(LN1 x)); x += drop(SrcMHA(LN2 x; enc)); x += drop(FFN(LN3 x)).
+    Same sub-module / parameter names as the reference block."""
+
+    def __init__(self, d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer, layer_norm_eps,
+                 ffn_activation, param_init, ffn_bottleneck_dim=0):
+        super().__init__()
+        from neural_sp_amd.modules import MultiheadAttentionMechanism as MHA, PositionwiseFeedForward as FFN
+        self.n_heads = n_heads
+        self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.self_attn = MHA(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, n_heads=n_heads,
+                             dropout=dropout_att, param_init=param_init)
+        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.src_attn = MHA(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, n_heads=n_heads,
+                            dropout=dropout_att, param_init=param_init)
+        self.norm3 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.feed_forward = FFN(d_model, d_ff, dropout, ffn_activation, param_init, ffn_bottleneck_dim)
+        self.dropout_p = dropout
+        self.dropout_layer = dropout_layer
+
+    def forward(self, ys, yy_mask, xs, xy_mask):
+        import random
+        if self.dropout_layer > 0 and self.training and random.random() < self.dropout_layer:
+            return ys
+        p = self.dropout_p
+        yn, ys = ops.layer_norm_split(ys, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        out = self.self_attn(yn, yn, yn, mask=yy_mask, residual=ys, out_dropout=p)[0]
+        on, out = ops.layer_norm_split(out, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        out = self.src_attn(xs, xs, on, mask=xy_mask, residual=out, out_dropout=p)[0]
+        on, out = ops.layer_norm_split(out, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return self.feed_forward(on, residual=out, alpha=1.0, out_dropout=p)
+
+
+class TransformerDecoder(DecoderBase):
+    """decoders/transformer.py:28-458, training side: hybrid CTC / attention loss of a Transformer
+    decoder (BASELINE config 3's loss head family).  forward() = CTC branch
+    (:349-357) + forward_att (:373-458): teacher-forced decoder stack on the HIP kernels, output
+    projection, and the fused label-smoothed XE / accuracy kernel (criterion.py:45-86).  MoChA source
+    attention, LM fusion and decoding are not built (NotImplementedError)."""
+
+    def __init__(self, special_symbols, enc_n_units, attn_type, n_heads, n_layers, d_model, d_ff,
+                 ffn_bottleneck_dim, pe_type, layer_norm_eps, ffn_activation, vocab, tie_embedding,
+                 dropout, dropout_emb, dropout_att, dropout_layer, lsm_prob, ctc_weight, ctc_lsm_prob,
+                 ctc_fc_list, backward, global_weight, mtl_per_batch, param_init):
+        super().__init__()
+        from neural_sp_amd.modules import PositionalEncoding
+        if attn_type != 'scaled_dot':
+            raise NotImplementedError('transformer_dec_attn_type=%s (MoChA source attention is SURVEY 8f rank 2)' % attn_type)
+        self.eos, self.unk = special_symbols['eos'], special_symbols['unk']
+        self.pad, self.blank = special_symbols['pad'], special_symbols['blank']
+        self.vocab, self.enc_n_units, self.d_model = vocab, enc_n_units, d_model
+        self.n_layers, self.n_heads, self.pe_type = n_layers, n_heads, pe_type
+        self.lsm_prob = lsm_prob
+        self.att_weight = global_weight - ctc_weight
+        self.ctc_weight = ctc_weight
+        self.bwd = backward
+        self.mtl_per_batch = mtl_per_batch
+        self.attn_type = attn_type
+        self.aws_dict, self.data_dict = {}, {}
+        if ctc_weight > 0:
+            self.ctc = CTC(eos=self.eos, blank=self.blank, enc_n_units=enc_n_units, vocab=vocab, dropout=dropout,
+                           lsm_prob=ctc_lsm_prob, fc_list=ctc_fc_list, param_init=0.1, backward=backward)
+        if self.att_weight > 0:
+            self.embed = nn.Embedding(vocab, d_model, padding_idx=self.pad)
+            self.pos_enc = PositionalEncoding(d_model, dropout_emb, pe_type, param_init)
+            self.layers = nn.ModuleList([copy.deepcopy(TransformerDecoderBlock(
+                d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer, layer_norm_eps, ffn_activation,
+                param_init, ffn_bottleneck_dim)) for _ in range(n_layers)])
+            self.norm_out = nn.LayerNorm(d_model, eps=layer_norm_eps)
+            self.output = nn.Linear(d_model, vocab)
+            if tie_embedding:
+                self.output.weight = self.embed.weight
+            if param_init == 'xavier_uniform':       # transformer.py:304-316
+                nn.init.normal_(self.embed.weight, mean=0., std=d_model ** -0.5)
+                nn.init.constant_(self.embed.weight[self.pad], 0.)
+                nn.init.xavier_uniform_(self.output.weight)
+                nn.init.constant_(self.output.bias, 0.)
+
+    def forward(self, eouts, elens, ys, task='all', teacher_logits=None, recog_params={}, idx2token=None,
+                trigger_points=None):
+        observation = {'loss': None, 'loss_att': None, 'loss_ctc': None, 'loss_mbr': None,
+                       'acc_att': None, 'ppl_att': None}
+        loss = eouts.new_zeros((1,))
+        if self.ctc_weight > 0 and (task == 'all' or 'ctc' in task):
+            loss_ctc, _ = self.ctc(eouts, elens, ys)
+            observation['loss_ctc'] = loss_ctc.detach()
+            loss = loss + (loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight)
+        if self.att_weight > 0 and (task == 'all' or 'ctc' not in task):
+            loss_att, acc_att, ppl_att = self.forward_att(eouts, elens, ys)
+            observation['loss_att'] = loss_att.detach()
+            observation['acc_att'] = acc_att
+            observation['ppl_att'] = ppl_att
+            loss = loss + (loss_att if self.mtl_per_batch else loss_att * self.att_weight)
+        observation['loss'] = loss.detach()
+        return loss, observation
+
+    def forward_att(self, eouts, elens, ys, trigger_points=None):
+        """transformer.py:373-458 -> (loss [1], acc (device scalar, %), ppl (device scalar))."""
+        from neural_sp_amd.modules import AttnMask
+        dev = eouts.device
+        B = len(ys)
+        ylens = [len(y) + 1 for y in ys]                      # +1 for <eos> (torch_utils.py:123)
+        L = max(ylens)
+        ys_in = np.full((B, L), self.pad, dtype=np.int64)     # append_sos_eos (torch_utils.py:97-126), sos = eos
+        ys_out = np.full((B, L), self.pad, dtype=np.int32)
+        for b, y in enumerate(ys):
+            yy = y[::-1] if self.bwd else y
+            ys_in[b, 0] = self.eos
+            ys_in[b, 1:len(yy) + 1] = yy
+            ys_out[b, :len(yy)] = yy
+            ys_out[b, len(yy)] = self.eos
+        ys_in_d = ops.h2d(ys_in, dev)
+        ys_out_d = ops.h2d(ys_out.reshape(-1), dev)
+        ylens_d = ops.h2d(np.asarray(ylens, dtype=np.int32), dev)
+        elens_d = ops.h2d(elens, dev, torch.int32)
+        # tgt mask = (key j is not <pad>) & causal (:392-396); src mask = key t < elens_b (:399)
+        yy_mask = AttnMask(ylens_d, causal=True, lookahead=0)
+        xy_mask = AttnMask(elens_d)
+        out = self.pos_enc(self.embed(ys_in_d), scale=True)   # scaled + dropout
+        for layer in self.layers:
+            out = layer(out, yy_mask, eouts, xy_mask)
+        out = ops.layer_norm(out, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps)
+        logits = ops.linear(out, self.output.weight, self.output.bias)
+        lsm = self.lsm_prob if self.training else 0.0         # criterion.py:64
+        loss, loss_rows, correct = ops.xe_lsm_loss(logits, ys_out_d, lsm, self.pad, B)
+        n_tokens = float(sum(ylens))
+        ppl = torch.exp(loss_rows.sum() / n_tokens)           # criterion.py:66 / :84
+        acc = correct.sum().float() * (100.0 / n_tokens)      # torch_utils.py:140-145
+        return loss, acc, ppl
+
+    def _plot_attention(self, save_path=None, n_cols=1):
+        pass
+
+    def _plot_ctc(self, save_path=None, topk=10):
+        if self.ctc_weight > 0:
+            self.ctc._plot_ctc(save_path, topk)
+
+    def greedy(self, *a, **k):
+        raise NotImplementedError('attention-decoder decoding is inference-side and not built')
+
+    def beam_search(self, *a, **k):
+        raise NotImplementedError('attention-decoder decoding is inference-side and not built')
+
+
 def build_decoder(args, special_symbols, enc_n_units, vocab, ctc_weight, global_weight, external_lm=None):
     """decoders/build.py:7-140 for the loss heads on the hot path."""
     if args.dec_type in ['lstm_transducer', 'gru_transducer']:
@@ -484,6 +629,19 @@ def build_decoder(args, special_symbols, enc_n_units, vocab, ctc_weight, global_
     if ctc_weight > 0 and abs(global_weight - ctc_weight) < 1e-12:
         return CTCOnlyDecoder(special_symbols, enc_n_units, vocab, args.dropout_dec, ctc_weight,
                               args.ctc_lsm_prob, args.ctc_fc_list, global_weight, args.mtl_per_batch)
+    if args.dec_type == 'transformer':
+        if external_lm is not None or getattr(args, 'lm_fusion', ''):
+            raise NotImplementedError('LM fusion in the Transformer decoder')
+        return TransformerDecoder(
+            special_symbols=special_symbols, enc_n_units=enc_n_units, attn_type=args.transformer_dec_attn_type,
+            n_heads=args.transformer_dec_n_heads, n_layers=args.dec_n_layers, d_model=args.transformer_dec_d_model,
+            d_ff=args.transformer_dec_d_ff, ffn_bottleneck_dim=args.transformer_ffn_bottleneck_dim,
+            pe_type=args.transformer_dec_pe_type, layer_norm_eps=args.transformer_layer_norm_eps,
+            ffn_activation=args.transformer_ffn_activation, vocab=vocab, tie_embedding=args.tie_embedding,
+            dropout=args.dropout_dec, dropout_emb=args.dropout_emb, dropout_att=args.dropout_att,
+            dropout_layer=args.dropout_dec_layer, lsm_prob=args.lsm_prob, ctc_weight=ctc_weight,
+            ctc_lsm_prob=args.ctc_lsm_prob, ctc_fc_list=args.ctc_fc_list, backward=False,
+            global_weight=global_weight, mtl_per_batch=args.mtl_per_batch, param_init=args.transformer_param_init)
     raise NotImplementedError(
-        'dec_type=%s with an attention loss: the LAS / Transformer / MoChA decoders are "next" rows '
-        '(SURVEY.md section 8f), not yet built' % args.dec_type)
+        'dec_type=%s with an attention loss: the LAS (RNN) and MoChA decoders are "next" rows '
+        '(SURVEY.md section 8f) and not built; dec_type=transformer is' % args.dec_type)

@@ -1062,6 +1062,39 @@ def ctc_loss(logits, labels, elens, ylens, lsm_prob=0.0, sum_elens=1, blank=0):
     return CTCLossFn.apply(logits, labels, elens, ylens, float(lsm_prob), int(sum_elens), int(blank))
 
 
+class XELossFn(torch.autograd.Function):
+    """criterion.py:45-86 cross_entropy_lsm (normalize_length=False): sum over the non-pad target
+    positions of the label-smoothed XE, divided by the batch size; also the per-position 'correct'
+    flags (torch_utils.py:129-145).  Loss, gradient and arg-max come out of ONE kernel."""
+
+    @staticmethod
+    def forward(ctx, logits, ys, lsm_prob, ignore_index, bs):
+        logits = _f32c(logits)
+        V = logits.shape[-1]
+        rows = logits.numel() // V
+        dev = logits.device
+        loss_rows = torch.empty((rows,), device=dev, dtype=torch.float32)
+        correct = torch.empty((rows,), device=dev, dtype=torch.int32)
+        need_grad = ctx.needs_input_grad[0]
+        grad = torch.empty_like(logits) if need_grad else None
+        _check(_lib.lib().nsp_xe_lsm_fwd_bwd(_p(logits), _p(ys), _p(loss_rows), _p(correct), _p(grad), rows, V,
+                                             ignore_index, lsm_prob, 1.0 / bs, _stream()), 'nsp_xe_lsm_fwd_bwd')
+        if need_grad:
+            ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(loss_rows, correct)
+        return (loss_rows.sum() / bs).view(1), loss_rows, correct
+
+    @staticmethod
+    def backward(ctx, dloss, _a, _b):
+        grad, = ctx.saved_tensors
+        return grad * dloss.view(*([1] * grad.dim())), None, None, None, None
+
+
+def xe_lsm_loss(logits, ys_int32, lsm_prob, ignore_index, bs):
+    """-> (loss [1], loss_rows [rows], correct int32 [rows]); ys_int32: int32 device tensor [rows]."""
+    return XELossFn.apply(logits, ys_int32, float(lsm_prob), int(ignore_index), int(bs))
+
+
 class RNNTJointLossFn(torch.autograd.Function):
     """mean_b -log P(y_b | x_b) of the RNN-Transducer from the joint inputs
     (rnn_transducer.py:239-256,262-276):

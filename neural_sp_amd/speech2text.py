@@ -364,6 +364,7 @@ class Speech2Text(nn.Module):
                 observation['loss.mbr'] = obs_fwd['loss_mbr']
                 observation['loss.quantity'] = obs_fwd.get('loss_quantity')
                 observation['loss.latency'] = obs_fwd.get('loss_latency')
+                observation = {k: v for k, v in observation.items()}
             observation['loss.ctc'] = obs_fwd['loss_ctc']
         return loss, self._finalize_observation(observation)
 

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 from oracle.ref_import import import_reference  # noqa: E402
 from oracle.rnnt_ref import rnnt_loss_ref  # noqa: E402
-from neural_sp_amd.configs import conformer_rnnt_args, transformer_ctc_args, synthetic_batch  # noqa: E402
+from neural_sp_amd.configs import conformer_rnnt_args, transformer_ctc_args, conformer_ctc_att_args, synthetic_batch  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
@@ -111,6 +111,16 @@ CASES = {
                                                                 ctc_fc_list='', ctc_lsm_prob=0.1,
                                                                 conformer_kernel_size=7),
                                     dict(B=4, t_range=(30, 83), u_range=(2, 7), vocab=43, seed=12)),
+    # hybrid CTC / attention loss with a Transformer decoder (BASELINE config 3 family):
+    # d_k = 64 encoder AND decoder (flash self-attention with the causal + pad mask, unfused source attention
+    # with T_q != T_k), label smoothing 0.1, vocab 43
+    'conformer_ctc_att_xs': (lambda: conformer_ctc_att_args('XS', n_layers=2, vocab=43, ctc_weight=0.3, dec_n_layers=2,
+                                                            ctc_fc_list='', ctc_lsm_prob=0.0,
+                                                            transformer_enc_d_model=64, transformer_enc_n_heads=1,
+                                                            transformer_enc_d_ff=128, conformer_kernel_size=7,
+                                                            transformer_dec_d_model=64, transformer_dec_n_heads=1,
+                                                            transformer_dec_d_ff=128),
+                             dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=13)),
 }
 KEEP_REFERENCE_INIT = {'conformer_rnnt_zero_bias_xs'}
 

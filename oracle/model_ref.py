@@ -320,7 +320,65 @@ def rnnt_branch(eouts, elens, ys, sd, args, p='dec_fwd'):
     return nll.mean()
 
 
-def speech2text_loss(sd, args, batch, dtype=torch.float64):
+def transformer_decoder_att(eouts, elens, ys, sd, args, training, p='dec_fwd'):
+    """decoders/transformer.py:373-458 + modules/transformer.py:171-260 (scaled-dot, no cache) +
+    criterion.py:45-86 -> (loss_att, acc %, ppl).  dropout / LayerDrop = 0."""
+    B, T, _ = eouts.shape
+    d, H = args.transformer_dec_d_model, args.transformer_dec_n_heads
+    eps = args.transformer_layer_norm_eps
+    ylens = [len(y) + 1 for y in ys]
+    L = max(ylens)
+    ys_in = torch.full((B, L), 3, dtype=torch.long)
+    ys_out = torch.full((B, L), 3, dtype=torch.long)
+    for b, y in enumerate(ys):
+        ys_in[b, 0] = 2
+        ys_in[b, 1:len(y) + 1] = torch.tensor(y)
+        ys_out[b, :len(y)] = torch.tensor(y)
+        ys_out[b, len(y)] = 2
+    j = torch.arange(L)
+    tgt_vis = (ys_out != 3)[:, None, :] & (j[None, :] <= j[:, None])[None]          # [B,L,L]
+    src_vis = (torch.arange(T)[None, :] < torch.tensor(elens)[:, None])[:, None, :].expand(B, L, T)
+    out = F.embedding(ys_in, sd[p + '.embed.weight'], padding_idx=3) * math.sqrt(d)
+    if args.transformer_dec_pe_type == 'add':
+        out = out + sd[p + '.pos_enc.pe'][:, :L].to(out.dtype)
+
+    def mha2(q_in, kv_in, vis, pp):
+        Bq, Lq, _ = q_in.shape
+        Tk = kv_in.shape[1]
+        dk = d // H
+        k = _lin(kv_in, sd, pp + '.w_key').view(Bq, Tk, H, dk)
+        v = _lin(kv_in, sd, pp + '.w_value').view(Bq, Tk, H, dk)
+        q = _lin(q_in, sd, pp + '.w_query').view(Bq, Lq, H, dk)
+        e = torch.einsum('bihd,bjhd->bijh', q, k) / math.sqrt(dk)
+        e = e.masked_fill(~vis[:, :, :, None], NEG_INF32)
+        aw = torch.softmax(e, dim=2)
+        cv = torch.einsum('bijh,bjhd->bihd', aw, v).reshape(Bq, Lq, d)
+        return _lin(cv, sd, pp + '.w_out')
+
+    for l in range(args.dec_n_layers):
+        q = '%s.layers.%d' % (p, l)
+        yn = _ln(out, sd, q + '.norm1', eps)
+        out = out + mha2(yn, yn, tgt_vis, q + '.self_attn')
+        on = _ln(out, sd, q + '.norm2', eps)
+        out = out + mha2(on, eouts, src_vis, q + '.src_attn')
+        out = out + ffn(_ln(out, sd, q + '.norm3', eps), sd, q + '.feed_forward', args.transformer_ffn_activation)
+    logits = _lin(_ln(out, sd, p + '.norm_out', eps), sd, p + '.output')
+    V = logits.shape[-1]
+    lg, yo = logits.view(-1, V), ys_out.view(-1)
+    mask = yo == 3
+    lsm = args.lsm_prob if training else 0.0
+    lp = torch.log_softmax(lg, dim=-1)
+    tgt = torch.full_like(lp, lsm / (V - 1))
+    tgt.scatter_(1, yo.masked_fill(mask, 0).unsqueeze(1), 1 - lsm)
+    rows = -(tgt * lp).sum(1).masked_fill(mask, 0)
+    n_tokens = float((~mask).sum())
+    loss = rows.sum() / B
+    ppl = math.exp(rows.sum().item() / n_tokens)
+    acc = float(((lg.argmax(1) == yo) & ~mask).sum()) * 100 / n_tokens
+    return loss, acc, ppl
+
+
+def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True):
     """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens)."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     xlens = [len(x) for x in batch['xs']]
@@ -341,4 +399,9 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64):
         lt = rnnt_branch(eouts, elens, batch['ys'], sd, args)
         obs['loss.transducer'] = lt.item()
         loss = loss + lt * (main_w - ctc_w)
+    if args.dec_type == 'transformer' and main_w - ctc_w > 0:
+        la, acc, ppl = transformer_decoder_att(eouts, elens, batch['ys'], sd, args, training)
+        obs.pop('loss.transducer')
+        obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})
+        loss = loss + la * (main_w - ctc_w)
     return loss, obs, eouts, elens

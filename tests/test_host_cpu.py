@@ -168,3 +168,29 @@ def test_dropout_seed_follows_torch_seed_and_rank(monkeypatch):
     ops.manual_dropout_seed(5)
     assert ops.next_dropout_seed() == (ops._mix64(5 ^ (0xD1342543DE82EF95 & ops._M64)), 0)
     ops._DROPOUT_STATE.update(seed=None, counter=0)
+
+
+def test_ctc_alignment_files_round_trip(tmp_path):
+    """ctc_forced_align.py:72-83 writes `<token> <frame>` lines + `<eos> <frame>`; datasets/alignment.py:98-112
+    reads the frame column back as np.int32 [L+1]; collate pads to [B, L_max+1]."""
+    import numpy as np
+    from neural_sp_amd import alignment
+    tp = np.array([[3, 9, 17, 40], [5, 12, 0, 0]], dtype=np.int32)
+    ys = [[11, 12, 13], [7]]
+    toks = [['▁he', 'll', 'o'], ['▁a']]
+    for b in range(2):
+        path = alignment.write_ctc_alignment(str(tmp_path), 'spk%d' % b, 'utt%d' % b, toks[b], tp[b])
+        assert path.endswith('spk%d/utt%d.txt' % (b, b))
+    assert open(str(tmp_path / 'spk0' / 'utt0.txt'), encoding='utf-8').read() == '▁he 3\nll 9\no 17\n<eos> 40\n'
+    assert alignment.load_ctc_alignment(str(tmp_path), 'spk1', 'utt1').tolist() == [5, 12]
+    assert alignment.load_ctc_alignment(str(tmp_path), 'spk1', 'missing') is None
+    got = alignment.collate_trigger_points(str(tmp_path), ['spk0', 'spk1'], ['utt0', 'utt1'], ys)
+    assert got.dtype == np.int32 and got.tolist() == [[3, 9, 17, 40], [5, 12, 0, 0]]
+    assert alignment.collate_trigger_points(str(tmp_path), ['spk0', 'nope'], ['utt0', 'x'], ys) is None
+
+    class FakeModel(object):
+        def ctc_forced_align(self, xs, ys_):
+            return tp[:len(xs)]
+    n = alignment.align_batches(FakeModel(), [{'xs': [0, 1], 'ys': ys, 'speakers': ['s', 's'], 'utt_ids': ['a', 'b']}],
+                                str(tmp_path / 'out'), lambda ids, return_list=True: ['t%d' % i for i in ids])
+    assert n == 2 and alignment.load_ctc_alignment(str(tmp_path / 'out'), 's', 'a').tolist() == [3, 9, 17, 40]

@@ -369,3 +369,32 @@ def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V):
         assert _rel(a.cpu().double(), r) < 3e-2, name
         cos = torch.nn.functional.cosine_similarity(a.cpu().double().flatten(), r.flatten(), dim=0).item()
         assert cos > 0.9995, (name, cos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('V,lsm', [(43, 0.1), (10000, 0.1), (1000, 0.0)])
+def test_xe_lsm_loss_matches_reference_formula(V, lsm):
+    """nsp_xe_lsm_fwd_bwd vs criterion.py:45-86 written out in torch fp64 (dense target distribution,
+    log_softmax, masked sum / batch size), its autograd gradient, and compute_accuracy's arg-max."""
+    from neural_sp_amd import ops
+    torch.manual_seed(V)
+    B, L, pad = 5, 17, 3
+    logits = (torch.randn(B, L, V, device=_dev()) * 2).requires_grad_()
+    ys = torch.randint(4, V, (B, L), device=_dev())
+    for b in range(B):
+        ys[b, L - 2 * b:] = pad
+    loss, rows, correct = ops.xe_lsm_loss(logits, ys.reshape(-1).int(), lsm, pad, B)
+    g, = torch.autograd.grad(loss, logits)
+    x = logits.detach().double().cpu().view(-1, V).requires_grad_()
+    yo = ys.cpu().view(-1)
+    mask = yo == pad
+    lp = torch.log_softmax(x, -1)
+    tgt = torch.full_like(lp, lsm / (V - 1))
+    tgt.scatter_(1, yo.masked_fill(mask, 0).unsqueeze(1), 1 - lsm)
+    ref_rows = -(tgt * lp).sum(1).masked_fill(mask, 0)
+    ref = ref_rows.sum() / B
+    rg, = torch.autograd.grad(ref, x)
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-5
+    assert _rel(rows.cpu().double(), ref_rows.detach()) < 1e-5
+    assert _rel(g.cpu().double().view(-1, V), rg) < 1e-4
+    assert torch.equal(correct.cpu().bool(), (x.argmax(1) == yo) & ~mask)
