@@ -28,7 +28,7 @@ def _oracle(model, margs, batch, dtype=torch.float32):
     from oracle import model_ref, rnnt_ref
     model_ref.rnnt_loss_ref = rnnt_ref.rnnt_loss_ref_diag   # same recursion, vectorised per anti-diagonal
     torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
-    sd = {k: v.detach().cpu().clone().to(dtype if v.is_floating_point() else v.dtype).requires_grad_(v.is_floating_point() and 'inv_freq' not in k and k != 'enc.pos_enc.pe')
+    sd = {k: v.detach().cpu().clone().to(dtype if v.is_floating_point() else v.dtype).requires_grad_(v.is_floating_point() and 'inv_freq' not in k and not k.endswith('pos_enc.pe'))
           for k, v in model.state_dict().items()}
     loss, obs, eouts, elens = model_ref.speech2text_loss(sd, margs, batch, dtype)
     loss.backward()
@@ -237,3 +237,32 @@ def test_specaugment_module_on_device_follows_reference_stream():
     for t0, t1 in tb:
         ref[:, t0:t1] = 0
     assert torch.equal(out, ref)
+
+
+def test_conformer_M_hybrid_ctc_attention_config3_full_size_bf16():
+    """BASELINE config 3 family at full size: Conformer-M (d=256, H=4 -> d_k=64, 12 layers, x8) + hybrid
+    CTC(0.3) / attention loss with a 6-layer Transformer decoder, V = 10000, label smoothing 0.1, B = 10,
+    T~U[1000,1600], U~U[30,80]; bf16 mode vs the fp32 CPU oracle.  Gates as for config 4: losses 1e-3,
+    every gradient tensor cosine >= 0.999 / norm within 2 % (the embedding rows of unseen tokens have an
+    exactly zero reference gradient and are part of the 'embed.weight' tensor like any other row)."""
+    from neural_sp_amd.configs import conformer_ctc_att_args, synthetic_batch
+    from neural_sp_amd.speech2text import Speech2Text
+    torch.manual_seed(8)
+    margs = conformer_ctc_att_args('M', n_layers=12, vocab=10000, dropout=0.0, ctc_weight=0.3, dec_n_layers=6)
+    model = Speech2Text(margs)
+    _randomise_biases(model, 9)
+    model.cuda(0)
+    batch = synthetic_batch(B=10, t_range=(1000, 1600), u_range=(30, 80), vocab=10000, seed=23)
+    loss, obs, grads = _hip(model, batch, 'bf16')
+    ref, robs, rgrads = _oracle(model, margs, batch)
+    print('[config3 bf16] loss hip %.5f oracle %.5f rel %.2e | ctc %.4f/%.4f att %.4f/%.4f acc %.3f/%.3f ppl %.2f/%.2f' % (
+        loss, ref, abs(loss - ref) / abs(ref), obs['loss.ctc'], robs['loss.ctc'], obs['loss.att'], robs['loss.att'],
+        obs['acc.att'], robs['acc.att'], obs['ppl.att'], robs['ppl.att']))
+    assert abs(loss - ref) / abs(ref) < 1e-3
+    for k in ('loss.ctc', 'loss.att', 'ppl.att'):
+        assert abs(obs[k] - robs[k]) / abs(robs[k]) < 1e-3, (k, obs[k], robs[k])
+    assert abs(obs['acc.att'] - robs['acc.att']) < 0.5      # a handful of near-tie arg-max decisions out of ~550 tokens
+    assert set(rgrads) == set(grads), set(rgrads) ^ set(grads)
+    bad, worst, skipped, n = _compare_grads(grads, rgrads, 0.999, 0.02)
+    print('[config3 bf16] %d gradient tensors, worst (cos, ratio) %s, skipped %s, outside: %s' % (n, worst, skipped, bad))
+    assert not bad, bad
