@@ -126,7 +126,8 @@ int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs, long long 
                   unsigned long long seed, unsigned long long offset, int a_dtype,
                   int b_dtype, int c_dtype, int pre_dtype, int dact_dtype, long long c_ss,
                   float* colsum_slabs, void* stream);
-/* colsum_slabs (bf16 operands, splitk == 1; may be NULL): fp32 [ceil(M/32), N], ZERO-INITIALISED by the caller.
+/* colsum_slabs (bf16 operands, splitk == 1; may be NULL): fp32 [4 * ceil(M/128), N] (the tile grid overhangs M),
+ * ZERO-INITIALISED by the caller.
  * Row (m / R) receives the column sums of the stored values of rows m .. m+R-1 for every R-row block a wave
  * owns (R = 64, or 32 on the 64-row-tile variant; untouched rows stay zero): summing the rows gives
  * sum_m C(m, n) -- the bias gradient when C is a d(pre-activation) -- without a separate pass over C. */

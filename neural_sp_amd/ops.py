@@ -1856,7 +1856,8 @@ class FFNFn(torch.autograd.Function):
         dpre = torch.empty((M, dff), device=dy.device, dtype=pre.dtype)
         if use16 and os.environ.get('NSP_FUSED_COLSUM', '1') != '0':
             wt = _weight_t_shadow(w2, True)   # [dff, roundup64(N)]
-            slabs = torch.zeros(((M + 31) // 32, dff), device=dy.device, dtype=torch.float32)
+            # one slab row per 32-row block of the tile grid (tiles may overhang M: up to the next multiple of 128)
+            slabs = torch.zeros(((M + 127) // 128 * 4, dff), device=dy.device, dtype=torch.float32)
             gemm_raw(M, dff, N, g2, g2.stride(0), 1, wt, 1, wt.stride(0), dpre, dff,
                      dact_src=pre, dact=act, dropout_p=p_h, seed=s1[0], offset=s1[1], colsum_slabs=slabs)
             db1 = colsum(slabs)
