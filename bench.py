@@ -167,6 +167,9 @@ def main():
     assert torch.cuda.is_available(), 'bench.py measures the HIP path; no GPU is visible'
     if a.same_device:
         local_rank = 0
+        # ranks sharing one device cannot guarantee co-residency of each other's grid-barrier kernels
+        # (two half-resident persistent grids wait on each other until the barrier times out)
+        os.environ['NSP_LSTM_PERSISTENT'] = '0'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if distributed:
