@@ -244,8 +244,121 @@ __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&
   }
 }
 
+// ---- fast standard epilogue: same staging and arithmetic as gemm_epilogue below, for the common case
+// (vector-aligned output, N % 4 == 0, no atomics, at most ONE side operand: residual or act' source).
+// gfx9 retires vector-memory operations in issue order, so a load that is issued after a store cannot
+// be waited for without also waiting for that store to reach L2 -- with a bias / residual / act' load
+// inside every row group the generic loop serialised 16 store round trips per tile (measured in the
+// step: 51200x512x2048 plain 147 us, with bias + residual 220 us; 51200x2048x512 with bias + 2 outputs
+// 346 us).  Here the bias is loaded once, and the side operand of row block mi+1 is requested BEFORE the
+// stores of block mi are issued, so a wait only ever covers stores that are a whole block old.
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
+                                                   int mrow0, int n, int lane, long long coff) {
+  constexpr int SP = 68;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int er = lane >> 4, ec = (lane & 15) * 4;
+  const bool colok = n < p.N;                       // N % 4 == 0: all four columns or none
+  const char* side = p.res ? reinterpret_cast<const char*>(p.res) : reinterpret_cast<const char*>(p.dact_src);
+  const bool side16 = !p.res && p.dact_dtype == NSP_DT_BF16;
+  const long long off0 = coff + (long long)(mrow0 + er) * p.ldc + n;
+  const long long ldc4 = 4ll * p.ldc;
+  float b4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && colok) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
+  }
+  uint4 raw[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[i][j] = make_uint4(0u, 0u, 0u, 0u);
+  auto request = [&](int mi, uint4 (&buf)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mrow0 + mi * 16 + er + 4 * j;
+      if (m < p.M && colok) {
+        const long long off = off0 + (long long)(mi * 4 + j) * ldc4;
+        if (side16) {
+          const uint2 h = *reinterpret_cast<const uint2*>(side + off * 2);
+          buf[j].x = h.x; buf[j].y = h.y;
+        } else {
+          buf[j] = *reinterpret_cast<const uint4*>(side + off * 4);
+        }
+      }
+    }
+  };
+  if (side) request(0, raw[0]);
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      *reinterpret_cast<float4*>(stage + fr * SP + ni * 16 + fg * 4) =
+          make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+    // (after the staging writes: acc[mi] is dead, so the second side buffer does not raise the register peak)
+    if (side && mi + 1 < MI) request(mi + 1, raw[(mi + 1) & 1]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_sched_barrier(0);   // one row group at a time: interleaving four of them costs ~24 VGPRs
+      const int row = er + 4 * j;
+      const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
+      const int m = mrow0 + mi * 16 + row;
+      if (m >= p.M || !colok) continue;
+      const long long off = off0 + (long long)(mi * 4 + j) * ldc4;
+      float v[4] = {a4.x + b4[0], a4.y + b4[1], a4.z + b4[2], a4.w + b4[3]};
+      if (p.pre_out) store4(p.pre_out, p.pre_dtype, off, v, 4, true);
+      if (p.act != NSP_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], p.act);
+      }
+      const uint4 sd = raw[mi & 1][j];
+      if (p.dact_src) {
+        float d[4];
+        if (side16) {
+          d[0] = __uint_as_float(sd.x << 16); d[1] = __uint_as_float(sd.x & 0xFFFF0000u);
+          d[2] = __uint_as_float(sd.y << 16); d[3] = __uint_as_float(sd.y & 0xFFFF0000u);
+        } else {
+          d[0] = __uint_as_float(sd.x); d[1] = __uint_as_float(sd.y);
+          d[2] = __uint_as_float(sd.z); d[3] = __uint_as_float(sd.w);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], p.dact);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      if (p.dropout_p > 0.f) {
+        float kp[4];
+        nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= kp[e];
+      }
+      if (p.res) {
+        v[0] += __uint_as_float(sd.x); v[1] += __uint_as_float(sd.y);
+        v[2] += __uint_as_float(sd.z); v[3] += __uint_as_float(sd.w);
+      }
+      store4(p.C, p.c_dtype, off, v, 4, true);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += v[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (p.epi_f3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      csum[e] += __shfl_xor(csum[e], 16, 64);
+      csum[e] += __shfl_xor(csum[e], 32, 64);
+    }
+    if (lane < 16 && colok)
+      *reinterpret_cast<float4*>(p.epi_f3 + (long long)(mrow0 / (16 * MI)) * p.N + n) =
+          make_float4(csum[0], csum[1], csum[2], csum[3]);
+  }
+}
+
 // ---- shared epilogue (see the comment inside): acc[mi][ni] -> global with full-line accesses
-template <int MI>  // MI 16-row fragments per wave along M (wave tile = 16*MI x 64)
+// GENERIC = false: the kernel is only launched when the fast path applies (the launcher's `fast_epi`); compiling both paths into one kernel costs 24 VGPRs = one workgroup per CU.
+template <int MI, bool GENERIC = true>  // MI 16-row fragments per wave along M (wave tile = 16*MI x 64)
 __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4],
                                               unsigned char* smem, int m0, int n0, int wm, int wn,
                                               int lane, int wave, long long coff, int c_vec) {
@@ -263,6 +376,11 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
   const bool atomic = p.splitk > 1 && p.c_ss == 0;
   constexpr int SP = 68;  // floats per staged row (64 + 4 pad)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
+  if (!GENERIC || (c_vec && (p.N & 3) == 0 && !atomic && !(p.res && p.dact_src))) {
+    gemm_epilogue_fast<MI>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64 + (lane & 15) * 4, lane, coff);
+    return;
+  }
+  if constexpr (!GENERIC) return;
   const int er = lane >> 4, ec = (lane & 15) * 4;  // read-back: row er + 4*j, cols ec..ec+3
   // optional: column sums of the STORED values (the bias gradient of the layer below, when C is that
   // layer's d(pre-activation)): per wave 16*MI rows x 64 cols -> one slab row, no atomics
@@ -423,7 +541,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
 // image cannot be padded: rows are exactly 128 B ([128 rows][64 k]) and the 16-B chunk index
 // is XOR-swizzled with (row & 7) on the SOURCE address and on the fragment read, which spreads
 // the 16 rows of a ds_read_b128 group over all banks.  Requires K % 64 == 0.
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_glds_kernel(const nsp_gemm_params p,
+__global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const nsp_gemm_params p,
                                                                      int tiles_m, int tiles_n,
                                                                      int c_vec) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
@@ -503,7 +621,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_glds_kernel(const nsp_g
     }
     __syncthreads();
   }
-  gemm_epilogue<4>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+  gemm_epilogue<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
 // ---- the same KC x KC tile with an NS-stage LDS ring.  The single-stage kernel above hides the
@@ -1199,6 +1317,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   if (p.res && !aligned16(p.res)) c_vec = 0;
   if (p.bias && !aligned16(p.bias)) c_vec = 0;
   dim3 grid(tiles_m * tiles_n, 1, p.batch1 * p.batch2 * p.splitk), block(NTHREADS);
+  const bool fast_epi = c_vec && p.N % 4 == 0 && !(p.splitk > 1 && p.c_ss == 0) && !(p.res && p.dact_src);
   if (a_kc && b_kc && p.K % BK == 0 && p.K >= BK) {
     // how many workgroups would share a CU decides how the load latency gets hidden
     static int ring_env = -1;
@@ -1256,8 +1375,10 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 4>), grid, block, 4 * 32768, st, p, tiles_m, tiles_n, c_vec);
     else if (ring_env && wgs <= ring2_max && nkt >= 2)
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
-    else
+    else if (fast_epi || p.epi_mode != NSP_EPI_NONE)
       hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+    else   // odd widths / unaligned outputs / atomic split-K on a large grid: the generic epilogue lives in the ring kernels
+      hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
   }
   else if (!a_kc && !b_kc && p.K % BK == 0 && p.K >= 2 * BK && p.M % 8 == 0 && p.N % 8 == 0 &&
            tiles_m * tiles_n >= 24 && rr_ring_stages() > 0) {
