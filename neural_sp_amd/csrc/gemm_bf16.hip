@@ -248,19 +248,43 @@ __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&
 // (vector-aligned output, N % 4 == 0, no atomics, at most ONE side operand: residual or act' source).
 // gfx9 retires vector-memory operations in issue order, so a load that is issued after a store cannot
 // be waited for without also waiting for that store to reach L2 -- with a bias / residual / act' load
-// inside every row group the generic loop serialised 16 store round trips per tile (measured in the
-// step: 51200x512x2048 plain 147 us, with bias + residual 220 us; 51200x2048x512 with bias + 2 outputs
-// 346 us).  Here the bias is loaded once, and the side operand of row block mi+1 is requested BEFORE the
-// stores of block mi are issued, so a wait only ever covers stores that are a whole block old.
-template <int MI>
+// inside every row group the generic loop serialised 16 store round trips per tile.  Here the bias is
+// loaded once, and the side operand of row block mi+1 is requested BEFORE the stores of block mi are
+// issued, so a wait only ever covers stores that are a whole block old.
+// That only works when the row loop is straight-line code: with the configuration tested at run time
+// (activation switch, dtype branches) hipcc's wait insertion falls back to vmcnt(0) in front of the
+// branchy region, i.e. it waits for the prefetch it has just issued AND for every older store
+// (measured, 51200 x 2048 x 512 back to back: bf16 out 158 us; + act' source 300 us whether the source
+// is bf16 or fp32 and whether act' is relu or swish; + residual 227 us).  The configurations the
+// training step uses are therefore compiled as specialisations (EpiSpec); everything else takes the
+// run-time version (EpiRuntime), which is correct but serialises as described.
+struct EpiRuntime { static constexpr bool kStatic = false; };
+template <int ACT_, int DACT_, bool C16_, bool PRE16_, bool RES_, bool DROP_>
+struct EpiSpec {
+  static constexpr bool kStatic = true;
+  static constexpr int ACT = ACT_, DACT = DACT_;   // DACT > 0: bf16 act' source
+  static constexpr bool C16 = C16_, PRE16 = PRE16_, RES = RES_, DROP = DROP_;
+};
+
+template <int MI, class S>
 __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
                                                    int mrow0, int n, int lane, long long coff) {
   constexpr int SP = 68;
   const int fr = lane & 15, fg = lane >> 4;
   const int er = lane >> 4, ec = (lane & 15) * 4;
   const bool colok = n < p.N;                       // N % 4 == 0: all four columns or none
-  const char* side = p.res ? reinterpret_cast<const char*>(p.res) : reinterpret_cast<const char*>(p.dact_src);
-  const bool side16 = !p.res && p.dact_dtype == NSP_DT_BF16;
+  bool has_res, has_dact, side16, has_pre, drop;
+  int act, dact, c_dt, pre_dt;
+  if constexpr (S::kStatic) {
+    has_res = S::RES; has_dact = S::DACT != NSP_ACT_NONE; side16 = has_dact; has_pre = S::PRE16; drop = S::DROP;
+    act = S::ACT; dact = S::DACT; c_dt = S::C16 ? NSP_DT_BF16 : NSP_DT_F32; pre_dt = NSP_DT_BF16;
+  } else {
+    has_res = p.res != nullptr; has_dact = p.dact_src != nullptr; side16 = !has_res && p.dact_dtype == NSP_DT_BF16;
+    has_pre = p.pre_out != nullptr; drop = p.dropout_p > 0.f;
+    act = p.act; dact = p.dact; c_dt = p.c_dtype; pre_dt = p.pre_dtype;
+  }
+  const bool has_side = has_res || has_dact;
+  const char* side = has_res ? reinterpret_cast<const char*>(p.res) : reinterpret_cast<const char*>(p.dact_src);
   const long long off0 = coff + (long long)(mrow0 + er) * p.ldc + n;
   const long long ldc4 = 4ll * p.ldc;
   float b4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -268,27 +292,32 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
     const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
     b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
   }
-  uint4 raw[2][4];
+  const uint32_t keep_thr = (uint32_t)(p.dropout_p * 65536.f);
+  const float keep_inv = nsp_rcp(1.f - p.dropout_p);
+  // side operand of the CURRENT row block, one 16-B (fp32) / 8-B (bf16) chunk per row group; the chunk of
+  // row group j of block mi+1 is requested into the same registers right after block mi consumed its copy
+  // and BEFORE block mi stores row group j: a wait for it covers only stores that are a block old
+  uint4 raw[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) raw[i][j] = make_uint4(0u, 0u, 0u, 0u);
-  auto request = [&](int mi, uint4 (&buf)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = mrow0 + mi * 16 + er + 4 * j;
-      if (m < p.M && colok) {
-        const long long off = off0 + (long long)(mi * 4 + j) * ldc4;
-        if (side16) {
-          const uint2 h = *reinterpret_cast<const uint2*>(side + off * 2);
-          buf[j].x = h.x; buf[j].y = h.y;
-        } else {
-          buf[j] = *reinterpret_cast<const uint4*>(side + off * 4);
-        }
-      }
+  for (int j = 0; j < 4; ++j) raw[j] = make_uint4(0u, 0u, 0u, 0u);
+  // (every lane requests: rows / columns beyond the edge are clamped to the last valid chunk instead of
+  // being predicated off -- a conditional load makes the buffer a phi of old and new value, and the copy
+  // that resolves it waits for the load in the row group that issued it)
+  const int ncl = min(n, p.N - 4);
+  auto request = [&](int mi, int j, uint4& buf) {
+    const int mcl = min(mrow0 + mi * 16 + er + 4 * j, p.M - 1);
+    const long long off = coff + (long long)mcl * p.ldc + ncl;
+    if (side16) {
+      const uint2 h = *reinterpret_cast<const uint2*>(side + off * 2);
+      buf.x = h.x; buf.y = h.y;
+    } else {
+      buf = *reinterpret_cast<const uint4*>(side + off * 4);
     }
   };
-  if (side) request(0, raw[0]);
+  if (has_side) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) request(0, j, raw[j]);
+  }
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -296,8 +325,6 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
     for (int ni = 0; ni < 4; ++ni)
       *reinterpret_cast<float4*>(stage + fr * SP + ni * 16 + fg * 4) =
           make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
-    // (after the staging writes: acc[mi] is dead, so the second side buffer does not raise the register peak)
-    if (side && mi + 1 < MI) request(mi + 1, raw[(mi + 1) & 1]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -305,16 +332,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
       const int row = er + 4 * j;
       const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
       const int m = mrow0 + mi * 16 + row;
-      if (m >= p.M || !colok) continue;
+      const bool ok = m < p.M && colok;              // only the stores are predicated
       const long long off = off0 + (long long)(mi * 4 + j) * ldc4;
+      const uint4 sd = raw[j];
+      if (has_side && mi + 1 < MI) request(mi + 1, j, raw[j]);
       float v[4] = {a4.x + b4[0], a4.y + b4[1], a4.z + b4[2], a4.w + b4[3]};
-      if (p.pre_out) store4(p.pre_out, p.pre_dtype, off, v, 4, true);
-      if (p.act != NSP_ACT_NONE) {
+      if (has_pre && ok) store4(p.pre_out, pre_dt, off, v, 4, true);
+      if (act != NSP_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], p.act);
+        for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], act);
       }
-      const uint4 sd = raw[mi & 1][j];
-      if (p.dact_src) {
+      if (has_dact) {
         float d[4];
         if (side16) {
           d[0] = __uint_as_float(sd.x << 16); d[1] = __uint_as_float(sd.x & 0xFFFF0000u);
@@ -324,23 +352,36 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
           d[2] = __uint_as_float(sd.z); d[3] = __uint_as_float(sd.w);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], p.dact);
+        for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], dact);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-      if (p.dropout_p > 0.f) {
+      if (drop) {
         float kp[4];
-        nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
+        if constexpr (S::kStatic) {
+          // (p.offset + off) is even here (the dispatcher checks p.offset): the two-mixes-per-four form of
+          // nsp_keep_scale4 without its per-lane parity branch
+          const unsigned long long base = (p.offset + (unsigned long long)off) >> 1;
+          const uint32_t h0 = nsp_hash_u32(p.seed, base), h1 = nsp_hash_u32(p.seed, base + 1ull);
+          kp[0] = (h0 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
+          kp[1] = (h0 >> 16) < keep_thr ? 0.f : keep_inv;
+          kp[2] = (h1 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
+          kp[3] = (h1 >> 16) < keep_thr ? 0.f : keep_inv;
+        } else {
+          nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= kp[e];
       }
-      if (p.res) {
+      if (has_res) {
         v[0] += __uint_as_float(sd.x); v[1] += __uint_as_float(sd.y);
         v[2] += __uint_as_float(sd.z); v[3] += __uint_as_float(sd.w);
       }
-      store4(p.C, p.c_dtype, off, v, 4, true);
+      if (ok) {
+        store4(p.C, c_dt, off, v, 4, true);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) csum[e] += v[e];
+        for (int e = 0; e < 4; ++e) csum[e] += v[e];
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -354,6 +395,37 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
       *reinterpret_cast<float4*>(p.epi_f3 + (long long)(mrow0 / (16 * MI)) * p.N + n) =
           make_float4(csum[0], csum[1], csum[2], csum[3]);
   }
+}
+
+// picks the specialisation for the epilogues of the training step (bf16 mode); SPECIALISE = false keeps a
+// kernel on the run-time version only (compile time / code size of the kernels that rarely see big grids)
+template <int MI, bool SPECIALISE>
+__device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
+                                                            int mrow0, int n, int lane, long long coff) {
+#define NSP_EPI(...) do { gemm_epilogue_fast<MI, EpiSpec<__VA_ARGS__>>(p, acc, stage, mrow0, n, lane, coff); return; } while (0)
+  if constexpr (SPECIALISE) {
+    const bool c16 = p.c_dtype == NSP_DT_BF16;
+    const bool drop = p.dropout_p > 0.f;
+    const bool even = (p.offset & 1ull) == 0ull;
+    if (even || !drop) {
+      if (p.pre_out && p.pre_dtype == NSP_DT_BF16 && c16 && !p.res && !p.dact_src) {           // FFN first linear
+        if (p.act == NSP_ACT_SWISH) { if (drop) NSP_EPI(NSP_ACT_SWISH, 0, true, true, false, true); NSP_EPI(NSP_ACT_SWISH, 0, true, true, false, false); }
+        if (p.act == NSP_ACT_RELU) { if (drop) NSP_EPI(NSP_ACT_RELU, 0, true, true, false, true); NSP_EPI(NSP_ACT_RELU, 0, true, true, false, false); }
+      } else if (p.dact_src && p.dact_dtype == NSP_DT_BF16 && c16 && !p.res && !p.pre_out && p.act == NSP_ACT_NONE) {
+        if (p.dact == NSP_ACT_SWISH) { if (drop) NSP_EPI(0, NSP_ACT_SWISH, true, false, false, true); NSP_EPI(0, NSP_ACT_SWISH, true, false, false, false); }
+        if (p.dact == NSP_ACT_RELU) { if (drop) NSP_EPI(0, NSP_ACT_RELU, true, false, false, true); NSP_EPI(0, NSP_ACT_RELU, true, false, false, false); }
+        if (p.dact == NSP_ACT_TANH_OUT && !drop) NSP_EPI(0, NSP_ACT_TANH_OUT, true, false, false, false);
+      } else if (p.res && !c16 && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE) {        // residual branches
+        if (drop) NSP_EPI(0, 0, false, false, true, true);
+        NSP_EPI(0, 0, false, false, true, false);
+      } else if (!p.res && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE && !drop) {      // plain (+ bias)
+        if (c16) NSP_EPI(0, 0, true, false, false, false);
+        NSP_EPI(0, 0, false, false, false, false);
+      }
+    }
+  }
+#undef NSP_EPI
+  gemm_epilogue_fast<MI, EpiRuntime>(p, acc, stage, mrow0, n, lane, coff);
 }
 
 // ---- shared epilogue (see the comment inside): acc[mi][ni] -> global with full-line accesses
@@ -377,7 +449,7 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
   constexpr int SP = 68;  // floats per staged row (64 + 4 pad)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   if (!GENERIC || (c_vec && (p.N & 3) == 0 && !atomic && !(p.res && p.dact_src))) {
-    gemm_epilogue_fast<MI>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64 + (lane & 15) * 4, lane, coff);
+    gemm_epilogue_fast_dispatch<MI, !GENERIC>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64 + (lane & 15) * 4, lane, coff);
     return;
   }
   if constexpr (!GENERIC) return;
