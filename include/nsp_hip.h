@@ -96,8 +96,9 @@ typedef struct {
    *   NSP_EPI_RNNT_LSE    : nothing is stored to C.  Per row and 64-column block: (max, sum exp(.-max))
    *                         -> epi_f0 [M, N/64, 2]; logit at column epi_blank -> epi_f1 [M]; logit at
    *                         column epi_lab[m] (>= 0) -> epi_f2 [M].
-   *   NSP_EPI_RNNT_DLOGITS: C (bf16 [M, ldc = N]) <- scale * (-(gb+gl) exp(logit - lse) + gb [n=blank]
-   *                         + gl [n=lab]) with lse = epi_f0 [M], gb = epi_f1 [M], gl = epi_f2 [M], zeros
+   *   NSP_EPI_RNNT_DLOGITS: C (bf16 [M, ldc = N]) <- -(gb+gl) exp(logit - lse) + gb [n=blank]
+   *                         + gl [n=lab] with one record per row {lse, gb * scale, gl * scale, bits(lab)}
+   *                         in epi_f0 (float4 [M]; nsp_rnnt_joint_gemm packs it from its f0/f1/f2), zeros
    *                         in the pad columns; column sums of every 64-row block -> epi_f3
    *                         [ceil(M/128)*2, N] (output-bias gradient slabs, no atomics).
    *   scale = epi_scale * (epi_scale_dev ? *epi_scale_dev : 1).                                  */
@@ -408,7 +409,8 @@ int nsp_rnnt_joint_tanh_compact(const float* e, const float* g, const int* label
                                 void* h16, int* lab, int B, int T, int U1, int J, void* stream);
 int nsp_rnnt_joint_gemm(int epi_mode, const void* h16, const void* w16, const float* bias, long long M,
                         int V, int Vp, int J, int blank, const int* lab, float* f0, float* f1, float* f2,
-                        float* f3, void* d16, float scale, const float* scale_dev, void* stream);
+                        float* f3, void* d16, float scale, const float* scale_dev,
+                        float* rec /* DLOGITS: workspace [M,4] fp32, 16-B aligned; LSE: NULL */, void* stream);
 int nsp_rnnt_lse_merge(const float* part, int npart, float* lse, float* raw_b_to_lpb, float* raw_l_to_lpl,
                        const int* lab, long long M, void* stream);
 int nsp_rnnt_lattice_compact(const float* lp_blank, const float* lp_label, const int* elens, const int* ylens,

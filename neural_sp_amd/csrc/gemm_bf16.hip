@@ -153,22 +153,37 @@ __device__ __forceinline__ void load4(const void* base, int dtype, long long off
 //             instead of 4 KB of fp32 logits).
 //   DLOGITS : d loss / d logits from the recomputed tile, written as the bf16 operand image of the
 //             two gradient GEMMs; column sums (output-bias gradient) per 64-row block, no atomics.
-template <int MI>
-__device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], unsigned char* smem,
-                                              int m0, int n0, int wm, int wn, int lane, int wave) {
+// Both are straight-line per row group (mode is a template parameter) and keep the per-row scalars
+// (label; log-sum-exp and the two lattice gradients) of ONE row block in registers, refilled for the next
+// block right after use with clamped, unconditional loads -- see gemm_epilogue_fast for why (in-order
+// vmcnt: a load issued behind a store cannot be waited for without waiting for the store).
+template <int MI, bool LSE>
+__device__ __forceinline__ void rnnt_epilogue_mode(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], unsigned char* smem,
+                                                   int m0, int n0, int wm, int wn, int lane, int wave) {
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int SP = 68;
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   const int er = lane >> 4, ec = (lane & 15) * 4;
   const int n = n0 + wn * 64 + ec;                   // first of this lane's 4 columns (n + 3 < N: N % 64 == 0)
-  const bool lse_mode = p.epi_mode == NSP_EPI_RNNT_LSE;
+  const int mrow0 = m0 + wm * (16 * MI);
   const int npart = p.N >> 6, pidx = (n0 >> 6) + wn;
+  const bool colok = n < p.N;
   float b4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias && n < p.N) {
+  if (p.bias && colok) {
     const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
     b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
   }
-  const float sc = lse_mode ? 1.f : p.epi_scale * (p.epi_scale_dev ? p.epi_scale_dev[0] : 1.f);
+  __bf16* cbase = reinterpret_cast<__bf16*>(p.C) + (long long)(mrow0 + er) * p.ldc + n;   // DLOGITS output, row er of block 0
+  const long long ldc4 = 4ll * p.ldc;
+  // per-row scalars of the current row block: LSE needs the label; DLOGITS one 16-B record per row
+  // {lse, g_blank * scale, g_label * scale, bits(label)} (epi_f0 as float4 [M], packed by nsp_rnnt_joint_gemm)
+  float4 rec[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int mcl = min(mrow0 + er + 4 * j, p.M - 1);
+    if (LSE) rec[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(p.epi_lab[mcl]));
+    else rec[j] = reinterpret_cast<const float4*>(p.epi_f0)[mcl];
+  }
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -179,12 +194,20 @@ __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
       const int row = er + 4 * j;
       const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
-      const int m = m0 + wm * (16 * MI) + mi * 16 + row;
-      const bool rowok = m < p.M && n < p.N;
+      const int m = mrow0 + mi * 16 + row;
+      const bool rowok = m < p.M && colok;
+      const int lab = __float_as_int(rec[j].w);
+      const float ls = rec[j].x, gb = rec[j].y, gl = rec[j].z;
+      if (mi + 1 < MI) {
+        const int mcl = min(m + 16, p.M - 1);
+        if (LSE) rec[j].w = __int_as_float(p.epi_lab[mcl]);
+        else rec[j] = reinterpret_cast<const float4*>(p.epi_f0)[mcl];
+      }
       float v[4] = {a4.x + b4[0], a4.y + b4[1], a4.z + b4[2], a4.w + b4[3]};
-      if (lse_mode) {
+      if (LSE) {
         float mx = -FLT_MAX;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (n + e < p.epi_ncols) mx = fmaxf(mx, v[e]);
@@ -198,7 +221,6 @@ __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&
         if (rowok) {
           if ((lane & 15) == 0)
             *reinterpret_cast<float2*>(p.epi_f0 + ((long long)m * npart + pidx) * 2) = make_float2(mx, sm);
-          const int lab = p.epi_lab[m];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (n + e == p.epi_blank) p.epi_f1[m] = v[e];
@@ -206,42 +228,42 @@ __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&
           }
         }
       } else {
+        const float gs = gb + gl;
         float g[4] = {0.f, 0.f, 0.f, 0.f};
-        if (rowok) {
-          const float ls = p.epi_f0[m];
-          const float gb = p.epi_f1[m] * sc, gl = p.epi_f2[m] * sc;
-          const int lab = p.epi_lab[m];
-          const float gs = gb + gl;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n + e < p.epi_ncols) {
-              float t = -gs * __expf(v[e] - ls);
-              if (n + e == p.epi_blank) t += gb;
-              if (n + e == lab) t += gl;
-              g[e] = t;
-            }
-          }
-          bf16x4 o;
-          o[0] = (__bf16)g[0]; o[1] = (__bf16)g[1]; o[2] = (__bf16)g[2]; o[3] = (__bf16)g[3];
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C) + (long long)m * p.ldc + n) = o;
+        for (int e = 0; e < 4; ++e) {
+          float t = -gs * __expf(v[e] - ls);
+          if (n + e == p.epi_blank) t += gb;
+          if (n + e == lab) t += gl;
+          g[e] = (rowok && n + e < p.epi_ncols) ? t : 0.f;
         }
+        bf16x4 o;
+        o[0] = (__bf16)g[0]; o[1] = (__bf16)g[1]; o[2] = (__bf16)g[2]; o[3] = (__bf16)g[3];
 #pragma unroll
         for (int e = 0; e < 4; ++e) csum[e] += g[e];
+        if (rowok) *reinterpret_cast<bf16x4*>(cbase + (long long)(mi * 4 + j) * ldc4) = o;
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (!lse_mode && p.epi_f3) {
+  if (!LSE && p.epi_f3) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       csum[e] += __shfl_xor(csum[e], 16, 64);
       csum[e] += __shfl_xor(csum[e], 32, 64);
     }
-    if (lane < 16 && n < p.N) {
-      const long long slab = (long long)(m0 + wm * (16 * MI)) / (16 * MI);   // one slab per 16*MI-row block
+    if (lane < 16 && colok) {
+      const long long slab = (long long)mrow0 / (16 * MI);   // one slab per 16*MI-row block
       *reinterpret_cast<float4*>(p.epi_f3 + slab * p.N + n) = make_float4(csum[0], csum[1], csum[2], csum[3]);
     }
   }
+}
+
+template <int MI>
+__device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], unsigned char* smem,
+                                              int m0, int n0, int wm, int wn, int lane, int wave) {
+  if (p.epi_mode == NSP_EPI_RNNT_LSE) rnnt_epilogue_mode<MI, true>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+  else rnnt_epilogue_mode<MI, false>(p, acc, smem, m0, n0, wm, wn, lane, wave);
 }
 
 // ---- fast standard epilogue: same staging and arithmetic as gemm_epilogue below, for the common case
@@ -434,9 +456,11 @@ template <int MI, bool GENERIC = true>  // MI 16-row fragments per wave along M 
 __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4],
                                               unsigned char* smem, int m0, int n0, int wm, int wn,
                                               int lane, int wave, long long coff, int c_vec) {
-  if (p.epi_mode != NSP_EPI_NONE) {
-    rnnt_epilogue<MI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
-    return;
+  if constexpr (GENERIC) {
+    if (p.epi_mode != NSP_EPI_NONE) {
+      rnnt_epilogue<MI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+      return;
+    }
   }
   const int fr = lane & 15, fg = lane >> 4;
   // ---- epilogue.  The MFMA leaves lane (fr, fg) with C[m0+..+fr][n .. n+3]: storing that
@@ -613,6 +637,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
 // image cannot be padded: rows are exactly 128 B ([128 rows][64 k]) and the 16-B chunk index
 // is XOR-swizzled with (row & 7) on the SOURCE address and on the fragment read, which spreads
 // the 16 rows of a ds_read_b128 group over all banks.  Requires K % 64 == 0.
+// EPI: 0 = standard epilogue (fast path only, see gemm_epilogue), 1 / 2 = the RNN-T LSE / DLOGITS epilogues.
+// Three kernels rather than one with a run-time switch: each epilogue then gets the 128-register
+// budget of 4 workgroups per CU to itself (one kernel holding all of them spilled into the row loop).
+template <int EPI>
 __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const nsp_gemm_params p,
                                                                      int tiles_m, int tiles_n,
                                                                      int c_vec) {
@@ -693,7 +721,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const ns
     }
     __syncthreads();
   }
-  gemm_epilogue<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+  if constexpr (EPI == 1) rnnt_epilogue_mode<4, true>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+  else if constexpr (EPI == 2) rnnt_epilogue_mode<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+  else gemm_epilogue<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
 // ---- the same KC x KC tile with an NS-stage LDS ring.  The single-stage kernel above hides the
@@ -1426,7 +1456,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     const char* kkp_e2 = getenv("NSP_GEMM_PERSIST_MIN_TILES");
     const int kkp_env = kkp_e ? atoi(kkp_e) : 0;   // OPT-IN: measured slower than the classic kernels (below)
     const long long kkp_min = kkp_e2 ? atoll(kkp_e2) : 1536;
-    if (kkp_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 2 && wgs >= kkp_min &&
+    if (kkp_env && p.epi_mode == NSP_EPI_NONE && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 2 && wgs >= kkp_min &&
         !(p.epi_mode == NSP_EPI_NONE && p.epi_f3)) {   // (its standard epilogue has no column-sum slabs)
       hipLaunchKernelGGL(gemm_bf16_kkp_kernel, dim3(512), block, 2 * 32768 + 8192, st, p, tiles_m, tiles_n, c_vec);
       NSP_LAUNCH_CHECK();
@@ -1447,8 +1477,12 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 4>), grid, block, 4 * 32768, st, p, tiles_m, tiles_n, c_vec);
     else if (ring_env && wgs <= ring2_max && nkt >= 2)
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
-    else if (fast_epi || p.epi_mode != NSP_EPI_NONE)
-      hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+    else if (p.epi_mode == NSP_EPI_RNNT_LSE)
+      hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel<1>, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+    else if (p.epi_mode == NSP_EPI_RNNT_DLOGITS)
+      hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel<2>, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+    else if (fast_epi)
+      hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel<0>, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
     else   // odd widths / unaligned outputs / atomic split-K on a large grid: the generic epilogue lives in the ring kernels
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
   }

@@ -234,15 +234,33 @@ extern "C" int nsp_rnnt_joint_tanh_compact(const float* e, const float* g, const
   return NSP_OK;
 }
 
+// one 16-B record per lattice node for the DLOGITS epilogue: {lse, g_blank * s, g_label * s, bits(label)}
+__global__ __launch_bounds__(256) void rnnt_pack_rows_kernel(const float* __restrict__ lse, const float* __restrict__ gb,
+                                                             const float* __restrict__ gl, const int* __restrict__ lab,
+                                                             float scale, const float* __restrict__ scale_dev,
+                                                             float4* __restrict__ rec, long long M) {
+  const float s = scale * (scale_dev ? scale_dev[0] : 1.f);
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256)
+    rec[m] = make_float4(lse[m], gb[m] * s, gl[m] * s, __int_as_float(lab[m]));
+}
+
 extern "C" int nsp_rnnt_joint_gemm(int epi_mode, const void* h16, const void* w16, const float* bias, long long M,
                                    int V, int Vp, int J, int blank, const int* lab, float* f0, float* f1,
                                    float* f2, float* f3, void* d16, float scale, const float* scale_dev,
-                                   void* stream) {
+                                   float* rec, void* stream) {
   if (M <= 0) return NSP_OK;
   if (M > 0x7fffffffLL || Vp % 64 || V > Vp || V < 1 || J % 8 || !h16 || !w16 || !lab || !f0 || !f1 || !f2)
     return NSP_EINVAL;
   if (epi_mode != NSP_EPI_RNNT_LSE && epi_mode != NSP_EPI_RNNT_DLOGITS) return NSP_EINVAL;
-  if (epi_mode == NSP_EPI_RNNT_DLOGITS && !d16) return NSP_EINVAL;
+  if (epi_mode == NSP_EPI_RNNT_DLOGITS && (!d16 || !rec || (reinterpret_cast<uintptr_t>(rec) & 15))) return NSP_EINVAL;
+  if (epi_mode == NSP_EPI_RNNT_DLOGITS) {
+    long long g = (M + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(rnnt_pack_rows_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, f0, f1, f2, lab, scale,
+                       scale_dev, reinterpret_cast<float4*>(rec), M);
+    NSP_LAUNCH_CHECK();
+    f0 = rec;
+  }
   nsp_gemm_params p;
   p.M = (int)M; p.N = Vp; p.K = J;
   p.A = h16; p.a_rs = J; p.a_cs = 1;

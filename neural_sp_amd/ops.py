@@ -1266,7 +1266,7 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         nll = torch.empty((B,), device=dev, dtype=torch.float32)
         _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_gemm, M, Vp, J,
                                      1, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(part),
-                                     _p(aux[1]), _p(aux[2]), None, None, 1.0, None, _stream()),
+                                     _p(aux[1]), _p(aux[2]), None, None, 1.0, None, None, _stream()),
                'nsp_rnnt_joint_gemm(lse)')
         _check(L.nsp_rnnt_lse_merge(_p(part), npart, _p(aux[0]), _p(aux[1]), _p(aux[2]), _p(lab), M, _stream()),
                'nsp_rnnt_lse_merge')
@@ -1291,9 +1291,10 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         d16 = torch.empty((max(M, 1), Vp), device=dev, dtype=torch.bfloat16)
         nslab = (M + 127) // 128 * 2
         dbpart = torch.zeros((max(nslab, 1), Vp), device=dev, dtype=torch.float32) if ctx.has_bias else None
+        rec = torch.empty((max(M, 1), 4), device=dev, dtype=torch.float32)   # per-node records of the DLOGITS epilogue
         _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_gemm, M, Vp, J,
                                      2, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
-                                     _p(aux[5]), _p(aux[6]), _p(dbpart), _p(d16), 1.0 / B, _p(dl), _stream()),
+                                     _p(aux[5]), _p(aux[6]), _p(dbpart), _p(d16), 1.0 / B, _p(dl), _p(rec), _stream()),
                'nsp_rnnt_joint_gemm(dlogits)')
         db = colsum(dbpart)[:V] if ctx.has_bias else None
         # dW = dlogits^T h  (split over the M rows, deterministic slab reduction)

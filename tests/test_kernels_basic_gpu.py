@@ -284,3 +284,65 @@ def test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch):
         ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c2, N, dropout_p=0.3, seed=11, offset=0)
         assert torch.equal(c == 0, c2 == 0) and _rel(c, c2) < 1e-6
         assert 0.2 < (c == 0).float().mean().item() < 0.4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K', [(8200, 1412, 128), (16389, 768, 64)])
+def test_specialised_epilogues_on_the_single_stage_kernel(M, N, K):
+    """Grids above 640 workgroups run gemm_bf16_kk_glds_kernel<0>, whose epilogue is one of the compile-time
+    specialisations of gemm_epilogue_fast (FFN first linear, act' source, residual, plain).  Each against
+    torch, with ragged M and a ragged last column tile (the side operand is loaded with clamped addresses
+    there); dropout masks must equal those of the run-time epilogue (small grid -> ring kernel) at the same
+    element offsets; column-sum slabs must equal the column sums of the stored values."""
+    from neural_sp_amd import ops
+    torch.manual_seed(M)
+    dev = _dev()
+    a = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.5).bfloat16()
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    src16 = torch.randn(M, N, device=dev).bfloat16()
+    src = src16.float()
+    ref = a.float() @ w.float().t()
+    small = 128            # rows of the small-grid comparison run (same N / ldc -> same element offsets)
+    with ops.compute_mode('bf16'):
+        g = lambda C, rows=M, **k: ops.gemm_raw(rows, N, K, a, K, 1, w, 1, K, C, N, **k)
+        c32 = torch.empty(M, N, device=dev)
+        c16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        g(c32)
+        assert _rel(c32, ref) < 1e-5
+        g(c16, bias=bias)
+        assert _rel(c16.float(), ref + bias) < 1e-2
+        for act, f in ((2, lambda z: z * torch.sigmoid(z)), (1, torch.relu)):
+            g(c16, bias=bias, act=act, pre_out=pre)
+            z = ref + bias
+            assert _rel(pre.float(), z) < 1e-2 and _rel(c16.float(), f(z)) < 1e-2
+            g(c16, bias=bias, act=act, pre_out=pre, dropout_p=0.25, seed=9)
+            s16 = torch.empty(small, N, device=dev, dtype=torch.bfloat16)
+            sp = torch.empty(small, N, device=dev, dtype=torch.bfloat16)
+            g(s16, rows=small, bias=bias, act=act, pre_out=sp, dropout_p=0.25, seed=9)
+            assert torch.equal(c16[:small], s16)
+            keep = c16.float() != 0
+            assert _rel(c16.float(), torch.where(keep, f(z) / 0.75, torch.zeros_like(z))) < 1e-2
+        s = torch.sigmoid(src)
+        for dact, d in ((2, s * (1 + src * (1 - s))), (1, (src > 0).float()), (6, 1 - src * src)):
+            slabs = torch.zeros(((M + 127) // 128 * 4, N), device=dev)
+            g(c16, dact_src=src16, dact=dact, colsum_slabs=slabs)
+            assert _rel(c16.float(), ref * d) < 1e-2
+            assert _rel(slabs.sum(0), (ref * d).sum(0)) < 2e-3
+            if dact != 6:
+                g(c16, dact_src=src16, dact=dact, dropout_p=0.25, seed=4)
+                s16 = torch.empty(small, N, device=dev, dtype=torch.bfloat16)
+                g(s16, rows=small, dact_src=src16, dact=dact, dropout_p=0.25, seed=4)
+                assert torch.equal(c16[:small], s16)
+        g(c32, bias=bias, res=res, alpha=0.5)
+        assert _rel(c32, 0.5 * (ref + bias) + res) < 1e-5
+        g(c32, bias=bias, res=res, alpha=0.5, dropout_p=0.25, seed=3)
+        s32 = torch.empty(small, N, device=dev)
+        g(s32, rows=small, bias=bias, res=res, alpha=0.5, dropout_p=0.25, seed=3)
+        # (fp32 output: the two kernels may contract mul+add differently -> compare the masks and the values)
+        assert torch.equal(c32[:small] == res[:small], s32 == res[:small]) and _rel(c32[:small], s32) < 1e-6
+        dropped = (c32 == res)
+        assert 0.2 < dropped.float().mean().item() < 0.3
+        assert _rel(torch.where(dropped, torch.zeros_like(c32), c32 - res), torch.where(dropped, torch.zeros_like(c32), 0.5 * (ref + bias) / 0.75)) < 1e-5
