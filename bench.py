@@ -32,9 +32,9 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=20)
     p.add_argument('--warmup', type=int, default=4)
-    p.add_argument('--batch', type=int, default=64,
-                   help='utterances per GPU (64 x T~1400 frames: sized for 288 GB of HBM, not for a 16-32 GB card; '
-                        'B=16 runs at ~0.72x the frames/s, see DESIGN.md section 7)')
+    p.add_argument('--batch', type=int, default=128,
+                   help='utterances per GPU (128 x T~1400 frames: sized for 288 GB of HBM, not for a 16-32 GB card; '
+                        'the line also carries the same step at 64 and 16 utterances, see DESIGN.md section 7)')
     p.add_argument('--size', default='L', choices=['L', 'M', 'S', 'XS'])
     p.add_argument('--tmin', type=int, default=1200)
     p.add_argument('--tmax', type=int, default=1600)
@@ -44,7 +44,7 @@ def parse():
     p.add_argument('--mode', default='bf16', choices=['bf16', 'f32'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-kernel-events', action='store_true')
-    p.add_argument('--no-b16', action='store_true', help='skip the secondary batch-16 measurement')
+    p.add_argument('--no-b16', action='store_true', help='skip the secondary batch-64 / batch-16 measurements')
     p.add_argument('--event-stride', type=int, default=4,
                    help='HIP events around every GEMM launch of every k-th timed step (roofline line)')
     p.add_argument('--cpu-batch', type=int, default=1, help='utterances in the CPU-baseline sample')
@@ -275,26 +275,30 @@ def main():
             ('encoder_fwd_ms', 'loss_fwd_ms', 'backward_ms', 'clip_adam_ms'), acc)}
         phases['steps_sampled'] = len(phase_ev)
 
-    # Secondary measurement (single GPU only, outside the timed region above): the same step at 16
-    # utterances per GPU, the upper end of the per-GPU batch SURVEY.md section 8(d) wrote down for
-    # this config, so that both operating points are on record in one line.
+    # Secondary measurements (single GPU only, outside the timed region above): the same step at 64 utterances
+    # per GPU (the round-1/2 default) and at 16 (the upper end of the per-GPU batch SURVEY.md section 8(d)
+    # wrote down for this config), so that all three operating points are on record in one line.
     also = None
-    if not distributed and a.batch != 16 and not a.no_b16:
-        batches = [synthetic_batch(B=16, t_range=(a.tmin, a.tmax), u_range=(a.umin, a.umax),
-                                   vocab=1000, seed=7000 + i) for i in range(4)]
-        for i in range(4):
-            step(i)
-        report_pending()
-        sync()
-        t1 = time.perf_counter()
-        f16 = 0
-        for i in range(12):
-            f16 += step(4 + i)[0]
-        report_pending()
-        sync()
-        dt16 = time.perf_counter() - t1
-        also = {'per_gpu_batch': 16, 'value': round(f16 / dt16, 1), 'unit': 'frames/s', 'steps': 12,
-                'ms_per_step': round(dt16 / 12 * 1e3, 2)}
+    if not distributed and not a.no_b16:
+        also = []
+        for b_also in (64, 16):
+            if b_also >= a.batch:
+                continue
+            batches = [synthetic_batch(B=b_also, t_range=(a.tmin, a.tmax), u_range=(a.umin, a.umax),
+                                       vocab=1000, seed=7000 + i) for i in range(4)]
+            for i in range(4):
+                step(i)
+            report_pending()
+            sync()
+            t1 = time.perf_counter()
+            f_also = 0
+            for i in range(12):
+                f_also += step(4 + i)[0]
+            report_pending()
+            sync()
+            dt_also = time.perf_counter() - t1
+            also.append({'per_gpu_batch': b_also, 'value': round(f_also / dt_also, 1), 'unit': 'frames/s', 'steps': 12,
+                         'ms_per_step': round(dt_also / 12 * 1e3, 2)})
 
     tot = torch.tensor([dt, float(frames), float(padded)], device=dev, dtype=torch.float64)
     padded_all = float(padded)
@@ -313,23 +317,30 @@ def main():
         roof = None
         if kev is not None and kev['launches'] > 0:
             ach = kev['flops'] / (kev['ms'] * 1e-3) / 1e12
-            roof = {'kernel': 'bf16 MFMA GEMM class of libnsp_hip.so: gemm_bf16_kk_glds_kernel (activations x weights, data '
-                              'gradients, RNN-T joint logits/dlogits/dz), gemm_bf16_rr_ring_kernel<2> / gemm_bf16_kernel<false,false> '
-                              '(weight gradients), gemm_bf16_kk_ring_kernel<NS,MI> (small grids); %d launches = every GEMM of '
-                              'every %d-th timed step, rank 0' % (kev['launches'], a.event_stride),
+            side = kev['side']
+            roof = {'kernel': 'bf16 MFMA GEMM class of libnsp_hip.so on the main stream: gemm_bf16_kk_glds_kernel<0|1|2> '
+                              '(activations x weights, data gradients; RNN-T joint logits / dlogits), gemm_bf16_rr_ring_kernel<2> / '
+                              'gemm_bf16_kernel<false,false> (weight gradients), gemm_bf16_kk_ring_kernel<NS,MI> (small grids); '
+                              '%d launches = every main-stream GEMM of every %d-th timed step, rank 0.  The %d side-stream '
+                              'launches of those steps (CTC head, prediction-network projections: %.1f %% of the GEMM flops) run '
+                              'beside main-stream kernels, so their event pairs (%.2f ms) measure co-scheduling and are kept out'
+                              % (kev['launches'], a.event_stride, side['launches'],
+                                 100.0 * side['flops'] / max(1.0, side['flops'] + kev['flops']), side['ms']),
                     'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak_tf, 4), 'traffic': None, 'traffic_measured_in_run': False,
                     'flop_per_launch': round(kev['flops'] / kev['launches'], 1),
                     'avg_launch_us': round(kev['ms'] * 1e3 / kev['launches'], 2),
+                    'achieved_all_streams': round((kev['flops'] + side['flops']) / ((kev['ms'] + side['ms']) * 1e-3) / 1e12, 2),
                     'gemm_share_of_step': round(kev['ms'] / (dt * 1e3 * len(range(0, a.steps, a.event_stride)) / a.steps), 3)}
             # HBM bytes per GEMM launch cannot be counted from inside the process: it is the committed result of
             # the rocprofv3 PMC passes over this same command and workload (profiles/pmc_gemm_traffic.json:
             # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction, with the git revision and the
             # workload they were taken on), valid only for the default workload in bf16 mode
             tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_gemm_traffic.json')
-            default_wl = (a.size, a.batch, a.tmin, a.tmax, a.umin, a.umax, a.mode) == ('L', 64, 1200, 1600, 120, 200, 'bf16')
-            if default_wl and os.path.exists(tj):
-                tjd = json.load(open(tj))
+            tjd0 = json.load(open(tj)) if os.path.exists(tj) else {}
+            default_wl = (a.size, a.batch, a.tmin, a.tmax, a.umin, a.umax, a.mode) == ('L', tjd0.get('per_gpu_batch', 64), 1200, 1600, 120, 200, 'bf16')
+            if default_wl and tjd0:
+                tjd = tjd0
                 roof['traffic'] = round(tjd['hbm_bytes_per_launch'])
                 roof['traffic_source'] = 'profiles/pmc_gemm_traffic.json (rocprofv3 PMC passes at %s, bytes per launch; NOT measured in this run)' % tjd.get('revision', 'unknown revision')
         out = {

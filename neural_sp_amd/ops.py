@@ -1430,8 +1430,19 @@ def lstm_cell_step(gates, h_prev, c_prev, update=None):
 # --------------------------------------------------------------------------
 # per-launch timing of the GEMM kernel with HIP events (bench.py roofline)
 # --------------------------------------------------------------------------
-_KEV = {'on': False, 'events': [], 'flops': 0.0}
+_KEV = {'on': False, 'events': [], 'flops': 0.0, 'side_events': [], 'side_flops': 0.0}
 _gemm_raw_untimed = gemm_raw
+
+
+def _kev_record(e0, e1, flops):
+    # launches on a side stream (CTC head, prediction-network projections) are kept apart: they run
+    # beside main-stream kernels, so their event pairs measure co-scheduling, not the kernel
+    if torch.cuda.current_stream() == torch.cuda.default_stream():
+        _KEV['events'].append((e0, e1))
+        _KEV['flops'] += flops
+    else:
+        _KEV['side_events'].append((e0, e1))
+        _KEV['side_flops'] += flops
 
 
 def _gemm_raw_timed(M, N, K, *a, **k):
@@ -1443,8 +1454,7 @@ def _gemm_raw_timed(M, N, K, *a, **k):
     _gemm_raw_untimed(M, N, K, *a, **k)
     e1.record()
     batch = k.get('batch', (1, 1))
-    _KEV['events'].append((e0, e1))
-    _KEV['flops'] += 2.0 * M * N * K * batch[0] * batch[1]
+    _kev_record(e0, e1, 2.0 * M * N * K * batch[0] * batch[1])
 
 
 gemm_raw = _gemm_raw_timed
@@ -1459,13 +1469,13 @@ def rnnt_joint_gemm_timed(fn, M, Vp, J, *args):
     e0.record()
     rc = fn(*args)
     e1.record()
-    _KEV['events'].append((e0, e1))
-    _KEV['flops'] += 2.0 * M * Vp * J
+    _kev_record(e0, e1, 2.0 * M * Vp * J)
     return rc
 
 
 def kernel_events_start():
     _KEV['on'], _KEV['events'], _KEV['flops'] = True, [], 0.0
+    _KEV['side_events'], _KEV['side_flops'] = [], 0.0
 
 
 def kernel_events_enable(on):
@@ -1475,12 +1485,15 @@ def kernel_events_enable(on):
 
 
 def kernel_events_stop():
-    """-> {'launches', 'ms' (sum of HIP-event durations on the launch stream), 'flops'}."""
+    """-> {'launches', 'ms' (sum of HIP-event durations on the launch stream), 'flops'} of the main-stream
+    launches, and the same three numbers of the side-stream launches under 'side'."""
     _KEV['on'] = False
     torch.cuda.synchronize()
     ms = sum(e0.elapsed_time(e1) for e0, e1 in _KEV['events'])
-    out = {'launches': len(_KEV['events']), 'ms': ms, 'flops': _KEV['flops']}
-    _KEV['events'] = []
+    sms = sum(e0.elapsed_time(e1) for e0, e1 in _KEV['side_events'])
+    out = {'launches': len(_KEV['events']), 'ms': ms, 'flops': _KEV['flops'],
+           'side': {'launches': len(_KEV['side_events']), 'ms': sms, 'flops': _KEV['side_flops']}}
+    _KEV['events'], _KEV['side_events'] = [], []
     return out
 
 

@@ -3,7 +3,7 @@
 FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced
 reads (MI355X_MICROARCH.md, HBM section) -> doubled here.  WRITE_SIZE is calibrated against the
 bf16 cast kernel, whose written bytes are known from its grid (see --calib).
-usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json revision]
+usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json revision per_gpu_batch]
 With out.json: also writes the GEMM-class aggregate (all gemm_bf16_* kernels) that bench.py quotes as roofline.traffic."""
 import collections
 import csv
@@ -48,12 +48,14 @@ if __name__ == '__main__':
     rows = main(sys.argv[1], sys.argv[2])
     if len(sys.argv) > 3:
         import json
+        BATCH = int(sys.argv[5]) if len(sys.argv) > 5 else 128
         g = [r for r in rows if r[1].startswith('gemm_bf16')]
         n = sum(r[2] for r in g)
         rd = sum(r[3] * r[2] for r in g) / n
         wr = sum(r[4] * r[2] for r in g) / n
         json.dump({'kernel_class': 'bf16 GEMM class (all gemm_bf16_* kernels of libnsp_hip.so, incl. the RNN-T joint GEMMs)',
-                   'workload': 'bench.py default (Conformer-L, per-GPU batch 64, bf16), 2 steps in the trace',
+                   'workload': 'bench.py default (Conformer-L, per-GPU batch %d, bf16), 2 steps in the trace' % BATCH,
+                   'per_gpu_batch': BATCH,
                    'launches': n, 'hbm_bytes_per_launch': rd + wr, 'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
                    'per_kernel': {r[1]: {'launches': r[2], 'read_MB_per_launch': round(r[3] / 1e6, 3),
                                          'write_MB_per_launch': round(r[4] / 1e6, 3), 'avg_us': round(r[5], 1)} for r in g},
