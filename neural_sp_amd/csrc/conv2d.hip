@@ -82,6 +82,10 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict_
           reinterpret_cast<const float4*>(w + (long long)co * 288)[q];
     }
   }
+  float4 bb[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+    bb[nb] = bias ? reinterpret_cast<const float4*>(bias + nb * 16 + g * 4)[0] : make_float4(0.f, 0.f, 0.f, 0.f);
   const long long ntiles = (long long)B * tiles_t * tiles_f;
   // bf16 mode: the halo of the NEXT tile is fetched into registers before the MFMAs of the current
   // one and written to the other LDS buffer after its epilogue: one barrier per tile and the
@@ -95,23 +99,28 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict_
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
   float4 pre[IO16 ? 1 : NST];
   u32x4_t pre16[IO16 ? NST : 1];
+  // Every lane loads (out-of-range pixels / chunk slots with clamped addresses) and the zero padding is
+  // applied at commit time from a bit mask: predicated loads become branches, behind which hipcc's wait
+  // insertion only knows vmcnt(0) -- and with in-order retirement that also waits for the tile's stores.
+  unsigned pre_ok = 0u;
   auto halo_fetch = [&](long long tl) {
     const int tf = (int)(tl % tiles_f);
     const int tt = (int)((tl / tiles_f) % tiles_t);
     const long long b = tl / ((long long)tiles_f * tiles_t);
+    pre_ok = 0u;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = min(tid + i * 256, HT * HF * CPP - 1);
       const int cc = idx % CPP, pix = idx / CPP;
       const int ht = pix / HF, hf = pix % HF;
       const int t = tt * TT + ht - 1, f = tf * TF + hf - 1;
-      const bool ok = idx < HT * HF * CPP && t >= 0 && t < T && f >= 0 && f < F;
+      const bool ok = t >= 0 && t < T && f >= 0 && f < F;
+      pre_ok |= (ok ? 1u : 0u) << i;
+      const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
       if constexpr (IO16) {
-        pre16[i] = u32x4_t{0u, 0u, 0u, 0u};
-        if (ok) pre16[i] = *reinterpret_cast<const u32x4_t*>(x + ((b * T + t) * F + f) * CH + cc * 8);
+        pre16[i] = *reinterpret_cast<const u32x4_t*>(x + ((b * T + tc) * F + fc) * CH + cc * 8);
       } else {
-        pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) pre[i] = ld4<TIO>(x + ((b * T + t) * F + f) * CH + cc * 4);
+        pre[i] = ld4<TIO>(x + ((b * T + tc) * F + fc) * CH + cc * 4);
       }
     }
   };
@@ -119,13 +128,15 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict_
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int idx = tid + i * 256;
+      const bool ok = (pre_ok >> i) & 1u;
       if (idx < HT * HF * CPP) {
         const int cc = idx % CPP, pix = idx / CPP;
         if constexpr (IO16) {
-          *reinterpret_cast<u32x4_t*>(dst + pix * PP + cc * 16) = pre16[i];
+          *reinterpret_cast<u32x4_t*>(dst + pix * PP + cc * 16) = ok ? pre16[i] : u32x4_t{0u, 0u, 0u, 0u};
         } else {
           bf16x4 h;
-          h[0] = (__bf16)pre[i].x; h[1] = (__bf16)pre[i].y; h[2] = (__bf16)pre[i].z; h[3] = (__bf16)pre[i].w;
+          h[0] = (__bf16)(ok ? pre[i].x : 0.f); h[1] = (__bf16)(ok ? pre[i].y : 0.f);
+          h[2] = (__bf16)(ok ? pre[i].z : 0.f); h[3] = (__bf16)(ok ? pre[i].w : 0.f);
           *reinterpret_cast<bf16x4*>(dst + pix * PP + cc * 8) = h;
         }
       }
@@ -199,8 +210,28 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict_
         }
       }
     }
-    // ---- epilogue: lane holds pixel (t0+2*wave+a, f0+r), co = nb*16 + g*4 .. +3
+    // ---- epilogue: lane holds pixel (t0+2*wave+a, f0+r), co = nb*16 + g*4 .. +3.
+    // All mask loads are issued before the first store (and the bias lives in registers, loaded once per
+    // workgroup): gfx9 retires vector-memory operations in order, so a load issued behind a store can only
+    // be waited for together with that store -- load/wait/store per output chunk exposed three store
+    // round trips per 128-pixel tile.
     const int f = f0 + r;
+    float4 mk[2][2];
+    if (mask_src) {
+      // (clamped, unconditional: a per-lane predicate around the load makes hipcc consume it inside the branch)
+      const int fc = min(f, F - 1);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int tc = min(t0 + wave * 2 + a, T - 1);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) mk[a][nb] = ld4<TIO>(mask_src + ((b * T + tc) * F + fc) * CH + nb * 16 + g * 4);
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) mk[a][nb] = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int t = t0 + wave * 2 + a;
@@ -209,19 +240,14 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict_
       for (int nb = 0; nb < 2; ++nb) {
         const int co = nb * 16 + g * 4;
         const long long off = ((b * T + t) * F + f) * CH + co;
-        float4 v = make_float4(acc[a][nb][0], acc[a][nb][1], acc[a][nb][2], acc[a][nb][3]);
-        if (bias) {
-          const float4 bb = reinterpret_cast<const float4*>(bias + co)[0];
-          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-        }
+        float4 v = make_float4(acc[a][nb][0] + bb[nb].x, acc[a][nb][1] + bb[nb].y, acc[a][nb][2] + bb[nb].z,
+                               acc[a][nb][3] + bb[nb].w);
         if (relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (mask_src) {
-          const float4 m = ld4<TIO>(mask_src + off);
-          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-          v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-        }
+        const float4 m = mk[a][nb];
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         st4<TIO>(y + off, v);
       }
     }
@@ -230,6 +256,177 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const TIO* __restrict_
       __syncthreads();  // next buffer complete, every wave done reading the current one
       cur ^= 1;
     }
+  }
+}
+
+// ---- bf16 feature maps, throughput mode: the kernel above restated with buffer addressing and a two-tile
+// prefetch.  Why: (1) gfx9 retires vector-memory operations in issue order, so waiting for a load that
+// was issued after a store also waits for that store to reach L2; the kernel above fetched the next halo
+// and the ReLU-mask chunks behind the previous tile's stores and exposed a store round trip per
+// 128-pixel tile (~5 us of work).  Here the halo of tile i+2 and the mask chunks of tile i+1 are
+// requested at the top of iteration i, i.e. BEFORE the stores of tile i, and are consumed in iteration
+// i+1: every wait covers only loads that are older than the last stores.  (2) that only holds if hipcc can
+// count: a predicated load or store is a branch, and behind a branch its wait insertion assumes the
+// minimum, which degenerates to vmcnt(0).  Buffer instructions return 0 / drop the write for offsets
+// beyond num_records, so edge pixels, the zero padding of the halo and tiles past the end are handled by
+// an out-of-range offset instead of a predicate and the tile loop is straight-line code.
+// Requires B*T*F*64 bytes < 4 GiB per launch (the launcher cuts the batch otherwise).
+typedef __attribute__((ext_vector_type(4))) unsigned int cu32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int cu32x2;
+
+template <bool HAS_MASK>
+__global__ __launch_bounds__(256) void conv3x3_c32_b16_kernel(const __bf16* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, __bf16* __restrict__ y,
+                                                              int B, int T, int F, int relu,
+                                                              const __bf16* __restrict__ mask_src, int tiles_f,
+                                                              int tiles_t, unsigned map_bytes) {
+  constexpr int PP = ConvCfg<0>::PIX_PITCH;
+  constexpr int NCH = HT * HF * 4;                 // 16-B chunks of one halo tile (4 per pixel)
+  constexpr int NST = (NCH + 255) / 256;
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, map_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, map_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(HAS_MASK ? mask_src : x), 0, map_bytes, 0x00020000);
+
+  bf16x8 bfrag[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float* wp = w + ((long long)(nb * 16 + r) * 9 + tap) * CH + g * 8;
+      const float4 lo = reinterpret_cast<const float4*>(wp)[0];
+      const float4 hi = reinterpret_cast<const float4*>(wp)[1];
+      bf16x8 h;
+      h[0] = (__bf16)lo.x; h[1] = (__bf16)lo.y; h[2] = (__bf16)lo.z; h[3] = (__bf16)lo.w;
+      h[4] = (__bf16)hi.x; h[5] = (__bf16)hi.y; h[6] = (__bf16)hi.z; h[7] = (__bf16)hi.w;
+      bfrag[tap][nb] = h;
+    }
+  float4 bb[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+    bb[nb] = bias ? reinterpret_cast<const float4*>(bias + nb * 16 + g * 4)[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long ntiles = (long long)B * tiles_t * tiles_f;
+  const long long G = gridDim.x;
+
+  // halo chunk slots of this thread (tile independent): LDS byte offset and (dt, df, channel chunk)
+  int h_ht[NST], h_hf[NST], h_cc[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int idx = tid + i * 256;
+    const int pix = idx / 4;
+    h_cc[i] = idx % 4; h_ht[i] = pix / HF; h_hf[i] = pix % HF;
+  }
+  auto fetch_halo = [&](long long tl, cu32x4 (&h)[NST]) {
+    const bool live = tl < ntiles;
+    const int tf = (int)(tl % tiles_f);
+    const int tt = (int)((tl / tiles_f) % tiles_t);
+    const long long b = tl / ((long long)tiles_f * tiles_t);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int t = tt * TT + h_ht[i] - 1, f = tf * TF + h_hf[i] - 1;
+      const bool ok = live && tid + i * 256 < NCH && t >= 0 && t < T && f >= 0 && f < F;
+      const unsigned off = ok ? (unsigned)((((b * T + t) * F + f) * CH + h_cc[i] * 8) * 2) : OOB;
+      h[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+    }
+  };
+  // output / mask chunk offsets of this lane in tile tl: pixel (t0 + 2*wave + a, f0 + r), channels nb*16 + g*4 .. +3
+  auto out_off = [&](long long tl, int a, int nb) -> unsigned {
+    const int tf = (int)(tl % tiles_f);
+    const int tt = (int)((tl / tiles_f) % tiles_t);
+    const long long b = tl / ((long long)tiles_f * tiles_t);
+    const int t = tt * TT + wave * 2 + a, f = tf * TF + r;
+    const bool ok = tl < ntiles && t < T && f < F;
+    return ok ? (unsigned)((((b * T + t) * F + f) * CH + nb * 16 + g * 4) * 2) : OOB;
+  };
+  auto fetch_mask = [&](long long tl, cu32x2 (&m)[2][2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        if constexpr (HAS_MASK) m[a][nb] = __builtin_amdgcn_raw_buffer_load_b64(rm, out_off(tl, a, nb), 0, 0);
+        else m[a][nb] = cu32x2{0u, 0u};
+      }
+  };
+  auto commit = [&](const cu32x4 (&h)[NST], unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+      if (tid + i * 256 < NCH)
+        *reinterpret_cast<cu32x4*>(dst + (h_ht[i] * HF + h_hf[i]) * PP + h_cc[i] * 16) = h[i];
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (not __syncthreads: its fence waits vmcnt(0) = for the stores)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  int cur = 0;
+  // one tile: MFMAs on LDS[cur], stage the next tile's halo (C.h) into LDS[cur^1], epilogue with C.m
+  auto body = [&](long long tile, const cu32x4 (&ch)[NST], const cu32x2 (&cm)[2][2]) {
+    const unsigned char* xs = smem + cur * (HT * HF * PP);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) acc[a][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dt = tap / 3, df = tap % 3;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int pix = (wave * 2 + a + dt) * HF + r + df;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(xs + pix * PP + g * 16);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[a][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[tap][nb], af, acc[a][nb], 0, 0, 0);
+      }
+    }
+    commit(ch, smem + (cur ^ 1) * (HT * HF * PP));
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        float v[4] = {acc[a][nb][0] + bb[nb].x, acc[a][nb][1] + bb[nb].y, acc[a][nb][2] + bb[nb].z,
+                      acc[a][nb][3] + bb[nb].w};
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (HAS_MASK) {
+          const cu32x2 m = cm[a][nb];
+          // bf16 > 0  <=>  sign bit clear and not (+-)zero
+          const unsigned mv[4] = {m.x << 16, m.x & 0xFFFF0000u, m.y << 16, m.y & 0xFFFF0000u};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(mv[e]) > 0.f ? v[e] : 0.f;
+        }
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2, h), ry, out_off(tile, a, nb), 0, 0);
+      }
+    lds_barrier();   // next halo complete in LDS[cur^1], every wave done reading LDS[cur]
+    cur ^= 1;
+  };
+
+  cu32x4 ha[NST], hb[NST];
+  cu32x2 ma[2][2], mb[2][2];
+  long long tile = blockIdx.x;
+  fetch_halo(tile, ha);
+  commit(ha, smem);
+  fetch_halo(tile + G, ha);
+  fetch_mask(tile, ma);
+  lds_barrier();
+  while (tile < ntiles) {
+    fetch_halo(tile + 2 * G, hb);
+    fetch_mask(tile + G, mb);
+    body(tile, ha, ma);
+    tile += G;
+    if (tile >= ntiles) break;
+    fetch_halo(tile + 2 * G, ha);
+    fetch_mask(tile + G, ma);
+    body(tile, hb, mb);
+    tile += G;
   }
 }
 
@@ -714,10 +911,27 @@ extern "C" int nsp_conv2d3x3_fwd(const void* x, const float* w, const float* bia
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // 4 persistent workgroups per CU
     if (mode == NSP_COMPUTE_BF16) {
       const size_t sh = 2 * HT * HF * ConvCfg<0>::PIX_PITCH;   // double-buffered halo
-      if (io16)
-        hipLaunchKernelGGL((conv3x3_c32_kernel<0, __bf16>), dim3(grid), dim3(256), sh, st, (const __bf16*)x, w, bias,
-                           (__bf16*)y, B, T, F, relu, (const __bf16*)mask_src, tiles_f, tiles_t);
-      else
+      if (io16) {
+        // buffer-addressed kernel: 32-bit byte offsets -> at most 4 GiB of map per launch (cut over the batch)
+        const long long per_utt = (long long)T * F * CH * 2;
+        if (per_utt >= 0xFFFFFFFFLL) return NSP_EUNSUPPORTED;
+        const int bmax = (int)(0xFFFFFFF0LL / per_utt);
+        for (int b0 = 0; b0 < B; b0 += bmax) {
+          const int bn = B - b0 < bmax ? B - b0 : bmax;
+          const long long nt = (long long)bn * tiles_f * tiles_t;
+          const int gr = (int)(nt < 1024 ? nt : 1024);
+          const __bf16* xb = (const __bf16*)x + (long long)b0 * T * F * CH;
+          __bf16* yb = (__bf16*)y + (long long)b0 * T * F * CH;
+          const __bf16* mb = mask_src ? (const __bf16*)mask_src + (long long)b0 * T * F * CH : nullptr;
+          const unsigned bytes = (unsigned)(per_utt * bn);
+          if (mask_src)
+            hipLaunchKernelGGL((conv3x3_c32_b16_kernel<true>), dim3(gr), dim3(256), sh, st, xb, w, bias, yb, bn, T, F, relu,
+                               mb, tiles_f, tiles_t, bytes);
+          else
+            hipLaunchKernelGGL((conv3x3_c32_b16_kernel<false>), dim3(gr), dim3(256), sh, st, xb, w, bias, yb, bn, T, F, relu,
+                               mb, tiles_f, tiles_t, bytes);
+        }
+      } else
         hipLaunchKernelGGL((conv3x3_c32_kernel<0, float>), dim3(grid), dim3(256), sh, st, (const float*)x, w, bias,
                            (float*)y, B, T, F, relu, (const float*)mask_src, tiles_f, tiles_t);
     } else {

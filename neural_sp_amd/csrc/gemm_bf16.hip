@@ -452,7 +452,8 @@ __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_param
 
 // ---- shared epilogue (see the comment inside): acc[mi][ni] -> global with full-line accesses
 // GENERIC = false: the kernel is only launched when the fast path applies (the launcher's `fast_epi`); compiling both paths into one kernel costs 24 VGPRs = one workgroup per CU.
-template <int MI, bool GENERIC = true>  // MI 16-row fragments per wave along M (wave tile = 16*MI x 64)
+// SPEC: compile the EpiSpec specialisations of the fast path into this kernel (default: only where GENERIC is off).
+template <int MI, bool GENERIC = true, bool SPEC = !GENERIC>  // MI 16-row fragments per wave along M (wave tile = 16*MI x 64)
 __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4],
                                               unsigned char* smem, int m0, int n0, int wm, int wn,
                                               int lane, int wave, long long coff, int c_vec) {
@@ -473,7 +474,7 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
   constexpr int SP = 68;  // floats per staged row (64 + 4 pad)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   if (!GENERIC || (c_vec && (p.N & 3) == 0 && !atomic && !(p.res && p.dact_src))) {
-    gemm_epilogue_fast_dispatch<MI, !GENERIC>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64 + (lane & 15) * 4, lane, coff);
+    gemm_epilogue_fast_dispatch<MI, SPEC>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64 + (lane & 15) * 4, lane, coff);
     return;
   }
   if constexpr (!GENERIC) return;
@@ -836,7 +837,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
     }
   }
   __syncthreads();  // the epilogue reuses the ring as its staging area
-  gemm_epilogue(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
+  // (the 2-stage / full-height ring is what mid-size grids of the step run on: it gets the specialisations too)
+  gemm_epilogue<MI, true, (NS == 2 && MI == 4)>(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
 // ---- KC x KC, 128 x 128 x 64, PERSISTENT with a DEFERRED epilogue.
