@@ -308,12 +308,14 @@ int nsp_relu_bwd(const float* y, const float* dy, float* dx, long long n, void* 
 /* MaxPool2d(kernel=stride=(pt,pf), ceil_mode=True) on [B,T,F,C]; if
  * to_btcf != 0 the output is written as [B,T',C,F'] (= the reference's
  * transpose(2,1).view(B,T',C*F'), conv.py:189) */
-int nsp_maxpool2d_fwd(const void* x, void* y, int* argmax, int B, int T, int F, int C,
+/* argmax: ONE BYTE per output element = position of the maximum inside its window, dt * pf + df
+ * (first maximum in scan order, like torch); pt * pf <= 256; C % 8 == 0 for bf16 inputs (C % 4 for fp32) */
+int nsp_maxpool2d_fwd(const void* x, void* y, unsigned char* argmax, int B, int T, int F, int C,
                       int pt, int pf, int to_btcf, int x_dtype, int y_dtype, void* stream);
 /* relu_src (optional, layout of dx): dx = relu_src > 0 ? dx : 0 (ReLU backward of the conv that
  * fed the pool, fused) */
 /* dy_dtype: type of dy; dx_dtype: type of dx and relu_src */
-int nsp_maxpool2d_bwd(const void* dy, const int* argmax, void* dx, int B, int T, int F,
+int nsp_maxpool2d_bwd(const void* dy, const unsigned char* argmax, void* dx, int B, int T, int F,
                       int C, int pt, int pf, int from_btcf, const void* relu_src,
                       int dy_dtype, int dx_dtype, void* stream);
 /* MaxPool1d(k=s=factor, ceil_mode=True) over time of [B,T,C]

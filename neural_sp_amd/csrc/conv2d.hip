@@ -798,20 +798,81 @@ __global__ __launch_bounds__(256) void conv3x3_c32_wgrad_mfma_kernel(
 }
 
 // ---- MaxPool2d(kernel=stride=(pt,pf), ceil_mode) on [B,T,F,C]
+// One thread owns 16 B of input channels (8 bf16 / 4 fp32) of one output pixel; the arg-max is kept as ONE
+// BYTE per element (position inside the window, dt * pf + df: the int32 absolute index of the first version
+// was two thirds of the bytes this kernel wrote and a fifth of what backward read).
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  }
+};
+template <> struct Vec16<__bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const __bf16* p, float (&v)[8]) {
+    const bf16x8 h = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+  }
+};
+template <typename T, int N> __device__ __forceinline__ void store_vec(T* p, const float (&v)[N]) {
+  if constexpr (sizeof(T) == 2) {
+    if constexpr (N == 8) {
+      bf16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
+      *reinterpret_cast<bf16x8*>(p) = h;
+    } else {
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+      *reinterpret_cast<bf16x4*>(p) = h;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q)
+      reinterpret_cast<float4*>(p)[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+  }
+}
+template <typename T, int N> __device__ __forceinline__ void load_vec(const T* p, float (&v)[N]) {
+  if constexpr (sizeof(T) == 2) {
+    if constexpr (N == 8) {
+      const bf16x8 h = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    } else {
+      const bf16x4 h = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)h[e];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+      const float4 f = reinterpret_cast<const float4*>(p)[q];
+      v[q * 4] = f.x; v[q * 4 + 1] = f.y; v[q * 4 + 2] = f.z; v[q * 4 + 3] = f.w;
+    }
+  }
+}
+
 template <typename TX, typename TY>
-__global__ void maxpool2d_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y,
-                                     int* __restrict__ argmax, int B, int T, int F, int C, int To,
-                                     int Fo, int pt, int pf, int to_btcf) {
-  const int C4 = C >> 2;
-  const long long total = (long long)B * To * Fo * C4;
+__global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y,
+                                                            unsigned char* __restrict__ argmax, int B, int T, int F, int C,
+                                                            int To, int Fo, int pt, int pf, int to_btcf) {
+  constexpr int V = Vec16<TX>::N;
+  const int CV = C / V;
+  const long long total = (long long)B * To * Fo * CV;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    const int c4 = (int)(idx % C4);
-    const int fo = (int)((idx / C4) % Fo);
-    const int to = (int)((idx / ((long long)C4 * Fo)) % To);
-    const long long b = idx / ((long long)C4 * Fo * To);
-    float best[4] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-    int bi[4] = {0, 0, 0, 0};
+    const int cv = (int)(idx % CV);
+    const int fo = (int)((idx / CV) % Fo);
+    const int to = (int)((idx / ((long long)CV * Fo)) % To);
+    const long long b = idx / ((long long)CV * Fo * To);
+    float best[V];
+    unsigned char bi[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { best[e] = -FLT_MAX; bi[e] = 0; }
     bool first = true;
     for (int dt = 0; dt < pt; ++dt) {
       const int t = to * pt + dt;
@@ -819,56 +880,80 @@ __global__ void maxpool2d_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ 
       for (int df = 0; df < pf; ++df) {
         const int f = fo * pf + df;
         if (f >= F) break;
-        const float4 v = ld4<TX>(x + ((b * T + t) * F + f) * C + c4 * 4);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float vv[V];
+        Vec16<TX>::load(x + ((b * T + t) * F + f) * C + cv * V, vv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (first || vv[e] > best[e]) { best[e] = vv[e]; bi[e] = t * F + f; }
+        for (int e = 0; e < V; ++e)
+          if (first || vv[e] > best[e]) { best[e] = vv[e]; bi[e] = (unsigned char)(dt * pf + df); }
         first = false;
       }
     }
     if (to_btcf) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const long long o = ((b * To + to) * C + c4 * 4 + e) * Fo + fo;
+      for (int e = 0; e < V; ++e) {
+        const long long o = ((b * To + to) * C + cv * V + e) * Fo + fo;
         y[o] = (TY)best[e];
         argmax[o] = bi[e];
       }
     } else {
-      st4<TY>(y + idx * 4, make_float4(best[0], best[1], best[2], best[3]));
-      reinterpret_cast<int4*>(argmax)[idx] = make_int4(bi[0], bi[1], bi[2], bi[3]);
+      store_vec<TY, V>(y + idx * V, best);
+      if constexpr (V == 8) {
+        uint2 pk;
+        pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
+        pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
+        *reinterpret_cast<uint2*>(argmax + idx * 8) = pk;
+      } else {
+        *reinterpret_cast<unsigned*>(argmax + idx * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
+      }
     }
   }
 }
 
+// TD: gradient type; TX: type of dx and relu_src.  One thread = 16 B of dx channels of one input pixel.
 template <typename TD, typename TX>
-__global__ void maxpool2d_bwd_kernel(const TD* __restrict__ dy, const int* __restrict__ argmax,
-                                     TX* __restrict__ dx, int B, int T, int F, int C, int To,
-                                     int Fo, int pt, int pf, int from_btcf,
-                                     const TX* __restrict__ relu_src) {
-  const int C4 = C >> 2;
-  const long long total = (long long)B * T * F * C4;
+__global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const TD* __restrict__ dy, const unsigned char* __restrict__ argmax,
+                                                            TX* __restrict__ dx, int B, int T, int F, int C, int To,
+                                                            int Fo, int pt, int pf, int from_btcf,
+                                                            const TX* __restrict__ relu_src) {
+  constexpr int V = Vec16<TX>::N;
+  const int CV = C / V;
+  const long long total = (long long)B * T * F * CV;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    const int c4 = (int)(idx % C4);
-    const int f = (int)((idx / C4) % F);
-    const int t = (int)((idx / ((long long)C4 * F)) % T);
-    const long long b = idx / ((long long)C4 * F * T);
+    const int cv = (int)(idx % CV);
+    const int f = (int)((idx / CV) % F);
+    const int t = (int)((idx / ((long long)CV * F)) % T);
+    const long long b = idx / ((long long)CV * F * T);
     const int to = t / pt, fo = f / pf;
-    const int self = t * F + f;
-    float o[4];
+    const unsigned self = (unsigned)((t - to * pt) * pf + (f - fo * pf));
+    float o[V];
+    if (from_btcf) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long long oi = from_btcf ? ((b * To + to) * C + c4 * 4 + e) * Fo + fo
-                                     : ((b * To + to) * Fo + fo) * C + c4 * 4 + e;
-      o[e] = argmax[oi] == self ? (float)dy[oi] : 0.f;
+      for (int e = 0; e < V; ++e) {
+        const long long oi = ((b * To + to) * C + cv * V + e) * Fo + fo;
+        o[e] = argmax[oi] == self ? (float)dy[oi] : 0.f;
+      }
+    } else {
+      const long long oi = ((b * To + to) * Fo + fo) * C + cv * V;
+      float g[V];
+      load_vec<TD, V>(dy + oi, g);
+      unsigned code[2];
+      if constexpr (V == 8) {
+        const uint2 pk = *reinterpret_cast<const uint2*>(argmax + oi);
+        code[0] = pk.x; code[1] = pk.y;
+      } else {
+        code[0] = *reinterpret_cast<const unsigned*>(argmax + oi); code[1] = 0u;
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = ((code[e >> 2] >> ((e & 3) * 8)) & 0xFFu) == self ? g[e] : 0.f;
     }
     if (relu_src) {  // fused ReLU backward of the layer that fed the pool (its output is relu_src)
-      const float4 m = ld4<TX>(relu_src + idx * 4);
-      o[0] = m.x > 0.f ? o[0] : 0.f; o[1] = m.y > 0.f ? o[1] : 0.f;
-      o[2] = m.z > 0.f ? o[2] : 0.f; o[3] = m.w > 0.f ? o[3] : 0.f;
+      float m[V];
+      Vec16<TX>::load(relu_src + idx * V, m);
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = m[e] > 0.f ? o[e] : 0.f;
     }
-    st4<TX>(dx + idx * 4, make_float4(o[0], o[1], o[2], o[3]));
+    store_vec<TX, V>(dx + idx * V, o);
   }
 }
 
@@ -991,11 +1076,13 @@ extern "C" int nsp_conv2d3x3_wgrad(const void* x, const void* dy, float* dw, flo
   return NSP_OK;
 }
 
-extern "C" int nsp_maxpool2d_fwd(const void* x, void* y, int* argmax, int B, int T, int F, int C,
+extern "C" int nsp_maxpool2d_fwd(const void* x, void* y, unsigned char* argmax, int B, int T, int F, int C,
                                  int pt, int pf, int to_btcf, int x_dtype, int y_dtype, void* stream) {
   if (C % 4) return NSP_EUNSUPPORTED;
   const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
-  const dim3 grid(ew_grid((long long)B * To * Fo * (C / 4)));
+  const int vec = x_dtype == NSP_DT_BF16 ? 8 : 4;
+  if (C % vec || pt * pf > 256 || pt < 1 || pf < 1) return NSP_EUNSUPPORTED;
+  const dim3 grid(ew_grid((long long)B * To * Fo * (C / vec)));
   hipStream_t st = (hipStream_t)stream;
 #define MPF(TX, TY) hipLaunchKernelGGL((maxpool2d_fwd_kernel<TX, TY>), grid, dim3(256), 0, st, (const TX*)x, (TY*)y, \
                                        argmax, B, T, F, C, To, Fo, pt, pf, to_btcf)
@@ -1009,12 +1096,14 @@ extern "C" int nsp_maxpool2d_fwd(const void* x, void* y, int* argmax, int B, int
 }
 
 // dy_dtype: type of the incoming gradient; dx_dtype: type of dx AND of relu_src
-extern "C" int nsp_maxpool2d_bwd(const void* dy, const int* argmax, void* dx, int B, int T, int F,
+extern "C" int nsp_maxpool2d_bwd(const void* dy, const unsigned char* argmax, void* dx, int B, int T, int F,
                                  int C, int pt, int pf, int from_btcf, const void* relu_src,
                                  int dy_dtype, int dx_dtype, void* stream) {
   if (C % 4) return NSP_EUNSUPPORTED;
   const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
-  const dim3 grid(ew_grid((long long)B * T * F * (C / 4)));
+  const int vec = dx_dtype == NSP_DT_BF16 ? 8 : 4;
+  if (C % vec || pt * pf > 256 || pt < 1 || pf < 1) return NSP_EUNSUPPORTED;
+  const dim3 grid(ew_grid((long long)B * T * F * (C / vec)));
   hipStream_t st = (hipStream_t)stream;
 #define MPB(TD, TX) hipLaunchKernelGGL((maxpool2d_bwd_kernel<TD, TX>), grid, dim3(256), 0, st, (const TD*)dy, argmax, \
                                        (TX*)dx, B, T, F, C, To, Fo, pt, pf, from_btcf, (const TX*)relu_src)

@@ -980,7 +980,7 @@ class MaxPool2dFn(torch.autograd.Function):
         To, Fo = (T + pt - 1) // pt, (F + pf - 1) // pf
         shape = (B, To, C, Fo) if to_btcf else (B, To, Fo, C)
         y = torch.empty(shape, device=x.device, dtype=x.dtype)
-        am = torch.empty(shape, device=x.device, dtype=torch.int32)
+        am = torch.empty(shape, device=x.device, dtype=torch.uint8)   # window-relative arg-max, 1 byte per element
         d16 = int(x.dtype == torch.bfloat16)
         _check(_lib.lib().nsp_maxpool2d_fwd(_p(x), _p(y), _p(am), B, T, F, C, pt, pf, int(to_btcf), d16, d16,
                                             _stream()), 'nsp_maxpool2d_fwd')
