@@ -860,15 +860,16 @@ template <typename TX, typename TY>
 __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y,
                                                             unsigned char* __restrict__ argmax, int B, int T, int F, int C,
                                                             int To, int Fo, int pt, int pf, int to_btcf) {
+  // one workgroup per output row (b, to): 32-bit index arithmetic only (the flat 64-bit idx / % chains of
+  // the first version were ~600 VALU instructions per 16 B moved -- the kernel was division-bound)
   constexpr int V = Vec16<TX>::N;
   const int CV = C / V;
-  const long long total = (long long)B * To * Fo * CV;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    const int cv = (int)(idx % CV);
-    const int fo = (int)((idx / CV) % Fo);
-    const int to = (int)((idx / ((long long)CV * Fo)) % To);
-    const long long b = idx / ((long long)CV * Fo * To);
+  const int to = blockIdx.x % To;
+  const long long b = blockIdx.x / To;
+  const int row_elems = Fo * CV;
+  for (int i = threadIdx.x; i < row_elems; i += blockDim.x) {
+    const int fo = i / CV, cv = i - fo * CV;
+    const long long idx = ((b * To + to) * Fo + fo) * CV + cv;
     float best[V];
     unsigned char bi[V];
 #pragma unroll
@@ -917,13 +918,12 @@ __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const TD* __restrict
                                                             const TX* __restrict__ relu_src) {
   constexpr int V = Vec16<TX>::N;
   const int CV = C / V;
-  const long long total = (long long)B * T * F * CV;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    const int cv = (int)(idx % CV);
-    const int f = (int)((idx / CV) % F);
-    const int t = (int)((idx / ((long long)CV * F)) % T);
-    const long long b = idx / ((long long)CV * F * T);
+  const int t = blockIdx.x % T;            // one workgroup per input row (b, t), 32-bit arithmetic inside
+  const long long b = blockIdx.x / T;
+  const int row_elems = F * CV;
+  for (int i = threadIdx.x; i < row_elems; i += blockDim.x) {
+    const int f = i / CV, cv = i - f * CV;
+    const long long idx = ((b * T + t) * F + f) * CV + cv;
     const int to = t / pt, fo = f / pf;
     const unsigned self = (unsigned)((t - to * pt) * pf + (f - fo * pf));
     float o[V];
@@ -952,6 +952,189 @@ __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const TD* __restrict
       Vec16<TX>::load(relu_src + idx * V, m);
 #pragma unroll
       for (int e = 0; e < V; ++e) o[e] = m[e] > 0.f ? o[e] : 0.f;
+    }
+    store_vec<TX, V>(dx + idx * V, o);
+  }
+}
+
+// ---- 2 x 2 windows, channels-last output (the two pools of the front-end at full map size): the generic
+// kernels above run one dependent load -> compare -> (load ...) -> store chain per thread and per
+// short-lived workgroup; measured 1.9 TB/s.  Here a thread owns UNR elements, issues ALL of their loads
+// first (clamped, unconditional: an edge row / column is simply read twice, which cannot change a
+// first-maximum) and only then compares and stores; workgroups cover RPB rows.
+template <typename TX, typename TY, int UNR>
+__global__ __launch_bounds__(256) void maxpool2d22_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y,
+                                                              unsigned char* __restrict__ argmax, int BTo, int T, int F,
+                                                              int To, int Fo, int cv_shift, int rpb) {
+  constexpr int V = Vec16<TX>::N;
+  const int CV = 1 << cv_shift, C = CV * V;
+  const int row_elems = Fo * CV, nel = rpb * row_elems;
+  const int g0 = blockIdx.x * rpb;
+  for (int e0 = threadIdx.x; e0 < nel; e0 += 256 * UNR) {
+    float v[UNR][4][V];
+    long long oidx[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int e = e0 + u * 256;
+      const int row = e / row_elems, j = e - row * row_elems;
+      const int gq = g0 + row;
+      ok[u] = e < nel && gq < BTo;
+      const int gcl = min(gq, BTo - 1);
+      const int b = gcl / To, to = gcl - b * To;
+      const int fo = j >> cv_shift, cv = j & (CV - 1);
+      oidx[u] = (long long)gcl * row_elems + j;
+      const int t0 = 2 * to, t1 = min(t0 + 1, T - 1), f0 = 2 * fo, f1 = min(f0 + 1, F - 1);
+      const TX* xb = x + (long long)b * T * F * C + cv * V;
+      Vec16<TX>::load(xb + ((long long)t0 * F + f0) * C, v[u][0]);
+      Vec16<TX>::load(xb + ((long long)t0 * F + f1) * C, v[u][1]);
+      Vec16<TX>::load(xb + ((long long)t1 * F + f0) * C, v[u][2]);
+      Vec16<TX>::load(xb + ((long long)t1 * F + f1) * C, v[u][3]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float best[V];
+      unsigned code[2] = {0u, 0u};
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        float bv = v[u][0][q];
+        unsigned bi = 0u;
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+          if (v[u][w][q] > bv) { bv = v[u][w][q]; bi = (unsigned)w; }
+        best[q] = bv;
+        code[q >> 2] |= bi << ((q & 3) * 8);
+      }
+      if (ok[u]) {
+        store_vec<TY, V>(y + oidx[u] * V, best);
+        if constexpr (V == 8) *reinterpret_cast<uint2*>(argmax + oidx[u] * 8) = make_uint2(code[0], code[1]);
+        else *reinterpret_cast<unsigned*>(argmax + oidx[u] * 4) = code[0];
+      }
+    }
+  }
+}
+
+template <typename TD, typename TX, int UNR>
+__global__ __launch_bounds__(256) void maxpool2d22_bwd_kernel(const TD* __restrict__ dy, const unsigned char* __restrict__ argmax,
+                                                              TX* __restrict__ dx, int BT, int T, int F, int To, int Fo,
+                                                              int cv_shift, int rpb, const TX* __restrict__ relu_src) {
+  constexpr int V = Vec16<TX>::N;
+  const int CV = 1 << cv_shift, C = CV * V;
+  const int row_elems = F * CV, nel = rpb * row_elems;
+  const int g0 = blockIdx.x * rpb;
+  for (int e0 = threadIdx.x; e0 < nel; e0 += 256 * UNR) {
+    float g[UNR][V], m[UNR][V];
+    unsigned code[UNR][2], self[UNR];
+    long long idx[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int e = e0 + u * 256;
+      const int row = e / row_elems, j = e - row * row_elems;
+      const int gq = g0 + row;
+      ok[u] = e < nel && gq < BT;
+      const int gcl = min(gq, BT - 1);
+      const int b = gcl / T, t = gcl - b * T;
+      const int f = j >> cv_shift, cv = j & (CV - 1);
+      idx[u] = (long long)gcl * row_elems + j;
+      self[u] = (unsigned)(((t & 1) << 1) | (f & 1));
+      const long long oi = (((long long)b * To + (t >> 1)) * Fo + (f >> 1)) * C + cv * V;
+      load_vec<TD, V>(dy + oi, g[u]);
+      if constexpr (V == 8) {
+        const uint2 pk = *reinterpret_cast<const uint2*>(argmax + oi);
+        code[u][0] = pk.x; code[u][1] = pk.y;
+      } else {
+        code[u][0] = *reinterpret_cast<const unsigned*>(argmax + oi); code[u][1] = 0u;
+      }
+      if (relu_src) Vec16<TX>::load(relu_src + idx[u] * V, m[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float o[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        o[q] = ((code[u][q >> 2] >> ((q & 3) * 8)) & 0xFFu) == self[u] ? g[u][q] : 0.f;
+        if (relu_src) o[q] = m[u][q] > 0.f ? o[q] : 0.f;
+      }
+      if (ok[u]) store_vec<TX, V>(dx + idx[u] * V, o);
+    }
+  }
+}
+
+// ---- 2 x 2 windows with the [B,T',C,F'] output order of the LAST pool (conv.py:189 flattens it to C*F'):
+// the transposition goes through LDS, so that global traffic is 16-B coalesced on both sides (the generic
+// kernels gather / scatter single bf16 values per channel: 16 two-byte accesses per thread).
+// One workgroup = one output row (b, to): C*Fo values (<= 4096).
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void maxpool2d22_btcf_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y,
+                                                                   unsigned char* __restrict__ argmax, int T, int F, int To,
+                                                                   int Fo, int cv_shift) {
+  constexpr int V = Vec16<TX>::N;
+  const int CV = 1 << cv_shift, C = CV * V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  TY* sy = reinterpret_cast<TY*>(sm);                       // [C][Fo]
+  unsigned char* sa = sm + (size_t)C * Fo * sizeof(TY);    // [C][Fo]
+  const int to = blockIdx.x % To;
+  const long long b = blockIdx.x / To;
+  const int t0 = 2 * to, t1 = min(t0 + 1, T - 1);
+  const TX* xb = x + b * T * F * C;
+  for (int i = threadIdx.x; i < Fo * CV; i += 256) {
+    const int fo = i >> cv_shift, cv = i & (CV - 1);
+    const int f0 = 2 * fo, f1 = min(f0 + 1, F - 1);
+    float v[4][V];
+    Vec16<TX>::load(xb + ((long long)t0 * F + f0) * C + cv * V, v[0]);
+    Vec16<TX>::load(xb + ((long long)t0 * F + f1) * C + cv * V, v[1]);
+    Vec16<TX>::load(xb + ((long long)t1 * F + f0) * C + cv * V, v[2]);
+    Vec16<TX>::load(xb + ((long long)t1 * F + f1) * C + cv * V, v[3]);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      float bv = v[0][q];
+      unsigned bi = 0u;
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        if (v[w][q] > bv) { bv = v[w][q]; bi = (unsigned)w; }
+      sy[(cv * V + q) * Fo + fo] = (TY)bv;
+      sa[(cv * V + q) * Fo + fo] = (unsigned char)bi;
+    }
+  }
+  __syncthreads();
+  const long long o0 = (b * To + to) * C * Fo;              // the row is contiguous in [B,T',C,F']
+  const int n = C * Fo;
+  for (int i = threadIdx.x; i < n; i += 256) { y[o0 + i] = sy[i]; argmax[o0 + i] = sa[i]; }
+}
+
+template <typename TD, typename TX>
+__global__ __launch_bounds__(256) void maxpool2d22_btcf_bwd_kernel(const TD* __restrict__ dy, const unsigned char* __restrict__ argmax,
+                                                                   TX* __restrict__ dx, int T, int F, int To, int Fo,
+                                                                   int cv_shift, const TX* __restrict__ relu_src) {
+  constexpr int V = Vec16<TX>::N;
+  const int CV = 1 << cv_shift, C = CV * V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  TD* sg = reinterpret_cast<TD*>(sm);                       // [C][Fo]
+  unsigned char* sa = sm + (size_t)C * Fo * sizeof(TD);
+  const int to = blockIdx.x % To;
+  const long long b = blockIdx.x / To;
+  const long long o0 = (b * To + to) * C * Fo;
+  const int n = C * Fo;
+  for (int i = threadIdx.x; i < n; i += 256) { sg[i] = dy[o0 + i]; sa[i] = argmax[o0 + i]; }
+  __syncthreads();
+  const int rows = min(2, T - 2 * to);
+  const int row_elems = F * CV;
+  for (int i = threadIdx.x; i < rows * row_elems; i += 256) {
+    const int dt = i >= row_elems ? 1 : 0;
+    const int j = i - dt * row_elems;
+    const int f = j >> cv_shift, cv = j & (CV - 1);
+    const int fo = f >> 1;
+    const unsigned self = (unsigned)((dt << 1) | (f & 1));
+    const long long idx = ((b * T + 2 * to + dt) * F + f) * CV + cv;
+    float m[V];
+    if (relu_src) Vec16<TX>::load(relu_src + idx * V, m);
+    float o[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const int k = (cv * V + q) * Fo + fo;
+      o[q] = sa[k] == self ? (float)sg[k] : 0.f;
+      if (relu_src) o[q] = m[q] > 0.f ? o[q] : 0.f;
     }
     store_vec<TX, V>(dx + idx * V, o);
   }
@@ -1082,9 +1265,42 @@ extern "C" int nsp_maxpool2d_fwd(const void* x, void* y, unsigned char* argmax, 
   const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
   const int vec = x_dtype == NSP_DT_BF16 ? 8 : 4;
   if (C % vec || pt * pf > 256 || pt < 1 || pf < 1) return NSP_EUNSUPPORTED;
-  const dim3 grid(ew_grid((long long)B * To * Fo * (C / vec)));
+  if ((long long)B * To > 0x7fffffffLL) return NSP_EUNSUPPORTED;
+  const int cvn = C / vec;
+  if (pt == 2 && pf == 2 && !to_btcf && (cvn & (cvn - 1)) == 0 && x_dtype == y_dtype) {
+    int sh = 0;
+    while ((1 << sh) < cvn) ++sh;
+    const int row_elems = Fo * cvn;
+    int rpb = 2048 / row_elems;          // ~2048 elements = 4 per thread x 2 rounds of UNR = 2 ... per workgroup
+    if (rpb < 1) rpb = 1;
+    const dim3 g2((B * To + rpb - 1) / rpb);
+    hipStream_t s2 = (hipStream_t)stream;
+    if (x_dtype == NSP_DT_BF16)
+      hipLaunchKernelGGL((maxpool2d22_fwd_kernel<__bf16, __bf16, 2>), g2, dim3(256), 0, s2, (const __bf16*)x, (__bf16*)y, argmax,
+                         B * To, T, F, To, Fo, sh, rpb);
+    else
+      hipLaunchKernelGGL((maxpool2d22_fwd_kernel<float, float, 2>), g2, dim3(256), 0, s2, (const float*)x, (float*)y, argmax,
+                         B * To, T, F, To, Fo, sh, rpb);
+    NSP_LAUNCH_CHECK();
+    return NSP_OK;
+  }
+  if (pt == 2 && pf == 2 && to_btcf && (cvn & (cvn - 1)) == 0 && x_dtype == y_dtype && C * Fo <= 8192) {
+    int sh = 0;
+    while ((1 << sh) < cvn) ++sh;
+    hipStream_t s2 = (hipStream_t)stream;
+    if (x_dtype == NSP_DT_BF16)
+      hipLaunchKernelGGL((maxpool2d22_btcf_fwd_kernel<__bf16, __bf16>), dim3(B * To), dim3(256), (size_t)C * Fo * 3, s2,
+                         (const __bf16*)x, (__bf16*)y, argmax, T, F, To, Fo, sh);
+    else
+      hipLaunchKernelGGL((maxpool2d22_btcf_fwd_kernel<float, float>), dim3(B * To), dim3(256), (size_t)C * Fo * 5, s2,
+                         (const float*)x, (float*)y, argmax, T, F, To, Fo, sh);
+    NSP_LAUNCH_CHECK();
+    return NSP_OK;
+  }
+  const dim3 grid(B * To);
+  const dim3 blk(Fo * (C / vec) > 128 ? 256 : 128);
   hipStream_t st = (hipStream_t)stream;
-#define MPF(TX, TY) hipLaunchKernelGGL((maxpool2d_fwd_kernel<TX, TY>), grid, dim3(256), 0, st, (const TX*)x, (TY*)y, \
+#define MPF(TX, TY) hipLaunchKernelGGL((maxpool2d_fwd_kernel<TX, TY>), grid, blk, 0, st, (const TX*)x, (TY*)y, \
                                        argmax, B, T, F, C, To, Fo, pt, pf, to_btcf)
   if (x_dtype == NSP_DT_BF16 && y_dtype == NSP_DT_BF16) MPF(__bf16, __bf16);
   else if (x_dtype == NSP_DT_BF16) MPF(__bf16, float);
@@ -1103,9 +1319,42 @@ extern "C" int nsp_maxpool2d_bwd(const void* dy, const unsigned char* argmax, vo
   const int To = (T + pt - 1) / pt, Fo = (F + pf - 1) / pf;
   const int vec = dx_dtype == NSP_DT_BF16 ? 8 : 4;
   if (C % vec || pt * pf > 256 || pt < 1 || pf < 1) return NSP_EUNSUPPORTED;
-  const dim3 grid(ew_grid((long long)B * T * F * (C / vec)));
+  if ((long long)B * T > 0x7fffffffLL) return NSP_EUNSUPPORTED;
+  const int cvn = C / vec;
+  if (pt == 2 && pf == 2 && !from_btcf && (cvn & (cvn - 1)) == 0 && dy_dtype == dx_dtype) {
+    int sh = 0;
+    while ((1 << sh) < cvn) ++sh;
+    const int row_elems = F * cvn;
+    int rpb = 4096 / row_elems;
+    if (rpb < 1) rpb = 1;
+    const dim3 g2((B * T + rpb - 1) / rpb);
+    hipStream_t s2 = (hipStream_t)stream;
+    if (dx_dtype == NSP_DT_BF16)
+      hipLaunchKernelGGL((maxpool2d22_bwd_kernel<__bf16, __bf16, 4>), g2, dim3(256), 0, s2, (const __bf16*)dy, argmax, (__bf16*)dx,
+                         B * T, T, F, To, Fo, sh, rpb, (const __bf16*)relu_src);
+    else
+      hipLaunchKernelGGL((maxpool2d22_bwd_kernel<float, float, 4>), g2, dim3(256), 0, s2, (const float*)dy, argmax, (float*)dx,
+                         B * T, T, F, To, Fo, sh, rpb, (const float*)relu_src);
+    NSP_LAUNCH_CHECK();
+    return NSP_OK;
+  }
+  if (pt == 2 && pf == 2 && from_btcf && (cvn & (cvn - 1)) == 0 && dy_dtype == dx_dtype && C * Fo <= 8192) {
+    int sh = 0;
+    while ((1 << sh) < cvn) ++sh;
+    hipStream_t s2 = (hipStream_t)stream;
+    if (dx_dtype == NSP_DT_BF16)
+      hipLaunchKernelGGL((maxpool2d22_btcf_bwd_kernel<__bf16, __bf16>), dim3(B * To), dim3(256), (size_t)C * Fo * 3, s2,
+                         (const __bf16*)dy, argmax, (__bf16*)dx, T, F, To, Fo, sh, (const __bf16*)relu_src);
+    else
+      hipLaunchKernelGGL((maxpool2d22_btcf_bwd_kernel<float, float>), dim3(B * To), dim3(256), (size_t)C * Fo * 5, s2,
+                         (const float*)dy, argmax, (float*)dx, T, F, To, Fo, sh, (const float*)relu_src);
+    NSP_LAUNCH_CHECK();
+    return NSP_OK;
+  }
+  const dim3 grid(B * T);
+  const dim3 blk(F * (C / vec) > 128 ? 256 : 128);
   hipStream_t st = (hipStream_t)stream;
-#define MPB(TD, TX) hipLaunchKernelGGL((maxpool2d_bwd_kernel<TD, TX>), grid, dim3(256), 0, st, (const TD*)dy, argmax, \
+#define MPB(TD, TX) hipLaunchKernelGGL((maxpool2d_bwd_kernel<TD, TX>), grid, blk, 0, st, (const TD*)dy, argmax, \
                                        (TX*)dx, B, T, F, C, To, Fo, pt, pf, from_btcf, (const TX*)relu_src)
   if (dy_dtype == NSP_DT_BF16 && dx_dtype == NSP_DT_BF16) MPB(__bf16, __bf16);
   else if (dy_dtype == NSP_DT_BF16) MPB(__bf16, float);

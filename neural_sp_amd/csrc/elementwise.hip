@@ -192,8 +192,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    // 8 slab loads in flight per thread (the rolled loop issued them one dependent add apart); the order of
+    // the additions is still s = 0, 1, 2, ...: bit-identical results
     float4 a = reinterpret_cast<const float4*>(part)[i];
-    for (int s = 1; s < splits; ++s) {
+    int s = 1;
+    for (; s + 8 <= splits; s += 8) {
+      float4 b[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[q] = reinterpret_cast<const float4*>(part + (long long)(s + q) * n)[i];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a.x += b[q].x; a.y += b[q].y; a.z += b[q].z; a.w += b[q].w; }
+    }
+    for (; s < splits; ++s) {
       const float4 b = reinterpret_cast<const float4*>(part + (long long)s * n)[i];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
