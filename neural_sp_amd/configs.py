@@ -108,6 +108,20 @@ def conformer_ctc_att_args(size='M', n_layers=12, vocab=10000, dropout=0.0, ctc_
     return argparse.Namespace(**a)
 
 
+def conformer_ctc_las_args(size='M', n_layers=12, vocab=10000, dropout=0.0, ctc_weight=0.3, attn_type='location', **kw):
+    """BASELINE config 3 as its recipe writes it: Conformer-M encoder + hybrid CTC / attention loss with the
+    LSTM decoder (decoders/las.py; 1 x 1024 units, location-aware attention, lsm_prob 0.1, V = 10k).
+    attn_type='mocha' gives the streaming decoder of config 5 (chunk size via mocha_chunk_size)."""
+    a = vars(conformer_rnnt_args(size, n_layers=n_layers, vocab=vocab, dropout=dropout, ctc_weight=ctc_weight))
+    big = size in ('L', 'M')
+    a.update(dec_type='lstm', dec_n_layers=1, dec_n_units=1024 if big else 64, dec_n_projs=0,
+             dec_bottleneck_dim=1024 if big else 48, emb_dim=512 if big else 32, attn_type=attn_type,
+             attn_dim=512 if big else 40, attn_conv_n_channels=10, attn_conv_width=201 if big else 21,
+             lsm_prob=0.1, dropout_dec=dropout, dropout_att=0.0, param_init=0.1)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
 def synthetic_batch(B, t_range, u_range, vocab, input_dim=80, seed=0):
     """The batch dict of datasets/asr/build.py:73-105 filled with synthetic data of the shapes in
     SURVEY.md section 8d: features ~ N(0,1), lengths uniform in the given ranges, labels ~ U[4,V)."""

@@ -642,6 +642,25 @@ def build_decoder(args, special_symbols, enc_n_units, vocab, ctc_weight, global_
             dropout_layer=args.dropout_dec_layer, lsm_prob=args.lsm_prob, ctc_weight=ctc_weight,
             ctc_lsm_prob=args.ctc_lsm_prob, ctc_fc_list=args.ctc_fc_list, backward=False,
             global_weight=global_weight, mtl_per_batch=args.mtl_per_batch, param_init=args.transformer_param_init)
-    raise NotImplementedError(
-        'dec_type=%s with an attention loss: the LAS (RNN) and MoChA decoders are "next" rows '
-        '(SURVEY.md section 8f) and not built; dec_type=transformer is' % args.dec_type)
+    if args.dec_type in ('lstm', 'gru'):
+        from neural_sp_amd.las import RNNDecoder      # decoders/build.py:88-140 (las.py uses LSTMCell for both)
+        return RNNDecoder(
+            special_symbols=special_symbols, enc_n_units=enc_n_units, n_units=args.dec_n_units,
+            n_projs=args.dec_n_projs, n_layers=args.dec_n_layers, bottleneck_dim=args.dec_bottleneck_dim,
+            emb_dim=args.emb_dim, vocab=vocab, tie_embedding=args.tie_embedding, attn_type=args.attn_type,
+            attn_dim=args.attn_dim, attn_sharpening_factor=args.attn_sharpening_factor,
+            attn_sigmoid_smoothing=args.attn_sigmoid, attn_conv_out_channels=args.attn_conv_n_channels,
+            attn_conv_kernel_size=args.attn_conv_width, attn_n_heads=args.attn_n_heads, dropout=args.dropout_dec,
+            dropout_emb=args.dropout_emb, dropout_att=args.dropout_att, lsm_prob=args.lsm_prob, ss_prob=args.ss_prob,
+            ctc_weight=ctc_weight, ctc_lsm_prob=args.ctc_lsm_prob, ctc_fc_list=args.ctc_fc_list,
+            mbr_training=args.mbr_training, mbr_ce_weight=args.mbr_ce_weight, external_lm=external_lm,
+            lm_fusion=args.lm_fusion, lm_init=args.lm_init, backward=False, global_weight=global_weight,
+            mtl_per_batch=args.mtl_per_batch, param_init=args.param_init, mocha_chunk_size=args.mocha_chunk_size,
+            mocha_n_heads_mono=args.mocha_n_heads_mono, mocha_init_r=args.mocha_init_r, mocha_eps=args.mocha_eps,
+            mocha_std=args.mocha_std, mocha_no_denominator=args.mocha_no_denominator, mocha_1dconv=args.mocha_1dconv,
+            mocha_decot_lookahead=args.mocha_decot_lookahead, quantity_loss_weight=args.mocha_quantity_loss_weight,
+            latency_metric=str(args.mocha_latency_metric), latency_loss_weight=args.mocha_latency_loss_weight,
+            mocha_stableemit_weight=args.mocha_stableemit_weight, gmm_attn_n_mixtures=args.gmm_attn_n_mixtures,
+            replace_sos=args.replace_sos, distillation_weight=args.distillation_weight,
+            discourse_aware=args.discourse_aware)
+    raise NotImplementedError('dec_type=%s' % args.dec_type)

@@ -352,6 +352,7 @@ class LinearFn(torch.autograd.Function):
                        dropout_p=dropout_p, seed=seed, offset=offset)
         ctx.save_for_backward(xa, weight, pre)
         ctx.act, ctx.alpha = act, alpha
+        ctx.mode = get_compute_mode()      # backward runs in the mode of its forward (nested compute_mode blocks)
         ctx.drop = (dropout_p, seed, offset)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         ctx.xshape = x.shape
@@ -367,15 +368,16 @@ class LinearFn(torch.autograd.Function):
         # bf16 image of the gradient; for N % 8 != 0 (e.g. a 10001-word CTC head) it is zero-padded to
         # roundup8(N) columns and the padded rows / entries of dW / db are dropped below
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        g = grad_prep(dy2d, pre, ctx.act, ctx.alpha, p, seed, offset, xa.dtype == torch.bfloat16, want_colsum=want_db)
-        dx = dw = db = None
-        if want_db:
-            g, db = g
-            db = db[:N]
-        if ctx.needs_input_grad[0]:
-            dx = linear_dgrad(g, weight)[:, :ctx.xshape[-1]].reshape(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dw = linear_wgrad(g, xa)[:N].view(weight.shape)
+        with compute_mode(ctx.mode):
+            g = grad_prep(dy2d, pre, ctx.act, ctx.alpha, p, seed, offset, xa.dtype == torch.bfloat16, want_colsum=want_db)
+            dx = dw = db = None
+            if want_db:
+                g, db = g
+                db = db[:N]
+            if ctx.needs_input_grad[0]:
+                dx = linear_dgrad(g, weight)[:, :ctx.xshape[-1]].reshape(ctx.xshape)
+            if ctx.needs_input_grad[1]:
+                dw = linear_wgrad(g, xa)[:N].view(weight.shape)
         return dx, dw, db, None, dres, None, None
 
 

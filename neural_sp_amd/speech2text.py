@@ -252,10 +252,14 @@ class Speech2Text(nn.Module):
         pass
 
     def trigger_quantity_loss(self):
-        pass
+        # speech2text.py:217-221 (main task only)
+        if hasattr(self, 'dec_fwd'):
+            self.dec_fwd.trigger_quantity_loss()
+            self.dec_fwd.trigger_latency_loss()
 
     def trigger_stableemit(self):
-        pass
+        if hasattr(self, 'dec_fwd'):
+            self.dec_fwd.trigger_stableemit()
 
     def reset_session(self):
         pass

@@ -378,7 +378,117 @@ def transformer_decoder_att(eouts, elens, ys, sd, args, training, p='dec_fwd'):
     return loss, acc, ppl
 
 
-def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True):
+def _xe_lsm(logits, ys_out, lsm, B):
+    """criterion.py:45-86 + torch_utils.py:128-145 -> (loss, acc %, ppl); pad id 3."""
+    V = logits.shape[-1]
+    lg, yo = logits.reshape(-1, V), ys_out.reshape(-1)
+    mask = yo == 3
+    lp = torch.log_softmax(lg, dim=-1)
+    tgt = torch.full_like(lp, lsm / (V - 1))
+    tgt.scatter_(1, yo.masked_fill(mask, 0).unsqueeze(1), 1 - lsm)
+    rows = -(tgt * lp).sum(1).masked_fill(mask, 0)
+    n_tokens = float((~mask).sum())
+    return rows.sum() / B, float(((lg.argmax(1) == yo) & ~mask).sum()) * 100 / n_tokens, math.exp(rows.sum().item() / n_tokens)
+
+
+def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='dec_fwd'):
+    """decoders/las.py:618-776 (teacher forcing, no LM / scheduled sampling) with the single-head attentions
+    of modules/attention.py:96-181 ('location', 'add') and the training-time MoChA of
+    modules/mocha/mocha.py:164-311, hma_train.py:12-67, mocha_train.py:13-58 (one head, additive energies,
+    no noise).  -> (loss_att, acc %, ppl, quantity loss or None); quantity_weight is applied by the caller (las.py:486-489)."""
+    B, T, D = eouts.shape
+    ylens = [len(y) + 1 for y in ys]
+    L = max(ylens)
+    ys_in = torch.full((B, L), 3, dtype=torch.long)
+    ys_out = torch.full((B, L), 3, dtype=torch.long)
+    for b, y in enumerate(ys):
+        ys_in[b, 0] = 2
+        ys_in[b, 1:len(y) + 1] = torch.tensor(y)
+        ys_out[b, :len(y)] = torch.tensor(y)
+        ys_out[b, len(y)] = 2
+    vis = (torch.arange(T)[None, :] < torch.tensor(elens)[:, None])               # [B,T]
+    nl, H = args.dec_n_layers, args.dec_n_units
+    hx = [eouts.new_zeros(B, H) for _ in range(nl)]
+    cx = [eouts.new_zeros(B, H) for _ in range(nl)]
+    cv = eouts.new_zeros(B, D)
+    emb = F.embedding(ys_in, sd[p + '.embed.weight'], padding_idx=3)
+    sc = p + '.score'
+    mocha = args.attn_type == 'mocha'
+    if mocha:
+        key_ma = _lin(eouts, sd, sc + '.monotonic_energy.w_key')
+        wv = sd[sc + '.monotonic_energy.v.weight_v']
+        v_ma = wv * (sd[sc + '.monotonic_energy.v.weight_g'].view(-1, 1) / wv.norm(dim=1, keepdim=True))
+        w = args.mocha_chunk_size
+        chunk = w > 1 or w == -1
+        if chunk:
+            key_ca = _lin(eouts, sd, sc + '.chunk_energy.w_key')
+        aw = eouts.new_zeros(B, T)
+        aw[:, 0] = 1.0
+    else:
+        key = _lin(eouts, sd, sc + '.w_key')
+        aw = eouts.new_zeros(B, T)
+
+    def excl_cumsum(x):
+        return torch.cumsum(torch.cat([x.new_zeros(x.shape[0], 1), x[:, :-1]], dim=-1), dim=-1)
+
+    def moving_sum(x, back, forward):
+        return F.conv1d(F.pad(x, [back, forward]).unsqueeze(1), x.new_ones(1, 1, back + forward + 1)).squeeze(1)
+
+    douts, cvs, aws = [], [], []
+    for i in range(L):
+        dout = torch.cat([emb[:, i], cv], dim=-1)
+        for l in range(nl):
+            q = '%s.rnn.%d' % (p, l)
+            gates = F.linear(dout, sd[q + '.weight_ih'], sd[q + '.bias_ih']) + F.linear(hx[l], sd[q + '.weight_hh'], sd[q + '.bias_hh'])
+            gi, gf, gg, go = gates.chunk(4, dim=1)
+            cx[l] = torch.sigmoid(gf) * cx[l] + torch.sigmoid(gi) * torch.tanh(gg)
+            hx[l] = torch.sigmoid(go) * torch.tanh(cx[l])
+            dout = hx[l]
+            if args.dec_n_projs > 0:
+                dout = torch.relu(_lin(dout, sd, '%s.proj.%d' % (p, l)))
+            if l == 0:
+                dscore = dout
+        if mocha:
+            e = (torch.relu(key_ma + F.linear(dscore, sd[sc + '.monotonic_energy.w_query.weight'])[:, None]) * v_ma.view(1, 1, -1)).sum(-1)
+            e = (e + sd[sc + '.monotonic_energy.r']).masked_fill(~vis, NEG_INF32)
+            pc = torch.sigmoid(e)
+            cp = torch.exp(excl_cumsum(torch.log(torch.clamp(1 - pc, min=args.mocha_eps, max=1.0))))
+            den = 1 if args.mocha_no_denominator else torch.clamp(cp, min=args.mocha_eps, max=1.0)
+            aw = pc * cp * torch.cumsum(aw / den, dim=-1)
+            att = aw
+            if chunk:
+                u = (torch.relu(key_ca + F.linear(dscore, sd[sc + '.chunk_energy.w_query.weight'])[:, None])
+                     * sd[sc + '.chunk_energy.v.weight'].view(1, 1, -1)).sum(-1).masked_fill(~vis, NEG_INF32)
+                u = u - u.max(dim=-1, keepdim=True)[0]
+                se = torch.clamp(torch.exp(u), min=1e-5)
+                if w == -1:
+                    att = se * moving_sum(aw * args.attn_sharpening_factor / torch.cumsum(se, dim=-1), 0, T - 1)
+                else:
+                    att = se * moving_sum(aw * args.attn_sharpening_factor / moving_sum(se, w - 1, 0), 0, w - 1)
+        else:
+            tmp = key + F.linear(dscore, sd[sc + '.w_query.weight'])[:, None]
+            if args.attn_type == 'location':
+                cw = sd[sc + '.conv.weight']
+                cf = F.conv2d(aw[:, None, None, :], cw, padding=(0, (cw.shape[-1] - 1) // 2)).squeeze(2).transpose(2, 1)
+                tmp = tmp + F.linear(cf, sd[sc + '.w_conv.weight'])
+            e = F.linear(torch.tanh(tmp), sd[sc + '.v.weight']).squeeze(-1).masked_fill(~vis, NEG_INF32)
+            aw = torch.softmax(e * args.attn_sharpening_factor, dim=-1)
+            att = aw
+        cv = torch.bmm(att[:, None], eouts).squeeze(1)
+        douts.append(dout)
+        cvs.append(cv)
+        aws.append(aw)
+    feats = torch.cat([torch.stack(douts, 1), torch.stack(cvs, 1)], dim=-1)
+    logits = _lin(torch.tanh(_lin(feats, sd, p + '.output_bn')), sd, p + '.output')
+    loss, acc, ppl = _xe_lsm(logits, ys_out, args.lsm_prob if training else 0.0, B)
+    lq = None
+    if mocha:
+        a = torch.stack(aws, 1).masked_fill((ys_out == 3)[:, :, None], 0)          # [B,L,T]
+        lq = torch.mean(torch.abs(a.sum(2).sum(1) - (ys_out != 3).sum(1).to(a.dtype)))
+    return loss, acc, ppl, lq
+
+
+def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quantity_weight=0.0):
     """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens)."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     xlens = [len(x) for x in batch['xs']]
@@ -403,5 +513,13 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True):
         la, acc, ppl = transformer_decoder_att(eouts, elens, batch['ys'], sd, args, training)
         obs.pop('loss.transducer')
         obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})
+        loss = loss + la * (main_w - ctc_w)
+    if args.dec_type in ('lstm', 'gru') and main_w - ctc_w > 0:
+        la, acc, ppl, lq = rnn_decoder_att(eouts, elens, batch['ys'], sd, args, training, quantity_weight)
+        obs.pop('loss.transducer')
+        obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})   # (recorded before the quantity loss is added)
+        if lq is not None:
+            obs['loss.quantity'] = lq.item()
+            la = la + lq * quantity_weight
         loss = loss + la * (main_w - ctc_w)
     return loss, obs, eouts, elens

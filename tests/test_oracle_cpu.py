@@ -50,7 +50,8 @@ def test_model_restatement_matches_reference_fixture(name):
     args = argparse.Namespace(**fix['args'])
     sd = {k: v.clone().double().requires_grad_(v.is_floating_point() and 'inv_freq' not in k and k != 'enc.pos_enc.pe')
           if v.is_floating_point() else v for k, v in fix['state_dict'].items()}
-    loss, obs, eouts, elens = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64)
+    qw = args.mocha_quantity_loss_weight if fix['meta'].get('trigger_quantity_loss') else 0.0
+    loss, obs, eouts, elens = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64, quantity_weight=qw)
     ref = fix['loss'].item()
     assert abs(loss.item() - ref) / abs(ref) < 2e-5, (loss.item(), ref)
     assert list(elens) == fix['elens'].tolist()
