@@ -228,17 +228,26 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_lds_kernel(const float* __re
   float4 acc[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t0 = ts; t0 < te; t0 += DW_RC) {
-    const int nr = min(DW_RC, te - t0);
-    __syncthreads();
-    for (int i = jg; i < nr + k - 1; i += 4) {
-      const int tt = t0 - pad + i;
-      xs[i * 64 + lane] = (active && tt >= 0 && tt < T) ? x4[(long long)tt * C4 + c4] : zero;
+  // The rows of chunk c+1 are fetched into registers while chunk c is multiplied out of LDS (the first version
+  // ran load -> barrier -> multiply -> barrier with two workgroups per CU: 2.5 TB/s).  Loads are unconditional
+  // with clamped row / channel indices and zeroed by a select when they are committed to LDS.
+  constexpr int NX = (DW_RC + 14 + 3) / 4, ND = DW_RC / 4;     // x / dy rows per thread and chunk (k <= 15)
+  float4 px[NX], pd[ND];
+  const int c4c = min(c4, C4 - 1);
+  int tf = ts;                 // next chunk to fetch
+  int tl = ts, nl = 0;         // chunk resident in LDS (nl rows; 0 = none yet)
+  while (true) {
+    const bool fetched = tf < te;
+    if (fetched) {
+#pragma unroll
+      for (int q = 0; q < NX; ++q) {
+        const int tt = min(max(tf - pad + jg + 4 * q, 0), T - 1);
+        px[q] = x4[(long long)tt * C4 + c4c];
+      }
+#pragma unroll
+      for (int q = 0; q < ND; ++q) pd[q] = d4[(long long)min(tf + jg + 4 * q, T - 1) * C4 + c4c];
     }
-    for (int i = jg; i < nr; i += 4) dys[i * 64 + lane] = active ? d4[(long long)(t0 + i) * C4 + c4] : zero;
-    __syncthreads();
-    for (int i = 0; i < nr; ++i) {
+    for (int i = 0; i < nl; ++i) {
       const float4 g = dys[i * 64 + lane];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -251,6 +260,27 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_lds_kernel(const float* __re
         }
       }
     }
+    if (!fetched) break;
+    __syncthreads();             // the resident chunk has been multiplied by every wave
+    tl = tf;
+    nl = min(DW_RC, te - tf);
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+      const int i = jg + 4 * q, tt = tl - pad + i;
+      // (component-wise: `cond ? px[q] : zero` on float4 objects makes hipcc select between two ADDRESSES and
+      // spill the whole prefetch array to scratch)
+      const bool okx = active && tt >= 0 && tt < T;
+      if (i < nl + k - 1)
+        xs[i * 64 + lane] = make_float4(okx ? px[q].x : 0.f, okx ? px[q].y : 0.f, okx ? px[q].z : 0.f, okx ? px[q].w : 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+      const int i = jg + 4 * q;
+      if (i < nl)
+        dys[i * 64 + lane] = make_float4(active ? pd[q].x : 0.f, active ? pd[q].y : 0.f, active ? pd[q].z : 0.f, active ? pd[q].w : 0.f);
+    }
+    __syncthreads();
+    tf += DW_RC;
   }
   if (active) {
     float* slab = part + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * (long long)(k + 1) * C;

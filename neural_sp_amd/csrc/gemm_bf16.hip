@@ -1395,6 +1395,11 @@ inline int rr_ring_stages() {
   return e ? atoi(e) : 2;   // round 2: -0.35 ms/step in an A/B inside the step (was +1 % in round 1)
 }
 
+inline int rr_ring_min_tiles() {
+  const char* e = getenv("NSP_GEMM_RR_RING_MIN_TILES");
+  return e ? atoi(e) : 24;
+}
+
 }  // namespace
 
 // called from nsp_gemm (gemm.hip) when both operands are bf16
@@ -1489,7 +1494,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
   }
   else if (!a_kc && !b_kc && p.K % BK == 0 && p.K >= 2 * BK && p.M % 8 == 0 && p.N % 8 == 0 &&
-           tiles_m * tiles_n >= 24 && rr_ring_stages() > 0) {
+           tiles_m * tiles_n >= rr_ring_min_tiles() && rr_ring_stages() > 0) {
     // weight gradients on the LDS-DMA ring with swizzled transposed reads.  OPT-IN: back to back it
     // beats the register-staged kernel (2 stages: 545 -> 660 TFLOP/s on dW[2048,512] over 51200
     // rows; 3 stages = 1 workgroup per CU is slower), but inside the training step it measured 1 %
