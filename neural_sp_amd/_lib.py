@@ -130,17 +130,6 @@ class LstmStackParams(ctypes.Structure):
     ]
 
 
-class _NoLaunch(object):
-    def __init__(self, real):
-        self._real = real
-
-    def __getattr__(self, name):
-        fn = getattr(self._real, name)
-        if name.startswith('nsp_') and name != 'nsp_version':
-            return lambda *a: 0
-        return fn
-
-
 _lib = None
 
 
@@ -157,11 +146,6 @@ def lib():
                                'mandatory, there is no CPU fallback')
         _lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         _declare_prototypes(_lib)
-        if os.environ.get('NSP_HOST_ONLY_PROFILING') == '1':
-            # tools/host_phases.py only: every kernel entry point becomes a no-op so that what is
-            # left is the host cost of the step (allocations, autograd, argument marshalling).
-            # Results are garbage by construction; never set this outside that tool.
-            _lib = _NoLaunch(_lib)
     return _lib
 
 

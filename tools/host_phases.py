@@ -4,7 +4,26 @@ is the step host-bound or GPU-bound?"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from neural_sp_amd import ops, parallel
+from neural_sp_amd import ops, parallel, _lib as nsp_lib
+
+
+class NoLaunch(object):
+    """HOST_ONLY=1 python tools/host_phases.py: every kernel entry point of libnsp_hip.so becomes a no-op, so
+    that what is left is the host cost of the step (allocations, autograd, argument marshalling).  Results are
+    garbage by construction; the wrapper lives here, in the tool, and nowhere in the package."""
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if name.startswith('nsp_') and name != 'nsp_version':
+            return lambda *a: 0
+        return fn
+
+
+if os.environ.get('HOST_ONLY') == '1':
+    nsp_lib._lib = NoLaunch(nsp_lib.lib())
 from neural_sp_amd.configs import conformer_rnnt_args, synthetic_batch
 from neural_sp_amd.speech2text import Speech2Text
 ops.set_compute_mode('bf16')
