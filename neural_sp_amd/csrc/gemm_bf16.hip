@@ -1361,6 +1361,87 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_rr_ring_kernel(const nsp_g
   gemm_epilogue<4>(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
+// ---- the same RC x RC tile with ONE LDS stage and four workgroups per CU (the weight-gradient analogue of
+// gemm_bf16_kk_glds_kernel): load -> wait -> barrier -> 32 MFMAs -> barrier per k-tile, the DMA latency of one
+// workgroup hidden by the three others instead of by a second stage.  NSP_GEMM_RR_RING=1 selects it.
+__global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_rr_glds_kernel(const nsp_gemm_params p, int tiles_m,
+                                                                        int tiles_n, int c_vec) {
+  __shared__ __attribute__((aligned(16))) unsigned char ring[32768];   // A image 16 KB | B image 16 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  int z = blockIdx.z;
+  const int split = z % p.splitk;
+  z /= p.splitk;
+  const int z2 = z % p.batch2, z1 = z / p.batch2;
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
+  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
+  const long long lda = p.a_cs, ldb = p.b_ks;
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    int nkt_all = p.K / BK;
+    int per = (nkt_all + p.splitk - 1) / p.splitk;
+    kbeg = split * per * BK;
+    kend = min(p.K, (split + 1) * per * BK);
+    if (kbeg >= kend) {
+      if (!p.c_ss) return;
+      kend = kbeg;
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lk = lane >> 4, lp = lane & 15;
+  // one base pointer per operand; DMA instruction i adds 4 k-rows (the swizzle of row 16w + 4i + lk depends
+  // on i only through bit 3 of the row: two variants per operand)
+  const int krow0 = wave * 16 + lk;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int nkt = (kend - kbeg) / BK;
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nkt; ++kt) {
+    unsigned char* sa = ring + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int krow = krow0 + i * 4;
+      const int csrc = lp ^ rr_swz(krow);
+      const int ma = (m0 + csrc * 8 < p.M) ? m0 + csrc * 8 : m0;
+      const int nb = (n0 + csrc * 8 < p.N) ? n0 + csrc * 8 : n0;
+      const long long kr = (long long)(kbeg + kt * BK + krow);
+      __builtin_amdgcn_global_load_lds((glb_void*)(A + kr * lda + ma), (lds_void*)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(B + kr * ldb + nb), (lds_void*)(sa + 16384 + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned char* smA = ring;
+    const unsigned char* smB = ring + 16384;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = rr_frag(smA, wm * 64 + i * 16, s, fr, fg);
+        bf[i] = rr_frag(smB, wn * 64 + i * 16, s, fr, fg);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // every wave has read the stage: it may be re-armed
+    asm volatile("" ::: "memory");
+  }
+  gemm_epilogue<4, false>(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);   // fast path only (launcher: fast_epi)
+}
+
 // fp32 [rows, cols] (row stride ld_in) -> bf16 [rows, ld_out] with zero fill; 8 elements per lane
 __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long long rows,
                                  int cols, long long ld_in, long long ld_out, int vec_in) {
@@ -1495,12 +1576,15 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   }
   else if (!a_kc && !b_kc && p.K % BK == 0 && p.K >= 2 * BK && p.M % 8 == 0 && p.N % 8 == 0 &&
            tiles_m * tiles_n >= rr_ring_min_tiles() && rr_ring_stages() > 0) {
-    // weight gradients on the LDS-DMA ring with swizzled transposed reads.  OPT-IN: back to back it
-    // beats the register-staged kernel (2 stages: 545 -> 660 TFLOP/s on dW[2048,512] over 51200
-    // rows; 3 stages = 1 workgroup per CU is slower), but inside the training step it measured 1 %
-    // SLOWER (97.5 vs 96.0 ms): its 64 KB of LDS per workgroup leave room for one instead of two
-    // workgroups beside the persistent LSTM kernel that runs concurrently on half of the CUs.
-    if (rr_ring_stages() >= 3) {
+    // weight gradients on the LDS-DMA ring with swizzled transposed reads (default: 2 stages, two workgroups
+    // per CU).  History: back to back it beat the register-staged kernel from the start (545 -> 660 TFLOP/s on
+    // dW[2048,512] over 51200 rows; 3 stages = 1 workgroup per CU is slower); inside the training step it was
+    // 1 % slower in round 1 and 0.35 ms/step faster in round 2's A/B, hence the default.  NSP_GEMM_RR_RING=1
+    // selects the single-stage / four-workgroup variant: measured equal or 3-6 % slower at the step's shapes
+    // with the current split-K factors (512 workgroups fill only half of its slots).
+    if (rr_ring_stages() == 1 && fast_epi) {
+      hipLaunchKernelGGL(gemm_bf16_rr_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
+    } else if (rr_ring_stages() >= 3) {
       (void)hipFuncSetAttribute((const void*)gemm_bf16_rr_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
       hipLaunchKernelGGL((gemm_bf16_rr_ring_kernel<3>), grid, block, 3 * 32768, st, p, tiles_m, tiles_n, c_vec);
     } else {
