@@ -20,7 +20,8 @@ def bench(fn, iters=30):
     return e0.elapsed_time(e1) * 1000 / iters
 
 
-for M, N, K in [(51200, 2048, 512)]:
+SHAPES = [tuple(int(v) for v in t.split('x')) for t in os.environ.get('PROBE_SHAPES', '51200x2048x512').split(',')]
+for M, N, K in SHAPES:
     a = (torch.randn(M, K, device='cuda') * 0.5).bfloat16()
     w = (torch.randn(N, K, device='cuda') * 0.5).bfloat16()
     c32 = torch.empty(M, N, device='cuda', dtype=torch.float32)
