@@ -21,7 +21,7 @@ key projections are computed once, the bottleneck + tanh + output layer run once
 
 Not built (NotImplementedError): LM fusion / initialisation, MBR training, scheduled sampling,
 multi-head / GMM / dot-family attention, MoChA with several heads, 1-d conv, DeCoT / latency losses,
-StableEmit, streaming / beam-search / greedy decoding of the attention decoder.
+StableEmit, streaming / beam-search decoding (greedy search of the LAS decoder is built: `RNNDecoder.greedy`).
 """
 import math
 
@@ -399,8 +399,53 @@ class RNNDecoder(DecoderBase):
         if self.ctc_weight > 0:
             self.ctc._plot_ctc(save_path, topk)
 
-    def greedy(self, *a, **k):
-        raise NotImplementedError('attention-decoder decoding is inference-side and not built')
+    def greedy(self, eouts, elens, max_len_ratio, idx2token=None, exclude_eos=False, refs_id=None, utt_ids=None,
+               speakers=None, trigger_points=None):
+        """las.py:893-1007 (what validate() runs with recog_beam_width 1): the teacher-forced step of
+        forward_att with the arg-max token fed back; stops when every utterance has emitted <eos> or after
+        ceil(T * max_len_ratio) steps.  -> (hyps: list of int arrays, None); the attention-weight plots of the
+        reference's second return value are not produced.  MoChA needs the hard (test-time) monotonic
+        attention, which is not built."""
+        if self.attn_type == 'mocha':
+            raise NotImplementedError("MoChA decoding needs the hard monotonic attention (mode='hard'), not built")
+        dev = eouts.device
+        B, T = eouts.shape[:2]
+        with torch.no_grad():
+            elens_d = ops.h2d(elens, dev, torch.int64)
+            src_mask = (torch.arange(T, device=dev).unsqueeze(0) < elens_d.unsqueeze(1)).unsqueeze(1)
+            hxs = [eouts.new_zeros(B, self.dec_n_units) for _ in range(self.n_layers)]
+            cxs = [eouts.new_zeros(B, self.dec_n_units) for _ in range(self.n_layers)]
+            cv = eouts.new_zeros(B, 1, self.enc_n_units)
+            self.score.reset()
+            aw = None
+            y = torch.full((B,), self.eos, dtype=torch.int64, device=dev)
+            hyps_batch = []
+            ylens = [0] * B
+            eos_flags = [False] * B
+            ymax = int(math.ceil(T * max_len_ratio))
+            with ops.compute_mode('f32'):
+                for i in range(ymax):
+                    x = torch.cat([self.dropout_emb(self.embed(y)), cv.squeeze(1)], dim=-1)
+                    hxs, cxs, dout_score, dout_gen = self._recurrency(x, hxs, cxs)
+                    cv, aw, _ = self.score(eouts, eouts, dout_score.unsqueeze(1), src_mask, aw, cache=True, mode='hard')
+                    attn_v = torch.tanh(ops.linear(torch.cat([dout_gen, cv.squeeze(1)], dim=-1),
+                                                   self.output_bn.weight, self.output_bn.bias))
+                    y = ops.argmax_rows(ops.linear(attn_v, self.output.weight, self.output.bias)).long()
+                    hyps_batch.append(y)
+                    yh = y.tolist()                         # the reference syncs here too (y[b].item())
+                    for b in range(B):
+                        if not eos_flags[b]:
+                            if yh[b] == self.eos:
+                                eos_flags[b] = True
+                            ylens[b] += 1                   # include <eos>
+                    if all(eos_flags) or i == ymax - 1:
+                        break
+            self.score.reset()
+            hb = torch.stack(hyps_batch, dim=1).cpu().numpy()
+        hyps = [hb[b, :ylens[b]][::-1] if self.bwd else hb[b, :ylens[b]] for b in range(B)]
+        if exclude_eos:
+            hyps = [(h[1:] if self.bwd else h[:-1]) if eos_flags[b] else h for b, h in enumerate(hyps)]
+        return hyps, None
 
     def beam_search(self, *a, **k):
         raise NotImplementedError('attention-decoder decoding is inference-side and not built')

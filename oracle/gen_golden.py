@@ -232,7 +232,8 @@ def run_decode():
               'recog_fwd_bwd_attention': False, 'recog_max_len_ratio': 1.0, 'recog_bwd_attention': False,
               'recog_batch_size': 1, 'recog_block_sync': False}
     out = {'params': params, 'cases': {}}
-    for name in ('conformer_ctc_xs', 'conformer_rnnt_xs', 'conformer_rnnt_dk64_xs', 'transformer_ctc_xs'):
+    for name in ('conformer_ctc_xs', 'conformer_rnnt_xs', 'conformer_rnnt_dk64_xs', 'transformer_ctc_xs',
+                 'conformer_ctc_att_xs', 'conformer_ctc_las_xs'):   # the last two: attention-decoder greedy search
         fix = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
         args = argparse.Namespace(**fix['args'])
         model = Speech2Text(args)
