@@ -21,7 +21,8 @@ key projections are computed once, the bottleneck + tanh + output layer run once
 
 Not built (NotImplementedError): LM fusion / initialisation, MBR training, scheduled sampling,
 multi-head / GMM / dot-family attention, MoChA with several heads, 1-d conv, DeCoT / latency losses,
-StableEmit, streaming / beam-search decoding (greedy search of the LAS decoder is built: `RNNDecoder.greedy`).
+StableEmit, streaming / linear-time / beam-search decoding (greedy search is built: `RNNDecoder.greedy`, with
+MoChA's test-time hard attention).
 """
 import math
 
@@ -187,13 +188,15 @@ class MoChA(nn.Module):
 
     def forward(self, key, value, query, mask, aw_prev=None, cache=False, mode='parallel', trigger_points=None,
                 streaming=False):
-        if mode != 'parallel':
-            raise NotImplementedError("MoChA mode '%s': only the training-time ('parallel') algorithm is built" % mode)
+        if mode not in ('parallel', 'hard'):
+            raise ValueError("mode must be 'parallel' or 'hard'.")
         bs, klen = key.shape[:2]
         if aw_prev is None:
             aw_prev = key.new_zeros(bs, 1, 1, klen)
             aw_prev[:, :, :, 0] = 1.0                                                 # [1, 0, 0, ...] (mocha.py:204-206)
         e_ma = self.monotonic_energy(key, query, mask, cache)                         # [B,1,1,T]
+        if mode == 'hard':
+            return self._forward_hard(key, value, query, mask, aw_prev, cache, e_ma)
         # parallel_monotonic_attention (hma_train.py:12-67) for qlen = 1
         if self.noise_std > 0:                                                        # (training AND eval, as the reference)
             e_ma = e_ma + torch.zeros_like(e_ma).normal_(std=self.noise_std)
@@ -216,6 +219,39 @@ class MoChA(nn.Module):
             beta = self.dropout_attn(beta)
         cv = torch.bmm((alpha if self.w == 1 else beta).squeeze(1), value)
         return cv, alpha, {'beta': beta, 'p_choose': p_choose}
+
+
+def _mocha_forward_hard(self, key, value, query, mask, aw_prev, cache, e_ma):
+    """Test-time MoChA (mocha.py:222-311 with linear_decoding / streaming off; hma_test.py:12-53,
+    mocha_test.py:16-60): p_choose thresholded at 0.5, alpha = the first selected frame at or after the
+    previous one, beta = softmax of the chunk energies over the w frames ending there.  Quirks kept:
+    `is_boundary` is decided for the whole batch; an utterance without a boundary in a step where another one
+    has one gets a softmax over an all-masked row, i.e. UNIFORM chunk attention (mocha_test.py:44-58)."""
+    bs, klen = key.shape[:2]
+    p_sel = (torch.sigmoid(e_ma) >= 0.5).to(e_ma.dtype) * torch.cumsum(aw_prev, dim=-1)          # hma_test.py:33-37
+    excl = torch.cumprod(torch.cat([p_sel.new_ones(bs, 1, 1, 1), 1 - p_sel[..., :-1]], dim=-1), dim=-1)
+    alpha = p_sel * excl
+    is_boundary = bool((alpha.sum() > 0).item())
+    beta = None
+    if self.chunk_energy is not None:
+        if not is_boundary:
+            beta = alpha.new_zeros(bs, 1, 1, klen)
+        else:
+            u = self.chunk_energy(key, query, mask, cache)
+            a = alpha[:, 0, 0]                                                                    # [B,T]
+            has = a.sum(-1) > 0
+            boundary = torch.argmax((a > 0).to(torch.int32), dim=-1)                              # first non-zero frame
+            j = torch.arange(klen, device=key.device).unsqueeze(0)
+            lo = torch.zeros_like(boundary) if self.milk else torch.clamp(boundary - self.w + 1, min=0)
+            win = (j >= lo.unsqueeze(1)) & (j <= boundary.unsqueeze(1)) & has.unsqueeze(1)
+            win = win | (a != 0)                                                                  # mask starts as alpha.byte()
+            beta = torch.softmax(u.masked_fill(~win.view(bs, 1, 1, klen), NEG_INF), dim=-1)
+            beta = self.dropout_attn(beta)
+    cv = torch.bmm((alpha if self.w == 1 else beta).squeeze(1), value)
+    return cv, alpha, {'beta': beta, 'p_choose': torch.sigmoid(e_ma)}
+
+
+MoChA._forward_hard = _mocha_forward_hard
 
 
 class RNNDecoder(DecoderBase):
@@ -404,10 +440,7 @@ class RNNDecoder(DecoderBase):
         """las.py:893-1007 (what validate() runs with recog_beam_width 1): the teacher-forced step of
         forward_att with the arg-max token fed back; stops when every utterance has emitted <eos> or after
         ceil(T * max_len_ratio) steps.  -> (hyps: list of int arrays, None); the attention-weight plots of the
-        reference's second return value are not produced.  MoChA needs the hard (test-time) monotonic
-        attention, which is not built."""
-        if self.attn_type == 'mocha':
-            raise NotImplementedError("MoChA decoding needs the hard monotonic attention (mode='hard'), not built")
+        reference's second return value are not produced.  MoChA decodes with its test-time (hard) attention."""
         dev = eouts.device
         B, T = eouts.shape[:2]
         with torch.no_grad():

@@ -233,7 +233,7 @@ def run_decode():
               'recog_batch_size': 1, 'recog_block_sync': False}
     out = {'params': params, 'cases': {}}
     for name in ('conformer_ctc_xs', 'conformer_rnnt_xs', 'conformer_rnnt_dk64_xs', 'transformer_ctc_xs',
-                 'conformer_ctc_att_xs', 'conformer_ctc_las_xs'):   # the last two: attention-decoder greedy search
+                 'conformer_ctc_att_xs', 'conformer_ctc_las_xs', 'conformer_ctc_mocha_xs'):   # the last three: attention-decoder greedy search
         fix = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
         args = argparse.Namespace(**fix['args'])
         model = Speech2Text(args)
@@ -244,6 +244,13 @@ def run_decode():
             p2 = dict(params, recog_ctc_weight=1.0)     # CTC best path of a joint CTC/RNN-T model
             hyps2, _ = model.decode(fix['batch']['xs'], p2, None, exclude_eos=True)
             entry['ctc'] = [[[int(v) for v in h] for h in nb] for nb in hyps2]
+        if getattr(args, 'attn_type', '') == 'mocha' and args.dec_type in ('lstm', 'gru'):
+            # the fixture's offset r ~ 0 never selects a frame; with larger offsets the monotonic head fires and
+            # the chunkwise softmax windows are exercised (hma_test.py / mocha_test.py)
+            for r_val in (0.6, 1.5):
+                model.dec_fwd.score.monotonic_energy.r.data.fill_(r_val)
+                hyps3, _ = model.decode(fix['batch']['xs'], dict(params), None, exclude_eos=True)
+                entry['r=%.1f' % r_val] = [[[int(v) for v in h] for h in nb] for nb in hyps3]
         out['cases'][name] = entry
         print('%-28s %s' % (name, {k: [len(nb[0]) for nb in v] for k, v in entry.items()}))
     torch.save(out, os.path.join(GOLDEN, 'decode_greedy.pt'))
