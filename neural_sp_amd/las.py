@@ -36,15 +36,6 @@ from neural_sp_amd.decoders import CTC, DecoderBase
 NEG_INF = float(np.finfo(np.float32).min)
 
 
-def _uniform_(module, param_init):
-    """initialization.py init_with_uniform: biases 0, everything else U(-param_init, param_init)."""
-    for n, p in module.named_parameters():
-        if p.dim() == 1:
-            nn.init.constant_(p, 0.)
-        else:
-            nn.init.uniform_(p, a=-param_init, b=param_init)
-
-
 class AttentionMechanism(nn.Module):
     """modules/attention.py:11-181, atype 'add' | 'location', single head."""
 
