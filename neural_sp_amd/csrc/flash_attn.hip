@@ -25,7 +25,12 @@
 namespace {
 
 constexpr int DK = 64;
-constexpr int KP = 144;  // LDS row pitch in bytes for [rows][64] bf16 tiles (128 + 16 pad)
+// LDS row pitch in bytes for [rows][64] bf16 tiles: 128 + 32 pad.  With 16 bytes of padding (the first
+// version) BOTH read patterns of these kernels ran at half rate: a ds_read_b128 row-per-lane fragment took 8
+// LDS cycles instead of 4 and a ds_read_b64_tr_b16 fragment 4 instead of 2 (lane groups of
+// MI355X_MICROARCH.md "LDS", simulated per instruction; rocprofv3 measured SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE = 31-36 % on the three kernels).  160 is conflict-free for both.
+constexpr int KP = 160;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;

@@ -26,9 +26,15 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
-constexpr int PITCH_KC = 144;  // bytes per row  (64 bf16 + 16 B pad)
-constexpr int PITCH_RC = 288;  // bytes per k    (128 bf16 + 32 B pad)
-constexpr int TILE_BYTES = 128 * PITCH_KC;  // == 64 * PITCH_RC == 18432
+// LDS images of the register-staged kernels.  KC tiles ([128 rows][64 k]): 128-B rows + 32 B of padding --
+// with 16 B (round 1) a ds_read_b128 fragment took 8 LDS cycles instead of 4.  RC tiles ([64 k][128 cols]):
+// unpadded 256-B rows with the 16-B chunk index XOR-swizzled by rr_swz(k) exactly like the LDS-DMA
+// weight-gradient kernel (padding cannot fix the transposed reads: 4 cycles instead of 2 at any pitch;
+// measured 33 % bank-conflict cycles on gemm_bf16_kernel<false,false>).
+constexpr int PITCH_KC = 160;
+constexpr int PITCH_RC = 256;
+constexpr int TILE_BYTES = 128 * PITCH_KC;  // 20480 >= 64 * PITCH_RC
+__device__ __forceinline__ int rr_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -65,7 +71,7 @@ struct Bf16TileLoader {
         *reinterpret_cast<u32x4*>(lds + row * PITCH_KC + c * 16) = r[i];
       } else {
         const int kk = idx >> 4, cb = idx & 15;
-        *reinterpret_cast<u32x4*>(lds + kk * PITCH_RC + cb * 16) = r[i];
+        *reinterpret_cast<u32x4*>(lds + kk * PITCH_RC + ((cb ^ rr_swz(kk)) << 4)) = r[i];
       }
     }
   }
@@ -78,7 +84,8 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int rbase,
     return *reinterpret_cast<const bf16x8*>(lds + (rbase + r) * PITCH_KC + (s * 4 + g) * 16);
   } else {
     const int a = r >> 2, b = r & 3;
-    const unsigned char* p = lds + (s * 32 + g * 8 + a) * PITCH_RC + (rbase + b * 4) * 2;
+    const int k0 = s * 32 + g * 8 + a, col = rbase + b * 4;      // rows k0 and k0 + 4 share their swizzle
+    const unsigned char* p = lds + k0 * PITCH_RC + (((col >> 3) ^ rr_swz(k0)) << 4) + ((col & 7) << 1);
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * PITCH_RC));
@@ -645,7 +652,7 @@ template <int EPI>
 __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const nsp_gemm_params p,
                                                                      int tiles_m, int tiles_n,
                                                                      int c_vec) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * 128];   // A | B image, 16 KB each (4 workgroups = 128 KB per CU)
   unsigned char* smA = smem;
   unsigned char* smB = smem + 128 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1253,8 +1260,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_kk256_kernel(const nsp_gemm_par
 // column pair a transposed read touches in row k is XOR-swizzled with (k & 3) | ((k >> 3) & 1) << 2
 // (on the source address of the DMA and on the read), which spreads the 4 rows of one 16-lane group
 // and the two row groups of a 32-lane pass over all 64 banks.  Requires K % 64 == 0.
-__device__ __forceinline__ int rr_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
-
 __device__ __forceinline__ bf16x8 rr_frag(const unsigned char* tile, int cbase, int s, int r, int g) {
   const int a = r >> 2, b = r & 3;
   const int k0 = s * 32 + g * 8 + a;          // rows k0 and k0 + 4 share (k & 3) and bit 3
