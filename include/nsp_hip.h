@@ -326,6 +326,68 @@ int nsp_maxpool1d_bwd(const float* dy, const int* argmax, float* dx, int B, int 
                       int factor, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * The other time subsamplers of encoders/subsampling.py on [B,T,C]         *
+ * (C % 4 == 0), To output frames, window of k frames starting at           *
+ * to*stride - pad (frames outside [0,T) count as zero):                    *
+ *   window SUM     y[b,to,c]       = s(to) * sum_j x[b, to*stride+j-pad, c] *
+ *     DropSubsampler (:97-128)     k=1, stride=f, To=ceil(T/f)              *
+ *     AddSubsampler (:131-172)     k=2, stride=2, To=ceil(T/2)              *
+ *     MeanPoolSubsampler (:212-246, AvgPool1d ceil_mode) k=stride=f, mean=1: *
+ *       s(to) = 1 / #frames of the window inside [0,T)                      *
+ *   window GATHER  y[b,to,j*C+c]   = x[b, to*stride+j-pad, c]  (im2col)      *
+ *     ConcatSubsampler (:13-52)    k=stride=f, pad=0, To=T/f, then Linear    *
+ *     Conv1dSubsampler (:55-94)    k=3, stride=f, pad=1, To=(T-1)/f+1, then  *
+ *       the GEMM with the [Co, k*Ci] view of the Conv1d weight              *
+ * The *_bwd entry points are the exact adjoints (one thread per input      *
+ * element gathers from every window that covers it: no atomics).           *
+ * ------------------------------------------------------------------------ */
+int nsp_time_window_sum_fwd(const float* x, float* y, int B, int T, int To, int C, int k, int stride,
+                            int pad, int mean, void* stream);
+int nsp_time_window_sum_bwd(const float* dy, float* dx, int B, int T, int To, int C, int k, int stride,
+                            int pad, int mean, void* stream);
+int nsp_time_window_gather_fwd(const float* x, float* y, int B, int T, int To, int C, int k, int stride,
+                               int pad, void* stream);
+int nsp_time_window_gather_bwd(const float* dy, float* dx, int B, int T, int To, int C, int k,
+                               int stride, int pad, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * BatchNorm1d / GroupNorm + activation of the Conformer convolution module *
+ * on the flattened rows x [M = B*T, C] (conformer_convolution.py:58-66,    *
+ * 119-124: `norm(xs.view(B*T, C, 1))` then Swish), C % 4 == 0.             *
+ * Column reductions run over nsp_col_reduce_slabs(M) row slabs;            *
+ * `part` is a caller-provided workspace of slabs*2*C floats.               *
+ * nsp_bn_stats: batch mean / 1/sqrt(biased var + eps) per channel (shifted *
+ *   moments, shift = row 0) and, when the pointers are non-NULL, the       *
+ *   running_mean / running_var (unbiased) / num_batches_tracked update of  *
+ *   nn.BatchNorm1d(momentum).                                              *
+ * nsp_bn_act_fwd: y = act(gamma * (x - mean) * rstd + beta); `scale` is    *
+ *   rstd (training: from nsp_bn_stats) or, with scale_is_var != 0, a       *
+ *   variance (eval: running_var) from which rstd = 1/sqrt(var + eps).      *
+ * nsp_bn_act_bwd: dz = dy*act'(z); dbeta = sum dz; dgamma = sum dz*xhat;   *
+ *   dx = gamma*rstd*(dz - (dbeta + xhat*dgamma)/M) when training != 0       *
+ *   (batch statistics), gamma*rstd*dz otherwise.                           *
+ * nsp_gn2_*: GroupNorm with groups of TWO adjacent channels -- what        *
+ *   `nn.GroupNorm(max(1, d_model // 2), d_model)` builds for every even    *
+ *   d_model (:61-63); statistics per row and pair, nothing saved.          *
+ * ------------------------------------------------------------------------ */
+int nsp_col_reduce_slabs(long long M);
+int nsp_bn_stats(const float* x, long long M, int C, float eps, float momentum, float* part,
+                 float* mean, float* rstd, float* running_mean, float* running_var,
+                 long long* num_batches_tracked, void* stream);
+int nsp_bn_act_fwd(const float* x, const float* mean, const float* scale, int scale_is_var, float eps,
+                   const float* gamma, const float* beta, int act, float* y, long long M, int C,
+                   void* stream);
+int nsp_bn_act_bwd(const float* x, const float* dy, const float* mean, const float* scale,
+                   int scale_is_var, float eps, const float* gamma, const float* beta, int act,
+                   int training, float* part, float* dgamma, float* dbeta, float* dx, long long M, int C,
+                   void* stream);
+int nsp_gn2_act_fwd(const float* x, const float* gamma, const float* beta, float eps, int act, float* y,
+                    long long M, int C, void* stream);
+int nsp_gn2_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, float eps,
+                    int act, float* part, float* dgamma, float* dbeta, float* dx, long long M, int C,
+                    void* stream);
+
+/* ------------------------------------------------------------------------ *
  * CTC: fused log-softmax + alpha/beta lattice + gradient w.r.t. logits.    *
  * Replaces ctc.py:139-150 (nn.CTCLoss(reduction='sum', zero_infinity=True) *
  * on logits.log_softmax(2)) and criterion.py:110-127 (kldiv_lsm_ctc).      *

@@ -867,6 +867,146 @@ def maxpool1d_time(x, factor):
     return MaxPool1dFn.apply(x, factor)
 
 
+class TimeWindowFn(torch.autograd.Function):
+    """Strided windows over time of [B,T,C] (the subsamplers of subsampling.py other than max-pool):
+    gather=False: y[b,to,:] = s(to) * sum_j x[b, to*stride+j-pad, :]  ([B,To,C]; s = 1/coverage if mean)
+    gather=True:  y[b,to,j*C:(j+1)*C] = x[b, to*stride+j-pad, :]        ([B,To,k*C], im2col for a GEMM)"""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, To, mean, gather):
+        x = _f32c(x)
+        B, T, C = x.shape
+        y = torch.empty((B, To, k * C if gather else C), device=x.device, dtype=torch.float32)
+        L = _lib.lib()
+        if gather:
+            _check(L.nsp_time_window_gather_fwd(_p(x), _p(y), B, T, To, C, k, stride, pad, _stream()),
+                   'nsp_time_window_gather_fwd')
+        else:
+            _check(L.nsp_time_window_sum_fwd(_p(x), _p(y), B, T, To, C, k, stride, pad, int(mean), _stream()),
+                   'nsp_time_window_sum_fwd')
+        ctx.cfg = (B, T, To, C, k, stride, pad, int(mean), gather)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, To, C, k, stride, pad, mean, gather = ctx.cfg
+        dy = _f32c(dy)
+        dx = torch.empty((B, T, C), device=dy.device, dtype=torch.float32)
+        L = _lib.lib()
+        if gather:
+            _check(L.nsp_time_window_gather_bwd(_p(dy), _p(dx), B, T, To, C, k, stride, pad, _stream()),
+                   'nsp_time_window_gather_bwd')
+        else:
+            _check(L.nsp_time_window_sum_bwd(_p(dy), _p(dx), B, T, To, C, k, stride, pad, mean, _stream()),
+                   'nsp_time_window_sum_bwd')
+        return dx, None, None, None, None, None, None
+
+
+def time_window_sum(x, k, stride, pad, To, mean=False):
+    return TimeWindowFn.apply(x, int(k), int(stride), int(pad), int(To), bool(mean), False)
+
+
+def time_window_gather(x, k, stride, pad, To):
+    return TimeWindowFn.apply(x, int(k), int(stride), int(pad), int(To), False, True)
+
+
+def _col_part(M, C, device):
+    """workspace of the two-level column reductions: [slabs, 2, C]"""
+    return torch.empty((_lib.lib().nsp_col_reduce_slabs(M), 2, C), device=device, dtype=torch.float32)
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """act(BatchNorm1d(x)) over the rows of x [..., C] (conformer_convolution.py:119-122 with
+    normalization='batch_norm': statistics over all B*T frames, padded ones included, like the
+    reference).  training: batch statistics + in-place running-statistics update (buffers are passed as
+    plain tensors); eval: running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum,
+                eps, act):
+        x = _f32c(x)
+        C = x.shape[-1]
+        M = x.numel() // C
+        L = _lib.lib()
+        y = torch.empty_like(x)
+        if training:
+            part = _col_part(M, C, x.device)
+            mean = torch.empty((C,), device=x.device, dtype=torch.float32)
+            scale = torch.empty((C,), device=x.device, dtype=torch.float32)
+            _check(L.nsp_bn_stats(_p(x), M, C, eps, momentum, _p(part), _p(mean), _p(scale),
+                                  _p(running_mean), _p(running_var), _p(num_batches_tracked), _stream()),
+                   'nsp_bn_stats')
+            is_var = 0
+        else:
+            mean, scale, is_var = running_mean, running_var, 1
+        _check(L.nsp_bn_act_fwd(_p(x), _p(mean), _p(scale), is_var, eps, _p(gamma), _p(beta), act, _p(y),
+                                M, C, _stream()), 'nsp_bn_act_fwd')
+        if training:
+            ctx.save_for_backward(x, gamma, beta, mean, scale)
+        else:
+            # the running buffers are updated in place by later training steps: keep this call's values
+            ctx.save_for_backward(x, gamma, beta, mean.clone(), scale.clone())
+        ctx.cfg = (M, C, is_var, eps, act, int(bool(training)))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, scale = ctx.saved_tensors
+        M, C, is_var, eps, act, training = ctx.cfg
+        dy = _f32c(dy)
+        part = _col_part(M, C, x.device)
+        dgamma = torch.empty((C,), device=x.device, dtype=torch.float32)
+        dbeta = torch.empty((C,), device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        _check(_lib.lib().nsp_bn_act_bwd(_p(x), _p(dy), _p(mean), _p(scale), is_var, eps, _p(gamma), _p(beta),
+                                         act, training, _p(part), _p(dgamma), _p(dbeta), _p(dx), M, C,
+                                         _stream()), 'nsp_bn_act_bwd')
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, training, act='none'):
+    """`bn`: an nn.BatchNorm1d used as the parameter / buffer container (affine, track_running_stats)."""
+    if not (bn.affine and bn.track_running_stats) or bn.momentum is None:
+        raise NotImplementedError('BatchNorm1d without affine / running statistics / momentum')
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, bool(training), float(bn.momentum), float(bn.eps),
+                                ACT[act])
+
+
+class GroupNorm2ActFn(torch.autograd.Function):
+    """act(GroupNorm(C/2 groups)(x)) over the rows of x [..., C]: every group is a pair of adjacent
+    channels (conformer_convolution.py:61-63 for any even d_model); nothing but x is saved."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act):
+        x = _f32c(x)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        _check(_lib.lib().nsp_gn2_act_fwd(_p(x), _p(gamma), _p(beta), eps, act, _p(y), M, C, _stream()),
+               'nsp_gn2_act_fwd')
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.cfg = (M, C, eps, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        M, C, eps, act = ctx.cfg
+        dy = _f32c(dy)
+        part = _col_part(M, C, x.device)
+        dgamma = torch.empty((C,), device=x.device, dtype=torch.float32)
+        dbeta = torch.empty((C,), device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        _check(_lib.lib().nsp_gn2_act_bwd(_p(x), _p(dy), _p(gamma), _p(beta), eps, act, _p(part), _p(dgamma),
+                                          _p(dbeta), _p(dx), M, C, _stream()), 'nsp_gn2_act_bwd')
+        return dx, dgamma, dbeta, None, None
+
+
+def group_norm2_act(x, gamma, beta, eps, act='none'):
+    return GroupNorm2ActFn.apply(x, gamma, beta, float(eps), ACT[act])
+
+
 # --------------------------------------------------------------------------
 # Conv2d frontend (channels-last)
 # --------------------------------------------------------------------------

@@ -1,0 +1,60 @@
+"""Build tests/hipemu/_build/libnsp_emu.so: selected csrc/*.hip files compiled by the HOST clang++
+against the emulation header (tests/hipemu/include/hip/hip_runtime.h) -- TEST INFRASTRUCTURE ONLY.
+
+Only sources without inline asm / gfx950 builtins can be emulated; the list below names them.
+Nothing under neural_sp_amd/ imports this module or loads the library it builds.
+"""
+import hashlib
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'neural_sp_amd', 'csrc')
+OUT = os.path.join(HERE, '_build')
+LIB = os.path.join(OUT, 'libnsp_emu.so')
+EMULATED_SOURCES = ['norm_subsample.hip']
+CXX_CANDIDATES = ['/opt/rocm/lib/llvm/bin/clang++', 'clang++']
+
+
+def _cxx():
+    for c in CXX_CANDIDATES:
+        try:
+            subprocess.run([c, '--version'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            return c
+        except (OSError, subprocess.CalledProcessError):
+            continue
+    return None
+
+
+def available():
+    return _cxx() is not None
+
+
+def build():
+    cxx = _cxx()
+    if cxx is None:
+        raise RuntimeError('no host clang++ (ext_vector_type / __bf16 support is needed) for the HIP emulator')
+    os.makedirs(OUT, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in EMULATED_SOURCES] + [os.path.join(HERE, 'emu_runtime.cpp')]
+    deps = srcs + [os.path.join(HERE, 'include', 'hip', 'hip_runtime.h'), os.path.join(CSRC, 'common.h'),
+                   os.path.join(ROOT, 'include', 'nsp_hip.h')]
+    h = hashlib.sha1()
+    for f in deps:
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    stamp = os.path.join(OUT, 'stamp')
+    if os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
+        return LIB
+    cmd = [cxx, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unused-value',
+           '-I', os.path.join(HERE, 'include'), '-x', 'c++'] + srcs + ['-o', LIB]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError('emulator build failed:\n' + res.stdout.decode(errors='replace'))
+    with open(stamp, 'w') as fh:
+        fh.write(h.hexdigest())
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build())

@@ -1,0 +1,159 @@
+// hip/hip_runtime.h -- HOST EMULATION of the HIP kernel language.  TEST INFRASTRUCTURE ONLY.
+//
+// There is no GPU in the build container, so a kernel written without one cannot be run before the
+// round-end GPU job.  This shim lets the *same* .hip source be compiled by the host clang++ (x86) and
+// executed on CPU threads, so that `-m "not gpu"` tests can check its indexing, reductions and
+// arithmetic against torch.  It is put first on the include path by tests/hipemu/build_emu.py; the
+// product build (neural_sp_amd/_lib.py, hipcc --offload-arch=gfx950) never sees this directory, and
+// nothing under neural_sp_amd/ loads the library it produces.
+//
+// Model: one launch = `block` host threads; each thread walks the grid's blocks in order (blocks are
+// serialised, so `__shared__` == function-local static storage is private to the running block);
+// __syncthreads() is a pthread barrier over the block; wave shuffles exchange through a per-wave slot
+// array guarded by a per-wave barrier.  Kernels must be convergent at every barrier / shuffle (no
+// early `return` before one) -- the kernels emulated here are written that way.
+// Not emulated: inline asm, MFMA / buffer / LDS-DMA builtins, dynamic shared memory, streams.
+#pragma once
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct int2 { int x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+#define __fdividef(a, b) ((a) / (b))
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
+namespace hipemu {
+struct Wave {
+  pthread_barrier_t bar;
+  int n;
+  uint64_t slot[64];
+};
+struct Launch {
+  dim3 grid, block;
+  pthread_barrier_t bar;
+  std::vector<Wave> waves;
+};
+extern thread_local Launch* cur;
+extern thread_local int tid_flat;
+}  // namespace hipemu
+
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+static inline void __syncthreads() { pthread_barrier_wait(&hipemu::cur->bar); }
+
+template <class T>
+static inline T hipemu_shfl(T v, int src_of_lane_fn(int, int), int arg) {
+  static_assert(sizeof(T) <= 8, "shuffle of <= 8-byte values only");
+  hipemu::Wave& w = hipemu::cur->waves[hipemu::tid_flat >> 6];
+  const int lane = hipemu::tid_flat & 63;
+  uint64_t raw = 0;
+  memcpy(&raw, &v, sizeof(T));
+  w.slot[lane] = raw;
+  pthread_barrier_wait(&w.bar);
+  int src = src_of_lane_fn(lane, arg);
+  if (src < 0 || src >= w.n) src = lane;  // inactive source lane: own value
+  raw = w.slot[src];
+  pthread_barrier_wait(&w.bar);
+  T r;
+  memcpy(&r, &raw, sizeof(T));
+  return r;
+}
+static inline int hipemu_src_xor(int lane, int m) { return lane ^ m; }
+static inline int hipemu_src_down(int lane, int d) { return lane + d; }
+static inline int hipemu_src_up(int lane, int d) { return lane - d; }
+static inline int hipemu_src_idx(int, int i) { return i; }
+template <class T> static inline T __shfl_xor(T v, int m, int = 64) { return hipemu_shfl(v, hipemu_src_xor, m); }
+template <class T> static inline T __shfl_down(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_down, d); }
+template <class T> static inline T __shfl_up(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_up, d); }
+template <class T> static inline T __shfl(T v, int i, int = 64) { return hipemu_shfl(v, hipemu_src_idx, i); }
+
+static inline float atomicAdd(float* p, float v) {
+  uint32_t* ip = reinterpret_cast<uint32_t*>(p);
+  uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), want;
+  float f;
+  do {
+    memcpy(&f, &old, 4);
+    f += v;
+    memcpy(&want, &f, 4);
+  } while (!__atomic_compare_exchange_n(ip, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  memcpy(&f, &old, 4);
+  return f;
+}
+
+namespace hipemu {
+template <class F>
+static inline void launch(dim3 grid, dim3 block, F body) {
+  Launch L;
+  L.grid = grid;
+  L.block = block;
+  const int nthr = (int)(block.x * block.y * block.z);
+  pthread_barrier_init(&L.bar, nullptr, nthr);
+  const int nw = (nthr + 63) / 64;
+  L.waves = std::vector<Wave>(nw);
+  for (int w = 0; w < nw; ++w) {
+    L.waves[w].n = (w == nw - 1) ? nthr - 64 * w : 64;
+    pthread_barrier_init(&L.waves[w].bar, nullptr, L.waves[w].n);
+  }
+  std::vector<std::thread> th;
+  th.reserve(nthr);
+  for (int t = 0; t < nthr; ++t) {
+    th.emplace_back([&L, t, grid, block, &body]() {
+      cur = &L;
+      tid_flat = t;
+      blockDim = block;
+      gridDim = grid;
+      threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+      for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+          for (unsigned bx = 0; bx < grid.x; ++bx) {
+            blockIdx = dim3(bx, by, bz);
+            body();
+            pthread_barrier_wait(&L.bar);  // a block ends before the next one reuses its statics
+          }
+    });
+  }
+  for (auto& t : th) t.join();
+  pthread_barrier_destroy(&L.bar);
+  for (auto& w : L.waves) pthread_barrier_destroy(&w.bar);
+}
+}  // namespace hipemu
+
+#define HIPEMU_KERNEL_NAME(...) __VA_ARGS__
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                     \
+  do {                                                                                  \
+    static_assert((shmem) == 0, "dynamic shared memory is not emulated");               \
+    (void)(stream);                                                                     \
+    hipemu::launch((grid), (block), [&]() { HIPEMU_KERNEL_NAME(kernel)(__VA_ARGS__); }); \
+  } while (0)

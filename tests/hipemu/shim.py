@@ -1,0 +1,42 @@
+"""Route neural_sp_amd.ops' C-ABI calls to the host-emulated kernels (tests/hipemu) -- TEST ONLY.
+
+`with emulated_kernels():` swaps the loader's `lib()` for the emulator library, lets `_p()` pass CPU
+addresses and makes `_stream()` a null stream, so the *real* ctypes glue and autograd Functions of
+ops.py run unchanged on CPU tensors for the kernels the emulator can build (EMULATED_SOURCES).  Any
+other symbol is absent from the emulator library and raises AttributeError: nothing silently falls back.
+"""
+import contextlib
+import ctypes
+
+from tests.hipemu import build_emu
+
+_emu = None
+
+
+def emu_lib():
+    global _emu
+    if _emu is None:
+        from neural_sp_amd import _lib
+        lib = ctypes.CDLL(build_emu.build())
+        for name, (ret, argtypes) in _lib.prototypes().items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                continue
+            fn.restype, fn.argtypes = ret, argtypes
+        _emu = lib
+    return _emu
+
+
+@contextlib.contextmanager
+def emulated_kernels():
+    from neural_sp_amd import _lib, ops
+    saved = (_lib.lib, ops._p, ops._stream)
+    lib = emu_lib()
+    _lib.lib = lambda: lib
+    ops._p = lambda t: None if t is None else t.data_ptr()
+    ops._stream = lambda: 0
+    try:
+        yield lib
+    finally:
+        _lib.lib, ops._p, ops._stream = saved
