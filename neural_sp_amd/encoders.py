@@ -227,6 +227,110 @@ class MaxPoolSubsampler(nn.Module):
         return xs, xlens
 
 
+class DropSubsampler(nn.Module):
+    """subsampling.py:97-128 (`--subsample_type drop`, the reference's default): keep frames 0, f, 2f, ..."""
+
+    def __init__(self, subsampling_factor):
+        super().__init__()
+        self.factor = subsampling_factor
+
+    def forward(self, xs, xlens, batch_first=True):
+        if self.factor == 1:
+            return xs, xlens
+        assert batch_first
+        f = self.factor
+        xs = ops.time_window_sum(xs, 1, f, 0, math.ceil(xs.size(1) / f))
+        xlens = torch.IntTensor([max(1, math.ceil(int(i) / f)) for i in xlens])
+        return xs, xlens
+
+
+class AddSubsampler(nn.Module):
+    """subsampling.py:131-172: x[2t] + x[2t+1] (a zero frame completes an odd length)."""
+
+    def __init__(self, subsampling_factor):
+        super().__init__()
+        self.factor = subsampling_factor
+        assert subsampling_factor <= 2
+
+    def forward(self, xs, xlens, batch_first=True):
+        if self.factor == 1:
+            return xs, xlens
+        assert batch_first
+        f = self.factor
+        xs = ops.time_window_sum(xs, 2, 2, 0, math.ceil(xs.size(1) / 2))
+        xlens = torch.IntTensor([max(1, math.ceil(int(i) / f)) for i in xlens])
+        return xs, xlens
+
+
+class MeanPoolSubsampler(nn.Module):
+    """subsampling.py:212-246: AvgPool1d(k = s = f, ceil_mode=True); the clipped last window is averaged over
+    the frames it covers.  Lengths follow update_lens_1d's non-max-pool branch (conv.py:446-448), i.e.
+    floor((len - f) / f) + 1 -- NOT the ceil of the tensor's own length (the reference's behaviour)."""
+
+    def __init__(self, subsampling_factor):
+        super().__init__()
+        self.factor = subsampling_factor
+
+    def forward(self, xs, xlens, batch_first=True):
+        if self.factor == 1:
+            return xs, xlens
+        assert batch_first
+        f = self.factor
+        xs = ops.time_window_sum(xs, f, f, 0, math.ceil(xs.size(1) / f), mean=True)
+        xlens = torch.IntTensor([math.floor((int(i) - (f - 1) - 1) // f + 1) for i in xlens])
+        return xs, xlens
+
+
+class ConcatSubsampler(nn.Module):
+    """subsampling.py:13-52: f successive frames side by side (oldest first; trailing frames that do not fill
+    a group are dropped) -> Linear(f * d, d) -> ReLU.  Window gather + one GEMM with the ReLU in its epilogue."""
+
+    def __init__(self, subsampling_factor, n_units):
+        super().__init__()
+        self.factor = subsampling_factor
+        if subsampling_factor > 1:
+            self.proj = nn.Linear(n_units * subsampling_factor, n_units)
+
+    def forward(self, xs, xlens, batch_first=True):
+        if self.factor == 1:
+            return xs, xlens
+        assert batch_first
+        f = self.factor
+        xs = ops.time_window_gather(xs, f, f, 0, xs.size(1) // f)
+        xs = ops.linear(xs, self.proj.weight, self.proj.bias, act='relu')
+        xlens = torch.IntTensor([max(1, int(i) // f) for i in xlens])
+        return xs, xlens
+
+
+class Conv1dSubsampler(nn.Module):
+    """subsampling.py:55-94: Conv1d(d, d, k=3, stride=f, padding=1) -> ReLU, as im2col over time + one GEMM
+    against the `[C_out, k * C_in]` view of the Conv1d weight (the parameter keeps the nn.Conv1d layout)."""
+
+    def __init__(self, subsampling_factor, n_units, kernel_size=3):
+        super().__init__()
+        assert kernel_size % 2 == 1, "Kernel size should be odd for 'same' conv."
+        self.factor = subsampling_factor
+        if subsampling_factor > 1:
+            self.conv1d = nn.Conv1d(in_channels=n_units, out_channels=n_units, kernel_size=kernel_size,
+                                    stride=subsampling_factor, padding=(kernel_size - 1) // 2)
+
+    def _out_len(self, n):   # conv.py:446-448
+        k, f, pad = self.conv1d.kernel_size[0], self.conv1d.stride[0], self.conv1d.padding[0]
+        return math.floor((n + 2 * pad - (k - 1) - 1) // f + 1)
+
+    def forward(self, xs, xlens, batch_first=True):
+        if self.factor == 1:
+            return xs, xlens
+        assert batch_first
+        k, f, pad = self.conv1d.kernel_size[0], self.conv1d.stride[0], self.conv1d.padding[0]
+        co, ci = self.conv1d.weight.shape[:2]
+        xs = ops.time_window_gather(xs, k, f, pad, self._out_len(xs.size(1)))
+        w2 = self.conv1d.weight.permute(0, 2, 1).contiguous().view(co, k * ci)   # [Co, Ci, k] -> [Co, k*Ci]
+        xs = ops.linear(xs, w2, self.conv1d.bias, act='relu')
+        xlens = torch.IntTensor([self._out_len(int(i)) for i in xlens])
+        return xs, xlens
+
+
 # --------------------------------------------------------------------------- blocks
 class TransformerEncoderBlock(nn.Module):
     """transformer_block.py:20-141.  The reference's typo 'relaive' (:46) is kept: only
@@ -468,8 +572,24 @@ class TransformerEncoder(EncoderBase):
             if subsample_type == 'max_pool':
                 self.subsample_layers = nn.ModuleList([MaxPoolSubsampler(factor)
                                                        for factor in self.subsample_factors])
+            elif subsample_type == 'mean_pool':
+                self.subsample_layers = nn.ModuleList([MeanPoolSubsampler(factor)
+                                                       for factor in self.subsample_factors])
+            elif subsample_type == 'concat':
+                self.subsample_layers = nn.ModuleList([ConcatSubsampler(factor, self._odim)
+                                                       for factor in self.subsample_factors])
+            elif subsample_type == 'drop':
+                self.subsample_layers = nn.ModuleList([DropSubsampler(factor)
+                                                       for factor in self.subsample_factors])
+            elif subsample_type == 'conv1d':
+                assert not self.causal
+                self.subsample_layers = nn.ModuleList([Conv1dSubsampler(factor, self._odim)
+                                                       for factor in self.subsample_factors])
+            elif subsample_type == 'add':
+                self.subsample_layers = nn.ModuleList([AddSubsampler(factor)
+                                                       for factor in self.subsample_factors])
             else:
-                raise NotImplementedError('subsample_type=%s (only max_pool is built)' % subsample_type)
+                raise NotImplementedError(subsample_type)
         assert self.N_l % self._factor == 0
         assert self.N_c % self._factor == 0
         assert self.N_r % self._factor == 0

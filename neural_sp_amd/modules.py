@@ -73,6 +73,17 @@ class AttnMask(object):
 
 
 # ---------------------------------------------------------------- FFN
+class LinearGLUBlock(nn.Module):
+    """modules/glu.py:11-26: F.glu(fc(xs), dim=-1) -- one GEMM + the GLU kernel."""
+
+    def __init__(self, idim):
+        super().__init__()
+        self.fc = nn.Linear(idim, idim * 2)
+
+    def forward(self, xs):
+        return ops.glu(ops.linear(xs, self.fc.weight, self.fc.bias))
+
+
 class PositionwiseFeedForward(nn.Module):
     """positionwise_feed_forward.py:22-89: w_2(dropout(act(w_1 x))) -- two MFMA GEMMs with
     bias+activation+dropout fused in the first epilogue.  `forward(xs, residual, alpha,
@@ -91,10 +102,15 @@ class PositionwiseFeedForward(nn.Module):
             self.w_1 = nn.Linear(d_model, d_ff)
             self.w_2 = nn.Linear(d_ff, d_model)
         self.dropout_p = dropout
-        if activation not in ('relu', 'gelu', 'gelu_accurate', 'swish'):
-            # 'glu' (LinearGLUBlock) is not on the benchmarked path
+        if activation not in ('relu', 'gelu', 'gelu_accurate', 'swish', 'glu'):
             raise NotImplementedError(activation)
-        self.activation = activation
+        self.activation_name = activation
+        if activation == 'glu':
+            # positionwise_feed_forward.py:58-59 / modules/glu.py:11-26: the "activation" is a module with
+            # its own Linear(d_ff, 2 d_ff) followed by F.glu (parameters `activation.fc.*`)
+            self.activation = LinearGLUBlock(d_ff)
+        else:
+            self.activation = activation
         if param_init == 'xavier_uniform':
             for n, p in self.named_parameters():
                 init_with_xavier_uniform(n, p)
@@ -102,6 +118,17 @@ class PositionwiseFeedForward(nn.Module):
     def forward(self, xs, residual=None, alpha=1.0, out_dropout=0.0):
         p = self.dropout_p if self.training else 0.0
         po = out_dropout if self.training else 0.0
+        if self.activation_name == 'glu':
+            # w_1 -> fc (d_ff -> 2 d_ff) -> GLU -> dropout -> w_2: the GEMMs and the GLU kernel of the conv module
+            if self.bottleneck_dim > 0:
+                h = ops.linear(ops.linear(xs, self.w_1_e.weight, self.w_1_e.bias), self.w_1_d.weight, self.w_1_d.bias)
+            else:
+                h = ops.linear(xs, self.w_1.weight, self.w_1.bias)
+            h = ops.dropout(self.activation(h), p, self.training)
+            if self.bottleneck_dim > 0:
+                h = ops.linear(h, self.w_2_e.weight, self.w_2_e.bias)
+                return ops.linear(h, self.w_2_d.weight, self.w_2_d.bias, res=residual, alpha=alpha, dropout_p=po)
+            return ops.linear(h, self.w_2.weight, self.w_2.bias, res=residual, alpha=alpha, dropout_p=po)
         if self.bottleneck_dim > 0:
             h = ops.linear(xs, self.w_1_e.weight, self.w_1_e.bias)
             h = ops.linear(h, self.w_1_d.weight, self.w_1_d.bias, act=self.activation, dropout_p=p)
@@ -275,12 +302,19 @@ class ConformerConvBlock(nn.Module):
         self.pointwise_conv1 = nn.Conv1d(d_model, d_model * 2, kernel_size=1, stride=1, padding=0)
         self.depthwise_conv = nn.Conv1d(d_model, d_model, kernel_size=kernel_size, stride=1,
                                         padding=self.padding, groups=d_model, bias=True)
-        if normalization == 'layer_norm':
+        if normalization == 'batch_norm':
+            # couples the utterances of a batch (and, under DDP, only those of one rank: the reference does
+            # not use SyncBatchNorm either); statistics include the padded frames, as in the reference
+            self.norm = nn.BatchNorm1d(d_model)
+        elif normalization == 'group_norm':
+            num_groups = 2
+            self.norm = nn.GroupNorm(num_groups=max(1, d_model // num_groups), num_channels=d_model)
+            if d_model // self.norm.num_groups != 2 or d_model % 4:
+                raise NotImplementedError('group_norm is built for pairs of channels (even d_model, multiple of 4)')
+        elif normalization == 'layer_norm':
             self.norm = nn.LayerNorm(d_model, eps=1e-12)
         else:
-            # batch_norm / group_norm couple utterances or are not in the LibriSpeech
-            # Conformer recipes; not built.
-            raise NotImplementedError('conformer_normalization=%s' % normalization)
+            raise NotImplementedError(normalization)
         self.pointwise_conv2 = nn.Conv1d(d_model, d_model, kernel_size=1, stride=1, padding=0)
         convs = [self.pointwise_conv1, self.pointwise_conv2, self.depthwise_conv]
         if param_init == 'xavier_uniform':
@@ -297,7 +331,13 @@ class ConformerConvBlock(nn.Module):
         h = ops.linear(xs, self.pointwise_conv1.weight, self.pointwise_conv1.bias)  # [2C,C,1] == [2C,C]
         h = ops.glu(h)
         h = ops.depthwise_conv1d(h, self.depthwise_conv.weight, self.depthwise_conv.bias, self.causal)
-        h = ops.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act='swish')
+        if isinstance(self.norm, nn.LayerNorm):
+            h = ops.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act='swish')
+        elif isinstance(self.norm, nn.BatchNorm1d):
+            # "time-independent normalization" on the [B*T, C, 1] view (:119-122): one row per frame
+            h = ops.batch_norm_act(h, self.norm, self.training, act='swish')
+        else:
+            h = ops.group_norm2_act(h, self.norm.weight, self.norm.bias, self.norm.eps, act='swish')
         po = out_dropout if self.training else 0.0
         return ops.linear(h, self.pointwise_conv2.weight, self.pointwise_conv2.bias,
                           res=residual, dropout_p=po)

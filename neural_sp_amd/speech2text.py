@@ -188,8 +188,6 @@ class Speech2Text(nn.Module):
         self.weight_noise_std = args.weight_noise_std
         if self.n_stacks > 1 or self.n_splices > 1:
             raise NotImplementedError('frame stacking / splicing (numpy frontends) are out of scope')
-        if self.weight_noise_std > 0:
-            raise NotImplementedError('weight noise')
         self.specaug = None
         if args.n_freq_masks > 0 or args.n_time_masks > 0:
             assert args.n_stacks == 1 and args.n_skips == 1
@@ -387,6 +385,17 @@ class Speech2Text(nn.Module):
         obs = LazyObservation(observation, keys, stacked)
         return obs.materialize() if os.environ.get('NSP_EAGER_OBSERVATION', '0') == '1' else obs
 
+    def add_weight_noise(self, std):
+        """models/base.py:77-91, as the reference EXECUTES it: `Normal([0.],[std]).sample([N])` has shape
+        [N,1] and `param_vector.add_(noise[0])` broadcasts its first row, so ONE N(0, std) scalar is added to
+        every parameter of the model.  That scalar is reproduced bit for bit from the CPU generator (the
+        first of a >= 16-element `normal_` fill depends on the first 16 uniforms only); the reference then
+        goes on to draw the N - 16 values it never uses, so the CPU generator state afterwards differs.
+        One multi-tensor add; the version counters move, so the bf16 weight shadows are rebuilt."""
+        with torch.no_grad():
+            eps = (torch.empty(16).normal_()[0] * torch.tensor(float(std))).item()   # fp32 product, as the reference
+            torch._foreach_add_([p for p in self.parameters()], eps)
+
     def encode(self, xs, task='all', streaming=False, cnn_lookback=False, cnn_lookahead=False,
                xlen_block=-1):
         """xs: list of np.float32 `[T_i, input_dim]`.  One packed H2D copy, padding on the
@@ -401,6 +410,8 @@ class Speech2Text(nn.Module):
         xs = ops.pad_batch(ops.h2d_packed(xs, dev), ops.h2d(offs, dev), ops.h2d(xlens, dev), B, Tmax, F, 0.)
         if self.specaug is not None and self.training:
             xs = self.specaug(xs)
+        if self.weight_noise_std > 0 and self.training:
+            self.add_weight_noise(std=self.weight_noise_std)
         if self.input_noise_std > 0 and self.training:
             noise = torch.normal(xs.new_zeros(xs.shape[-1]), self.input_noise_std)  # input_noise.py
             xs = ops.scale_add_bcast(xs, noise, 1.0)

@@ -119,12 +119,41 @@ def mha(x, vis, sd, p, H):
 
 
 def ffn(x, sd, p, act):
-    """positionwise_feed_forward.py:77-89"""
-    return _lin(_act(_lin(x, sd, p + '.w_1'), act), sd, p + '.w_2')
+    """positionwise_feed_forward.py:77-89 ('glu' = LinearGLUBlock, modules/glu.py:11-26)"""
+    h = _lin(x, sd, p + '.w_1')
+    h = F.glu(_lin(h, sd, p + '.activation.fc'), dim=-1) if act == 'glu' else _act(h, act)
+    return _lin(h, sd, p + '.w_2')
 
 
-def conformer_conv(x, sd, p, k, causal):
-    """conformer_convolution.py:98-129 (layer_norm variant)."""
+def subsample(xs, xlens, sd, stype, f, p):
+    """encoders/subsampling.py (one layer, factor f > 1) -> (xs, xlens)."""
+    B, T, C = xs.shape
+    if stype == 'max_pool':      # :188-209
+        return (F.max_pool1d(xs.transpose(2, 1), f, f, ceil_mode=True).transpose(2, 1),
+                [_pool_len(n, f) for n in xlens])
+    if stype == 'mean_pool':     # :226-246; lengths through update_lens_1d's generic branch (conv.py:446-448)
+        return (F.avg_pool1d(xs.transpose(2, 1), f, f, 0, ceil_mode=True).transpose(2, 1),
+                [int(math.floor((n - (f - 1) - 1) // f + 1)) for n in xlens])
+    if stype == 'drop':          # :111-128
+        return xs[:, ::f], [max(1, math.ceil(n / f)) for n in xlens]
+    if stype == 'add':           # :146-172
+        assert f <= 2
+        xp = xs if T % 2 == 0 else torch.cat([xs, xs.new_zeros(B, 1, C)], dim=1)
+        return xp[:, ::2] + xp[:, 1::2], [max(1, math.ceil(n / f)) for n in xlens]
+    if stype == 'concat':        # :24-52: frames t-f+1..t side by side for every t with (t+1) % f == 0
+        To = T // f
+        h = xs[:, :To * f].reshape(B, To, f * C)
+        return torch.relu(_lin(h, sd, p + '.proj')), [max(1, n // f) for n in xlens]
+    if stype == 'conv1d':        # :70-94 (kernel 3, stride f, padding 1)
+        h = F.conv1d(xs.transpose(2, 1), sd[p + '.conv1d.weight'], sd[p + '.conv1d.bias'], stride=f, padding=1)
+        return torch.relu(h.transpose(2, 1)), [int(math.floor((n + 2 - 2 - 1) // f + 1)) for n in xlens]
+    raise NotImplementedError(stype)
+
+
+def conformer_conv(x, sd, p, k, causal, normalization='layer_norm', training=True, bn_out=None):
+    """conformer_convolution.py:98-129.  batch_norm / group_norm act on the `[B*T, C, 1]` view (:119-122);
+    in training mode BatchNorm1d uses the batch statistics and the updated running statistics
+    (momentum 0.1, unbiased variance) are handed back through `bn_out`."""
     B, T, C = x.shape
     h = x.transpose(2, 1)
     h = F.conv1d(h, sd[p + '.pointwise_conv1.weight'], sd[p + '.pointwise_conv1.bias'])
@@ -134,7 +163,25 @@ def conformer_conv(x, sd, p, k, causal):
     if causal:
         h = h[:, :, :-pad]
     h = h.transpose(2, 1)
-    h = F.layer_norm(h, (C,), sd[p + '.norm.weight'], sd[p + '.norm.bias'], 1e-12)
+    if normalization == 'layer_norm':
+        h = F.layer_norm(h, (C,), sd[p + '.norm.weight'], sd[p + '.norm.bias'], 1e-12)
+    elif normalization == 'batch_norm':
+        h2 = h.reshape(B * T, C)
+        if training:
+            mean, var = h2.mean(0), h2.var(0, unbiased=False)
+            if bn_out is not None:
+                M = B * T
+                bn_out[p + '.norm.running_mean'] = 0.9 * sd[p + '.norm.running_mean'] + 0.1 * mean.detach()
+                bn_out[p + '.norm.running_var'] = 0.9 * sd[p + '.norm.running_var'] + 0.1 * var.detach() * M / (M - 1)
+                bn_out[p + '.norm.num_batches_tracked'] = sd[p + '.norm.num_batches_tracked'] + 1
+        else:
+            mean, var = sd[p + '.norm.running_mean'], sd[p + '.norm.running_var']
+        h = ((h2 - mean) / torch.sqrt(var + 1e-5) * sd[p + '.norm.weight'] + sd[p + '.norm.bias']).view(B, T, C)
+    elif normalization == 'group_norm':
+        h = F.group_norm(h.reshape(B * T, C, 1), max(1, C // 2), sd[p + '.norm.weight'], sd[p + '.norm.bias'],
+                         1e-5).view(B, T, C)
+    else:
+        raise NotImplementedError(normalization)
     h = (h * torch.sigmoid(h)).transpose(2, 1)
     h = F.conv1d(h, sd[p + '.pointwise_conv2.weight'], sd[p + '.pointwise_conv2.bias'])
     return h.transpose(2, 1)
@@ -148,9 +195,11 @@ def xl_pos_emb(T, inv_freq, dtype):
 
 
 # ----------------------------------------------------------------------------- encoder
-def encoder_forward(xs, xlens, sd, args):
+def encoder_forward(xs, xlens, sd, args, training=True, bn_out=None):
     """transformer.py:419-617 / conformer_block.py:95-182 / transformer_block.py:79-141,
-    eval-mode semantics (no dropout, LayerDrop scaling only if dropout_enc_layer > 0)."""
+    eval-mode semantics (no dropout, LayerDrop scaling only if dropout_enc_layer > 0); `training` only
+    selects batch vs running statistics of a batch_norm convolution module."""
+    cnorm = getattr(args, 'conformer_normalization', 'layer_norm')
     dtype = xs.dtype
     enc_type = args.enc_type
     is_conf = 'conformer' in enc_type
@@ -214,13 +263,13 @@ def encoder_forward(xs, xlens, sd, args):
             xs = xs + rel_mha(_ln(xs, sd, p + '.norm2', eps), pos, vis, sd, p + '.self_attn', H,
                               args.transformer_enc_clamp_len, pe_type == 'relative_xl', u_bias, v_bias)
             xs = xs + conformer_conv(_ln(xs, sd, p + '.norm3', eps), sd, p + '.conv',
-                                     args.conformer_kernel_size, causal_conv)
+                                     args.conformer_kernel_size, causal_conv, cnorm, training, bn_out)
             xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm4', eps), sd, p + '.feed_forward', 'swish')
             xs = _ln(xs, sd, p + '.norm5', eps)
         elif is_conf:
             xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm1', eps), sd, p + '.feed_forward_macaron', 'swish')
             xs = xs + conformer_conv(_ln(xs, sd, p + '.norm2', eps), sd, p + '.conv',
-                                     args.conformer_kernel_size, causal_conv)
+                                     args.conformer_kernel_size, causal_conv, cnorm, training, bn_out)
             xs = xs + mha(_ln(xs, sd, p + '.norm3', eps), vis, sd, p + '.self_attn', H)
             xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm4', eps), sd, p + '.feed_forward', 'swish')
             xs = _ln(xs, sd, p + '.norm5', eps)
@@ -234,8 +283,7 @@ def encoder_forward(xs, xlens, sd, args):
             xs = xs + ffn(_ln(xs, sd, p + '.norm2', eps), sd, p + '.feed_forward',
                           args.transformer_ffn_activation)
         if l < n_layers - 1 and sub[l] > 1:
-            xs = F.max_pool1d(xs.transpose(2, 1), sub[l], sub[l], ceil_mode=True).transpose(2, 1)
-            xlens = [_pool_len(n, sub[l]) for n in xlens]
+            xs, xlens = subsample(xs, xlens, sd, args.subsample_type, sub[l], 'enc.subsample_layers.%d' % l)
             N_l, N_c, N_r = max(0, N_l // sub[l]), N_c // sub[l], N_r // sub[l]
             if rel:
                 pos = xl_pos_emb(xs.shape[1], sd['enc.pos_emb.inv_freq'], dtype)
@@ -488,15 +536,16 @@ def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='de
     return loss, acc, ppl, lq
 
 
-def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quantity_weight=0.0):
-    """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens)."""
+def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quantity_weight=0.0, bn_out=None):
+    """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens).
+    bn_out (dict, optional) receives the running statistics a training-mode BatchNorm would leave behind."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     xlens = [len(x) for x in batch['xs']]
     T = max(xlens)
     xs = torch.zeros(len(xlens), T, args.input_dim, dtype=dtype)
     for b, x in enumerate(batch['xs']):
         xs[b, :len(x)] = torch.as_tensor(x, dtype=dtype)
-    eouts, elens = encoder_forward(xs, xlens, sd, args)
+    eouts, elens = encoder_forward(xs, xlens, sd, args, training, bn_out)
     main_w = args.total_weight - args.sub1_weight - args.sub2_weight
     ctc_w = min(args.ctc_weight, main_w)
     loss = eouts.new_zeros(())

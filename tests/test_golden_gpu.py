@@ -23,6 +23,18 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt')))
 
 
+# bf16-mode loss gate: the north-star bar (1e-3) everywhere, except where rounding the GEMM operands to bf16 ALONE
+# (tools/bf16_sensitivity.py: the fp64 oracle with bf16-rounded Linear operands, no GPU involved) already moves the
+# fixture's loss by more: ConcatSubsampler's un-normalised ReLU(Linear(3d -> d)) with torch's default init gives
+# 1.2e-3 .. 1.5e-3 for every seed and batch size tried.
+BF16_LOSS_GATE = {'conformer_concat_ctc_xs': 3e-3}
+# fp32-mode gradient gate (fraction of each tensor's max): 2e-3 for every fixture.  Fixtures may list a wider one here when
+# the REFERENCE's own fp32 gradients (the fixture) sit far from the fp64 oracle (tools/bf16_sensitivity.py, last column)
+# because fp32 rounding decided a max-pool arg-max / ReLU mask in the front-end (tools/fixture_tie_check.py); the
+# variant fixtures were re-seeded until that distance was <= 6e-5, so none needs it today.
+FP32_GRAD_GATE = {}
+
+
 def _load(name):
     return torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
 
@@ -74,7 +86,13 @@ def test_golden_fp32(name):
     gmax = _robust_gmax(fix['grads'])
     err = {n: ((grads[n] - g).abs().max() / max(g.abs().max().item(), 1e-5 * gmax)).item()
            for n, g in fix['grads'].items()}
-    bad = {n: e for n, e in err.items() if e > 2e-3}
+    if fix['args'].get('conformer_normalization') == 'batch_norm':
+        # BatchNorm removes a per-channel shift, so the depthwise-conv bias has a true gradient of ZERO: both sides
+        # hold only the rounding noise of a sum over all frames (reference: 6e-6 against tensor maxima of ~40)
+        for n in [n for n in err if n.endswith('.conv.depthwise_conv.bias')]:
+            assert grads[n].abs().max() < 1e-4 * gmax and fix['grads'][n].abs().max() < 1e-4 * gmax, n
+            del err[n]
+    bad = {n: e for n, e in err.items() if e > FP32_GRAD_GATE.get(name, 2e-3)}
     assert not bad, (max(err.values()), bad)
 
 
@@ -83,7 +101,7 @@ def test_golden_bf16(name):
     fix = _load(name)
     loss, obs, eout, elens, grads, _ = _run(fix, 'bf16')
     ref = fix['loss'].item()
-    assert abs(loss - ref) / abs(ref) < 1e-3, (loss, ref)
+    assert abs(loss - ref) / abs(ref) < BF16_LOSS_GATE.get(name, 1e-3), (loss, ref)
     cos = {}
     gmax = _robust_gmax(fix['grads'])
     for n, g in fix['grads'].items():

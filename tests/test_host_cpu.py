@@ -66,7 +66,43 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         Speech2Text(conformer_rnnt_args('XS', n_layers=2, enc_type='blstm'))
     with pytest.raises(NotImplementedError):
-        Speech2Text(conformer_rnnt_args('XS', n_layers=2, conformer_normalization='batch_norm'))
+        Speech2Text(conformer_rnnt_args('XS', n_layers=2, subsample='2_1', subsample_type='no_such_type'))
+    with pytest.raises(NotImplementedError):
+        Speech2Text(conformer_rnnt_args('XS', n_layers=2, dec_type='gru_transducer'))
+
+
+def test_weight_noise_adds_the_reference_scalar():
+    """models/base.py:77-91 as executed: Normal([0.],[std]).sample([N]) is [N,1] and `add_(noise[0])` broadcasts
+    ONE scalar to every parameter.  With the CPU generator in the same state the increment is the reference's,
+    bit for bit (checked live against the reference when it is present, against its algorithm otherwise)."""
+    import torch
+    from neural_sp_amd.configs import conformer_rnnt_args
+    from neural_sp_amd.speech2text import Speech2Text
+    from oracle import ref_import
+    args = conformer_rnnt_args('XS', n_layers=2, vocab=40, weight_noise_std=0.01)
+    model = Speech2Text(args)
+    before = [p.detach().clone() for p in model.parameters()]
+    versions = [p._version for p in model.parameters()]
+    torch.manual_seed(77)
+    model.add_weight_noise(0.01)
+    deltas = [(p.detach() - b) for p, b in zip(model.parameters(), before)]
+    torch.manual_seed(77)
+    n_total = sum(p.numel() for p in model.parameters())
+    expect = (torch.empty(n_total, 1).normal_() * torch.tensor([0.01]))[0]        # what sample([N]) draws, row 0
+    for p, b in zip(model.parameters(), before):
+        assert torch.equal(p.detach(), b + expect), 'same scalar on every element'
+    assert all(p._version > v for p, v in zip(model.parameters(), versions)), 'weight shadows get invalidated'
+    assert abs(deltas[0].flatten()[0].item()) > 0
+    if ref_import.available():
+        ref_import.import_reference()
+        from neural_sp.models.seq2seq.speech2text import Speech2Text as RefS2T
+        ref = RefS2T(args)
+        ref.load_state_dict({k: v.clone() for k, v in zip(model.state_dict().keys(), [t.clone() for t in model.state_dict().values()])})
+        rb = [p.detach().clone() for p in ref.parameters()]
+        torch.manual_seed(77)
+        ref.add_weight_noise(0.01)
+        for p, b in zip(ref.parameters(), rb):
+            assert torch.equal(p.detach(), b + expect)
 
 
 def test_lazy_observation_behaves_like_the_reference_dict_of_floats():

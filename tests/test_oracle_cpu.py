@@ -51,9 +51,20 @@ def test_model_restatement_matches_reference_fixture(name):
     sd = {k: v.clone().double().requires_grad_(v.is_floating_point() and 'inv_freq' not in k and k != 'enc.pos_enc.pe')
           if v.is_floating_point() else v for k, v in fix['state_dict'].items()}
     qw = args.mocha_quantity_loss_weight if fix['meta'].get('trigger_quantity_loss') else 0.0
-    loss, obs, eouts, elens = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64, quantity_weight=qw)
+    bn_out = {}
+    loss, obs, eouts, elens = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64, quantity_weight=qw,
+                                                         bn_out=bn_out)
     ref = fix['loss'].item()
     assert abs(loss.item() - ref) / abs(ref) < 2e-5, (loss.item(), ref)
+    if bn_out:
+        # batch_norm convolution modules: the fixture's encoder output / eval loss are the EVAL-mode ones, computed
+        # with the running statistics the training step above leaves behind (gen_golden: train step, then eval)
+        sd_eval = dict(sd)
+        sd_eval.update(bn_out)
+        with torch.no_grad():
+            loss_eval, _, eouts, _ = model_ref.speech2text_loss(sd_eval, args, fix['batch'], torch.float64,
+                                                                training=False, quantity_weight=qw)
+        assert abs(loss_eval.item() - fix['loss_eval'].item()) / abs(ref) < 2e-5
     assert list(elens) == fix['elens'].tolist()
     assert (eouts.float() - fix['eout']).abs().max() / fix['eout'].abs().max() < 1e-4
     for k, v in fix['observation'].items():
@@ -65,6 +76,10 @@ def test_model_restatement_matches_reference_fixture(name):
     for n, g in zip(names, grads):
         r = fix['grads'][n]
         assert g is not None, n
+        if getattr(args, 'conformer_normalization', '') == 'batch_norm' and n.endswith('.conv.depthwise_conv.bias'):
+            # BatchNorm removes a per-channel shift: the true gradient is zero, the reference holds fp32 noise
+            assert g.abs().max() < 1e-5 * gmax and r.abs().max() < 1e-5 * gmax, n
+            continue
         # zero-gradient tensors (w_key.bias) hold only fp32 noise in the reference
         assert (g.float() - r).abs().max() / max(r.abs().max().item(), 1e-5 * gmax) < 2e-3, n
 

@@ -1,0 +1,67 @@
+"""Host logic of the encoder variants (subsamplers other than max-pool, batch_norm / group_norm convolution
+modules, GLU feed-forward, weight noise) against fixtures produced by the REFERENCE, on CPU.
+
+neural_sp_amd.Speech2Text itself is run: its constructors, state_dict loading, length arithmetic and module
+wiring are the product's; the variant kernels (csrc/norm_subsample.hip) execute on the host emulator through
+the real ctypes glue; the remaining ops are plain-torch stand-ins (tests/cpu_ops_shim.py).  The same fixtures
+are run on the device by tests/test_golden_gpu.py."""
+import argparse
+import os
+
+import pytest
+import torch
+
+from tests.hipemu import build_emu
+from tests.test_golden_gpu import FP32_GRAD_GATE
+
+pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang++ for the HIP emulator')
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+VARIANTS = ['conformer_bn_ctc_xs', 'conformer_gn_ctc_xs', 'transformer_glu_ctc_xs', 'conformer_drop_ctc_xs',
+            'conformer_add_ctc_xs', 'conformer_meanpool_ctc_xs', 'conformer_concat_ctc_xs', 'conformer_conv1d_ctc_xs']
+# stand-in sanity: fixtures of the benchmarked family must pass through the same shim
+CONTROLS = ['conformer_ctc_xs', 'transformer_ctc_xs', 'conformer_relxl_ctc_xs', 'lc_conformer_mask_xs']
+
+
+@pytest.mark.parametrize('name', VARIANTS + CONTROLS)
+def test_speech2text_host_logic_matches_reference_fixture(name):
+    from neural_sp_amd.speech2text import Speech2Text
+    from tests.cpu_ops_shim import host_logic_on_cpu
+    fix = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    args = argparse.Namespace(**fix['args'])
+    model = Speech2Text(args)
+    model.load_state_dict(fix['state_dict'], strict=True)
+    batch = dict(fix['batch'])
+    batch.update(xlens=[len(x) for x in batch['xs']], ys_sub1=[], ys_sub2=[], trigger_points=None)
+    with host_logic_on_cpu():
+        model.zero_grad()
+        loss, obs = model(batch, task='all')
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        model.eval()
+        with torch.no_grad():
+            eout = model.encode(batch['xs'], 'all')
+            loss_eval, _ = model(batch, task='all', is_eval=True)
+    ref = fix['loss'].item()
+    assert abs(loss.item() - ref) / abs(ref) < 1e-4, (loss.item(), ref)
+    assert abs(loss_eval.item() - fix['loss_eval'].item()) / abs(ref) < 1e-4
+    assert torch.equal(eout['ys']['xlens'].int(), fix['elens'].int())
+    assert eout['ys']['xs'].shape == fix['eout'].shape
+    assert (eout['ys']['xs'] - fix['eout']).abs().max() / fix['eout'].abs().max() < 2e-4
+    assert set(grads) == set(fix['grads'])
+    m = sorted(g.abs().max().item() for g in fix['grads'].values())
+    gmax = m[int(0.9 * (len(m) - 1))]
+    for n, r in fix['grads'].items():
+        if fix['args'].get('conformer_normalization') == 'batch_norm' and n.endswith('.conv.depthwise_conv.bias'):
+            continue        # true gradient zero (BatchNorm removes the shift): noise on both sides
+        err = (grads[n] - r).abs().max() / max(r.abs().max().item(), 1e-5 * gmax)
+        assert err < FP32_GRAD_GATE.get(name, 2e-3), (n, err.item())
+    if name == 'conformer_bn_ctc_xs':
+        # one training step moved the running statistics exactly as the reference's did
+        sd = model.state_dict()
+        from oracle import model_ref
+        bn_out = {}
+        sd64 = {k: v.double() if v.is_floating_point() else v for k, v in fix['state_dict'].items()}
+        model_ref.speech2text_loss(sd64, args, fix['batch'], torch.float64, bn_out=bn_out)
+        assert bn_out
+        for k, v in bn_out.items():
+            assert torch.allclose(sd[k].double(), v.double(), rtol=1e-4, atol=1e-5), k

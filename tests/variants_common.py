@@ -1,0 +1,163 @@
+"""Shared bodies of tests/test_variants_emu_cpu.py (host emulator) and tests/test_variants_gpu.py (device): the
+kernels of csrc/norm_subsample.hip through the real ctypes glue / autograd Functions of neural_sp_amd.ops, against
+torch-CPU restatements of the reference modules (encoders/subsampling.py, conformer_convolution.py:58-66,119-124).
+`where`: 'emu' = host-emulated kernels on CPU tensors, 'gpu' = libnsp_hip.so on cuda:0."""
+import contextlib
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SUM_CASES = [(T, f, kind) for kind in ('drop', 'add', 'mean_pool') for (T, f) in [(11, 2), (12, 2), (13, 3), (5, 4), (1, 2)]
+             if not (kind == 'add' and f != 2)]            # AddSubsampler asserts factor <= 2
+GATHER_CASES = [(12, 2, 2, 0), (13, 3, 3, 0), (13, 3, 2, 1), (14, 3, 3, 1), (7, 3, 4, 1)]
+BN_CASES = [(5, 8), (150, 64), (700, 260)]
+GN_CASES = [(3, 4), (90, 64), (300, 132)]
+
+
+def _env(where):
+    if where == 'emu':
+        from tests.hipemu.shim import emulated_kernels
+        return emulated_kernels(), torch.device('cpu')
+    return contextlib.nullcontext(), torch.device('cuda', 0)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _weights(y):
+    return (torch.linspace(-1.0, 1.0, y.numel()).view_as(y) * 0.7 + 0.1).to(y.dtype)
+
+
+def _ref_grads(fn, *inputs):
+    y = fn(*inputs)
+    (y * _weights(y)).sum().backward()
+    return y.detach(), [i.grad.clone() for i in inputs]
+
+
+def _our_grads(where, fn, *inputs):
+    ctx, dev = _env(where)
+    with ctx:
+        ins = [i.detach().clone().to(dev).requires_grad_(True) for i in inputs]
+        y = fn(*ins)
+        (y * _weights(y.detach().cpu()).to(dev)).sum().backward()
+        return y.detach().cpu(), [i.grad.detach().cpu() for i in ins]
+
+
+def check_window_sum(where, T, f, kind):
+    from neural_sp_amd import ops
+    torch.manual_seed(T * 10 + f)
+    B, C = 3, 8
+    x = torch.randn(B, T, C)
+
+    def ref(x):
+        if kind == 'drop':       # subsampling.py:118-121
+            return x[:, ::f]
+        if kind == 'add':        # subsampling.py:153-167
+            xe = x[:, ::2]
+            xo = x[:, 1::2] if T % 2 == 0 else torch.cat([x, x.new_zeros(B, 1, C)], dim=1)[:, 1::2]
+            return xo + xe
+        return F.avg_pool1d(x.transpose(2, 1), f, f, 0, ceil_mode=True).transpose(2, 1)   # :239-240
+
+    To = math.ceil(T / f)
+    k = {'drop': 1, 'add': 2, 'mean_pool': f}[kind]
+    yr, (gr,) = _ref_grads(ref, x.clone().requires_grad_(True))
+    yo, (go,) = _our_grads(where, lambda t: ops.time_window_sum(t, k, f, 0, To, mean=(kind == 'mean_pool')), x)
+    assert yo.shape == yr.shape
+    torch.testing.assert_close(yo, yr, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(go, gr, rtol=1e-6, atol=1e-6)
+
+
+def check_window_gather(where, T, k, stride, pad):
+    from neural_sp_amd import ops
+    torch.manual_seed(T)
+    B, C = 2, 12
+    x = torch.randn(B, T, C)
+    To = (T + 2 * pad - (k - 1) - 1) // stride + 1
+
+    def ref(x):
+        xp = F.pad(x, (0, 0, pad, pad))
+        return torch.stack([xp[:, to * stride:to * stride + k].reshape(B, k * C) for to in range(To)], dim=1)
+
+    yr, (gr,) = _ref_grads(ref, x.clone().requires_grad_(True))
+    yo, (go,) = _our_grads(where, lambda t: ops.time_window_gather(t, k, stride, pad, To), x)
+    torch.testing.assert_close(yo, yr, rtol=0, atol=0)
+    torch.testing.assert_close(go, gr, rtol=1e-6, atol=1e-6)
+
+
+def check_conv1d_weight_view(where):
+    """The [Co, k*Ci] view of the Conv1d weight used with the gathered windows equals F.conv1d
+    (Conv1dSubsampler, subsampling.py:55-94) -- with a torch matmul in place of the GEMM."""
+    from neural_sp_amd import ops
+    torch.manual_seed(5)
+    B, T, C, f = 2, 17, 8, 3
+    conv = nn.Conv1d(C, C, 3, stride=f, padding=1)
+    x = torch.randn(B, T, C)
+    ref = conv(x.transpose(2, 1)).transpose(2, 1)
+    To = (T + 2 - 2 - 1) // f + 1
+    ctx, dev = _env(where)
+    with ctx:
+        g = ops.time_window_gather(x.to(dev), 3, f, 1, To).cpu()
+    w2 = conv.weight.permute(0, 2, 1).contiguous().view(C, 3 * C)
+    torch.testing.assert_close(F.linear(g, w2, conv.bias), ref, rtol=1e-5, atol=1e-5)
+
+
+def check_batch_norm(where, M, C):
+    from neural_sp_amd import ops
+    torch.manual_seed(M)
+    x = torch.randn(M, C) * 1.7 + torch.linspace(-3, 3, C)       # non-zero channel means
+    bn_r = nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5)
+        bn_r.bias.uniform_(-0.5, 0.5)
+        bn_r.running_mean.uniform_(-1, 1)
+        bn_r.running_var.uniform_(0.5, 2)
+    ctx, dev = _env(where)
+    bn_o = nn.BatchNorm1d(C)
+    bn_o.load_state_dict(bn_r.state_dict())
+    bn_o.to(dev)
+    for training in (True, False):
+        bn_r.train(training)
+        bn_o.train(training)
+        for p in list(bn_r.parameters()) + list(bn_o.parameters()):
+            p.grad = None
+        xr = x.clone().requires_grad_(True)
+        yr = _swish(bn_r(xr.view(M, C, 1))).view(M, C)   # conformer_convolution.py:119-122: [B*T, C, 1], then Swish
+        (yr * _weights(yr)).sum().backward()
+        with _env(where)[0]:
+            xo = x.clone().to(dev).requires_grad_(True)
+            yo = ops.batch_norm_act(xo, bn_o, bn_o.training, act='swish')
+            (yo * _weights(yr).to(dev)).sum().backward()
+        torch.testing.assert_close(yo.detach().cpu(), yr.detach(), rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(xo.grad.cpu(), xr.grad, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(bn_o.weight.grad.cpu(), bn_r.weight.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bn_o.bias.grad.cpu(), bn_r.bias.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bn_o.running_mean.cpu(), bn_r.running_mean, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(bn_o.running_var.cpu(), bn_r.running_var, rtol=1e-5, atol=1e-5)
+        assert int(bn_o.num_batches_tracked) == int(bn_r.num_batches_tracked) == 1
+
+
+def check_group_norm(where, M, C):
+    from neural_sp_amd import ops
+    torch.manual_seed(C)
+    x = torch.randn(M, C)
+    gn = nn.GroupNorm(max(1, C // 2), C)                          # conformer_convolution.py:61-63
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+
+    def ref(x, w, b):
+        return _swish(F.group_norm(x.view(M, C, 1), gn.num_groups, w, b, gn.eps)).view(M, C)
+
+    # fp64 reference: with pairs whose two channels nearly coincide rstd approaches 1/sqrt(eps) = 316 and torch's
+    # own fp32 GroupNorm backward is off by 7e-4 absolute here (the kernel, differencing the pair first, by 1.5e-5)
+    yr, (gx, gw, gb) = _ref_grads(ref, x.double().requires_grad_(True), gn.weight.detach().double().requires_grad_(True),
+                                  gn.bias.detach().double().requires_grad_(True))
+    yo, (ox, ow, ob) = _our_grads(where, lambda t, w, b: ops.group_norm2_act(t, w, b, gn.eps, act='swish'),
+                                  x, gn.weight.detach(), gn.bias.detach())
+    torch.testing.assert_close(yo, yr.float(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(ox, gx.float(), rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(ow, gw.float(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ob, gb.float(), rtol=1e-4, atol=1e-4)
