@@ -1,15 +1,28 @@
 """csrc/norm_subsample.hip on the device (the bodies of tests/variants_common.py with where='gpu'), plus shapes the
-host emulator is too slow for.  The model-level parity of the variants is in tests/test_golden_gpu.py (fixtures
-conformer_{bn,gn,drop,add,meanpool,concat,conv1d}_ctc_xs, transformer_glu_ctc_xs).
+host emulator is too slow for, and the model-level parity of the variants against their reference-generated fixtures
+(conformer_{bn,gn,drop,add,meanpool,concat,conv1d}_ctc_xs, transformer_glu_ctc_xs) through the functions of
+tests/test_golden_gpu.py.
 
 NOTE (round 2): written after the round's GPU minutes were spent -- these tests had only run on the emulator
 (tests/test_variants_emu_cpu.py) when they were committed."""
 import pytest
 import torch
 
+from tests import test_golden_gpu as golden
 from tests import variants_common as vc
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', golden.VARIANT_CASES)
+def test_variant_golden_fp32(name):
+    """loss 1e-4, encoder output 2e-4 of max, every gradient 2e-3 of its max against the reference's fixture"""
+    golden.test_golden_fp32(name)
+
+
+@pytest.mark.parametrize('name', golden.VARIANT_CASES)
+def test_variant_golden_bf16(name):
+    golden.test_golden_bf16(name)
 
 
 @pytest.mark.parametrize('T,f,kind', vc.SUM_CASES + [(801, 3, 'drop'), (800, 2, 'add'), (799, 4, 'mean_pool')])

@@ -12,12 +12,11 @@ import pytest
 import torch
 
 from tests.hipemu import build_emu
-from tests.test_golden_gpu import FP32_GRAD_GATE
+from tests.test_golden_gpu import FP32_GRAD_GATE, VARIANT_CASES
 
 pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang++ for the HIP emulator')
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-VARIANTS = ['conformer_bn_ctc_xs', 'conformer_gn_ctc_xs', 'transformer_glu_ctc_xs', 'conformer_drop_ctc_xs',
-            'conformer_add_ctc_xs', 'conformer_meanpool_ctc_xs', 'conformer_concat_ctc_xs', 'conformer_conv1d_ctc_xs']
+VARIANTS = list(VARIANT_CASES)
 # stand-in sanity: fixtures of the benchmarked family must pass through the same shim
 CONTROLS = ['conformer_ctc_xs', 'transformer_ctc_xs', 'conformer_relxl_ctc_xs', 'lc_conformer_mask_xs']
 
