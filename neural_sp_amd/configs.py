@@ -122,9 +122,11 @@ def conformer_ctc_las_args(size='M', n_layers=12, vocab=10000, dropout=0.0, ctc_
     return argparse.Namespace(**a)
 
 
-def synthetic_batch(B, t_range, u_range, vocab, input_dim=80, seed=0):
+def synthetic_batch(B, t_range, u_range, vocab, input_dim=80, seed=0, vocab_sub1=0, vocab_sub2=0):
     """The batch dict of datasets/asr/build.py:73-105 filled with synthetic data of the shapes in
-    SURVEY.md section 8d: features ~ N(0,1), lengths uniform in the given ranges, labels ~ U[4,V)."""
+    SURVEY.md section 8d: features ~ N(0,1), lengths uniform in the given ranges, labels ~ U[4,V).
+    vocab_sub{1,2} > 0 add the transcripts of the auxiliary tasks (their own generator: the main stream of
+    random numbers, hence every existing batch, is unchanged)."""
     import numpy as np
     rng = np.random.RandomState(seed)
     tl = rng.randint(t_range[0], t_range[1] + 1, size=B)
@@ -132,7 +134,12 @@ def synthetic_batch(B, t_range, u_range, vocab, input_dim=80, seed=0):
     ul = rng.randint(u_range[0], u_range[1] + 1, size=B)
     xs = [rng.randn(int(t), input_dim).astype(np.float32) for t in tl]
     ys = [rng.randint(4, vocab, size=int(u)).tolist() for u in ul]
-    return {'xs': xs, 'xlens': [int(t) for t in tl], 'ys': ys, 'ys_sub1': [], 'ys_sub2': [],
+    subs = {}
+    for k, (name, v) in enumerate((('ys_sub1', vocab_sub1), ('ys_sub2', vocab_sub2))):
+        rs = np.random.RandomState(seed + 7919 * (k + 1))
+        subs[name] = [rs.randint(4, v, size=int(u)).tolist()
+                      for u in rs.randint(u_range[0], u_range[1] + 1, size=B)] if v > 0 else []
+    return {'xs': xs, 'xlens': [int(t) for t in tl], 'ys': ys, 'ys_sub1': subs['ys_sub1'], 'ys_sub2': subs['ys_sub2'],
             'utt_ids': ['utt%d' % i for i in range(B)], 'speakers': ['spk'] * B,
             'sessions': ['sess'] * B, 'text': [''] * B, 'feat_path': [''] * B,
             'trigger_points': None}

@@ -602,26 +602,51 @@ class TransformerEncoder(EncoderBase):
                 self.v_bias = nn.Parameter(torch.Tensor(n_heads, d_model // n_heads))
         else:
             self.pos_enc = PositionalEncoding(d_model, dropout_in, pe_type, param_init)
-        self.layers = self._make_layers(d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer,
-                                        layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
-                                        ffn_bottleneck_dim, n_layers)
+        mk = (d_model, d_ff, n_heads, dropout, dropout_att, layer_norm_eps, ffn_activation, param_init, pe_type,
+              clamp_len, ffn_bottleneck_dim)
+        self.layers = nn.ModuleList([copy.deepcopy(self._make_block(dropout_layer * (lth + 1) / n_layers, *mk))
+                                     for lth in range(n_layers)])
         self.norm_out = nn.LayerNorm(d_model, eps=layer_norm_eps)
         self._odim = d_model
-        if n_layers_sub1 > 0 or n_layers_sub2 > 0:
-            raise NotImplementedError('auxiliary-task outputs (sub1/sub2) are not on the benchmarked path')
+        # auxiliary-task outputs of hierarchical multi-task training (transformer.py:233-263, conformer.py:92-106):
+        # taken after layer n_layers_sub{1,2}, optionally through a task-specific extra block, then bridge / LayerNorm
+        for sub, n_sub in (('sub1', n_layers_sub1), ('sub2', n_layers_sub2)):
+            if n_sub > 0:
+                if task_specific_layer:
+                    setattr(self, 'layer_' + sub, self._make_block(dropout_layer * n_sub / n_layers, *mk))
+                odim_sub = d_model
+                if last_proj_dim > 0 and last_proj_dim != self.output_dim:
+                    setattr(self, 'bridge_' + sub, nn.Linear(self._odim, last_proj_dim))
+                    odim_sub = last_proj_dim
+                setattr(self, 'norm_out_' + sub,
+                        None if n_sub == n_layers else nn.LayerNorm(odim_sub, eps=layer_norm_eps))
         if last_proj_dim > 0 and last_proj_dim != self.output_dim:
             self.bridge = nn.Linear(self._odim, last_proj_dim)
             self._odim = last_proj_dim
         self.reset_parameters(param_init)
         self.reset_cache()
 
-    def _make_layers(self, d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer,
-                     layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
-                     ffn_bottleneck_dim, n_layers):
-        return nn.ModuleList([copy.deepcopy(TransformerEncoderBlock(
-            d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer * (lth + 1) / n_layers,
-            layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len, ffn_bottleneck_dim))
-            for lth in range(n_layers)])
+    def _make_block(self, dropout_layer, d_model, d_ff, n_heads, dropout, dropout_att, layer_norm_eps,
+                    ffn_activation, param_init, pe_type, clamp_len, ffn_bottleneck_dim):
+        return TransformerEncoderBlock(d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer,
+                                       layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
+                                       ffn_bottleneck_dim)
+
+    def sub_module(self, xs, xx_mask, lth, pos_embs=None, module='sub1'):
+        """transformer.py:619-630 (the task-specific block is called without the global u/v biases, as there)."""
+        xs_sub = xs
+        if self.task_specific_layer:
+            layer = getattr(self, 'layer_' + module)
+            xs_sub, _ = layer(xs, xx_mask, pos_embs=pos_embs)
+            if not self.training:
+                self.aws_dict['xx_aws_%s_layer%d' % (module, lth)] = layer.xx_aws
+        bridge = getattr(self, 'bridge_' + module)
+        if bridge is not None:
+            xs_sub = ops.linear(xs_sub, bridge.weight, bridge.bias)
+        norm = getattr(self, 'norm_out_' + module)
+        if norm is not None:
+            xs_sub = ops.layer_norm(xs_sub, norm.weight, norm.bias, norm.eps)
+        return xs_sub
 
     def reset_parameters(self, param_init):
         """transformer.py:346-364"""
@@ -629,9 +654,10 @@ class TransformerEncoder(EncoderBase):
             if self.conv is None:
                 nn.init.xavier_uniform_(self.embed.weight)
                 nn.init.constant_(self.embed.bias, 0.)
-            if self.bridge is not None:
-                nn.init.xavier_uniform_(self.bridge.weight)
-                nn.init.constant_(self.bridge.bias, 0.)
+            for bridge in (self.bridge, self.bridge_sub1, self.bridge_sub2):
+                if bridge is not None:
+                    nn.init.xavier_uniform_(bridge.weight)
+                    nn.init.constant_(bridge.bias, 0.)
             if self.pe_type == 'relative_xl':
                 nn.init.xavier_uniform_(self.u_bias)
                 nn.init.xavier_uniform_(self.v_bias)
@@ -713,6 +739,19 @@ class TransformerEncoder(EncoderBase):
                 if not self.training:
                     self.aws_dict['xx_aws_layer%d' % lth] = layer.xx_aws  # device tensor (plot on demand)
                     self.data_dict['elens%d' % lth] = xlens.numpy()
+                # outputs of the auxiliary tasks are picked up before the projection layer (transformer.py:568-580)
+                if lth == self.n_layers_sub1 - 1:
+                    xs_sub1 = self.sub_module(xs, xx_mask, lth, rel_pos_embs, 'sub1')
+                    xlens_sub1 = xlens.clone()
+                    if task == 'ys_sub1':
+                        eouts[task]['xs'], eouts[task]['xlens'] = xs_sub1, xlens_sub1
+                        return eouts
+                if lth == self.n_layers_sub2 - 1:
+                    xs_sub2 = self.sub_module(xs, xx_mask, lth, rel_pos_embs, 'sub2')
+                    xlens_sub2 = xlens.clone()
+                    if task == 'ys_sub2':
+                        eouts[task]['xs'], eouts[task]['xlens'] = xs_sub2, xlens_sub2
+                        return eouts
                 if lth < len(self.layers) - 1:
                     if self.subsample_factors[lth] > 1:
                         xs, xlens = self.subsample_layers[lth](xs, xlens)
@@ -726,6 +765,10 @@ class TransformerEncoder(EncoderBase):
             xs = ops.linear(xs, self.bridge.weight, self.bridge.bias)
         if task in ['all', 'ys']:
             eouts['ys']['xs'], eouts['ys']['xlens'] = xs, xlens
+        if self.n_layers_sub1 >= 1 and task == 'all':
+            eouts['ys_sub1']['xs'], eouts['ys_sub1']['xlens'] = xs_sub1, xlens_sub1
+        if self.n_layers_sub2 >= 1 and task == 'all':
+            eouts['ys_sub2']['xs'], eouts['ys_sub2']['xlens'] = xs_sub2, xlens_sub2
         return eouts
 
 
@@ -749,17 +792,13 @@ class ConformerEncoder(TransformerEncoder):
                          task_specific_layer, param_init, clamp_len, lookahead,
                          chunk_size_left, chunk_size_current, chunk_size_right, streaming_type)
 
-    def _make_layers(self, d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer,
-                     layer_norm_eps, ffn_activation, param_init, pe_type, clamp_len,
-                     ffn_bottleneck_dim, n_layers):
+    def _make_block(self, dropout_layer, d_model, d_ff, n_heads, dropout, dropout_att, layer_norm_eps,
+                    ffn_activation, param_init, pe_type, clamp_len, ffn_bottleneck_dim):
         kernel_size, normalization, v2 = self._conformer_cfg
         causal = self.unidir or (self.streaming_type == 'mask')
         block = ConformerEncoderBlock_v2 if v2 else ConformerEncoderBlock
-        return nn.ModuleList([copy.deepcopy(block(
-            d_model, d_ff, n_heads, kernel_size, dropout, dropout_att,
-            dropout_layer * (lth + 1) / n_layers, layer_norm_eps, ffn_activation, param_init,
-            pe_type, clamp_len, ffn_bottleneck_dim, causal, normalization))
-            for lth in range(n_layers)])
+        return block(d_model, d_ff, n_heads, kernel_size, dropout, dropout_att, dropout_layer, layer_norm_eps,
+                     ffn_activation, param_init, pe_type, clamp_len, ffn_bottleneck_dim, causal, normalization)
 
 
 def build_encoder(args):

@@ -11,6 +11,7 @@ is built; beam search / streaming raise NotImplementedError; the plot hooks are 
 import logging
 import random
 
+import copy
 import os
 
 import numpy as np
@@ -179,8 +180,8 @@ class Speech2Text(nn.Module):
         self.utt_id_prev = None
         if self.input_type != 'speech':
             raise NotImplementedError("input_type='text'")
-        if self.sub1_weight > 0 or self.sub2_weight > 0 or self.bwd_weight > 0 or self.mbr_training:
-            raise NotImplementedError('sub-task / backward / MBR decoders are outside the hot path')
+        if self.bwd_weight > 0 or self.mbr_training:
+            raise NotImplementedError('backward / MBR decoders are outside the hot path')
         self.input_noise_std = args.input_noise_std
         self.n_stacks = args.n_stacks
         self.n_skips = args.n_skips
@@ -217,6 +218,18 @@ class Speech2Text(nn.Module):
             dec = build_decoder(args, special_symbols, self.enc.output_dim, args.vocab,
                                 self.ctc_weight, self.main_weight - self.bwd_weight, None)
             setattr(self, 'dec_' + dir, dec)
+        # auxiliary tasks of hierarchical multi-task training (speech2text.py:170-184): their own decoder on the
+        # encoder's intermediate output, configured like the main one except for `dec_config_sub{1,2}`
+        for sub in ['sub1', 'sub2']:
+            if getattr(self, sub + '_weight') > 0:
+                args_sub = copy.deepcopy(args)
+                if hasattr(args, 'dec_config_' + sub):
+                    for k, v in getattr(args, 'dec_config_' + sub).items():
+                        setattr(args_sub, k, v)
+                dec_sub = build_decoder(args_sub, special_symbols, getattr(self.enc, 'output_dim_' + sub),
+                                        getattr(self, 'vocab_' + sub), getattr(self, 'ctc_weight_' + sub),
+                                        getattr(self, sub + '_weight'), None)
+                setattr(self, 'dec_fwd_' + sub, dec_sub)
 
     # ---- bookkeeping members touched by neural_sp/bin/asr/train.py (speech2text.py:206-237, base.py)
     @property
@@ -339,7 +352,7 @@ class Speech2Text(nn.Module):
         return loss, observation
 
     def _forward(self, batch, task):
-        if isinstance(getattr(self, 'dec_fwd', None), RNNT) and (task == 'all' or 'ctc' not in task):
+        if isinstance(getattr(self, 'dec_fwd', None), RNNT) and task in ('all', 'ys'):
             # the prediction network overlaps with the encoder on a side stream; it is enqueued
             # right after the encoder's front-end so that neither stream starts the step idle
             dec, ys = self.dec_fwd, batch['ys']
@@ -368,6 +381,23 @@ class Speech2Text(nn.Module):
                 observation['loss.latency'] = obs_fwd.get('loss_latency')
                 observation = {k: v for k, v in observation.items()}
             observation['loss.ctc'] = obs_fwd['loss_ctc']
+        # only forward decoders for the auxiliary tasks (speech2text.py:326-343)
+        for sub in ['sub1', 'sub2']:
+            if (getattr(self, 'fwd_weight_' + sub) > 0 or getattr(self, 'ctc_weight_' + sub) > 0) \
+                    and task in ['all', 'ys_' + sub, 'ys_' + sub + '.ctc']:
+                if len(batch['ys_' + sub]) == 0:
+                    continue  # evaluation sets without the auxiliary transcripts
+                dec_sub = getattr(self, 'dec_fwd_' + sub)
+                loss_sub, obs_sub = dec_sub(eout_dict['ys_' + sub]['xs'], eout_dict['ys_' + sub]['xlens'],
+                                            batch['ys_' + sub], task)
+                loss = loss + loss_sub
+                if isinstance(dec_sub, RNNT):
+                    observation['loss.transducer-' + sub] = obs_sub['loss_transducer']
+                else:
+                    observation['loss.att-' + sub] = obs_sub['loss_att']
+                    observation['acc.att-' + sub] = obs_sub['acc_att']
+                    observation['ppl.att-' + sub] = obs_sub['ppl_att']
+                observation['loss.ctc-' + sub] = obs_sub['loss_ctc']
         return loss, self._finalize_observation(observation)
 
     @staticmethod

@@ -172,6 +172,26 @@ CASES.update({
     'conformer_conv1d_ctc_xs': (_variant(subsample='3_2_1', subsample_type='conv1d'),
                                 dict(B=3, t_range=(121, 191), u_range=(3, 8), vocab=40, seed=228)),
 })
+# Hierarchical multi-task training (examples/aishell/.../conformer_..._2mtl.yaml, ci_test/conf/asr/transformer_2mtl.yaml):
+# auxiliary decoders on intermediate encoder outputs (speech2text.py:170-184,326-343; transformer.py:233-263,568-580)
+CASES.update({
+    # CTC-only auxiliary task after layer 2 of 4 through a task-specific Conformer block (called without the
+    # global u/v biases, transformer.py:621) -- relative_xl so that this matters; main task CTC-only
+    'conformer_2mtl_ctc_xs': (_variant(n_layers=4, ctc_weight=1.0, enc_n_layers_sub1=2, sub1_weight=0.2,
+                                       ctc_weight_sub1=0.2, vocab_sub1=30, task_specific_layer=True,
+                                       transformer_enc_pe_type='relative_xl', dec_config_sub1={'ctc_fc_list': '16'}),
+                              dict(B=3, t_range=(61, 95), u_range=(2, 5), vocab=40, seed=31, vocab_sub1=30)),
+    # two auxiliary tasks on a Transformer encoder without task-specific layers: sub1 = hybrid CTC/attention
+    # Transformer decoder after layer 2, sub2 = CTC after layer 1; main task hybrid CTC/attention
+    'transformer_3mtl_att_xs': (lambda: conformer_ctc_att_args(
+        'XS', n_layers=3, vocab=43, ctc_weight=0.3, dec_n_layers=1, enc_type='conv_transformer',
+        transformer_enc_pe_type='add', subsample='1_1_1', ctc_fc_list='', ctc_lsm_prob=0.0,
+        transformer_enc_d_model=64, transformer_enc_n_heads=1, transformer_enc_d_ff=128,
+        transformer_dec_d_model=64, transformer_dec_n_heads=1, transformer_dec_d_ff=128,
+        enc_n_layers_sub1=2, enc_n_layers_sub2=1, sub1_weight=0.2, ctc_weight_sub1=0.1, vocab_sub1=30,
+        sub2_weight=0.1, ctc_weight_sub2=0.1, vocab_sub2=20, dec_config_sub1={'dec_n_layers': 1}),
+        dict(B=3, t_range=(61, 95), u_range=(2, 6), vocab=43, seed=32, vocab_sub1=30, vocab_sub2=20)),
+})
 KEEP_REFERENCE_INIT = {'conformer_rnnt_zero_bias_xs'}
 TRIGGER_QUANTITY_LOSS = {'conformer_ctc_mocha_xs'}   # model.trigger_quantity_loss() before the step (train.py curriculum)
 
@@ -225,7 +245,7 @@ def run_case(name):
     fix = {
         'meta': {'case': name, 'torch': torch.__version__, 'trigger_quantity_loss': name in TRIGGER_QUANTITY_LOSS,
                  'rnnt_loss_source': 'oracle/rnnt_ref.py (warprnnt_pytorch absent)' if args.ctc_weight < 1 else 'n/a'},
-        'args': vars(args), 'batch': {k: batch[k] for k in ('xs', 'ys')},
+        'args': vars(args), 'batch': {k: batch[k] for k in ('xs', 'ys', 'ys_sub1', 'ys_sub2') if k in ('xs', 'ys') or batch[k]},
         'state_dict': state_before,
         'loss': loss.detach().clone(), 'loss_eval': loss_eval.detach().clone(), 'observation': obs,
         'eout': eout['ys']['xs'].clone(), 'elens': eout['ys']['xlens'].clone(), 'grads': grads,

@@ -195,11 +195,12 @@ def xl_pos_emb(T, inv_freq, dtype):
 
 
 # ----------------------------------------------------------------------------- encoder
-def encoder_forward(xs, xlens, sd, args, training=True, bn_out=None):
+def encoder_forward(xs, xlens, sd, args, training=True, bn_out=None, sub_out=None):
     """transformer.py:419-617 / conformer_block.py:95-182 / transformer_block.py:79-141,
     eval-mode semantics (no dropout, LayerDrop scaling only if dropout_enc_layer > 0); `training` only
     selects batch vs running statistics of a batch_norm convolution module."""
     cnorm = getattr(args, 'conformer_normalization', 'layer_norm')
+    n_sub = {'sub1': getattr(args, 'enc_n_layers_sub1', 0), 'sub2': getattr(args, 'enc_n_layers_sub2', 0)}
     dtype = xs.dtype
     enc_type = args.enc_type
     is_conf = 'conformer' in enc_type
@@ -254,14 +255,14 @@ def encoder_forward(xs, xlens, sd, args, training=True, bn_out=None):
         return visible_mask(xlens, xs.shape[1], unidir, las[lth])
 
     vis = mask(0)
-    for l in range(n_layers):
-        p = 'enc.layers.%d' % l
+    def block(xs, p, scale_ld, vis, pos, ub, vb):
+        """one encoder block with parameter prefix p"""
         if ld > 0:
-            xs = xs / (1 - ld * (l + 1) / n_layers)
+            xs = xs / (1 - scale_ld)
         if is_conf and not v2:
             xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm1', eps), sd, p + '.feed_forward_macaron', 'swish')
             xs = xs + rel_mha(_ln(xs, sd, p + '.norm2', eps), pos, vis, sd, p + '.self_attn', H,
-                              args.transformer_enc_clamp_len, pe_type == 'relative_xl', u_bias, v_bias)
+                              args.transformer_enc_clamp_len, pe_type == 'relative_xl', ub, vb)
             xs = xs + conformer_conv(_ln(xs, sd, p + '.norm3', eps), sd, p + '.conv',
                                      args.conformer_kernel_size, causal_conv, cnorm, training, bn_out)
             xs = xs + 0.5 * ffn(_ln(xs, sd, p + '.norm4', eps), sd, p + '.feed_forward', 'swish')
@@ -277,11 +278,27 @@ def encoder_forward(xs, xlens, sd, args, training=True, bn_out=None):
             xn = _ln(xs, sd, p + '.norm1', eps)
             if pe_type == 'relative_xl':  # the 'relaive' typo: only relative_xl is RelMHA here
                 xs = xs + rel_mha(xn, pos, vis, sd, p + '.self_attn', H, args.transformer_enc_clamp_len,
-                                  True, u_bias, v_bias)
+                                  True, ub, vb)
             else:
                 xs = xs + mha(xn, vis, sd, p + '.self_attn', H)
             xs = xs + ffn(_ln(xs, sd, p + '.norm2', eps), sd, p + '.feed_forward',
                           args.transformer_ffn_activation)
+        return xs
+
+    for l in range(n_layers):
+        xs = block(xs, 'enc.layers.%d' % l, ld * (l + 1) / n_layers, vis, pos, u_bias, v_bias)
+        for name, n in n_sub.items():
+            # transformer.py:568-580,619-630: picked up after layer n, task-specific block WITHOUT the global u/v
+            # biases, then bridge / LayerNorm
+            if n > 0 and l == n - 1 and sub_out is not None:
+                xsub = xs
+                if getattr(args, 'task_specific_layer', False):
+                    xsub = block(xs, 'enc.layer_' + name, ld * n / n_layers, vis, pos, None, None)
+                if ('enc.bridge_%s.weight' % name) in sd:
+                    xsub = _lin(xsub, sd, 'enc.bridge_' + name)
+                if ('enc.norm_out_%s.weight' % name) in sd:
+                    xsub = _ln(xsub, sd, 'enc.norm_out_' + name, eps)
+                sub_out[name] = (xsub, list(xlens))
         if l < n_layers - 1 and sub[l] > 1:
             xs, xlens = subsample(xs, xlens, sd, args.subsample_type, sub[l], 'enc.subsample_layers.%d' % l)
             N_l, N_c, N_r = max(0, N_l // sub[l]), N_c // sub[l], N_r // sub[l]
@@ -536,6 +553,15 @@ def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='de
     return loss, acc, ppl, lq
 
 
+def _sub_args(args, sub):
+    """speech2text.py:172-177: the auxiliary decoder is configured like the main one except for dec_config_sub*"""
+    import argparse
+    a = argparse.Namespace(**vars(args))
+    for k, v in (getattr(args, 'dec_config_' + sub, None) or {}).items():
+        setattr(a, k, v)
+    return a
+
+
 def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quantity_weight=0.0, bn_out=None):
     """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens).
     bn_out (dict, optional) receives the running statistics a training-mode BatchNorm would leave behind."""
@@ -545,7 +571,8 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quanti
     xs = torch.zeros(len(xlens), T, args.input_dim, dtype=dtype)
     for b, x in enumerate(batch['xs']):
         xs[b, :len(x)] = torch.as_tensor(x, dtype=dtype)
-    eouts, elens = encoder_forward(xs, xlens, sd, args, training, bn_out)
+    sub_out = {}
+    eouts, elens = encoder_forward(xs, xlens, sd, args, training, bn_out, sub_out)
     main_w = args.total_weight - args.sub1_weight - args.sub2_weight
     ctc_w = min(args.ctc_weight, main_w)
     loss = eouts.new_zeros(())
@@ -571,4 +598,27 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quanti
             obs['loss.quantity'] = lq.item()
             la = la + lq * quantity_weight
         loss = loss + la * (main_w - ctc_w)
+    # auxiliary tasks (speech2text.py:326-343): forward decoders only
+    for sub in ('sub1', 'sub2'):
+        w = getattr(args, sub + '_weight', 0.0)
+        ys_sub = batch.get('ys_' + sub) or []
+        if w <= 0 or len(ys_sub) == 0:
+            continue
+        a = _sub_args(args, sub)
+        es, el = sub_out[sub]
+        p = 'dec_fwd_' + sub
+        cw = min(getattr(args, 'ctc_weight_' + sub), w)
+        if cw > 0:
+            lc = ctc_loss_ref(ctc_head(es, sd, p + '.ctc'), el, ys_sub, a.ctc_lsm_prob)
+            obs['loss.ctc-' + sub] = lc.item()
+            loss = loss + lc * cw
+        if w - cw > 0:
+            if a.dec_type == 'transformer':
+                la, acc, ppl = transformer_decoder_att(es, el, ys_sub, sd, a, training, p=p)
+            elif a.dec_type in ('lstm', 'gru'):
+                la, acc, ppl, _ = rnn_decoder_att(es, el, ys_sub, sd, a, training, 0.0, p=p)
+            else:
+                raise NotImplementedError(a.dec_type)
+            obs.update({'loss.att-' + sub: la.item(), 'acc.att-' + sub: acc, 'ppl.att-' + sub: ppl})
+            loss = loss + la * (w - cw)
     return loss, obs, eouts, elens

@@ -24,7 +24,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # tests/test_variants_gpu.py -- the LAST file of the suite, so that under `pytest -x` a first-contact failure in them
 # cannot hide the results of everything that has already been measured on hardware.
 VARIANT_CASES = ['conformer_bn_ctc_xs', 'conformer_gn_ctc_xs', 'transformer_glu_ctc_xs', 'conformer_drop_ctc_xs',
-                 'conformer_add_ctc_xs', 'conformer_meanpool_ctc_xs', 'conformer_concat_ctc_xs', 'conformer_conv1d_ctc_xs']
+                 'conformer_add_ctc_xs', 'conformer_meanpool_ctc_xs', 'conformer_concat_ctc_xs', 'conformer_conv1d_ctc_xs',
+                 'conformer_2mtl_ctc_xs', 'transformer_3mtl_att_xs']
 CASES = sorted(set(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt'))) - set(VARIANT_CASES))
 
 
@@ -54,7 +55,9 @@ def _run(fix, mode):
     if fix['meta'].get('trigger_quantity_loss'):
         model.trigger_quantity_loss()        # train.py's curriculum switch (MoChA quantity loss)
     batch = dict(fix['batch'])
-    batch.update(xlens=[len(x) for x in batch['xs']], ys_sub1=[], ys_sub2=[], trigger_points=None)
+    batch.update(xlens=[len(x) for x in batch['xs']], trigger_points=None)
+    batch.setdefault('ys_sub1', [])        # auxiliary-task transcripts (multi-task fixtures only)
+    batch.setdefault('ys_sub2', [])
     with ops.compute_mode(mode):
         model.zero_grad()
         loss, obs = model(batch, task='all')
