@@ -350,6 +350,16 @@ int nsp_time_window_gather_fwd(const float* x, float* y, int B, int T, int To, i
 int nsp_time_window_gather_bwd(const float* dy, float* dx, int B, int T, int To, int C, int k,
                                int stride, int pad, void* stream);
 
+/* pack_padded_sequence / pad_packed_sequence around the (B)LSTM layers of    *
+ * encoders/rnn.py:534-541, as data movement on [B,T,C] (C % 4 == 0; rows may *
+ * be strided: x_ld / y_ld floats per frame, multiples of 4):                *
+ *   y[b,t,:] = t < lens[b] ? x[b, flip ? lens[b]-1-t : t, :] : 0            *
+ * flip = 0: zero the frames past each utterance's end; flip = 1: also       *
+ * reverse every utterance inside its own length (a left-to-right LSTM over  *
+ * the result is the backward direction of a packed BLSTM).  Self-adjoint.   */
+int nsp_time_flip_mask(const float* x, long long x_ld, float* y, long long y_ld, const int* lens,
+                       int B, int T, int C, int flip, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * BatchNorm1d / GroupNorm + activation of the Conformer convolution module *
  * on the flattened rows x [M = B*T, C] (conformer_convolution.py:58-66,    *

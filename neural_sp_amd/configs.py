@@ -122,6 +122,18 @@ def conformer_ctc_las_args(size='M', n_layers=12, vocab=10000, dropout=0.0, ctc_
     return argparse.Namespace(**a)
 
 
+def blstm_ctc_args(n_layers=5, n_units=256, vocab=64, dropout=0.0, **kw):
+    """BASELINE config 1: TIMIT BLSTM-CTC (examples/timit/s5/conf/blstm_ctc.yaml: 5 x 256-unit BLSTM layers, no CNN,
+    no subsampling, CTC only; SURVEY 8d: 40-dim features, ~64 output symbols)."""
+    a = dict(enc_type='blstm', dec_type='lstm', enc_n_layers=n_layers, enc_n_units=n_units, enc_n_projs=0,
+             subsample='_'.join(['1'] * n_layers), subsample_type='drop', input_dim=40, vocab=vocab,
+             conv_poolings='(1,1)_(1,1)', ctc_weight=1.0, ctc_lsm_prob=0.0, ctc_fc_list='',
+             dropout_in=dropout, dropout_enc=dropout, dropout_dec=dropout, dropout_emb=dropout, param_init=0.1,
+             lc_chunk_size_left='0', lc_chunk_size_current='0', lc_chunk_size_right='0')
+    a.update(kw)
+    return base_args(**a)
+
+
 def synthetic_batch(B, t_range, u_range, vocab, input_dim=80, seed=0, vocab_sub1=0, vocab_sub2=0):
     """The batch dict of datasets/asr/build.py:73-105 filled with synthetic data of the shapes in
     SURVEY.md section 8d: features ~ N(0,1), lengths uniform in the given ranges, labels ~ U[4,V).

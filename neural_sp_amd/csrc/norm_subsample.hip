@@ -129,6 +129,32 @@ __global__ __launch_bounds__(256) void window_gather_bwd_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// What pack_padded_sequence / pad_packed_sequence do around a (B)LSTM (encoders/rnn.py:534-541), as data movement:
+//   y[b,t,:] = t < len_b ? x[b, flip ? len_b-1-t : t, :] : 0        (rows of x / y may be strided: x_ld, y_ld)
+// flip = 0 zeroes the frames past each utterance's end (what the padded output of a packed LSTM holds);
+// flip = 1 additionally reverses every utterance inside its OWN length, so a left-to-right LSTM over the result
+// is the backward direction of a packed bidirectional LSTM.  The op is its own adjoint.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_flip_mask_kernel(const float* __restrict__ x, long long x_ld,
+                                                             float* __restrict__ y, long long y_ld,
+                                                             const int* __restrict__ lens, int B, int T,
+                                                             int C, int flip) {
+  const int C4 = C >> 2;
+  const long long total = (long long)B * T * C4;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gstride) {
+    const int c4 = (int)(idx % C4);
+    const int t = (int)((idx / C4) % T);
+    const long long b = idx / ((long long)C4 * T);
+    int len = lens[b];
+    if (len > T) len = T;
+    float4 v = f4(0.f);
+    if (t < len) v = ld4(x + (b * T + (flip ? len - 1 - t : t)) * x_ld + 4 * c4);
+    st4(y + (b * T + t) * y_ld + 4 * c4, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-column parameters of the normalisations, one float4 of channels per lane
 // ---------------------------------------------------------------------------------------------
 struct ColParams {
@@ -443,6 +469,16 @@ extern "C" int nsp_time_window_gather_bwd(const float* dy, float* dx, int B, int
   if (B == 0) return NSP_OK;
   hipLaunchKernelGGL(window_gather_bwd_kernel, dim3(ew_grid((long long)B * T * (C / 4))), dim3(256), 0,
                      (hipStream_t)stream, dy, dx, B, T, To, C, k, stride, pad);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_time_flip_mask(const float* x, long long x_ld, float* y, long long y_ld, const int* lens,
+                                  int B, int T, int C, int flip, void* stream) {
+  if (B < 0 || T < 1 || C < 4 || C % 4 || x_ld % 4 || y_ld % 4 || x_ld < C || y_ld < C) return NSP_EUNSUPPORTED;
+  if (B == 0) return NSP_OK;
+  hipLaunchKernelGGL(time_flip_mask_kernel, dim3(ew_grid((long long)B * T * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, x_ld, y, y_ld, lens, B, T, C, flip);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

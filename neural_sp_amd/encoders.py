@@ -854,8 +854,17 @@ def build_encoder(args):
             lookahead=args.transformer_enc_lookaheads, chunk_size_left=args.lc_chunk_size_left,
             chunk_size_current=args.lc_chunk_size_current, chunk_size_right=args.lc_chunk_size_right,
             streaming_type=args.lc_type, **common)
-    elif args.enc_type == 'conv':
-        raise NotImplementedError("enc_type='conv' alone")
-    raise NotImplementedError(
-        'enc_type=%s: RNN/TDS/gated-conv encoders are outside the hot-path scope '
-        '(SURVEY.md section 2 row 17); use the reference implementation' % args.enc_type)
+    if args.enc_type in ('tds', 'gated_conv') or 'gru' in args.enc_type:
+        raise NotImplementedError('enc_type=%s: TDS / gated-conv / GRU encoders are not built' % args.enc_type)
+    # build.py:127-150: everything else is the (B)LSTM encoder -- BASELINE configs[0] (TIMIT BLSTM-CTC)
+    from neural_sp_amd.rnn_encoder import RNNEncoder
+    return RNNEncoder(
+        input_dim=args.input_dim if args.input_type == 'speech' else args.emb_dim, enc_type=args.enc_type,
+        n_units=args.enc_n_units, n_projs=args.enc_n_projs,
+        last_proj_dim=args.transformer_dec_d_model if 'transformer' in args.dec_type else 0,
+        n_layers=args.enc_n_layers, n_layers_sub1=args.enc_n_layers_sub1, n_layers_sub2=args.enc_n_layers_sub2,
+        dropout_in=args.dropout_in, dropout=args.dropout_enc, subsample=args.subsample,
+        subsample_type=args.subsample_type, n_stacks=args.n_stacks, n_splices=args.n_splices, frontend_conv=conv,
+        bidir_sum_fwd_bwd=args.bidirectional_sum_fwd_bwd, task_specific_layer=args.task_specific_layer,
+        param_init=args.param_init, chunk_size_current=args.lc_chunk_size_left,  # (sic) build.py:146
+        chunk_size_right=args.lc_chunk_size_right, cnn_lookahead=args.cnn_lookahead, rsp_prob=args.rsp_prob_enc)

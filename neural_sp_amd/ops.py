@@ -910,6 +910,70 @@ def time_window_gather(x, k, stride, pad, To):
     return TimeWindowFn.apply(x, int(k), int(stride), int(pad), int(To), False, True)
 
 
+def _flip_mask_raw(x, x_ld, y, y_ld, lens_dev, B, T, C, flip):
+    _check(_lib.lib().nsp_time_flip_mask(_p(x), x_ld, _p(y), y_ld, _p(lens_dev), B, T, C, int(flip), _stream()),
+           'nsp_time_flip_mask')
+
+
+class TimeFlipMaskFn(torch.autograd.Function):
+    """y[b,t] = x[b, flip ? len_b-1-t : t] for t < len_b, 0 beyond (what packing does around an LSTM,
+    encoders/rnn.py:534-541).  Self-adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, lens_dev, flip):
+        x = _f32c(x)
+        B, T, C = x.shape
+        y = torch.empty_like(x)
+        _flip_mask_raw(x, C, y, C, lens_dev, B, T, C, flip)
+        ctx.save_for_backward(lens_dev)
+        ctx.flip = flip
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lens_dev, = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, T, C = dy.shape
+        dx = torch.empty_like(dy)
+        _flip_mask_raw(dy, C, dx, C, lens_dev, B, T, C, ctx.flip)
+        return dx, None, None
+
+
+def time_flip_mask(x, lens_dev, flip):
+    return TimeFlipMaskFn.apply(x, lens_dev, bool(flip))
+
+
+class BiDirMergeFn(torch.autograd.Function):
+    """[mask(y_fwd) | flip_mask(y_bwd_reversed)] -> `[B,T,2H]`: the padded output of a packed bidirectional LSTM
+    layer from its two left-to-right runs, written straight into the halves of one buffer (no concat pass)."""
+
+    @staticmethod
+    def forward(ctx, y_f, y_r, lens_dev):
+        y_f, y_r = _f32c(y_f), _f32c(y_r)
+        B, T, H = y_f.shape
+        out = torch.empty((B, T, 2 * H), device=y_f.device, dtype=torch.float32)
+        _flip_mask_raw(y_f, H, out, 2 * H, lens_dev, B, T, H, 0)
+        _flip_mask_raw(y_r, H, out[:, :, H:], 2 * H, lens_dev, B, T, H, 1)
+        ctx.save_for_backward(lens_dev)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lens_dev, = ctx.saved_tensors
+        dout = _f32c(dout)
+        B, T, H2 = dout.shape
+        H = H2 // 2
+        d_f = torch.empty((B, T, H), device=dout.device, dtype=torch.float32)
+        d_r = torch.empty((B, T, H), device=dout.device, dtype=torch.float32)
+        _flip_mask_raw(dout, H2, d_f, H, lens_dev, B, T, H, 0)
+        _flip_mask_raw(dout[:, :, H:], H2, d_r, H, lens_dev, B, T, H, 1)
+        return d_f, d_r, None
+
+
+def bidir_merge(y_f, y_r, lens_dev):
+    return BiDirMergeFn.apply(y_f, y_r, lens_dev)
+
+
 def _col_part(M, C, device):
     """workspace of the two-level column reductions: [slabs, 2, C]"""
     return torch.empty((_lib.lib().nsp_col_reduce_slabs(M), 2, C), device=device, dtype=torch.float32)

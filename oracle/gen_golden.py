@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 from oracle.ref_import import import_reference  # noqa: E402
 from oracle.rnnt_ref import rnnt_loss_ref  # noqa: E402
 from neural_sp_amd.configs import (conformer_rnnt_args, transformer_ctc_args, conformer_ctc_att_args,  # noqa: E402
-                                  conformer_ctc_las_args, synthetic_batch)  # noqa: E402
+                                  conformer_ctc_las_args, blstm_ctc_args, synthetic_batch)  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
@@ -191,6 +191,17 @@ CASES.update({
         enc_n_layers_sub1=2, enc_n_layers_sub2=1, sub1_weight=0.2, ctc_weight_sub1=0.1, vocab_sub1=30,
         sub2_weight=0.1, ctc_weight_sub2=0.1, vocab_sub2=20, dec_config_sub1={'dec_n_layers': 1}),
         dict(B=3, t_range=(61, 95), u_range=(2, 6), vocab=43, seed=32, vocab_sub1=30, vocab_sub2=20)),
+})
+# (B)LSTM encoders (encoders/rnn.py) -- BASELINE configs[0], examples/timit/s5/conf/blstm_ctc.yaml
+CASES.update({
+    # the TIMIT recipe's shape scaled down: 40-dim features, no CNN, 3 x 64-unit BLSTM layers, CTC only
+    'blstm_ctc_xs': (lambda: blstm_ctc_args(n_layers=3, n_units=64, vocab=40),
+                     dict(B=4, t_range=(30, 83), u_range=(2, 7), vocab=40, seed=41)),
+    # CNN front-end + BLSTM with projection layers, `drop` subsampling between layers and summed directions
+    'conv_blstm_proj_drop_xs': (lambda: blstm_ctc_args(n_layers=3, n_units=64, vocab=40, enc_type='conv_blstm', input_dim=80,
+                                                       enc_n_projs=16, subsample='1_2_1', subsample_type='drop',
+                                                       bidirectional_sum_fwd_bwd=True, conv_poolings='(2,2)_(2,2)'),
+                                dict(B=3, t_range=(61, 95), u_range=(2, 5), vocab=40, seed=142)),
 })
 KEEP_REFERENCE_INIT = {'conformer_rnnt_zero_bias_xs'}
 TRIGGER_QUANTITY_LOSS = {'conformer_ctc_mocha_xs'}   # model.trigger_quantity_loss() before the step (train.py curriculum)

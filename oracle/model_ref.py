@@ -344,11 +344,12 @@ def ctc_loss_ref(logits, elens, ys, lsm_prob):
     return loss
 
 
-def lstm_ref(x, sd, p):
-    """nn.LSTM(1 layer, batch_first) with zero initial state (rnn_transducer.py:278-311)."""
+def lstm_ref(x, sd, p, sfx=''):
+    """nn.LSTM(1 layer, batch_first) with zero initial state (rnn_transducer.py:278-311); sfx='_reverse' selects
+    the parameters of the backward direction of a bidirectional layer."""
     B, L, _ = x.shape
-    w_ih, w_hh = sd[p + '.weight_ih_l0'], sd[p + '.weight_hh_l0']
-    b = sd[p + '.bias_ih_l0'] + sd[p + '.bias_hh_l0']
+    w_ih, w_hh = sd[p + '.weight_ih_l0' + sfx], sd[p + '.weight_hh_l0' + sfx]
+    b = sd[p + '.bias_ih_l0' + sfx] + sd[p + '.bias_hh_l0' + sfx]
     n = w_hh.shape[1]
     h = x.new_zeros(B, n)
     c = x.new_zeros(B, n)
@@ -361,6 +362,49 @@ def lstm_ref(x, sd, p):
         h = torch.sigmoid(o) * torch.tanh(c)
         outs.append(h)
     return torch.stack(outs, dim=1)
+
+
+def rnn_encoder_forward(xs, xlens, sd, args, sub_out=None):
+    """encoders/rnn.py:268-383, full-context (B)LSTM encoder, eval-mode semantics (no dropout).  A packed
+    (bidirectional) LSTM (rnn.py:534-541) = every utterance run on its own frames, the backward direction from its
+    own last frame, zeros in the padded output beyond its length."""
+    xlens = list(xlens)
+    if 'conv' in args.enc_type:
+        xs, xlens = conv_frontend(xs, xlens, sd, args)
+    bidir = 'blstm' in args.enc_type
+    n_layers, H = args.enc_n_layers, args.enc_n_units
+    sub = [1] * n_layers
+    for i, f in enumerate(map(int, args.subsample.split('_')[:n_layers])):
+        sub[i] = f
+    n_sub = {'sub1': getattr(args, 'enc_n_layers_sub1', 0), 'sub2': getattr(args, 'enc_n_layers_sub2', 0)}
+    B = xs.shape[0]
+    for l in range(n_layers):
+        T = max(xlens)
+        p = 'enc.rnn.%d' % l
+        out = xs.new_zeros(B, T, H * (2 if bidir else 1))
+        for b in range(B):
+            n = xlens[b]
+            out[b, :n, :H] = lstm_ref(xs[b:b + 1, :n], sd, p)[0]
+            if bidir:
+                out[b, :n, H:] = lstm_ref(xs[b:b + 1, :n].flip(1), sd, p, '_reverse')[0].flip(0)
+        if bidir and args.bidirectional_sum_fwd_bwd:
+            out = out[..., :H] + out[..., H:]
+        xs = out
+        for name, n in n_sub.items():          # rnn.py:512-524
+            if n > 0 and l == n - 1 and sub_out is not None:
+                xsub = xs
+                if getattr(args, 'task_specific_layer', False):
+                    xsub = torch.relu(_lin(xs, sd, 'enc.layer_' + name))
+                if ('enc.bridge_%s.weight' % name) in sd:
+                    xsub = _lin(xsub, sd, 'enc.bridge_' + name)
+                sub_out[name] = (xsub, list(xlens))
+        if args.enc_n_projs > 0 and l != n_layers - 1:
+            xs = torch.relu(_lin(xs, sd, 'enc.proj.%d' % l))
+        if sub[l] > 1:
+            xs, xlens = subsample(xs, xlens, sd, args.subsample_type, sub[l], 'enc.subsample.%d' % l)
+    if 'enc.bridge.weight' in sd:
+        xs = _lin(xs, sd, 'enc.bridge')
+    return xs[:, :max(xlens)], xlens
 
 
 def rnnt_branch(eouts, elens, ys, sd, args, p='dec_fwd'):
@@ -572,7 +616,10 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quanti
     for b, x in enumerate(batch['xs']):
         xs[b, :len(x)] = torch.as_tensor(x, dtype=dtype)
     sub_out = {}
-    eouts, elens = encoder_forward(xs, xlens, sd, args, training, bn_out, sub_out)
+    if 'former' in args.enc_type:
+        eouts, elens = encoder_forward(xs, xlens, sd, args, training, bn_out, sub_out)
+    else:
+        eouts, elens = rnn_encoder_forward(xs, xlens, sd, args, sub_out)
     main_w = args.total_weight - args.sub1_weight - args.sub2_weight
     ctc_w = min(args.ctc_weight, main_w)
     loss = eouts.new_zeros(())

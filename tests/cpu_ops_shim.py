@@ -129,6 +129,22 @@ def _ctc_loss(logits, labels, elens, ylens, lsm_prob=0.0, sum_elens=1, blank=0):
     return loss.view(1), nll
 
 
+def _lstm(x, w_ih, w_hh, b_ih, b_hh):
+    """ops.lstm: one nn.LSTM layer, batch_first, zero initial state, gate order i,f,g,o (nsp_lstm_fwd)."""
+    B, L, _ = x.shape
+    H = w_hh.shape[1]
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    gi = F.linear(x, w_ih, b_ih + b_hh)
+    outs = []
+    for t in range(L):
+        i, f, g, o = (gi[:, t] + F.linear(h, w_hh)).chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
 def _h2d_packed(arrays, device):
     import numpy as np
     return torch.from_numpy(np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1) for a in arrays]))
@@ -159,7 +175,7 @@ def host_logic_on_cpu():
         conv3x3_relu=_conv3x3_relu, maxpool2d=_maxpool2d, scale=lambda x, a: x * a,
         dropout=lambda x, p, training: x if (p == 0 or not training) else (_ for _ in ()).throw(AssertionError('dropout')),
         add=lambda x, z, alpha=1.0, beta=1.0: alpha * x + beta * z, scale_add_bcast=_scale_add_bcast,
-        xl_pos_table=_xl_pos_table, ctc_loss=_ctc_loss, h2d_packed=_h2d_packed, pad_batch=_pad_batch,
+        xl_pos_table=_xl_pos_table, ctc_loss=_ctc_loss, h2d_packed=_h2d_packed, pad_batch=_pad_batch, lstm=_lstm,
     )
     saved = {k: getattr(ops, k) for k in fakes}
     mode = ops.get_compute_mode()

@@ -25,7 +25,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # cannot hide the results of everything that has already been measured on hardware.
 VARIANT_CASES = ['conformer_bn_ctc_xs', 'conformer_gn_ctc_xs', 'transformer_glu_ctc_xs', 'conformer_drop_ctc_xs',
                  'conformer_add_ctc_xs', 'conformer_meanpool_ctc_xs', 'conformer_concat_ctc_xs', 'conformer_conv1d_ctc_xs',
-                 'conformer_2mtl_ctc_xs', 'transformer_3mtl_att_xs']
+                 'conformer_2mtl_ctc_xs', 'transformer_3mtl_att_xs', 'blstm_ctc_xs', 'conv_blstm_proj_drop_xs']
 CASES = sorted(set(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt'))) - set(VARIANT_CASES))
 
 

@@ -64,7 +64,7 @@ def test_unsupported_configurations_fail_loudly():
     from neural_sp_amd.configs import conformer_rnnt_args
     from neural_sp_amd.speech2text import Speech2Text
     with pytest.raises(NotImplementedError):
-        Speech2Text(conformer_rnnt_args('XS', n_layers=2, enc_type='blstm'))
+        Speech2Text(conformer_rnnt_args('XS', n_layers=2, enc_type='tds'))
     with pytest.raises(NotImplementedError):
         Speech2Text(conformer_rnnt_args('XS', n_layers=2, subsample='2_1', subsample_type='no_such_type'))
     with pytest.raises(NotImplementedError):

@@ -31,3 +31,7 @@ def test_batch_norm_swish_training_and_eval(M, C):
 @pytest.mark.parametrize('M,C', vc.GN_CASES)
 def test_group_norm_pairs_swish(M, C):
     vc.check_group_norm('emu', M, C)
+
+
+def test_flip_mask_and_bidirectional_merge():
+    vc.check_flip_mask_and_merge('emu')

@@ -49,6 +49,76 @@ def test_group_norm_pairs_swish(M, C):
     vc.check_group_norm('gpu', M, C)
 
 
+def test_flip_mask_and_bidirectional_merge():
+    vc.check_flip_mask_and_merge('gpu')
+
+
+@pytest.mark.parametrize('bidir_sum', [False, True])
+def test_blstm_layer_matches_packed_torch_lstm(bidir_sum):
+    """RNNEncoder._lstm_layer (two left-to-right runs of the LSTM kernels + nsp_time_flip_mask) against
+    pack_padded_sequence -> nn.LSTM(bidirectional) -> pad_packed_sequence on the CPU (rnn.py:534-547), fp32 mode:
+    outputs and every gradient."""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from neural_sp_amd import ops
+    from neural_sp_amd.rnn_encoder import RNNEncoder
+    torch.manual_seed(11)
+    B, T, I, H = 5, 37, 48, 64
+    lens = [37, 30, 22, 9, 1]
+    enc = RNNEncoder(I, 'blstm', H, 0, 0, 1, 0, 0, 0.0, 0.0, '1', 'drop', 1, 1, None, bidir_sum, False, 0.1, '0', '0', True, 0.0)
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.uniform_(-0.3, 0.3)
+    ref = torch.nn.LSTM(I, H, 1, batch_first=True, bidirectional=True)
+    ref.load_state_dict(enc.rnn[0].state_dict())
+    x = torch.randn(B, T, I)
+    xr = x.clone().requires_grad_(True)
+    yr = pad_packed_sequence(ref(pack_padded_sequence(xr, lens, batch_first=True))[0], batch_first=True)[0]
+    if bidir_sum:
+        yr = yr[..., :H] + yr[..., H:]
+    w = torch.randn_like(yr)
+    (yr * w).sum().backward()
+    enc.cuda(0)
+    with ops.compute_mode('f32'):
+        xo = x.clone().cuda(0).requires_grad_(True)
+        yo = enc._lstm_layer(xo, torch.tensor(lens, dtype=torch.int32, device='cuda:0'), enc.rnn[0])
+        (yo * w.cuda(0)).sum().backward()
+    torch.testing.assert_close(yo.detach().cpu(), yr.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xo.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-5)
+    for (n, p), (_, q) in zip(enc.rnn[0].named_parameters(), ref.named_parameters()):
+        assert (p.grad.cpu() - q.grad).abs().max() < 1e-3 * q.grad.abs().max() + 1e-5, n
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_timit_blstm_ctc_config1_full_size(mode):
+    """BASELINE configs[0] at its real size (examples/timit/s5/conf/blstm_ctc.yaml): 5 x 256-unit
+    BLSTM layers, CTC, 40-dim features, B=16, T~U[150,500], U~U[20,60], ~64 output symbols -- against
+    oracle/model_ref.py (pinned to the reference by the blstm fixtures) in fp32 on the host.
+    Gates: fp32 mode loss 1e-4, every gradient 5e-3 of its max; bf16 mode loss 1e-3, cosine >= 0.999 / norm 2 %."""
+    from tests import test_fullsize_parity_gpu as fs
+    from neural_sp_amd.configs import blstm_ctc_args, synthetic_batch
+    from neural_sp_amd.speech2text import Speech2Text
+    torch.manual_seed(9)
+    margs = blstm_ctc_args(n_layers=5, n_units=256, vocab=64)
+    model = Speech2Text(margs)
+    fs._randomise_biases(model, 7)
+    model.cuda(0)
+    batch = synthetic_batch(B=16, t_range=(150, 500), u_range=(20, 60), vocab=64, input_dim=40, seed=19)
+    loss, obs, grads = fs._hip(model, batch, mode)
+    ref, robs, rgrads = fs._oracle(model, margs, batch)
+    print('[config 1 %s] loss hip %.6f oracle %.6f rel %.2e' % (mode, loss, ref, abs(loss - ref) / abs(ref)))
+    assert set(rgrads) == set(grads), set(rgrads) ^ set(grads)
+    if mode == 'f32':
+        assert abs(loss - ref) / abs(ref) < 1e-4, (loss, ref)
+        err = {n: ((grads[n] - g).abs().max() / g.abs().max().clamp(min=1e-12)).item() for n, g in rgrads.items()}
+        bad = {n: e for n, e in err.items() if e > 5e-3}
+        assert not bad, bad
+    else:
+        assert abs(loss - ref) / abs(ref) < 1e-3, (loss, ref)
+        bad, worst, skipped, n = fs._compare_grads(grads, rgrads, 0.999, 0.02)
+        print('[config 1 bf16] %d tensors, worst (cos, norm ratio) %s, outside the gate: %s' % (n, worst, bad))
+        assert not bad, bad
+
+
 def test_weight_noise_on_device():
     """one multi-tensor add on device parameters; bf16 weight shadows follow the version counters"""
     from neural_sp_amd import ops

@@ -161,3 +161,36 @@ def check_group_norm(where, M, C):
     torch.testing.assert_close(ox, gx.float(), rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(ow, gw.float(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(ob, gb.float(), rtol=1e-4, atol=1e-4)
+
+
+def check_flip_mask_and_merge(where):
+    """nsp_time_flip_mask: what packing does around a BLSTM layer (encoders/rnn.py:534-541), incl. strided halves"""
+    from neural_sp_amd import ops
+    torch.manual_seed(0)
+    B, T, H = 4, 9, 8
+    lens = torch.tensor([9, 5, 1, 7], dtype=torch.int32)
+    yf, yr = torch.randn(B, T, H), torch.randn(B, T, H)
+
+    def ref(yf, yr):
+        out = torch.zeros(B, T, 2 * H)
+        for b in range(B):
+            n = int(lens[b])
+            out[b, :n, :H] = yf[b, :n]
+            out[b, :n, H:] = yr[b, :n].flip(0)
+        return out
+
+    yr_, (gf, gr) = _ref_grads(ref, yf.clone().requires_grad_(True), yr.clone().requires_grad_(True))
+    ctx, dev = _env(where)
+    with ctx:
+        ld = lens.to(dev)
+        a, b = yf.clone().to(dev).requires_grad_(True), yr.clone().to(dev).requires_grad_(True)
+        out = ops.bidir_merge(a, b, ld)
+        (out * _weights(yr_).to(dev)).sum().backward()
+        x = torch.randn(B, T, H)
+        xf = ops.time_flip_mask(x.to(dev), ld, True).cpu()
+        xm = ops.time_flip_mask(x.to(dev), ld, False).cpu()
+    assert torch.equal(out.detach().cpu(), yr_) and torch.equal(a.grad.cpu(), gf) and torch.equal(b.grad.cpu(), gr)
+    for bb in range(B):
+        n = int(lens[bb])
+        assert torch.equal(xf[bb, :n], x[bb, :n].flip(0)) and torch.equal(xm[bb, :n], x[bb, :n])
+        assert xf[bb, n:].abs().sum() == 0 and xm[bb, n:].abs().sum() == 0
