@@ -19,12 +19,14 @@ fused step kernels (energy + softmax + context; alpha recurrence as a wavefront 
 step.  Everything that does not feed back into the recurrence is hoisted out of the loop: the
 key projections are computed once, the bottleneck + tanh + output layer run once over all steps.
 
-Not built (NotImplementedError): LM fusion / initialisation, MBR training, scheduled sampling,
+Not built (NotImplementedError): LM fusion / initialisation, MBR training,
 multi-head / GMM / dot-family attention, MoChA with several heads, 1-d conv, DeCoT / latency losses,
 StableEmit, streaming / linear-time / beam-search decoding (greedy search is built: `RNNDecoder.greedy`, with
 MoChA's test-time hard attention).
 """
 import math
+
+import random
 
 import numpy as np
 import torch
@@ -258,7 +260,7 @@ class RNNDecoder(DecoderBase):
                  mocha_stableemit_weight, gmm_attn_n_mixtures, replace_sos, distillation_weight, discourse_aware):
         super().__init__()
         for flag, what in ((mbr_training, 'MBR training'), (external_lm is not None or lm_fusion or lm_init, 'LM fusion / init'),
-                           (ss_prob > 0, 'scheduled sampling'), (attn_n_heads > 1, 'multi-head attention'),
+                           (attn_n_heads > 1, 'multi-head attention'),
                            (bool(latency_metric), 'latency losses / DeCoT'), (replace_sos, 'replace_sos'),
                            (bool(discourse_aware), 'discourse-aware training')):
             if flag:
@@ -321,6 +323,10 @@ class RNNDecoder(DecoderBase):
 
     def trigger_quantity_loss(self):
         self._quantity_loss_weight = self.quantity_loss_weight
+
+    def trigger_scheduled_sampling(self):
+        """las.py:351-353 (train.py switches it on at `ss_start_epoch`)"""
+        self._ss_prob = self.ss_prob
 
     def forward(self, eouts, elens, ys, task='all', teacher_logits=None, recog_params={}, idx2token=None,
                 trigger_points=None):
@@ -394,7 +400,20 @@ class RNNDecoder(DecoderBase):
         # The one large GEMM of the decoder, the output layer over V, stays in the ambient mode below.
         with ops.compute_mode('f32'):
             for i in range(L):
-                x = torch.cat([ys_emb[:, i], cv.squeeze(1)], dim=-1)
+                # scheduled sampling (las.py:668,675-676): with probability ss_prob the step is fed the arg-max of
+                # the model's own previous output distribution instead of the reference token.  Python's global
+                # `random` stream, drawn only for i > 0 and only once sampling has been triggered -- in eval-mode
+                # forwards too -- exactly as the reference does (same seed => same steps sampled).
+                is_sample = i > 0 and self._ss_prob > 0 and random.random() < self._ss_prob
+                if is_sample:
+                    with torch.no_grad():
+                        feat = torch.cat([douts[-1], cvs[-1]], dim=-1)
+                        prev = torch.tanh(ops.linear(feat, self.output_bn.weight, self.output_bn.bias))
+                        y_prev = ops.argmax_rows(ops.linear(prev, self.output.weight, self.output.bias)).long()
+                    y_emb = self.dropout_emb(self.embed(y_prev))
+                else:
+                    y_emb = ys_emb[:, i]
+                x = torch.cat([y_emb, cv.squeeze(1)], dim=-1)
                 hxs, cxs, dout_score, dout_gen = self._recurrency(x, hxs, cxs)
                 cv, aw, _ = self.score(eouts, eouts, dout_score.unsqueeze(1), src_mask, aw, cache=True, mode='parallel')
                 douts.append(dout_gen)

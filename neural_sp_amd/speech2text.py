@@ -260,7 +260,10 @@ class Speech2Text(nn.Module):
         pass  # no cuDNN/MIOpen autotuning on the hand-written path
 
     def trigger_scheduled_sampling(self):
-        pass
+        # speech2text.py:206-215: main and auxiliary-task decoders
+        for name in ('dec_fwd', 'dec_bwd', 'dec_fwd_sub1', 'dec_fwd_sub2'):
+            if hasattr(self, name):
+                getattr(self, name).trigger_scheduled_sampling()
 
     def trigger_quantity_loss(self):
         # speech2text.py:217-221 (main task only)

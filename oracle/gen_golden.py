@@ -13,6 +13,7 @@ oracle/rnnt_ref.py (fp64 lattice, cast to the input dtype) -- every other op is 
 reference's.  The fixture records this in `meta['rnnt_loss_source']`.
 """
 import os
+import random
 import sys
 import types
 
@@ -204,6 +205,14 @@ CASES.update({
                                 dict(B=3, t_range=(61, 95), u_range=(2, 5), vocab=40, seed=142)),
 })
 KEEP_REFERENCE_INIT = {'conformer_rnnt_zero_bias_xs'}
+# scheduled sampling (las.py:668,675-676; ss_prob 0.2 in 39 of the reference's recipes, BASELINE config 3's among them):
+# triggered as train.py does at ss_start_epoch; Python's global `random` stream is re-seeded right before the training
+# forward and again before the eval-mode forward (the reference samples there too), the seed is kept in `meta`
+CASES['conformer_ctc_las_ss_xs'] = (
+    lambda: conformer_ctc_las_args('XS', n_layers=2, vocab=43, ctc_weight=0.3, dec_n_layers=1, ss_prob=0.4,
+                                   ctc_fc_list='', ctc_lsm_prob=0.0, conformer_kernel_size=7),
+    dict(B=4, t_range=(60, 131), u_range=(5, 14), vocab=43, seed=51))
+TRIGGER_SCHEDULED_SAMPLING = {'conformer_ctc_las_ss_xs': 2024}   # name -> random.seed value
 TRIGGER_QUANTITY_LOSS = {'conformer_ctc_mocha_xs'}   # model.trigger_quantity_loss() before the step (train.py curriculum)
 
 
@@ -235,6 +244,8 @@ def run_case(name):
         p.data = p.data.view(1, 1)
     if name in TRIGGER_QUANTITY_LOSS:
         model.trigger_quantity_loss()
+    if name in TRIGGER_SCHEDULED_SAMPLING:
+        model.trigger_scheduled_sampling()
     batch = synthetic_batch(input_dim=args.input_dim, **bkw)
     wrapped = CPUWrapperASR(model)
     # taken BEFORE the step: a training-mode forward moves BatchNorm's running statistics (the eval-mode
@@ -242,12 +253,16 @@ def run_case(name):
     # the same train step -> eval sequence will); parameters do not change (no optimizer step)
     state_before = {k: v.clone() for k, v in model.state_dict().items()}
     model.zero_grad()
+    if name in TRIGGER_SCHEDULED_SAMPLING:
+        random.seed(TRIGGER_SCHEDULED_SAMPLING[name])
     loss, obs = wrapped(batch, task='all')
     loss.backward()
     grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     model.eval()
     with torch.no_grad():
         eout = model.encode(batch['xs'], 'all')
+        if name in TRIGGER_SCHEDULED_SAMPLING:
+            random.seed(TRIGGER_SCHEDULED_SAMPLING[name])
         loss_eval, _ = model(batch, task='all', is_eval=True)
     for p in wn_fix:
         p.data = p.data.view(1)
@@ -255,6 +270,7 @@ def run_case(name):
     state_before = {k: (v.view(1) if k.endswith('v.weight_g') else v) for k, v in state_before.items()}
     fix = {
         'meta': {'case': name, 'torch': torch.__version__, 'trigger_quantity_loss': name in TRIGGER_QUANTITY_LOSS,
+                 'scheduled_sampling_seed': TRIGGER_SCHEDULED_SAMPLING.get(name),
                  'rnnt_loss_source': 'oracle/rnnt_ref.py (warprnnt_pytorch absent)' if args.ctc_weight < 1 else 'n/a'},
         'args': vars(args), 'batch': {k: batch[k] for k in ('xs', 'ys', 'ys_sub1', 'ys_sub2') if k in ('xs', 'ys') or batch[k]},
         'state_dict': state_before,

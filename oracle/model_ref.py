@@ -500,8 +500,10 @@ def _xe_lsm(logits, ys_out, lsm, B):
     return rows.sum() / B, float(((lg.argmax(1) == yo) & ~mask).sum()) * 100 / n_tokens, math.exp(rows.sum().item() / n_tokens)
 
 
-def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='dec_fwd'):
-    """decoders/las.py:618-776 (teacher forcing, no LM / scheduled sampling) with the single-head attentions
+def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='dec_fwd', ss_prob=0.0):
+    """decoders/las.py:618-776 (teacher forcing; ss_prob > 0 = scheduled sampling after it has been triggered,
+    :668,675-676: Python's global `random` stream decides per step, the arg-max of the previous step's own output
+    distribution is fed back; no LM) with the single-head attentions
     of modules/attention.py:96-181 ('location', 'add') and the training-time MoChA of
     modules/mocha/mocha.py:164-311, hma_train.py:12-67, mocha_train.py:13-58 (one head, additive energies,
     no noise).  -> (loss_att, acc %, ppl, quantity loss or None); quantity_weight is applied by the caller (las.py:486-489)."""
@@ -543,9 +545,16 @@ def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='de
     def moving_sum(x, back, forward):
         return F.conv1d(F.pad(x, [back, forward]).unsqueeze(1), x.new_ones(1, 1, back + forward + 1)).squeeze(1)
 
+    import random
     douts, cvs, aws = [], [], []
     for i in range(L):
-        dout = torch.cat([emb[:, i], cv], dim=-1)
+        y_emb = emb[:, i]
+        if i > 0 and ss_prob > 0 and random.random() < ss_prob:
+            with torch.no_grad():
+                prev = torch.tanh(_lin(torch.cat([douts[-1], cvs[-1]], dim=-1), sd, p + '.output_bn'))
+                y_prev = _lin(prev, sd, p + '.output').argmax(-1)
+            y_emb = F.embedding(y_prev, sd[p + '.embed.weight'], padding_idx=3)
+        dout = torch.cat([y_emb, cv], dim=-1)
         for l in range(nl):
             q = '%s.rnn.%d' % (p, l)
             gates = F.linear(dout, sd[q + '.weight_ih'], sd[q + '.bias_ih']) + F.linear(hx[l], sd[q + '.weight_hh'], sd[q + '.bias_hh'])
@@ -606,7 +615,8 @@ def _sub_args(args, sub):
     return a
 
 
-def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quantity_weight=0.0, bn_out=None):
+def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quantity_weight=0.0, bn_out=None,
+                     scheduled_sampling=False):
     """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens).
     bn_out (dict, optional) receives the running statistics a training-mode BatchNorm would leave behind."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
@@ -638,7 +648,8 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quanti
         obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})
         loss = loss + la * (main_w - ctc_w)
     if args.dec_type in ('lstm', 'gru') and main_w - ctc_w > 0:
-        la, acc, ppl, lq = rnn_decoder_att(eouts, elens, batch['ys'], sd, args, training, quantity_weight)
+        la, acc, ppl, lq = rnn_decoder_att(eouts, elens, batch['ys'], sd, args, training, quantity_weight,
+                                           ss_prob=args.ss_prob if scheduled_sampling else 0.0)
         obs.pop('loss.transducer')
         obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})   # (recorded before the quantity loss is added)
         if lq is not None:

@@ -14,6 +14,7 @@ whose gradient is amplified 1e6x by the eps=1e-12 zero-variance LayerNorm rows (
 import argparse
 import glob
 import os
+import random
 
 import pytest
 import torch
@@ -25,7 +26,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # cannot hide the results of everything that has already been measured on hardware.
 VARIANT_CASES = ['conformer_bn_ctc_xs', 'conformer_gn_ctc_xs', 'transformer_glu_ctc_xs', 'conformer_drop_ctc_xs',
                  'conformer_add_ctc_xs', 'conformer_meanpool_ctc_xs', 'conformer_concat_ctc_xs', 'conformer_conv1d_ctc_xs',
-                 'conformer_2mtl_ctc_xs', 'transformer_3mtl_att_xs', 'blstm_ctc_xs', 'conv_blstm_proj_drop_xs']
+                 'conformer_2mtl_ctc_xs', 'transformer_3mtl_att_xs', 'blstm_ctc_xs', 'conv_blstm_proj_drop_xs',
+                 'conformer_ctc_las_ss_xs']
 CASES = sorted(set(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt'))) - set(VARIANT_CASES))
 
 
@@ -54,18 +56,25 @@ def _run(fix, mode):
     model.cuda(0)
     if fix['meta'].get('trigger_quantity_loss'):
         model.trigger_quantity_loss()        # train.py's curriculum switch (MoChA quantity loss)
+    ss_seed = fix['meta'].get('scheduled_sampling_seed')
+    if ss_seed is not None:
+        model.trigger_scheduled_sampling()   # train.py's ss_start_epoch switch; Python's `random` decides per step
     batch = dict(fix['batch'])
     batch.update(xlens=[len(x) for x in batch['xs']], trigger_points=None)
     batch.setdefault('ys_sub1', [])        # auxiliary-task transcripts (multi-task fixtures only)
     batch.setdefault('ys_sub2', [])
     with ops.compute_mode(mode):
         model.zero_grad()
+        if ss_seed is not None:
+            random.seed(ss_seed)
         loss, obs = model(batch, task='all')
         loss.backward()
         grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
         model.eval()
         with torch.no_grad():
             eout = model.encode(batch['xs'], 'all')
+            if ss_seed is not None:
+                random.seed(ss_seed)         # the reference samples in eval-mode forwards too (las.py:668)
             loss_eval, _ = model(batch, task='all', is_eval=True)
     return loss.item(), obs, eout['ys']['xs'].cpu(), eout['ys']['xlens'], grads, loss_eval.item()
 

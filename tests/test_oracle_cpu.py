@@ -52,8 +52,12 @@ def test_model_restatement_matches_reference_fixture(name):
           if v.is_floating_point() else v for k, v in fix['state_dict'].items()}
     qw = args.mocha_quantity_loss_weight if fix['meta'].get('trigger_quantity_loss') else 0.0
     bn_out = {}
+    ss_seed = fix['meta'].get('scheduled_sampling_seed')
+    if ss_seed is not None:
+        import random
+        random.seed(ss_seed)      # scheduled sampling: the same Python random stream as the reference's training forward
     loss, obs, eouts, elens = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64, quantity_weight=qw,
-                                                         bn_out=bn_out)
+                                                         bn_out=bn_out, scheduled_sampling=ss_seed is not None)
     ref = fix['loss'].item()
     assert abs(loss.item() - ref) / abs(ref) < 2e-5, (loss.item(), ref)
     if bn_out:
