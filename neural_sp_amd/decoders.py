@@ -46,7 +46,9 @@ class DecoderBase(nn.Module):
         pass
 
     def trigger_stableemit(self):
-        pass
+        # decoder_base.py:45-50
+        if getattr(self, 'attn_type', '') == 'mocha' and hasattr(self, 'score'):
+            self.score.trigger_stableemit()
 
 
 def _labels_to_device(ys, device, pad=0):

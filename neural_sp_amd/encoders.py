@@ -166,6 +166,8 @@ class ConvEncoder(EncoderBase):
             raise NotImplementedError('Conv1dBlock frontend is not on the benchmarked path')
         self.is_1dconv = False
         self.in_channel = in_channel
+        if in_channel != 1:
+            raise NotImplementedError('conv_in_channel = %d (the conv kernels take one input channel)' % in_channel)
         assert input_dim % in_channel == 0
         self.input_freq = input_dim // in_channel
         self.residual = residual
@@ -802,7 +804,9 @@ class ConformerEncoder(TransformerEncoder):
 
 
 def build_encoder(args):
-    """build.py:7-152 for the conv / transformer / conformer families."""
+    """build.py:7-152 for the conv / transformer / conformer / (B)LSTM families."""
+    if args.enc_type in ('tds', 'gated_conv') or 'gru' in args.enc_type:
+        raise NotImplementedError('enc_type=%s: TDS / gated-conv / GRU encoders are not built' % args.enc_type)
     if 'conv' in args.enc_type:
         assert args.n_stacks == 1 and args.n_splices == 1
         conv = ConvEncoder(args.input_dim, in_channel=args.conv_in_channel, channels=args.conv_channels,
@@ -854,8 +858,6 @@ def build_encoder(args):
             lookahead=args.transformer_enc_lookaheads, chunk_size_left=args.lc_chunk_size_left,
             chunk_size_current=args.lc_chunk_size_current, chunk_size_right=args.lc_chunk_size_right,
             streaming_type=args.lc_type, **common)
-    if args.enc_type in ('tds', 'gated_conv') or 'gru' in args.enc_type:
-        raise NotImplementedError('enc_type=%s: TDS / gated-conv / GRU encoders are not built' % args.enc_type)
     # build.py:127-150: everything else is the (B)LSTM encoder -- BASELINE configs[0] (TIMIT BLSTM-CTC)
     from neural_sp_amd.rnn_encoder import RNNEncoder
     return RNNEncoder(

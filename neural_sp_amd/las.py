@@ -163,8 +163,11 @@ class MoChA(nn.Module):
                  init_r=-4, eps=1e-6, noise_std=1.0, no_denominator=False, sharpening_factor=1.0, dropout=0.,
                  decot=False, decot_delta=2, stableemit_weight=0.0):
         super().__init__()
-        if atype != 'add' or n_heads_mono != 1 or n_heads_chunk != 1 or conv1d or decot or stableemit_weight > 0:
-            raise NotImplementedError('MoChA: built for additive energies, one head, no 1-d conv / DeCoT / StableEmit')
+        if atype != 'add' or n_heads_mono != 1 or n_heads_chunk != 1 or conv1d or decot:
+            raise NotImplementedError('MoChA: built for additive energies, one head, no 1-d conv / DeCoT')
+        assert stableemit_weight >= 0
+        self.stableemit_weight = stableemit_weight
+        self._stableemit_weight = 0          # curriculum: trigger_stableemit() (mocha.py:97-99,157-159)
         self.w = chunk_size
         self.milk = chunk_size == -1
         self.n_heads, self.H_ma, self.H_ca, self.H_total = 1, 1, 1, 1
@@ -178,6 +181,9 @@ class MoChA(nn.Module):
         self.monotonic_energy.reset()
         if self.chunk_energy is not None:
             self.chunk_energy.reset()
+
+    def trigger_stableemit(self):
+        self._stableemit_weight = self.stableemit_weight
 
     def forward(self, key, value, query, mask, aw_prev=None, cache=False, mode='parallel', trigger_points=None,
                 streaming=False):
@@ -194,6 +200,8 @@ class MoChA(nn.Module):
         if self.noise_std > 0:                                                        # (training AND eval, as the reference)
             e_ma = e_ma + torch.zeros_like(e_ma).normal_(std=self.noise_std)
         p_choose = torch.sigmoid(e_ma)
+        if self._stableemit_weight > 0:                                               # StableEmit (hma_train.py:43-44)
+            p_choose = (1 - self._stableemit_weight) * p_choose
         cumprod_1mp = _safe_cumprod(1 - p_choose, self.eps)
         denom = 1 if self.no_denom else torch.clamp(cumprod_1mp, min=self.eps, max=1.0)
         alpha = p_choose * cumprod_1mp * torch.cumsum(aw_prev / denom, dim=-1)

@@ -11,6 +11,7 @@ Reference files (relative to the reference root):
   neural_sp/models/modules/initialization.py
 """
 import logging
+import copy
 import math
 
 import torch
@@ -363,9 +364,33 @@ class XLPositionalEmbedding(nn.Module):
         return xs, pos_emb.unsqueeze(1)
 
 
+class CausalConv1d(nn.Module):
+    """causal_conv.py:15-71 (dilation 1, groups 1): Conv1d(padding = k-1) with the last k-1 outputs dropped, i.e.
+    y[t] = b + sum_j W[:,:,j] x[t + j - (k-1)].  Channels-last: window gather over time (left-padded) + one MFMA GEMM
+    against the `[C_out, k*C_in]` view of the weight; `act` goes into the GEMM's caller."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, param_init=''):
+        super().__init__()
+        self.padding = kernel_size - 1
+        self.conv1d = nn.Conv1d(in_channels, out_channels, kernel_size, padding=self.padding)
+        if param_init == 'xavier_uniform':
+            for n, p in self.named_parameters():
+                init_with_xavier_uniform(n, p)
+        elif param_init == 'lecun':
+            for n, p in self.named_parameters():
+                init_with_lecun_normal(n, p, 0.1)
+
+    def forward(self, xs):
+        co, ci, k = self.conv1d.weight.shape
+        g = ops.time_window_gather(xs, k, 1, self.padding, xs.size(1))
+        w2 = self.conv1d.weight.permute(0, 2, 1).contiguous().view(co, k * ci)
+        return ops.linear(g, w2, self.conv1d.bias)
+
+
 class PositionalEncoding(nn.Module):
-    """positional_embedding.py:18-95, pe_type in {'add', 'none'} ('1dconv' variants are
-    decoder-side and not built)."""
+    """positional_embedding.py:18-95: pe_type 'none', 'add' (sinusoidal table) or '1dconv<N>L' (N causal Conv1d ->
+    LayerNorm -> ReLU -> Dropout stages over the token embeddings: the decoder-side encoding of the reference's
+    Transformer recipes; the N stages start from ONE deep-copied initialisation, as there)."""
 
     def __init__(self, d_model, dropout, pe_type, param_init, max_len=5000,
                  conv_kernel_size=3, layer_norm_eps=1e-12):
@@ -374,7 +399,12 @@ class PositionalEncoding(nn.Module):
         self.pe_type = pe_type
         self.scale = math.sqrt(d_model)
         if '1dconv' in pe_type:
-            raise NotImplementedError(pe_type)
+            causal_conv1d = CausalConv1d(d_model, d_model, conv_kernel_size, param_init=param_init)
+            layers = []
+            for _ in range(int(pe_type.replace('1dconv', '')[0])):
+                layers += [copy.deepcopy(causal_conv1d), nn.LayerNorm(d_model, eps=layer_norm_eps), nn.ReLU(),
+                           nn.Dropout(p=dropout)]
+            self.pe = nn.Sequential(*layers)        # parameter container: `pe.{0,4,8}.conv1d.*`, `pe.{1,5,9}.*`
         elif pe_type != 'none':
             pe = torch.zeros(max_len, d_model, dtype=torch.float32)
             position = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
@@ -390,6 +420,13 @@ class PositionalEncoding(nn.Module):
             xs = ops.scale(xs, alpha) if alpha != 1.0 else xs
         elif self.pe_type == 'add':
             xs = ops.scale_add_bcast(xs, self.pe[0, offset:xs.size(1) + offset].contiguous(), alpha)
+        elif '1dconv' in self.pe_type:
+            xs = ops.scale(xs, alpha) if alpha != 1.0 else xs
+            for n in range(len(self.pe) // 4):
+                conv, norm = self.pe[4 * n], self.pe[4 * n + 1]
+                xs = ops.layer_norm(conv(xs), norm.weight, norm.bias, norm.eps, act='relu')
+                xs = ops.dropout(xs, self.dropout_p, self.training)
+            return xs                                # no further dropout on this branch (positional_embedding.py:92-93)
         else:
             raise NotImplementedError(self.pe_type)
         return ops.dropout(xs, self.dropout_p, self.training)

@@ -14,8 +14,12 @@ The reference sorts the batch by length for packing and un-sorts at the end; utt
 sort is not reproduced.  Parameter names are those of the reference (`enc.rnn.{l}.weight_ih_l0[_reverse]`, ...),
 so checkpoints are interchangeable.
 
-Not built (NotImplementedError): GRU cells, latency-controlled BLSTM (chunk sizes > 0), streaming / state
-carry-over (random state passing), the NiN layers.
+The reference's BLSTM recipes (`lc_chunk_size_right: 40`, `lc_chunk_size_left: -1`) select a second variant, the
+"latency-controlled" encoder in full-context mode (rnn.py:104,385-425): separate `rnn` / `rnn_bwd` unidirectional
+LSTMs over the whole padded batch, no packing, no masking -- built as `_lstm_layer_full_context`.
+
+Not built (NotImplementedError): GRU cells, latency-controlled BLSTM with chunked training (lc_chunk_size_left > 0),
+streaming / state carry-over (random state passing), the NiN layers.
 """
 import logging
 
@@ -56,9 +60,18 @@ class RNNEncoder(EncoderBase):
         self.bidir_sum = bidir_sum_fwd_bwd
         self.N_c = int(str(chunk_size_current).split('_')[0]) // n_stacks
         self.N_r = int(str(chunk_size_right).split('_')[0]) // n_stacks
-        if (self.N_c > 0 or self.N_r > 0) and self.bidirectional:
-            raise NotImplementedError('latency-controlled BLSTM')
-        self.lc_bidir = False
+        # rnn.py:104: what the BLSTM recipes of the reference actually run -- `lc_chunk_size_right: 40` with the default
+        # `lc_chunk_size_left: -1` selects the "latency-controlled" encoder in its FULL-CONTEXT mode (N_c <= 0,
+        # rnn.py:385-425, "pre-training of the LC-BLSTM"): separate forward / backward unidirectional LSTMs
+        # (`rnn`, `rnn_bwd`) run over the whole PADDED batch without packing -- the backward direction starts in the
+        # padding, nothing is masked -- instead of one packed bidirectional nn.LSTM.  Chunked training (N_c > 0) is
+        # not built.
+        self.lc_bidir = (self.N_c > 0 or self.N_r > 0) and self.bidirectional
+        if self.lc_bidir:
+            assert enc_type not in ['lstm', 'conv_lstm']
+            assert n_layers_sub2 == 0
+            if self.N_c > 0:
+                raise NotImplementedError('latency-controlled BLSTM with chunked training (lc_chunk_size_left > 0)')
         if rsp_prob > 0:
             raise NotImplementedError('random state passing')
         self.n_layers_sub1 = n_layers_sub1
@@ -75,10 +88,16 @@ class RNNEncoder(EncoderBase):
             raise NotImplementedError('cnn_lookahead=False belongs to the latency-controlled encoder')
         if enc_type != 'conv':
             self.rnn = nn.ModuleList()
+            if self.lc_bidir:
+                self.rnn_bwd = nn.ModuleList()
             self.proj = nn.ModuleList() if n_projs > 0 else None
             self.subsample = nn.ModuleList() if np.prod(subsamples) > 1 else None
             for lth in range(n_layers):
-                self.rnn += [nn.LSTM(self._odim, n_units, 1, batch_first=True, bidirectional=self.bidirectional)]
+                if self.lc_bidir:
+                    self.rnn += [nn.LSTM(self._odim, n_units, 1, batch_first=True)]
+                    self.rnn_bwd += [nn.LSTM(self._odim, n_units, 1, batch_first=True)]
+                else:
+                    self.rnn += [nn.LSTM(self._odim, n_units, 1, batch_first=True, bidirectional=self.bidirectional)]
                 self._odim = n_units if bidir_sum_fwd_bwd else n_units * self.n_dirs
                 for sub, n_sub in (('sub1', n_layers_sub1), ('sub2', n_layers_sub2)):
                     if lth == n_sub - 1 and task_specific_layer:
@@ -109,6 +128,16 @@ class RNNEncoder(EncoderBase):
 
     def reset_cache(self):
         self.hx_fwd = [None] * self.n_layers
+
+    def _lstm_layer_full_context(self, xs, full_dev, rnn, rnn_bwd):
+        """rnn.py:404-411: flip(rnn_bwd(flip(xs))) and rnn(xs) over the padded batch; `full_dev` holds T for every
+        utterance, so nsp_time_flip_mask reverses the whole time axis and masks nothing."""
+        y_f = ops.lstm(xs, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
+        y_r = ops.lstm(ops.time_flip_mask(xs, full_dev, True), rnn_bwd.weight_ih_l0, rnn_bwd.weight_hh_l0,
+                       rnn_bwd.bias_ih_l0, rnn_bwd.bias_hh_l0)
+        if self.bidir_sum:
+            return ops.add(y_f, ops.time_flip_mask(y_r, full_dev, True))
+        return ops.bidir_merge(y_f, y_r, full_dev)
 
     def _lstm_layer(self, xs, lens_dev, rnn):
         """Padding.forward (rnn.py:534-547) for one (bidirectional) layer."""
@@ -150,10 +179,15 @@ class RNNEncoder(EncoderBase):
         self.reset_cache()
         xs_sub = {}
         for lth in range(self.n_layers):
-            if xs.size(1) > int(xlens.max()):
-                xs = xs[:, :int(xlens.max())].contiguous()      # pad_packed_sequence returns max(xlens) frames
-            lens_dev = ops.h2d(xlens, xs.device, torch.int32)
-            xs = self._lstm_layer(xs, lens_dev, self.rnn[lth])
+            if self.lc_bidir:
+                full = torch.full((xs.size(0),), xs.size(1), dtype=torch.int32)
+                xs = self._lstm_layer_full_context(xs, ops.h2d(full, xs.device, torch.int32), self.rnn[lth],
+                                                   self.rnn_bwd[lth])
+            else:
+                if xs.size(1) > int(xlens.max()):
+                    xs = xs[:, :int(xlens.max())].contiguous()      # pad_packed_sequence returns max(xlens) frames
+                lens_dev = ops.h2d(xlens, xs.device, torch.int32)
+                xs = self._lstm_layer(xs, lens_dev, self.rnn[lth])
             xs = ops.dropout(xs, self.dropout_p, self.training)
             for sub, n_sub in (('sub1', self.n_layers_sub1), ('sub2', self.n_layers_sub2)):
                 if lth == n_sub - 1:

@@ -203,6 +203,12 @@ CASES.update({
                                                        enc_n_projs=16, subsample='1_2_1', subsample_type='drop',
                                                        bidirectional_sum_fwd_bwd=True, conv_poolings='(2,2)_(2,2)'),
                                 dict(B=3, t_range=(61, 95), u_range=(2, 5), vocab=40, seed=142)),
+    # what the reference's BLSTM recipes really run (csj/.../blstm_las.yaml: lc_chunk_size_right 40, left -1): the
+    # latency-controlled encoder in full-context mode, separate rnn / rnn_bwd LSTMs over the padded batch, no packing
+    'conv_blstm_fullcontext_xs': (lambda: blstm_ctc_args(n_layers=2, n_units=64, vocab=40, enc_type='conv_blstm', input_dim=80,
+                                                         subsample='1_2', subsample_type='drop', lc_chunk_size_left='-1',
+                                                         lc_chunk_size_right='40', conv_poolings='(2,2)_(2,2)'),
+                                  dict(B=3, t_range=(61, 95), u_range=(2, 5), vocab=40, seed=143)),
 })
 KEEP_REFERENCE_INIT = {'conformer_rnnt_zero_bias_xs'}
 # scheduled sampling (las.py:668,675-676; ss_prob 0.2 in 39 of the reference's recipes, BASELINE config 3's among them):
@@ -212,8 +218,25 @@ CASES['conformer_ctc_las_ss_xs'] = (
     lambda: conformer_ctc_las_args('XS', n_layers=2, vocab=43, ctc_weight=0.3, dec_n_layers=1, ss_prob=0.4,
                                    ctc_fc_list='', ctc_lsm_prob=0.0, conformer_kernel_size=7),
     dict(B=4, t_range=(60, 131), u_range=(5, 14), vocab=43, seed=51))
+# '1dconv3L' positional encoding of the Transformer decoder (positional_embedding.py:41-53): what every Transformer-
+# decoder recipe of the reference sets (`transformer_dec_pe_type: 1dconv3L`, 15 recipes incl. librispeech transformer.yaml)
+CASES['conformer_ctc_att_1dconv_xs'] = (
+    lambda: conformer_ctc_att_args('XS', n_layers=2, vocab=43, ctc_weight=0.3, dec_n_layers=1, ctc_fc_list='',
+                                   ctc_lsm_prob=0.0, transformer_enc_d_model=64, transformer_enc_n_heads=1,
+                                   transformer_enc_d_ff=128, conformer_kernel_size=7, transformer_dec_d_model=64,
+                                   transformer_dec_n_heads=1, transformer_dec_d_ff=128, transformer_dec_pe_type='1dconv3L'),
+    dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=261))
+# StableEmit (hma_train.py:43-44; `mocha_stableemit_weight` in the uni-Conformer MoChA recipes, SURVEY 8d config 5's
+# alternative): selection probabilities scaled by (1 - weight) once train.py triggers it; quantity loss on as well
+CASES['conformer_ctc_mocha_stableemit_xs'] = (
+    lambda: conformer_ctc_las_args('XS', n_layers=2, vocab=43, ctc_weight=0.3, attn_type='mocha', mocha_chunk_size=4,
+                                   mocha_std=0.0, mocha_init_r=-1, mocha_quantity_loss_weight=0.5,
+                                   mocha_stableemit_weight=0.2, ctc_fc_list='', ctc_lsm_prob=0.0,
+                                   conformer_kernel_size=7, enc_type='conv_uni_conformer'),
+    dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=371))
+TRIGGER_STABLEEMIT = {'conformer_ctc_mocha_stableemit_xs'}
 TRIGGER_SCHEDULED_SAMPLING = {'conformer_ctc_las_ss_xs': 2024}   # name -> random.seed value
-TRIGGER_QUANTITY_LOSS = {'conformer_ctc_mocha_xs'}   # model.trigger_quantity_loss() before the step (train.py curriculum)
+TRIGGER_QUANTITY_LOSS = {'conformer_ctc_mocha_xs', 'conformer_ctc_mocha_stableemit_xs'}   # model.trigger_quantity_loss() before the step (train.py curriculum)
 
 
 def run_case(name):
@@ -246,6 +269,8 @@ def run_case(name):
         model.trigger_quantity_loss()
     if name in TRIGGER_SCHEDULED_SAMPLING:
         model.trigger_scheduled_sampling()
+    if name in TRIGGER_STABLEEMIT:
+        model.trigger_stableemit()
     batch = synthetic_batch(input_dim=args.input_dim, **bkw)
     wrapped = CPUWrapperASR(model)
     # taken BEFORE the step: a training-mode forward moves BatchNorm's running statistics (the eval-mode
@@ -271,6 +296,7 @@ def run_case(name):
     fix = {
         'meta': {'case': name, 'torch': torch.__version__, 'trigger_quantity_loss': name in TRIGGER_QUANTITY_LOSS,
                  'scheduled_sampling_seed': TRIGGER_SCHEDULED_SAMPLING.get(name),
+                 'trigger_stableemit': name in TRIGGER_STABLEEMIT,
                  'rnnt_loss_source': 'oracle/rnnt_ref.py (warprnnt_pytorch absent)' if args.ctc_weight < 1 else 'n/a'},
         'args': vars(args), 'batch': {k: batch[k] for k in ('xs', 'ys', 'ys_sub1', 'ys_sub2') if k in ('xs', 'ys') or batch[k]},
         'state_dict': state_before,

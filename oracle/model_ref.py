@@ -378,18 +378,29 @@ def rnn_encoder_forward(xs, xlens, sd, args, sub_out=None):
         sub[i] = f
     n_sub = {'sub1': getattr(args, 'enc_n_layers_sub1', 0), 'sub2': getattr(args, 'enc_n_layers_sub2', 0)}
     B = xs.shape[0]
+    # rnn.py:104: N_c / N_r come from lc_chunk_size_left (sic, build.py:146) / lc_chunk_size_right
+    N_c = int(str(args.lc_chunk_size_left).split('_')[0]) // args.n_stacks
+    N_r = int(str(args.lc_chunk_size_right).split('_')[0]) // args.n_stacks
+    lc_bidir = (N_c > 0 or N_r > 0) and bidir
+    assert not (lc_bidir and N_c > 0), 'chunked LC-BLSTM training is not restated'
     for l in range(n_layers):
-        T = max(xlens)
         p = 'enc.rnn.%d' % l
-        out = xs.new_zeros(B, T, H * (2 if bidir else 1))
-        for b in range(B):
-            n = xlens[b]
-            out[b, :n, :H] = lstm_ref(xs[b:b + 1, :n], sd, p)[0]
-            if bidir:
-                out[b, :n, H:] = lstm_ref(xs[b:b + 1, :n].flip(1), sd, p, '_reverse')[0].flip(0)
-        if bidir and args.bidirectional_sum_fwd_bwd:
-            out = out[..., :H] + out[..., H:]
-        xs = out
+        if lc_bidir:
+            # _forward_full_context (rnn.py:404-411): no packing -- both directions see the padded frames
+            yf = lstm_ref(xs, sd, p)
+            yb = lstm_ref(xs.flip(1), sd, 'enc.rnn_bwd.%d' % l).flip(1)
+            xs = yf + yb if args.bidirectional_sum_fwd_bwd else torch.cat([yf, yb], dim=-1)
+        else:
+            T = max(xlens)
+            out = xs.new_zeros(B, T, H * (2 if bidir else 1))
+            for b in range(B):
+                n = xlens[b]
+                out[b, :n, :H] = lstm_ref(xs[b:b + 1, :n], sd, p)[0]
+                if bidir:
+                    out[b, :n, H:] = lstm_ref(xs[b:b + 1, :n].flip(1), sd, p, '_reverse')[0].flip(0)
+            if bidir and args.bidirectional_sum_fwd_bwd:
+                out = out[..., :H] + out[..., H:]
+            xs = out
         for name, n in n_sub.items():          # rnn.py:512-524
             if n > 0 and l == n - 1 and sub_out is not None:
                 xsub = xs
@@ -450,6 +461,14 @@ def transformer_decoder_att(eouts, elens, ys, sd, args, training, p='dec_fwd'):
     out = F.embedding(ys_in, sd[p + '.embed.weight'], padding_idx=3) * math.sqrt(d)
     if args.transformer_dec_pe_type == 'add':
         out = out + sd[p + '.pos_enc.pe'][:, :L].to(out.dtype)
+    elif '1dconv' in args.transformer_dec_pe_type:
+        # positional_embedding.py:41-53,92-93: N x (causal Conv1d k=3 -> LayerNorm -> ReLU [-> Dropout])
+        for n in range(int(args.transformer_dec_pe_type.replace('1dconv', '')[0])):
+            q = '%s.pos_enc.pe.%d' % (p, 4 * n)
+            w = sd[q + '.conv1d.weight']
+            pad = w.shape[-1] - 1
+            out = F.conv1d(out.transpose(2, 1), w, sd[q + '.conv1d.bias'], padding=pad)[:, :, :-pad].transpose(2, 1)
+            out = torch.relu(_ln(out, sd, '%s.pos_enc.pe.%d' % (p, 4 * n + 1), args.transformer_layer_norm_eps))
 
     def mha2(q_in, kv_in, vis, pp):
         Bq, Lq, _ = q_in.shape
@@ -500,7 +519,7 @@ def _xe_lsm(logits, ys_out, lsm, B):
     return rows.sum() / B, float(((lg.argmax(1) == yo) & ~mask).sum()) * 100 / n_tokens, math.exp(rows.sum().item() / n_tokens)
 
 
-def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='dec_fwd', ss_prob=0.0):
+def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='dec_fwd', ss_prob=0.0, stableemit=0.0):
     """decoders/las.py:618-776 (teacher forcing; ss_prob > 0 = scheduled sampling after it has been triggered,
     :668,675-676: Python's global `random` stream decides per step, the arg-max of the previous step's own output
     distribution is fed back; no LM) with the single-head attentions
@@ -570,6 +589,8 @@ def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='de
             e = (torch.relu(key_ma + F.linear(dscore, sd[sc + '.monotonic_energy.w_query.weight'])[:, None]) * v_ma.view(1, 1, -1)).sum(-1)
             e = (e + sd[sc + '.monotonic_energy.r']).masked_fill(~vis, NEG_INF32)
             pc = torch.sigmoid(e)
+            if stableemit > 0:          # StableEmit once triggered (hma_train.py:43-44)
+                pc = (1 - stableemit) * pc
             cp = torch.exp(excl_cumsum(torch.log(torch.clamp(1 - pc, min=args.mocha_eps, max=1.0))))
             den = 1 if args.mocha_no_denominator else torch.clamp(cp, min=args.mocha_eps, max=1.0)
             aw = pc * cp * torch.cumsum(aw / den, dim=-1)
@@ -616,7 +637,7 @@ def _sub_args(args, sub):
 
 
 def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quantity_weight=0.0, bn_out=None,
-                     scheduled_sampling=False):
+                     scheduled_sampling=False, stableemit=False):
     """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens).
     bn_out (dict, optional) receives the running statistics a training-mode BatchNorm would leave behind."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
@@ -649,7 +670,8 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quanti
         loss = loss + la * (main_w - ctc_w)
     if args.dec_type in ('lstm', 'gru') and main_w - ctc_w > 0:
         la, acc, ppl, lq = rnn_decoder_att(eouts, elens, batch['ys'], sd, args, training, quantity_weight,
-                                           ss_prob=args.ss_prob if scheduled_sampling else 0.0)
+                                           ss_prob=args.ss_prob if scheduled_sampling else 0.0,
+                                           stableemit=args.mocha_stableemit_weight if stableemit else 0.0)
         obs.pop('loss.transducer')
         obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})   # (recorded before the quantity loss is added)
         if lq is not None:

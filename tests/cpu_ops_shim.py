@@ -145,6 +145,19 @@ def _lstm(x, w_ih, w_hh, b_ih, b_hh):
     return torch.stack(outs, dim=1)
 
 
+def _xe_lsm_loss(logits, ys_int32, lsm_prob, ignore_index, bs):
+    """nsp_xe_lsm_fwd_bwd (criterion.py:45-86, torch_utils.py:129-145) -> (loss [1], loss_rows, correct)"""
+    V = logits.shape[-1]
+    lg, yo = logits.reshape(-1, V), ys_int32.reshape(-1).long()
+    mask = yo == ignore_index
+    lp = torch.log_softmax(lg, dim=-1)
+    tgt = torch.full_like(lp, lsm_prob / (V - 1))
+    tgt.scatter_(1, yo.masked_fill(mask, 0).unsqueeze(1), 1 - lsm_prob)
+    rows = -(tgt * lp).sum(1).masked_fill(mask, 0)
+    correct = ((lg.argmax(1) == yo) & ~mask).int()
+    return (rows.sum() / bs).view(1), rows.detach(), correct
+
+
 def _h2d_packed(arrays, device):
     import numpy as np
     return torch.from_numpy(np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1) for a in arrays]))
@@ -176,6 +189,7 @@ def host_logic_on_cpu():
         dropout=lambda x, p, training: x if (p == 0 or not training) else (_ for _ in ()).throw(AssertionError('dropout')),
         add=lambda x, z, alpha=1.0, beta=1.0: alpha * x + beta * z, scale_add_bcast=_scale_add_bcast,
         xl_pos_table=_xl_pos_table, ctc_loss=_ctc_loss, h2d_packed=_h2d_packed, pad_batch=_pad_batch, lstm=_lstm,
+        xe_lsm_loss=_xe_lsm_loss, argmax_rows=lambda x2d: x2d.argmax(-1).int(),
     )
     saved = {k: getattr(ops, k) for k in fakes}
     mode = ops.get_compute_mode()

@@ -27,7 +27,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 VARIANT_CASES = ['conformer_bn_ctc_xs', 'conformer_gn_ctc_xs', 'transformer_glu_ctc_xs', 'conformer_drop_ctc_xs',
                  'conformer_add_ctc_xs', 'conformer_meanpool_ctc_xs', 'conformer_concat_ctc_xs', 'conformer_conv1d_ctc_xs',
                  'conformer_2mtl_ctc_xs', 'transformer_3mtl_att_xs', 'blstm_ctc_xs', 'conv_blstm_proj_drop_xs',
-                 'conformer_ctc_las_ss_xs']
+                 'conformer_ctc_las_ss_xs', 'conv_blstm_fullcontext_xs',
+                 'conformer_ctc_att_1dconv_xs', 'conformer_ctc_mocha_stableemit_xs']
 CASES = sorted(set(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt'))) - set(VARIANT_CASES))
 
 
@@ -57,6 +58,8 @@ def _run(fix, mode):
     if fix['meta'].get('trigger_quantity_loss'):
         model.trigger_quantity_loss()        # train.py's curriculum switch (MoChA quantity loss)
     ss_seed = fix['meta'].get('scheduled_sampling_seed')
+    if fix['meta'].get('trigger_stableemit'):
+        model.trigger_stableemit()           # train.py's mocha_stableemit_start_epoch switch
     if ss_seed is not None:
         model.trigger_scheduled_sampling()   # train.py's ss_start_epoch switch; Python's `random` decides per step
     batch = dict(fix['batch'])

@@ -57,7 +57,8 @@ def test_model_restatement_matches_reference_fixture(name):
         import random
         random.seed(ss_seed)      # scheduled sampling: the same Python random stream as the reference's training forward
     loss, obs, eouts, elens = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64, quantity_weight=qw,
-                                                         bn_out=bn_out, scheduled_sampling=ss_seed is not None)
+                                                         bn_out=bn_out, scheduled_sampling=ss_seed is not None,
+                                                         stableemit=bool(fix['meta'].get('trigger_stableemit')))
     ref = fix['loss'].item()
     assert abs(loss.item() - ref) / abs(ref) < 2e-5, (loss.item(), ref)
     if bn_out:

@@ -7,6 +7,7 @@ the real ctypes glue; the remaining ops are plain-torch stand-ins (tests/cpu_ops
 are run on the device by tests/test_golden_gpu.py."""
 import argparse
 import os
+import random
 
 import pytest
 import torch
@@ -16,7 +17,7 @@ from tests.test_golden_gpu import FP32_GRAD_GATE, VARIANT_CASES
 
 pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang++ for the HIP emulator')
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-VARIANTS = [c for c in VARIANT_CASES if c not in ('transformer_3mtl_att_xs', 'conformer_ctc_las_ss_xs')]   # attention decoders: no CPU stand-ins
+VARIANTS = list(VARIANT_CASES)
 # stand-in sanity: fixtures of the benchmarked family must pass through the same shim
 CONTROLS = ['conformer_ctc_xs', 'transformer_ctc_xs', 'conformer_relxl_ctc_xs', 'lc_conformer_mask_xs']
 
@@ -33,14 +34,25 @@ def test_speech2text_host_logic_matches_reference_fixture(name):
     batch.update(xlens=[len(x) for x in batch['xs']], trigger_points=None)
     batch.setdefault('ys_sub1', [])
     batch.setdefault('ys_sub2', [])
+    if fix['meta'].get('trigger_quantity_loss'):
+        model.trigger_quantity_loss()
+    ss_seed = fix['meta'].get('scheduled_sampling_seed')
+    if fix['meta'].get('trigger_stableemit'):
+        model.trigger_stableemit()           # train.py's mocha_stableemit_start_epoch switch
+    if ss_seed is not None:
+        model.trigger_scheduled_sampling()
     with host_logic_on_cpu():
         model.zero_grad()
+        if ss_seed is not None:
+            random.seed(ss_seed)
         loss, obs = model(batch, task='all')
         loss.backward()
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         model.eval()
         with torch.no_grad():
             eout = model.encode(batch['xs'], 'all')
+            if ss_seed is not None:
+                random.seed(ss_seed)
             loss_eval, _ = model(batch, task='all', is_eval=True)
     ref = fix['loss'].item()
     assert abs(loss.item() - ref) / abs(ref) < 1e-4, (loss.item(), ref)
