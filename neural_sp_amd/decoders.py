@@ -43,7 +43,9 @@ class DecoderBase(nn.Module):
         pass
 
     def trigger_latency_loss(self):
-        pass
+        # decoder_base.py:40-43
+        if getattr(self, 'attn_type', '') == 'mocha':
+            self._latency_loss_weight = getattr(self, 'latency_loss_weight', 0)
 
     def trigger_stableemit(self):
         # decoder_base.py:45-50

@@ -163,8 +163,9 @@ class MoChA(nn.Module):
                  init_r=-4, eps=1e-6, noise_std=1.0, no_denominator=False, sharpening_factor=1.0, dropout=0.,
                  decot=False, decot_delta=2, stableemit_weight=0.0):
         super().__init__()
-        if atype != 'add' or n_heads_mono != 1 or n_heads_chunk != 1 or conv1d or decot:
-            raise NotImplementedError('MoChA: built for additive energies, one head, no 1-d conv / DeCoT')
+        if atype != 'add' or n_heads_mono != 1 or n_heads_chunk != 1 or conv1d:
+            raise NotImplementedError('MoChA: built for additive energies, one head, no 1-d conv')
+        self.decot, self.decot_delta = decot, decot_delta
         assert stableemit_weight >= 0
         self.stableemit_weight = stableemit_weight
         self._stableemit_weight = 0          # curriculum: trigger_stableemit() (mocha.py:97-99,157-159)
@@ -205,6 +206,12 @@ class MoChA(nn.Module):
         cumprod_1mp = _safe_cumprod(1 - p_choose, self.eps)
         denom = 1 if self.no_denom else torch.clamp(cumprod_1mp, min=self.eps, max=1.0)
         alpha = p_choose * cumprod_1mp * torch.cumsum(aw_prev / denom, dim=-1)
+        if self.decot:
+            # delay-constrained training (hma_train.py:59-63): nothing may be selected more than `decot_delta`
+            # frames after the token's reference boundary
+            assert trigger_points is not None
+            j = torch.arange(klen, device=key.device).view(1, 1, 1, klen)
+            alpha = alpha.masked_fill(j > (trigger_points.view(bs, 1, 1, 1).long() + self.decot_delta), 0)
         beta = None
         if self.chunk_energy is not None:
             # soft_chunkwise_attention (mocha_train.py:13-58)
@@ -269,7 +276,7 @@ class RNNDecoder(DecoderBase):
         super().__init__()
         for flag, what in ((mbr_training, 'MBR training'), (external_lm is not None or lm_fusion or lm_init, 'LM fusion / init'),
                            (attn_n_heads > 1, 'multi-head attention'),
-                           (bool(latency_metric), 'latency losses / DeCoT'), (replace_sos, 'replace_sos'),
+                           (latency_metric == 'interval', "latency metric 'interval'"), (replace_sos, 'replace_sos'),
                            (bool(discourse_aware), 'discourse-aware training')):
             if flag:
                 raise NotImplementedError('RNNDecoder: %s is not built' % what)
@@ -283,6 +290,8 @@ class RNNDecoder(DecoderBase):
         self.bwd, self.mtl_per_batch = backward, mtl_per_batch
         self.quantity_loss_weight, self._quantity_loss_weight = quantity_loss_weight, 0
         self.latency_metric, self.latency_loss_weight, self._latency_loss_weight = latency_metric, latency_loss_weight, 0
+        if 'ctc_sync' in latency_metric:
+            assert 0 < self.ctc_weight < 1          # las.py:161-162
         self.aws_dict, self.data_dict = {}, {}
         if ctc_weight > 0:
             self.ctc = CTC(eos=self.eos, blank=self.blank, enc_n_units=enc_n_units, vocab=vocab, dropout=dropout,
@@ -293,7 +302,7 @@ class RNNDecoder(DecoderBase):
                 self.score = MoChA(enc_n_units, qdim, attn_dim, enc_n_units, atype='add', chunk_size=mocha_chunk_size,
                                    n_heads_mono=mocha_n_heads_mono, init_r=mocha_init_r, eps=mocha_eps,
                                    noise_std=mocha_std, no_denominator=mocha_no_denominator, conv1d=mocha_1dconv,
-                                   sharpening_factor=attn_sharpening_factor, decot=False,
+                                   sharpening_factor=attn_sharpening_factor, decot='decot' in latency_metric,
                                    decot_delta=mocha_decot_lookahead, stableemit_weight=mocha_stableemit_weight)
             else:
                 self.score = AttentionMechanism(enc_n_units, qdim, attn_dim, attn_type,
@@ -341,12 +350,20 @@ class RNNDecoder(DecoderBase):
         observation = {'loss': None, 'loss_att': None, 'loss_ctc': None, 'loss_mbr': None,
                        'acc_att': None, 'ppl_att': None}
         loss = eouts.new_zeros((1,))
+        ctc_trigger_points = None
         if self.ctc_weight > 0 and (task == 'all' or 'ctc' in task):
-            loss_ctc, _ = self.ctc(eouts, elens, ys)
+            # CTC-synchronous training (las.py:463-465): the reference boundaries of the latency loss are the
+            # forced alignment of this very CTC branch (nsp_ctc_forced_align), recomputed every step
+            loss_ctc, ctc_trigger_points = self.ctc(eouts, elens, ys,
+                                                    forced_align='ctc_sync' in self.latency_metric and self.training)
             observation['loss_ctc'] = loss_ctc.detach()
             loss = loss + (loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight)
+        forced = None
+        if self.latency_metric in ['minlt', 'decot', 'decot_ctc_sync'] and trigger_points is not None:
+            forced = ops.h2d(np.asarray(trigger_points, dtype=np.int32), eouts.device)      # batch['trigger_points'] (:471-472)
         if self.att_weight > 0 and (task == 'all' or 'ctc' not in task):
-            loss_att, acc_att, ppl_att, loss_quantity = self.forward_att(eouts, elens, ys)
+            loss_att, acc_att, ppl_att, loss_quantity, loss_latency = self.forward_att(
+                eouts, elens, ys, ctc_trigger_points=ctc_trigger_points, forced_trigger_points=forced)
             observation['loss_att'] = loss_att.detach()
             observation['acc_att'] = acc_att
             observation['ppl_att'] = ppl_att
@@ -354,6 +371,10 @@ class RNNDecoder(DecoderBase):
                 if self._quantity_loss_weight > 0:
                     loss_att = loss_att + loss_quantity * self._quantity_loss_weight
                 observation['loss_quantity'] = loss_quantity.detach()
+            if self.latency_metric:
+                if self._latency_loss_weight > 0:
+                    loss_att = loss_att + loss_latency * self._latency_loss_weight
+                observation['loss_latency'] = loss_latency.detach() if self.training else 0
             loss = loss + (loss_att if self.mtl_per_batch else loss_att * self.att_weight)
         observation['loss'] = loss.detach()
         return loss, observation
@@ -377,8 +398,8 @@ class RNNDecoder(DecoderBase):
                 dout_score = dout                       # the FIRST layer's output scores the attention
         return new_h, new_c, dout_score, dout
 
-    def forward_att(self, eouts, elens, ys):
-        """-> (loss [1], acc (device scalar, %), ppl (device scalar), quantity loss (device scalar))"""
+    def forward_att(self, eouts, elens, ys, ctc_trigger_points=None, forced_trigger_points=None):
+        """-> (loss [1], acc (device scalar, %), ppl (device scalar), quantity loss, latency loss (device scalars))"""
         dev = eouts.device
         B, T = eouts.shape[:2]
         ylens = [len(y) + 1 for y in ys]
@@ -391,6 +412,10 @@ class RNNDecoder(DecoderBase):
             ys_in[b, 1:len(yy) + 1] = yy
             ys_out[b, :len(yy)] = yy
             ys_out[b, len(yy)] = self.eos
+        if forced_trigger_points is not None:
+            forced_trigger_points = forced_trigger_points.clone()
+            for b in range(B):
+                forced_trigger_points[b, ylens[b] - 1] = int(elens[b]) - 1     # the boundary of <eos> (las.py:647-649)
         ys_in_d = ops.h2d(ys_in, dev)
         ys_out_d = ops.h2d(ys_out.reshape(-1), dev)
         elens_d = ops.h2d(elens, dev, torch.int64)
@@ -423,7 +448,8 @@ class RNNDecoder(DecoderBase):
                     y_emb = ys_emb[:, i]
                 x = torch.cat([y_emb, cv.squeeze(1)], dim=-1)
                 hxs, cxs, dout_score, dout_gen = self._recurrency(x, hxs, cxs)
-                cv, aw, _ = self.score(eouts, eouts, dout_score.unsqueeze(1), src_mask, aw, cache=True, mode='parallel')
+                cv, aw, _ = self.score(eouts, eouts, dout_score.unsqueeze(1), src_mask, aw, cache=True, mode='parallel',
+                                       trigger_points=forced_trigger_points[:, i:i + 1] if forced_trigger_points is not None else None)
                 douts.append(dout_gen)
                 cvs.append(cv.squeeze(1))
                 aws.append(aw)
@@ -438,13 +464,23 @@ class RNNDecoder(DecoderBase):
         ppl = torch.exp(loss_rows.sum() / n_tokens)
         acc = correct.sum().float() * (100.0 / n_tokens)
         loss_quantity = eouts.new_zeros(())
-        if self.attn_type == 'mocha':
+        loss_latency = eouts.new_zeros(())
+        have_points = ctc_trigger_points is not None or forced_trigger_points is not None
+        if self.attn_type == 'mocha' or have_points:
             aws_t = torch.cat(aws, dim=2)                                                        # [B,1,L,T]
             tgt_mask = (ys_out_d.view(B, L) != self.pad)
             aws_t = aws_t.masked_fill(~tgt_mask.view(B, 1, L, 1), 0)                             # attention padding (:724-726)
+        if self.attn_type == 'mocha':
             n_pred = aws_t.sum(3).sum(2).sum(1) / aws_t.shape[1]
             loss_quantity = torch.mean(torch.abs(n_pred - tgt_mask.sum(1).float()))              # :731-736
-        return loss, acc, ppl, loss_quantity
+        if ctc_trigger_points is not None or ('ctc_sync' not in self.latency_metric and forced_trigger_points is not None):
+            # CTC-synchronous / minimum-latency / delay-constrained training (las.py:757-769): distance between the
+            # expected attended frame of every token and its reference boundary (pad positions: 0 against 0)
+            points = ctc_trigger_points if 'ctc_sync' in self.latency_metric else forced_trigger_points
+            js = torch.arange(T, dtype=torch.float32, device=dev).view(1, 1, 1, T)
+            exp_points = (js * aws_t).sum(3)                                                     # [B,1,L]
+            loss_latency = torch.abs(exp_points - points[:, :L].float().unsqueeze(1)).sum() / float(sum(ylens))
+        return loss, acc, ppl, loss_quantity, loss_latency
 
     def _plot_attention(self, save_path=None, n_cols=1):
         pass

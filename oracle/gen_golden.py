@@ -234,9 +234,25 @@ CASES['conformer_ctc_mocha_stableemit_xs'] = (
                                    mocha_stableemit_weight=0.2, ctc_fc_list='', ctc_lsm_prob=0.0,
                                    conformer_kernel_size=7, enc_type='conv_uni_conformer'),
     dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=371))
+# latency losses of MoChA (las.py:757-769; SURVEY 8f rank 2 "quantity/latency losses"): CTC-synchronous training
+# (reference boundaries = forced alignment of the model's own CTC branch, recomputed every step) and delay-constrained
+# training (DeCoT: boundaries come with the batch -- here the same CTC alignment -- and nothing may be attended more than
+# `mocha_decot_lookahead` frames after them).  train.py switches the weights on together with the quantity loss.
+def _mocha_lat(metric, **kw):
+    return lambda: conformer_ctc_las_args('XS', n_layers=2, vocab=43, ctc_weight=0.3, attn_type='mocha', mocha_chunk_size=4,
+                                          mocha_std=0.0, mocha_init_r=-1, mocha_quantity_loss_weight=0.5,
+                                          mocha_latency_metric=metric, mocha_latency_loss_weight=0.3, ctc_fc_list='',
+                                          ctc_lsm_prob=0.0, conformer_kernel_size=7, **kw)
+
+
+CASES['conformer_ctc_mocha_ctcsync_xs'] = (_mocha_lat('ctc_sync'), dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=81))
+CASES['conformer_ctc_mocha_decot_xs'] = (_mocha_lat('decot', mocha_decot_lookahead=2),
+                                         dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=82))
+CTC_ALIGNED = {'conformer_ctc_mocha_ctcsync_xs': 'ctc_sync', 'conformer_ctc_mocha_decot_xs': 'batch'}
 TRIGGER_STABLEEMIT = {'conformer_ctc_mocha_stableemit_xs'}
 TRIGGER_SCHEDULED_SAMPLING = {'conformer_ctc_las_ss_xs': 2024}   # name -> random.seed value
-TRIGGER_QUANTITY_LOSS = {'conformer_ctc_mocha_xs', 'conformer_ctc_mocha_stableemit_xs'}   # model.trigger_quantity_loss() before the step (train.py curriculum)
+TRIGGER_QUANTITY_LOSS = {'conformer_ctc_mocha_xs', 'conformer_ctc_mocha_stableemit_xs', 'conformer_ctc_mocha_ctcsync_xs',
+                         'conformer_ctc_mocha_decot_xs'}   # model.trigger_quantity_loss() before the step (train.py curriculum)
 
 
 def run_case(name):
@@ -272,6 +288,16 @@ def run_case(name):
     if name in TRIGGER_STABLEEMIT:
         model.trigger_stableemit()
     batch = synthetic_batch(input_dim=args.input_dim, **bkw)
+    ctc_tp = None
+    if name in CTC_ALIGNED:
+        # the reference's own forced aligner (ctc.py:628-753) on this model's CTC posteriors, train mode, dropout 0
+        model.train()
+        with torch.no_grad():
+            eo = model.encode(batch['xs'], 'all')
+            ctc_tp = model.dec_fwd.ctc.forced_aligner(model.dec_fwd.ctc.output(eo['ys']['xs']).clone(), eo['ys']['xlens'],
+                                                      batch['ys'], torch.IntTensor([len(y) for y in batch['ys']]))
+        if CTC_ALIGNED[name] == 'batch':
+            batch['trigger_points'] = ctc_tp.numpy().astype(np.int32)      # what datasets/alignment.py would load
     wrapped = CPUWrapperASR(model)
     # taken BEFORE the step: a training-mode forward moves BatchNorm's running statistics (the eval-mode
     # outputs below are computed with the moved ones, as a consumer that loads this state_dict and repeats
@@ -298,7 +324,9 @@ def run_case(name):
                  'scheduled_sampling_seed': TRIGGER_SCHEDULED_SAMPLING.get(name),
                  'trigger_stableemit': name in TRIGGER_STABLEEMIT,
                  'rnnt_loss_source': 'oracle/rnnt_ref.py (warprnnt_pytorch absent)' if args.ctc_weight < 1 else 'n/a'},
-        'args': vars(args), 'batch': {k: batch[k] for k in ('xs', 'ys', 'ys_sub1', 'ys_sub2') if k in ('xs', 'ys') or batch[k]},
+        'args': vars(args), 'batch': {k: batch[k] for k in ('xs', 'ys', 'ys_sub1', 'ys_sub2', 'trigger_points')
+                                      if k in ('xs', 'ys') or (batch[k] is not None and len(batch[k]))},
+        'ctc_trigger_points': ctc_tp,
         'state_dict': state_before,
         'loss': loss.detach().clone(), 'loss_eval': loss_eval.detach().clone(), 'observation': obs,
         'eout': eout['ys']['xs'].clone(), 'elens': eout['ys']['xlens'].clone(), 'grads': grads,

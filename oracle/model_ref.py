@@ -519,7 +519,8 @@ def _xe_lsm(logits, ys_out, lsm, B):
     return rows.sum() / B, float(((lg.argmax(1) == yo) & ~mask).sum()) * 100 / n_tokens, math.exp(rows.sum().item() / n_tokens)
 
 
-def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='dec_fwd', ss_prob=0.0, stableemit=0.0):
+def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='dec_fwd', ss_prob=0.0, stableemit=0.0,
+                    ctc_trigger_points=None, forced_trigger_points=None):
     """decoders/las.py:618-776 (teacher forcing; ss_prob > 0 = scheduled sampling after it has been triggered,
     :668,675-676: Python's global `random` stream decides per step, the arg-max of the previous step's own output
     distribution is fed back; no LM) with the single-head attentions
@@ -565,6 +566,11 @@ def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='de
         return F.conv1d(F.pad(x, [back, forward]).unsqueeze(1), x.new_ones(1, 1, back + forward + 1)).squeeze(1)
 
     import random
+    metric = getattr(args, 'mocha_latency_metric', '')
+    if forced_trigger_points is not None:      # las.py:647-649: the boundary of <eos> is the last frame
+        forced_trigger_points = forced_trigger_points.clone()
+        for b in range(B):
+            forced_trigger_points[b, ylens[b] - 1] = elens[b] - 1
     douts, cvs, aws = [], [], []
     for i in range(L):
         y_emb = emb[:, i]
@@ -594,6 +600,9 @@ def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='de
             cp = torch.exp(excl_cumsum(torch.log(torch.clamp(1 - pc, min=args.mocha_eps, max=1.0))))
             den = 1 if args.mocha_no_denominator else torch.clamp(cp, min=args.mocha_eps, max=1.0)
             aw = pc * cp * torch.cumsum(aw / den, dim=-1)
+            if 'decot' in metric:              # hma_train.py:59-63
+                limit = forced_trigger_points[:, i:i + 1].long() + args.mocha_decot_lookahead
+                aw = aw.masked_fill(torch.arange(T)[None, :] > limit, 0)
             att = aw
             if chunk:
                 u = (torch.relu(key_ca + F.linear(dscore, sd[sc + '.chunk_energy.w_query.weight'])[:, None])
@@ -621,9 +630,16 @@ def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='de
     logits = _lin(torch.tanh(_lin(feats, sd, p + '.output_bn')), sd, p + '.output')
     loss, acc, ppl = _xe_lsm(logits, ys_out, args.lsm_prob if training else 0.0, B)
     lq = None
+    a = torch.stack(aws, 1).masked_fill((ys_out == 3)[:, :, None], 0)              # [B,L,T] (attention padding, :724-726)
     if mocha:
-        a = torch.stack(aws, 1).masked_fill((ys_out == 3)[:, :, None], 0)          # [B,L,T]
         lq = torch.mean(torch.abs(a.sum(2).sum(1) - (ys_out != 3).sum(1).to(a.dtype)))
+    if ctc_trigger_points is not None or ('ctc_sync' not in metric and forced_trigger_points is not None):
+        # las.py:757-769: |expected attended frame - reference boundary| per token, over the number of tokens
+        pts = ctc_trigger_points if 'ctc_sync' in metric else forced_trigger_points
+        exp_pts = (torch.arange(T, dtype=a.dtype)[None, None, :] * a).sum(2)
+        rnn_decoder_att.last_latency = torch.abs(exp_pts - pts[:, :L].to(a.dtype)).sum() / float(sum(ylens))
+    else:
+        rnn_decoder_att.last_latency = None
     return loss, acc, ppl, lq
 
 
@@ -637,7 +653,7 @@ def _sub_args(args, sub):
 
 
 def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quantity_weight=0.0, bn_out=None,
-                     scheduled_sampling=False, stableemit=False):
+                     scheduled_sampling=False, stableemit=False, ctc_trigger_points=None, latency_weight=0.0):
     """speech2text.py:271-345 -> (loss, {'loss.ctc', 'loss.transducer'}, eouts, elens).
     bn_out (dict, optional) receives the running statistics a training-mode BatchNorm would leave behind."""
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
@@ -671,12 +687,18 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quanti
     if args.dec_type in ('lstm', 'gru') and main_w - ctc_w > 0:
         la, acc, ppl, lq = rnn_decoder_att(eouts, elens, batch['ys'], sd, args, training, quantity_weight,
                                            ss_prob=args.ss_prob if scheduled_sampling else 0.0,
-                                           stableemit=args.mocha_stableemit_weight if stableemit else 0.0)
+                                           stableemit=args.mocha_stableemit_weight if stableemit else 0.0,
+                                           ctc_trigger_points=ctc_trigger_points if training else None,
+                                           forced_trigger_points=(torch.as_tensor(batch['trigger_points']).long()
+                                                                  if batch.get('trigger_points') is not None and getattr(args, 'mocha_latency_metric', '') in ('minlt', 'decot', 'decot_ctc_sync') else None))
         obs.pop('loss.transducer')
         obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})   # (recorded before the quantity loss is added)
         if lq is not None:
             obs['loss.quantity'] = lq.item()
             la = la + lq * quantity_weight
+        if getattr(args, 'mocha_latency_metric', '') and rnn_decoder_att.last_latency is not None:
+            obs['loss.latency'] = rnn_decoder_att.last_latency.item() if training else 0
+            la = la + rnn_decoder_att.last_latency * latency_weight     # las.py:488-491, after trigger_latency_loss()
         loss = loss + la * (main_w - ctc_w)
     # auxiliary tasks (speech2text.py:326-343): forward decoders only
     for sub in ('sub1', 'sub2'):

@@ -177,6 +177,16 @@ def _xl_pos_table(inv_freq, L):
     return torch.cat([s.sin(), s.cos()], dim=-1)
 
 
+FORCED_ALIGN = {'result': None}
+
+
+def _ctc_forced_align(logits, labels, elens, ylens, blank=0):
+    """nsp_ctc_forced_align is pinned bit-exact on the device (tests/golden/ctc_align.pt); the host-logic tests hand
+    in the trigger points the REFERENCE aligner produced for the fixture (stored in it) instead of restating it"""
+    assert FORCED_ALIGN['result'] is not None, 'set cpu_ops_shim.FORCED_ALIGN["result"] to the fixture\'s trigger points'
+    return FORCED_ALIGN['result'].to(torch.int32)
+
+
 @contextlib.contextmanager
 def host_logic_on_cpu():
     from neural_sp_amd import ops
@@ -189,7 +199,7 @@ def host_logic_on_cpu():
         dropout=lambda x, p, training: x if (p == 0 or not training) else (_ for _ in ()).throw(AssertionError('dropout')),
         add=lambda x, z, alpha=1.0, beta=1.0: alpha * x + beta * z, scale_add_bcast=_scale_add_bcast,
         xl_pos_table=_xl_pos_table, ctc_loss=_ctc_loss, h2d_packed=_h2d_packed, pad_batch=_pad_batch, lstm=_lstm,
-        xe_lsm_loss=_xe_lsm_loss, argmax_rows=lambda x2d: x2d.argmax(-1).int(),
+        xe_lsm_loss=_xe_lsm_loss, argmax_rows=lambda x2d: x2d.argmax(-1).int(), ctc_forced_align=_ctc_forced_align,
     )
     saved = {k: getattr(ops, k) for k in fakes}
     mode = ops.get_compute_mode()

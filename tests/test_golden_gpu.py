@@ -28,7 +28,8 @@ VARIANT_CASES = ['conformer_bn_ctc_xs', 'conformer_gn_ctc_xs', 'transformer_glu_
                  'conformer_add_ctc_xs', 'conformer_meanpool_ctc_xs', 'conformer_concat_ctc_xs', 'conformer_conv1d_ctc_xs',
                  'conformer_2mtl_ctc_xs', 'transformer_3mtl_att_xs', 'blstm_ctc_xs', 'conv_blstm_proj_drop_xs',
                  'conformer_ctc_las_ss_xs', 'conv_blstm_fullcontext_xs',
-                 'conformer_ctc_att_1dconv_xs', 'conformer_ctc_mocha_stableemit_xs']
+                 'conformer_ctc_att_1dconv_xs', 'conformer_ctc_mocha_stableemit_xs', 'conformer_ctc_mocha_ctcsync_xs',
+                 'conformer_ctc_mocha_decot_xs']
 CASES = sorted(set(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt'))) - set(VARIANT_CASES))
 
 
@@ -63,7 +64,8 @@ def _run(fix, mode):
     if ss_seed is not None:
         model.trigger_scheduled_sampling()   # train.py's ss_start_epoch switch; Python's `random` decides per step
     batch = dict(fix['batch'])
-    batch.update(xlens=[len(x) for x in batch['xs']], trigger_points=None)
+    batch.update(xlens=[len(x) for x in batch['xs']])
+    batch.setdefault('trigger_points', None)   # reference boundaries that come with the batch (DeCoT / MinLT fixtures)
     batch.setdefault('ys_sub1', [])        # auxiliary-task transcripts (multi-task fixtures only)
     batch.setdefault('ys_sub2', [])
     with ops.compute_mode(mode):

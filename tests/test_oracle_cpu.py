@@ -58,7 +58,10 @@ def test_model_restatement_matches_reference_fixture(name):
         random.seed(ss_seed)      # scheduled sampling: the same Python random stream as the reference's training forward
     loss, obs, eouts, elens = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64, quantity_weight=qw,
                                                          bn_out=bn_out, scheduled_sampling=ss_seed is not None,
-                                                         stableemit=bool(fix['meta'].get('trigger_stableemit')))
+                                                         stableemit=bool(fix['meta'].get('trigger_stableemit')),
+                                                         ctc_trigger_points=fix.get('ctc_trigger_points'),
+                                                         latency_weight=(getattr(args, 'mocha_latency_loss_weight', 0.0)
+                                                                         if fix['meta'].get('trigger_quantity_loss') else 0.0))
     ref = fix['loss'].item()
     assert abs(loss.item() - ref) / abs(ref) < 2e-5, (loss.item(), ref)
     if bn_out:
