@@ -46,9 +46,19 @@ def main():
         sd = {k: v.clone().double().requires_grad_(v.is_floating_point() and 'inv_freq' not in k and k != 'enc.pos_enc.pe')
               if v.is_floating_point() else v for k, v in fix['state_dict'].items()}
         qw = args.mocha_quantity_loss_weight if fix['meta'].get('trigger_quantity_loss') else 0.0
+        ss_seed = fix['meta'].get('scheduled_sampling_seed')
+        kw = dict(quantity_weight=qw, scheduled_sampling=ss_seed is not None,
+                  stableemit=bool(fix['meta'].get('trigger_stableemit')), ctc_trigger_points=fix.get('ctc_trigger_points'),
+                  latency_weight=getattr(args, 'mocha_latency_loss_weight', 0.0) if fix['meta'].get('trigger_quantity_loss') else 0.0)
+
+        def seed():
+            if ss_seed is not None:
+                import random
+                random.seed(ss_seed)
         F.linear, F.conv1d = lin16, conv1d16
         try:
-            loss = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64, quantity_weight=qw)[0]
+            seed()
+            loss = model_ref.speech2text_loss(sd, args, fix['batch'], torch.float64, **kw)[0]
         finally:
             F.linear, F.conv1d = lin, c1
         ref = fix['loss'].item()
@@ -68,7 +78,8 @@ def main():
         # <= 1.2e-5 elsewhere) -> the per-fixture gates FP32_GRAD_GATE of tests/test_golden_gpu.py
         sd64 = {k: v.clone().double().requires_grad_(v.is_floating_point() and 'inv_freq' not in k and k != 'enc.pos_enc.pe')
                 if v.is_floating_point() else v for k, v in fix['state_dict'].items()}
-        l64 = model_ref.speech2text_loss(sd64, args, fix['batch'], torch.float64, quantity_weight=qw)[0]
+        seed()
+        l64 = model_ref.speech2text_loss(sd64, args, fix['batch'], torch.float64, **kw)[0]
         g64 = torch.autograd.grad(l64, [sd64[n] for n in gn], allow_unused=True)
         noise = max(((fix['grads'][n].double() - g).abs().max() / max(g.abs().max().item(), 1e-5 * gmax)).item()
                     for n, g in zip(gn, g64) if g is not None and not (
