@@ -6,6 +6,7 @@ Nothing under neural_sp_amd/ imports this module or loads the library it builds.
 """
 import hashlib
 import os
+import re
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -13,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'neural_sp_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libnsp_emu.so')
-EMULATED_SOURCES = ['norm_subsample.hip']
+EMULATED_SOURCES = ['norm_subsample.hip', 'elementwise.hip', 'xent.hip', 'decode.hip', 'layernorm.hip', 'ctc.hip',
+                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip']
 CXX_CANDIDATES = ['/opt/rocm/lib/llvm/bin/clang++', 'clang++']
 
 
@@ -31,6 +33,19 @@ def available():
     return _cxx() is not None
 
 
+_DYN = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w:]*)\s+(\w+)\[\];')
+
+
+def _rewrite(src, dst):
+    """copy a .hip source for the host build: `extern __shared__ T name[];` -> pointer to the launch's buffer;
+    the include of common.h is redirected to the real csrc directory"""
+    text = open(src).read()
+    text = _DYN.sub(r'\1* \2 = reinterpret_cast<\1*>(HIPEMU_DYN_SHARED);', text)
+    text = text.replace('#include "common.h"', '#include "%s"' % os.path.join(CSRC, 'common.h'))
+    with open(dst, 'w') as fh:
+        fh.write(text)
+
+
 def build():
     cxx = _cxx()
     if cxx is None:
@@ -46,8 +61,13 @@ def build():
     stamp = os.path.join(OUT, 'stamp')
     if os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
         return LIB
-    cmd = [cxx, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unused-value',
-           '-I', os.path.join(HERE, 'include'), '-x', 'c++'] + srcs + ['-o', LIB]
+    gen = []
+    for src in srcs[:-1]:
+        dst = os.path.join(OUT, os.path.basename(src).replace('.hip', '_emu.cpp'))
+        _rewrite(src, dst)
+        gen.append(dst)
+    cmd = [cxx, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unused-value', '-Wno-unused-result',
+           '-I', os.path.join(HERE, 'include'), '-x', 'c++'] + gen + [srcs[-1]] + ['-o', LIB]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if res.returncode != 0:
         raise RuntimeError('emulator build failed:\n' + res.stdout.decode(errors='replace'))

@@ -12,7 +12,8 @@
 // __syncthreads() is a pthread barrier over the block; wave shuffles exchange through a per-wave slot
 // array guarded by a per-wave barrier.  Kernels must be convergent at every barrier / shuffle (no
 // early `return` before one) -- the kernels emulated here are written that way.
-// Not emulated: inline asm, MFMA / buffer / LDS-DMA builtins, dynamic shared memory, streams.
+// Dynamic shared memory: `extern __shared__ T name[];` is rewritten by tests/hipemu/build_emu.py into a pointer to a
+// per-launch buffer (HIPEMU_DYN_SHARED).  Not emulated: inline asm, MFMA / buffer / LDS-DMA builtins, streams.
 #pragma once
 #include <float.h>
 #include <math.h>
@@ -37,7 +38,19 @@ struct dim3 {
 typedef void* hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  memset(p, v, n);
+  return hipSuccess;
+}
+template <class T> static inline T min(T a, T b) { return b < a ? b : a; }
+template <class T> static inline T max(T a, T b) { return a < b ? b : a; }
+static inline long long min(long long a, int b) { return a < b ? a : b; }
+static inline long long min(int a, long long b) { return a < b ? a : b; }
+static inline long long max(long long a, int b) { return a > b ? a : b; }
+static inline long long max(int a, long long b) { return a > b ? a : b; }
 
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
@@ -64,6 +77,7 @@ struct Launch {
   dim3 grid, block;
   pthread_barrier_t bar;
   std::vector<Wave> waves;
+  std::vector<double> dyn;  // dynamic shared memory of the running block (8-byte storage: any alignment <= 16 via offset)
 };
 extern thread_local Launch* cur;
 extern thread_local int tid_flat;
@@ -71,7 +85,14 @@ extern thread_local int tid_flat;
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 static inline void __syncthreads() { pthread_barrier_wait(&hipemu::cur->bar); }
+// 16-byte aligned base of the launch's dynamic shared memory
+#define HIPEMU_DYN_SHARED \
+  (reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(hipemu::cur->dyn.data()) + 15) & ~uintptr_t(15)))
 
 template <class T>
 static inline T hipemu_shfl(T v, int src_of_lane_fn(int, int), int arg) {
@@ -99,6 +120,8 @@ template <class T> static inline T __shfl_down(T v, int d, int = 64) { return hi
 template <class T> static inline T __shfl_up(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_up, d); }
 template <class T> static inline T __shfl(T v, int i, int = 64) { return hipemu_shfl(v, hipemu_src_idx, i); }
 
+static inline float atomicAdd(float* p, float v);
+static inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }
 static inline float atomicAdd(float* p, float v) {
   uint32_t* ip = reinterpret_cast<uint32_t*>(p);
   uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), want;
@@ -114,10 +137,11 @@ static inline float atomicAdd(float* p, float v) {
 
 namespace hipemu {
 template <class F>
-static inline void launch(dim3 grid, dim3 block, F body) {
+static inline void launch(dim3 grid, dim3 block, size_t shmem, F body) {
   Launch L;
   L.grid = grid;
   L.block = block;
+  L.dyn.assign(shmem / 8 + 4, 0.0);
   const int nthr = (int)(block.x * block.y * block.z);
   pthread_barrier_init(&L.bar, nullptr, nthr);
   const int nw = (nthr + 63) / 64;
@@ -153,7 +177,6 @@ static inline void launch(dim3 grid, dim3 block, F body) {
 #define HIPEMU_KERNEL_NAME(...) __VA_ARGS__
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                     \
   do {                                                                                  \
-    static_assert((shmem) == 0, "dynamic shared memory is not emulated");               \
     (void)(stream);                                                                     \
-    hipemu::launch((grid), (block), [&]() { HIPEMU_KERNEL_NAME(kernel)(__VA_ARGS__); }); \
+    hipemu::launch((grid), (block), (size_t)(shmem), [&]() { HIPEMU_KERNEL_NAME(kernel)(__VA_ARGS__); }); \
   } while (0)
