@@ -13,7 +13,8 @@
 // array guarded by a per-wave barrier.  Kernels must be convergent at every barrier / shuffle (no
 // early `return` before one) -- the kernels emulated here are written that way.
 // Dynamic shared memory: `extern __shared__ T name[];` is rewritten by tests/hipemu/build_emu.py into a pointer to a
-// per-launch buffer (HIPEMU_DYN_SHARED).  Not emulated: inline asm, MFMA / buffer / LDS-DMA builtins, streams.
+// per-launch buffer (HIPEMU_DYN_SHARED).  The two MFMA builtins of gemm.hip are emulated as wave collectives.
+// Not emulated: inline asm, buffer / LDS-DMA / transposed-LDS-read builtins, streams.
 #pragma once
 #include <float.h>
 #include <math.h>
@@ -72,6 +73,7 @@ struct Wave {
   pthread_barrier_t bar;
   int n;
   uint64_t slot[64];
+  alignas(16) unsigned char frag[64][32];   // MFMA operand fragments: A (16 B) | B (16 B) per lane
 };
 struct Launch {
   dim3 grid, block;
@@ -119,6 +121,59 @@ template <class T> static inline T __shfl_xor(T v, int m, int = 64) { return hip
 template <class T> static inline T __shfl_down(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_down, d); }
 template <class T> static inline T __shfl_up(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_up, d); }
 template <class T> static inline T __shfl(T v, int i, int = 64) { return hipemu_shfl(v, hipemu_src_idx, i); }
+
+// ---- MFMA as a wave collective (register layouts: cdna_hip_programming.md, "Fragment layout") ----
+//   v_mfma_f32_16x16x4_f32 : lane l holds A[l&15][k=l>>4], B[k=l>>4][l&15]; D/C reg r: row (l>>4)*4+r, col l&15
+//   v_mfma_f32_16x16x32_bf16: lane l holds A[l&15][8*(l>>4)+e], B[8*(l>>4)+e][l&15], e = 0..7; same C/D map
+// products are accumulated in k order with fmaf (the f32 form is documented as an exact fmaf chain).
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline void hipemu_wave_barrier() { pthread_barrier_wait(&hipemu::cur->waves[hipemu::tid_flat >> 6].bar); }
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+  hipemu::Wave& w = hipemu::cur->waves[hipemu::tid_flat >> 6];
+  const int l = hipemu::tid_flat & 63;
+  memcpy(w.frag[l], &a, 4);
+  memcpy(w.frag[l] + 16, &b, 4);
+  pthread_barrier_wait(&w.bar);
+  const int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      memcpy(&av, w.frag[k * 16 + row], 4);
+      memcpy(&bv, w.frag[k * 16 + col] + 16, 4);
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  pthread_barrier_wait(&w.bar);
+  return c;
+}
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c, int, int, int) {
+  hipemu::Wave& w = hipemu::cur->waves[hipemu::tid_flat >> 6];
+  const int l = hipemu::tid_flat & 63;
+  memcpy(w.frag[l], &a, 16);
+  memcpy(w.frag[l] + 16, &b, 16);
+  pthread_barrier_wait(&w.bar);
+  const int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int g = 0; g < 4; ++g) {
+      hipemu_bf16x8 av, bv;
+      memcpy(&av, w.frag[g * 16 + row], 16);
+      memcpy(&bv, w.frag[g * 16 + col] + 16, 16);
+      for (int e = 0; e < 8; ++e) acc = fmaf((float)av[e], (float)bv[e], acc);
+    }
+    c[r] = acc;
+  }
+  pthread_barrier_wait(&w.bar);
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_f32_16x16x32_bf16
+#define __builtin_amdgcn_wave_barrier hipemu_wave_barrier
 
 static inline float atomicAdd(float* p, float v);
 static inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }

@@ -3,8 +3,10 @@ host emulator is too slow for, and the model-level parity of the variants agains
 (conformer_{bn,gn,drop,add,meanpool,concat,conv1d}_ctc_xs, transformer_glu_ctc_xs) through the functions of
 tests/test_golden_gpu.py.
 
-NOTE (round 2): written after the round's GPU minutes were spent -- these tests had only run on the emulator
-(tests/test_variants_emu_cpu.py) when they were committed."""
+NOTE (round 2): written after the round's GPU minutes were (almost) spent.  The kernel tests of this file (window / flip /
+group_norm / batch_norm: 32 cases) passed on an MI355X at first contact in the round's last call
+(profiles/r02d_variants_kernels_gpu.log); the model-level tests (test_variant_golden_*, config 1 at full size, the BLSTM
+layer, weight noise) had only run through the CPU shim / emulator when they were committed."""
 import pytest
 import torch
 
