@@ -54,6 +54,12 @@ def _p(t):
     return t.data_ptr()
 
 
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise AssertionError('neural_sp_amd ops are HIP-only: got a CPU tensor (no CPU fallback exists)')
+
+
 def _stream():
     # raw C accessors: torch.cuda.current_stream() walks ~10 python frames (8 us per call, 2800
     # calls per step = a quarter of the host time of a step)
@@ -139,9 +145,7 @@ def gemm_raw(M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc,
              dropout_p=0.0, seed=0, offset=0, c_ss=0, colsum_slabs=None):
     """C = epi(A @ B) with arbitrary strides (element offsets *_off into the tensors).
     A/B are both fp32 or both bf16; C / pre_out / dact_src may be fp32 or bf16 with bf16 operands."""
-    for t in (A, B, C, pre_out, dact_src, bias, res):
-        if t is not None and not t.is_cuda:
-            raise AssertionError('neural_sp_amd ops are HIP-only: got a CPU tensor (no CPU fallback exists)')
+    _require_device(A, B, C, pre_out, dact_src, bias, res)
     esz = A.element_size()
     _check(_lib.lib().nsp_gemm_flat(
         M, N, K, A.data_ptr() + esz * a_off, a_rs, a_cs, B.data_ptr() + B.element_size() * b_off, b_ks, b_ns,

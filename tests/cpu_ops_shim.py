@@ -188,7 +188,10 @@ def _ctc_forced_align(logits, labels, elens, ylens, blank=0):
 
 
 @contextlib.contextmanager
-def host_logic_on_cpu():
+def host_logic_on_cpu(real_kernels=False):
+    """real_kernels=True: ONLY the ops whose kernels the emulator cannot build (conv front-end: inline asm; LSTM:
+    gfx950 builtins; pinned-memory staging) are replaced; GEMMs (fp32 MFMA emulated as wave collectives), attention
+    soft-max, LayerNorm, CTC, XE, depthwise conv, GLU, pooling over time, dropout, ... all run the real .hip kernels."""
     from neural_sp_amd import ops
     from tests.hipemu.shim import emulated_kernels
     fakes = dict(
@@ -201,6 +204,8 @@ def host_logic_on_cpu():
         xl_pos_table=_xl_pos_table, ctc_loss=_ctc_loss, h2d_packed=_h2d_packed, pad_batch=_pad_batch, lstm=_lstm,
         xe_lsm_loss=_xe_lsm_loss, argmax_rows=lambda x2d: x2d.argmax(-1).int(), ctc_forced_align=_ctc_forced_align,
     )
+    if real_kernels:
+        fakes = {k: fakes[k] for k in ('conv3x3_relu', 'maxpool2d', 'lstm', 'h2d_packed')}
     saved = {k: getattr(ops, k) for k in fakes}
     mode = ops.get_compute_mode()
     for k, v in fakes.items():

@@ -32,13 +32,14 @@ def emu_lib():
 def emulated_kernels():
     from neural_sp_amd import _lib, ops
     import torch
-    saved = (_lib.lib, ops._p, ops._stream, ops.zeros_small)
+    saved = (_lib.lib, ops._p, ops._stream, ops.zeros_small, ops._require_device)
     lib = emu_lib()
     _lib.lib = lambda: lib
     ops._p = lambda t: None if t is None else t.data_ptr()
     ops._stream = lambda: 0
     ops.zeros_small = lambda shape, device, dtype=torch.float32: torch.zeros(shape, device=device, dtype=dtype)
+    ops._require_device = lambda *tensors: None
     try:
         yield lib
     finally:
-        _lib.lib, ops._p, ops._stream, ops.zeros_small = saved
+        _lib.lib, ops._p, ops._stream, ops.zeros_small, ops._require_device = saved
