@@ -511,6 +511,16 @@ int nsp_lstm_fwd(const float* gi, const void* Whh /*[4H,H]*/, float* y /*[B,L,H]
 int nsp_lstm_bwd(const float* dy /*[B,L,H]*/, const void* WhhT /*[H,4H]*/, const float* c_all,
                  const float* gates, float* dgates /*[B,L,4H]*/, void* dgshadow /*bf16*/,
                  float* dc /*[B,H] scratch*/, int B, int L, int H, int mode, void* stream);
+/* The same step kernels over the steps [t_begin, t_end) only -- an LSTM with a given initial state and a gradient
+ * w.r.t. its final state (forward direction of the latency-controlled BLSTM, encoders/rnn.py:466-475, whose state is
+ * carried from chunk to chunk): the caller lays the sequence out in rows 1..n of buffers with L = n + 2 rows, puts
+ * (h0, c0) into row 0 of y / yshadow / c_all and runs [1, n+1); backward: dy[:, n] carries the final-h gradient,
+ * `dc` the final-c gradient, dgates[:, n+1] = 0, steps n..1; afterwards `dc` is d/dc0 and dgates[:, 1] W_hh d/dh0. */
+int nsp_lstm_fwd_range(const float* gi, const void* Whh, float* y, void* yshadow, float* c_all, float* gates,
+                       int B, int L, int H, int mode, int t_begin, int t_end, void* stream);
+int nsp_lstm_bwd_range(const float* dy, const void* WhhT, const float* c_all, const float* gates, float* dgates,
+                       void* dgshadow, float* dc, int B, int L, int H, int mode, int t_begin, int t_end,
+                       void* stream);
 
 /* ------------------------------------------------------------------------ *
  * The whole LSTM stack of the prediction network as ONE wavefront over        *

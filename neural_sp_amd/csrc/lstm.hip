@@ -668,14 +668,20 @@ __global__ __launch_bounds__(1024) void lstm_stack_bwd_persistent_kernel(const n
 
 // Runs all L steps.  Whh: [4H,H] (bf16 shadow in NSP_COMPUTE_BF16, fp32 in NSP_COMPUTE_F32);
 // yshadow: bf16 [B,L,H] written alongside y (mode bf16; pass y itself in mode f32).
-extern "C" int nsp_lstm_fwd(const float* gi, const void* Whh, float* y, void* yshadow, float* c_all,
-                            float* gates, int B, int L, int H, int mode, void* stream) {
+// Steps t_begin .. t_end-1 only (the same step kernels, nothing else changes): with t_begin = 1 the step reads
+// its previous state from row 0 of yshadow / c_all, which the caller has filled -- an LSTM with a given
+// INITIAL STATE (encoders/rnn.py:466-475: the forward direction of the latency-controlled BLSTM carries its state
+// from chunk to chunk).
+extern "C" int nsp_lstm_fwd_range(const float* gi, const void* Whh, float* y, void* yshadow, float* c_all,
+                                  float* gates, int B, int L, int H, int mode, int t_begin, int t_end,
+                                  void* stream) {
   if (B <= 0 || L <= 0 || H <= 0 || H % 16) return NSP_EUNSUPPORTED;
   if (mode == NSP_COMPUTE_BF16 && H % 8) return NSP_EUNSUPPORTED;
+  if (t_begin < 0 || t_end > L || t_begin > t_end) return NSP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(H / 4, nsp_cdiv(B, 16)), block(256);
   const int Kw = ((H + 3) / 4 + 7) / 8 * 8;  // per-wave slice of the reduction (whole bf16x8 chunks)
-  for (int t = 0; t < L; ++t) {
+  for (int t = t_begin; t < t_end; ++t) {
     if (mode == NSP_COMPUTE_BF16)
       hipLaunchKernelGGL((lstm_step_fwd_kernel<0>), grid, block, 0, st, gi, Whh, y, yshadow, c_all, gates, B, L, H, t, Kw);
     else
@@ -685,16 +691,25 @@ extern "C" int nsp_lstm_fwd(const float* gi, const void* Whh, float* y, void* ys
   return NSP_OK;
 }
 
+extern "C" int nsp_lstm_fwd(const float* gi, const void* Whh, float* y, void* yshadow, float* c_all,
+                            float* gates, int B, int L, int H, int mode, void* stream) {
+  return nsp_lstm_fwd_range(gi, Whh, y, yshadow, c_all, gates, B, L, H, mode, 0, L, stream);
+}
+
 // dy: [B,L,H] gradient w.r.t. the outputs; produces dgates [B,L,4H] (+ bf16 shadow) from which
 // the caller derives dx, dW_ih, dW_hh, db with GEMMs.  dc: [B,H] scratch.
-extern "C" int nsp_lstm_bwd(const float* dy, const void* WhhT, const float* c_all, const float* gates,
-                            float* dgates, void* dgshadow, float* dc, int B, int L, int H, int mode,
-                            void* stream) {
+// Steps t_end-1 down to t_begin.  With t_end < L the first step executed reads the incoming cell-state gradient
+// from `dc` and the recurrent term from dgates[:, t_end] (the caller fills both: the gradient w.r.t. the FINAL
+// state); after the last step `dc` holds the gradient w.r.t. the cell state BEFORE step t_begin.
+extern "C" int nsp_lstm_bwd_range(const float* dy, const void* WhhT, const float* c_all, const float* gates,
+                                  float* dgates, void* dgshadow, float* dc, int B, int L, int H, int mode,
+                                  int t_begin, int t_end, void* stream) {
   if (B <= 0 || L <= 0 || H <= 0 || H % 16) return NSP_EUNSUPPORTED;
+  if (t_begin < 0 || t_end > L || t_begin > t_end) return NSP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(H / 16, nsp_cdiv(B, 16)), block(1024);
   const int Kw = ((4 * H + 15) / 16 + 7) / 8 * 8;
-  for (int t = L - 1; t >= 0; --t) {
+  for (int t = t_end - 1; t >= t_begin; --t) {
     if (mode == NSP_COMPUTE_BF16)
       hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), grid, block, 0, st, dy, WhhT, c_all, gates, dgates, dgshadow, dc, B, L, H, t, Kw);
     else
@@ -702,6 +717,12 @@ extern "C" int nsp_lstm_bwd(const float* dy, const void* WhhT, const float* c_al
   }
   NSP_LAUNCH_CHECK();
   return NSP_OK;
+}
+
+extern "C" int nsp_lstm_bwd(const float* dy, const void* WhhT, const float* c_all, const float* gates,
+                            float* dgates, void* dgshadow, float* dc, int B, int L, int H, int mode,
+                            void* stream) {
+  return nsp_lstm_bwd_range(dy, WhhT, c_all, gates, dgates, dgshadow, dc, B, L, H, mode, 0, L, stream);
 }
 
 static int lstm_stack_check(const nsp_lstm_stack_params* p) {

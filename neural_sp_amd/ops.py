@@ -1778,6 +1778,81 @@ class LSTMFn(torch.autograd.Function):
         return dx, dw_ih, dw_hh, db, db
 
 
+class LSTMStateFn(torch.autograd.Function):
+    """(y, h_n, c_n) = LSTM(x | h0, c0) for one layer, batch_first: an LSTM that starts from a GIVEN state and hands
+    its final state on, differentiable in both (the forward direction of the latency-controlled BLSTM carries its
+    state from chunk to chunk and is trained through it, encoders/rnn.py:466-475).  The step kernels are those of
+    LSTMFn: the n steps live in rows 1..n of buffers with n + 2 rows, row 0 holds the initial state, row n + 1 is the
+    zero "next step" through which the gradient w.r.t. the final state enters (nsp_lstm_*_range)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0):
+        B, n, I = x.shape
+        H = w_hh.shape[1]
+        L = n + 2
+        dev = x.device
+        use16 = bf16_mode()
+        bias = axpby(b_ih, b_hh, 1.0, 1.0)
+        x_ext = torch.zeros((B, L, I), device=dev, dtype=torch.float32)
+        x_ext[:, 1:n + 1] = _f32c(x)
+        x2d = x_ext.view(B * L, I)
+        xa = to_bf16(x2d) if (use16 and I % 8 == 0) else x2d
+        gi = linear_fwd(xa, w_ih, bias)                                  # [B*L, 4H] (rows 0 and n+1 unused)
+        y = torch.zeros((B, L, H), device=dev, dtype=torch.float32)
+        c_all = torch.zeros((B, L, H), device=dev, dtype=torch.float32)
+        y[:, 0] = h0
+        c_all[:, 0] = c0
+        if use16:
+            ysh = torch.zeros((B, L, H), device=dev, dtype=torch.bfloat16)
+            ysh[:, 0] = h0.to(torch.bfloat16)
+        else:
+            ysh = y
+        gates = torch.zeros((B, L, 4 * H), device=dev, dtype=torch.float32)
+        whh = weight_bf16(w_hh) if use16 else w_hh
+        _check(_lib.lib().nsp_lstm_fwd_range(_p(gi), _p(whh), _p(y), _p(ysh), _p(c_all), _p(gates), B, L, H,
+                                             _COMPUTE_MODE['mode'], 1, n + 1, _stream()), 'nsp_lstm_fwd_range')
+        ctx.save_for_backward(xa, w_ih, w_hh, ysh, c_all, gates)
+        ctx.dims = (B, n, I, H)
+        ctx.use16 = use16
+        return y[:, 1:n + 1], y[:, n].clone(), c_all[:, n].clone()
+
+    @staticmethod
+    def backward(ctx, dy, dh_n, dc_n):
+        xa, w_ih, w_hh, ysh, c_all, gates = ctx.saved_tensors
+        B, n, I, H = ctx.dims
+        L = n + 2
+        dev = xa.device
+        use16 = ctx.use16
+        dy_ext = torch.zeros((B, L, H), device=dev, dtype=torch.float32)
+        if dy is not None:
+            dy_ext[:, 1:n + 1] = dy
+        if dh_n is not None:
+            dy_ext[:, n] += dh_n
+        dgates = torch.zeros((B, L, 4 * H), device=dev, dtype=torch.float32)
+        dgsh = torch.zeros((B, L, 4 * H), device=dev, dtype=torch.bfloat16) if use16 else dgates
+        dc = _f32c(dc_n).clone() if dc_n is not None else torch.zeros((B, H), device=dev, dtype=torch.float32)
+        whh_t = _weight_t_shadow(w_hh, use16)
+        _check(_lib.lib().nsp_lstm_bwd_range(_p(dy_ext), _p(whh_t), _p(c_all), _p(gates), _p(dgates), _p(dgsh), _p(dc),
+                                             B, L, H, 0 if use16 else 1, 1, n + 1, _stream()), 'nsp_lstm_bwd_range')
+        g2d = dgsh.view(B * L, 4 * H)
+        hprev = torch.zeros_like(ysh)
+        hprev[:, 1:] = ysh[:, :-1]                   # h_{t-1}; row 1 sees the initial state
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(g2d, w_ih)[:, :I].reshape(B, L, I)[:, 1:n + 1]
+        dw_ih = linear_wgrad(g2d, xa).view(w_ih.shape)
+        dw_hh = linear_wgrad(g2d, hprev.view(B * L, H)).view(w_hh.shape)
+        db = colsum(g2d)
+        # d/dh0 = dgates_1 W_hh (the recurrent term a step 0 would have received); d/dc0 = what the kernel left in dc
+        dh0 = linear_dgrad((dgsh if use16 else dgates)[:, 1].contiguous(), w_hh)[:, :H] if ctx.needs_input_grad[5] else None
+        dc0 = dc if ctx.needs_input_grad[6] else None
+        return dx, dw_ih, dw_hh, db, db, dh0, dc0
+
+
+def lstm_state(x, w_ih, w_hh, b_ih, b_hh, h0, c0):
+    return LSTMStateFn.apply(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
+
+
 def _cat_cached(owner, name, parts, build):
     """torch.cat of derived weight shadows, cached on `owner` and keyed by the versions of `parts`."""
     key = tuple(p._version for p in parts)

@@ -18,10 +18,15 @@ The reference's BLSTM recipes (`lc_chunk_size_right: 40`, `lc_chunk_size_left: -
 "latency-controlled" encoder in full-context mode (rnn.py:104,385-425): separate `rnn` / `rnn_bwd` unidirectional
 LSTMs over the whole padded batch, no packing, no masking -- built as `_lstm_layer_full_context`.
 
-Not built (NotImplementedError): GRU cells, latency-controlled BLSTM with chunked training (lc_chunk_size_left > 0),
-streaming / state carry-over (random state passing), the NiN layers.
+With `lc_chunk_size_left > 0` the same encoder trains in chunks (`_forward_latency_controlled`, rnn.py:427-510): the
+forward LSTM carries its state from chunk to chunk (`ops.lstm_state`: the step kernels started from a given state,
+differentiable through it), the backward LSTM sees the chunk plus N_r frames of right context.
+
+Not built (NotImplementedError): GRU cells, streaming inference / random state passing, blockwise CNN
+(`cnn_lookahead=False`), the NiN layers.
 """
 import logging
+import math
 
 import numpy as np
 import torch
@@ -64,14 +69,12 @@ class RNNEncoder(EncoderBase):
         # `lc_chunk_size_left: -1` selects the "latency-controlled" encoder in its FULL-CONTEXT mode (N_c <= 0,
         # rnn.py:385-425, "pre-training of the LC-BLSTM"): separate forward / backward unidirectional LSTMs
         # (`rnn`, `rnn_bwd`) run over the whole PADDED batch without packing -- the backward direction starts in the
-        # padding, nothing is masked -- instead of one packed bidirectional nn.LSTM.  Chunked training (N_c > 0) is
-        # not built.
+        # padding, nothing is masked -- instead of one packed bidirectional nn.LSTM.  N_c > 0 is the chunked
+        # (streaming) training of `_forward_latency_controlled`.
         self.lc_bidir = (self.N_c > 0 or self.N_r > 0) and self.bidirectional
         if self.lc_bidir:
             assert enc_type not in ['lstm', 'conv_lstm']
             assert n_layers_sub2 == 0
-            if self.N_c > 0:
-                raise NotImplementedError('latency-controlled BLSTM with chunked training (lc_chunk_size_left > 0)')
         if rsp_prob > 0:
             raise NotImplementedError('random state passing')
         self.n_layers_sub1 = n_layers_sub1
@@ -139,6 +142,59 @@ class RNNEncoder(EncoderBase):
             return ops.add(y_f, ops.time_flip_mask(y_r, full_dev, True))
         return ops.bidir_merge(y_f, y_r, full_dev)
 
+    def _forward_latency_controlled(self, xs, xlens, N_c, N_r):
+        """rnn.py:427-510, training path: the utterance is cut into chunks of N_c frames, each seen with N_r frames of
+        right context.  Per chunk and layer: the backward LSTM runs over chunk + context from a zero state; the forward
+        LSTM continues from the state it reached at the end of the previous chunk's N_c frames (`ops.lstm_state`, the
+        state is trained through), a second run from there covers the right-context frames (they only feed the next
+        layer's backward direction).  Only the first N_c (subsampled) frames of every chunk are emitted."""
+        bs, xmax, _ = xs.size()
+        n_chunks = math.ceil(xmax / N_c)
+        xlens_sub1 = xlens.clone() if self.n_layers_sub1 > 0 else None
+        xs_chunks, xs_chunks_sub1 = [], []
+        H = self.n_units
+        states = [(xs.new_zeros(bs, H), xs.new_zeros(bs, H)) for _ in range(self.n_layers)]
+        for chunk_idx, t in enumerate(range(0, N_c * n_chunks, N_c)):
+            xs_chunk = xs[:, t:t + (N_c + N_r)].contiguous()
+            _N_c = N_c
+            for lth in range(self.n_layers):
+                rnn, rnn_bwd = self.rnn[lth], self.rnn_bwd[lth]
+                full = ops.h2d(torch.full((bs,), xs_chunk.size(1), dtype=torch.int32), xs.device, torch.int32)
+                y_r = ops.lstm(ops.time_flip_mask(xs_chunk, full, True), rnn_bwd.weight_ih_l0, rnn_bwd.weight_hh_l0,
+                               rnn_bwd.bias_ih_l0, rnn_bwd.bias_hh_l0)
+                w = (rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
+                h0, c0 = states[lth]
+                if xs_chunk.size(1) <= _N_c:                   # last chunk
+                    y_f, h1, c1 = ops.lstm_state(xs_chunk, *w, h0, c0)
+                    states[lth] = (h1, c1)
+                else:
+                    y_1, h1, c1 = ops.lstm_state(xs_chunk[:, :_N_c].contiguous(), *w, h0, c0)
+                    states[lth] = (h1, c1)
+                    y_2, _, _ = ops.lstm_state(xs_chunk[:, _N_c:].contiguous(), *w, h1, c1)
+                    y_f = torch.cat([y_1, y_2], dim=1)
+                if self.bidir_sum:
+                    xs_chunk = ops.add(y_f, ops.time_flip_mask(y_r, full, True))
+                else:
+                    xs_chunk = ops.bidir_merge(y_f, y_r, full)
+                xs_chunk = ops.dropout(xs_chunk, self.dropout_p, self.training)
+                if lth == self.n_layers_sub1 - 1:
+                    xs_chunks_sub1.append(xs_chunk[:, :_N_c])
+                    if chunk_idx == 0:
+                        xlens_sub1 = xlens.clone()
+                if self.proj is not None and lth != self.n_layers - 1:
+                    xs_chunk = ops.linear(xs_chunk, self.proj[lth].weight, self.proj[lth].bias, act='relu')
+                if self.subsample is not None:
+                    xs_chunk, xlens_tmp = self.subsample[lth](xs_chunk, xlens)
+                    if chunk_idx == 0:
+                        xlens = xlens_tmp
+                    _N_c = _N_c // self.subsample[lth].factor
+            xs_chunks.append(xs_chunk[:, :_N_c])
+        xs = torch.cat(xs_chunks, dim=1)
+        xs_sub1 = None
+        if self.n_layers_sub1 > 0:
+            xs_sub1 = self.sub_module(torch.cat(xs_chunks_sub1, dim=1), xlens_sub1, 'sub1')
+        return xs, xlens, xs_sub1
+
     def _lstm_layer(self, xs, lens_dev, rnn):
         """Padding.forward (rnn.py:534-547) for one (bidirectional) layer."""
         y_f = ops.lstm(xs, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
@@ -178,7 +234,16 @@ class RNNEncoder(EncoderBase):
                 return eouts
         self.reset_cache()
         xs_sub = {}
-        for lth in range(self.n_layers):
+        chunked = self.lc_bidir and self.N_c > 0
+        if chunked:
+            xs, xlens, sub1 = self._forward_latency_controlled(xs, xlens, self.N_c // self.conv_factor,
+                                                               self.N_r // self.conv_factor)
+            if sub1 is not None:
+                xs_sub['sub1'] = sub1
+                if task == 'ys_sub1':
+                    eouts[task]['xs'], eouts[task]['xlens'] = sub1
+                    return eouts
+        for lth in range(0 if not chunked else self.n_layers, self.n_layers):
             if self.lc_bidir:
                 full = torch.full((xs.size(0),), xs.size(1), dtype=torch.int32)
                 xs = self._lstm_layer_full_context(xs, ops.h2d(full, xs.device, torch.int32), self.rnn[lth],

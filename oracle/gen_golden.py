@@ -209,6 +209,12 @@ CASES.update({
                                                          subsample='1_2', subsample_type='drop', lc_chunk_size_left='-1',
                                                          lc_chunk_size_right='40', conv_poolings='(2,2)_(2,2)'),
                                   dict(B=3, t_range=(61, 95), u_range=(2, 5), vocab=40, seed=143)),
+    # the streaming recipes (lcblstm_*_chunk4040.yaml): chunked training of the same encoder, 16-frame chunks with 16
+    # frames of right context after the x4 CNN (lc_chunk_size_left = right = 64 input frames), `drop` subsampling x2
+    'conv_lcblstm_chunk_xs': (lambda: blstm_ctc_args(n_layers=2, n_units=64, vocab=40, enc_type='conv_blstm', input_dim=80,
+                                                     subsample='1_2', subsample_type='drop', lc_chunk_size_left='64',
+                                                     lc_chunk_size_right='64', conv_poolings='(2,2)_(2,2)'),
+                              dict(B=3, t_range=(161, 215), u_range=(2, 5), vocab=40, seed=244)),
 })
 KEEP_REFERENCE_INIT = {'conformer_rnnt_zero_bias_xs'}
 # scheduled sampling (las.py:668,675-676; ss_prob 0.2 in 39 of the reference's recipes, BASELINE config 3's among them):

@@ -344,15 +344,14 @@ def ctc_loss_ref(logits, elens, ys, lsm_prob):
     return loss
 
 
-def lstm_ref(x, sd, p, sfx=''):
+def lstm_ref(x, sd, p, sfx='', state=None, return_state=False):
     """nn.LSTM(1 layer, batch_first) with zero initial state (rnn_transducer.py:278-311); sfx='_reverse' selects
     the parameters of the backward direction of a bidirectional layer."""
     B, L, _ = x.shape
     w_ih, w_hh = sd[p + '.weight_ih_l0' + sfx], sd[p + '.weight_hh_l0' + sfx]
     b = sd[p + '.bias_ih_l0' + sfx] + sd[p + '.bias_hh_l0' + sfx]
     n = w_hh.shape[1]
-    h = x.new_zeros(B, n)
-    c = x.new_zeros(B, n)
+    h, c = state if state is not None else (x.new_zeros(B, n), x.new_zeros(B, n))
     outs = []
     gi = F.linear(x, w_ih, b)
     for t in range(L):
@@ -361,7 +360,8 @@ def lstm_ref(x, sd, p, sfx=''):
         c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
         h = torch.sigmoid(o) * torch.tanh(c)
         outs.append(h)
-    return torch.stack(outs, dim=1)
+    y = torch.stack(outs, dim=1)
+    return (y, (h, c)) if return_state else y
 
 
 def rnn_encoder_forward(xs, xlens, sd, args, sub_out=None):
@@ -382,7 +382,44 @@ def rnn_encoder_forward(xs, xlens, sd, args, sub_out=None):
     N_c = int(str(args.lc_chunk_size_left).split('_')[0]) // args.n_stacks
     N_r = int(str(args.lc_chunk_size_right).split('_')[0]) // args.n_stacks
     lc_bidir = (N_c > 0 or N_r > 0) and bidir
-    assert not (lc_bidir and N_c > 0), 'chunked LC-BLSTM training is not restated'
+    if lc_bidir and N_c > 0:
+        # _forward_latency_controlled (rnn.py:427-510): chunks of N_c frames with N_r frames of right context; the forward
+        # LSTM carries its state over the chunk centres, the backward LSTM is local to chunk + context
+        fac = 1
+        if 'conv' in args.enc_type:
+            for q in args.conv_poolings.split('_'):
+                fac *= int(q.strip('()').split(',')[0])
+        N_c, N_r = N_c // fac, N_r // fac
+        T = xs.shape[1]
+        states = [None] * n_layers
+        outs = []
+        import math as _m
+        xl = list(xlens)
+        for ci in range(_m.ceil(T / N_c)):
+            ch = xs[:, ci * N_c:ci * N_c + N_c + N_r]
+            nc = N_c
+            for l in range(n_layers):
+                yb = lstm_ref(ch.flip(1), sd, 'enc.rnn_bwd.%d' % l).flip(1)
+                if ch.shape[1] <= nc:
+                    yf, states[l] = lstm_ref(ch, sd, 'enc.rnn.%d' % l, state=states[l], return_state=True)
+                else:
+                    y1, states[l] = lstm_ref(ch[:, :nc], sd, 'enc.rnn.%d' % l, state=states[l], return_state=True)
+                    y2 = lstm_ref(ch[:, nc:], sd, 'enc.rnn.%d' % l, state=states[l])
+                    yf = torch.cat([y1, y2], dim=1)
+                ch = yf + yb if args.bidirectional_sum_fwd_bwd else torch.cat([yf, yb], dim=-1)
+                if args.enc_n_projs > 0 and l != n_layers - 1:
+                    ch = torch.relu(_lin(ch, sd, 'enc.proj.%d' % l))
+                if sub[l] > 1:
+                    ch, xl_new = subsample(ch, xl, sd, args.subsample_type, sub[l], 'enc.subsample.%d' % l)
+                    if ci == 0:
+                        xl = xl_new
+                    nc = nc // sub[l]
+            outs.append(ch[:, :nc])
+        xs = torch.cat(outs, dim=1)
+        xlens = xl
+        if 'enc.bridge.weight' in sd:
+            xs = _lin(xs, sd, 'enc.bridge')
+        return xs[:, :max(xlens)], xlens
     for l in range(n_layers):
         p = 'enc.rnn.%d' % l
         if lc_bidir:

@@ -129,12 +129,18 @@ def _ctc_loss(logits, labels, elens, ylens, lsm_prob=0.0, sum_elens=1, blank=0):
     return loss.view(1), nll
 
 
-def _lstm(x, w_ih, w_hh, b_ih, b_hh):
+def _lstm_state(x, w_ih, w_hh, b_ih, b_hh, h0, c0):
+    """ops.lstm_state: the same layer started from (h0, c0) -> (y, h_n, c_n)"""
+    y, h, c = _lstm(x, w_ih, w_hh, b_ih, b_hh, h0, c0, True)
+    return y, h, c
+
+
+def _lstm(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, return_state=False):
     """ops.lstm: one nn.LSTM layer, batch_first, zero initial state, gate order i,f,g,o (nsp_lstm_fwd)."""
     B, L, _ = x.shape
     H = w_hh.shape[1]
-    h = x.new_zeros(B, H)
-    c = x.new_zeros(B, H)
+    h = x.new_zeros(B, H) if h0 is None else h0
+    c = x.new_zeros(B, H) if c0 is None else c0
     gi = F.linear(x, w_ih, b_ih + b_hh)
     outs = []
     for t in range(L):
@@ -142,7 +148,8 @@ def _lstm(x, w_ih, w_hh, b_ih, b_hh):
         c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
         h = torch.sigmoid(o) * torch.tanh(c)
         outs.append(h)
-    return torch.stack(outs, dim=1)
+    y = torch.stack(outs, dim=1)
+    return (y, h, c) if return_state else y
 
 
 def _xe_lsm_loss(logits, ys_int32, lsm_prob, ignore_index, bs):
@@ -189,9 +196,10 @@ def _ctc_forced_align(logits, labels, elens, ylens, blank=0):
 
 @contextlib.contextmanager
 def host_logic_on_cpu(real_kernels=False):
-    """real_kernels=True: ONLY the ops whose kernels the emulator cannot build (conv front-end: inline asm; LSTM:
-    gfx950 builtins; pinned-memory staging) are replaced; GEMMs (fp32 MFMA emulated as wave collectives), attention
-    soft-max, LayerNorm, CTC, XE, depthwise conv, GLU, pooling over time, dropout, ... all run the real .hip kernels."""
+    """real_kernels=True: ONLY the ops whose kernels the emulator cannot build (the conv front-end and its 2-D pooling:
+    inline asm; pinned-memory staging) are replaced; GEMMs and the LSTM step kernels (fp32 MFMA emulated as wave
+    collectives), attention soft-max, LayerNorm, CTC, XE, depthwise conv, GLU, pooling over time, dropout, ... all run
+    the real .hip kernels."""
     from neural_sp_amd import ops
     from tests.hipemu.shim import emulated_kernels
     fakes = dict(
@@ -201,11 +209,11 @@ def host_logic_on_cpu(real_kernels=False):
         conv3x3_relu=_conv3x3_relu, maxpool2d=_maxpool2d, scale=lambda x, a: x * a,
         dropout=lambda x, p, training: x if (p == 0 or not training) else (_ for _ in ()).throw(AssertionError('dropout')),
         add=lambda x, z, alpha=1.0, beta=1.0: alpha * x + beta * z, scale_add_bcast=_scale_add_bcast,
-        xl_pos_table=_xl_pos_table, ctc_loss=_ctc_loss, h2d_packed=_h2d_packed, pad_batch=_pad_batch, lstm=_lstm,
+        xl_pos_table=_xl_pos_table, ctc_loss=_ctc_loss, h2d_packed=_h2d_packed, pad_batch=_pad_batch, lstm=_lstm, lstm_state=_lstm_state,
         xe_lsm_loss=_xe_lsm_loss, argmax_rows=lambda x2d: x2d.argmax(-1).int(), ctc_forced_align=_ctc_forced_align,
     )
     if real_kernels:
-        fakes = {k: fakes[k] for k in ('conv3x3_relu', 'maxpool2d', 'lstm', 'h2d_packed')}
+        fakes = {k: fakes[k] for k in ('conv3x3_relu', 'maxpool2d', 'h2d_packed')}
     saved = {k: getattr(ops, k) for k in fakes}
     mode = ops.get_compute_mode()
     for k, v in fakes.items():

@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, 'neural_sp_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libnsp_emu.so')
 EMULATED_SOURCES = ['norm_subsample.hip', 'elementwise.hip', 'xent.hip', 'decode.hip', 'layernorm.hip', 'ctc.hip',
-                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip']
+                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip', 'lstm.hip']
 CXX_CANDIDATES = ['/opt/rocm/lib/llvm/bin/clang++', 'clang++']
 
 
@@ -41,6 +41,8 @@ def _rewrite(src, dst):
     the include of common.h is redirected to the real csrc directory"""
     text = open(src).read()
     text = _DYN.sub(r'\1* \2 = reinterpret_cast<\1*>(HIPEMU_DYN_SHARED);', text)
+    text = re.sub(r'asm volatile\("s_waitcnt[^;]*;', '/* s_waitcnt: no-op on the host */;', text)
+    text = text.replace('__attribute__((address_space(1)))', '')
     text = text.replace('#include "common.h"', '#include "%s"' % os.path.join(CSRC, 'common.h'))
     with open(dst, 'w') as fh:
         fh.write(text)

@@ -19,6 +19,7 @@
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -46,6 +47,19 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return hipSuccess;
 }
+// persistent (grid-barrier) kernels need all blocks resident at once; the emulator serialises blocks, so the
+// occupancy query fails and the launchers refuse the persistent path (callers fall back to per-step kernels)
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipGetDevice(int*) { return 100; }
+static inline hipError_t hipDeviceGetAttribute(int*, int, int) { return 100; }
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int*, K, int, size_t) { return 100; }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __HIP_MEMORY_SCOPE_SYSTEM 0
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __builtin_amdgcn_s_sleep(n) sched_yield()
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 template <class T> static inline T min(T a, T b) { return b < a ? b : a; }
 template <class T> static inline T max(T a, T b) { return a < b ? b : a; }
 static inline long long min(long long a, int b) { return a < b ? a : b; }

@@ -6,11 +6,12 @@ same sources for host threads -- the fp32 MFMA GEMM with its fused epilogues (v_
 collective), data / weight gradients and split-K, attention soft-max with relative positions and masks, LayerNorm
 (+Swish), depthwise conv, GLU, pooling / subsampling, dropout plumbing, CTC loss + label smoothing.  Only the ops whose
 kernels use inline asm or gfx950-only builtins are plain-torch stand-ins: the 3x3 conv front-end and its 2-D pooling,
-the LSTM cell kernels, pinned-memory staging (tests/cpu_ops_shim.py, real_kernels=True).
+pinned-memory staging (tests/cpu_ops_shim.py, real_kernels=True); the LSTM step kernels run too (blstm_ctc_xs: no
+stand-in at all on the device side).
 Gates: loss 1e-5 (the two runs below reproduce the reference's loss to the last printed digit), every gradient 2e-3 of
 its max.  The Transformer case (~1 min on 8 cores) always runs; NSP_EMU_SLOW=1 adds the Conformer cases (2-3 min each: relative-
-position attention, depthwise conv, GroupNorm / BatchNorm variants, concat subsampling; conformer_ctc_xs and
-conformer_gn_ctc_xs measured: loss identical to the fixture, gradients within 7e-6 of max)."""
+position attention, depthwise conv, GroupNorm / BatchNorm variants, concat subsampling, all measured: loss identical
+to the fixture, gradients within 7e-6 of max) and the (B)LSTM encoders incl. chunked latency-controlled training."""
 import argparse
 import os
 
@@ -23,7 +24,8 @@ pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = ['transformer_ctc_xs']
 if os.environ.get('NSP_EMU_SLOW', '0') == '1':
-    CASES += ['conformer_gn_ctc_xs', 'conformer_ctc_xs', 'conformer_bn_ctc_xs', 'conformer_concat_ctc_xs']
+    CASES += ['conformer_gn_ctc_xs', 'conformer_ctc_xs', 'conformer_bn_ctc_xs', 'conformer_concat_ctc_xs', 'blstm_ctc_xs',
+              'conv_lcblstm_chunk_xs']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -47,5 +49,7 @@ def test_speech2text_on_emulated_kernels_matches_reference_fixture(name):
     m = sorted(g.abs().max().item() for g in fix['grads'].values())
     gmax = m[int(0.9 * (len(m) - 1))]
     for n, r in fix['grads'].items():
+        if fix['args'].get('conformer_normalization') == 'batch_norm' and n.endswith('.conv.depthwise_conv.bias'):
+            continue        # true gradient zero (BatchNorm removes the shift): rounding noise on both sides
         err = ((grads[n] - r).abs().max() / max(r.abs().max().item(), 1e-5 * gmax)).item()
         assert err < 2e-3, (n, err)

@@ -212,3 +212,43 @@ def test_rnnt_lattice_kernels_against_the_fp64_oracle():
     assert _rel(work, g_ref.float()) < 1e-4
     assert work[1, 5:].abs().max() == 0 and work[2, :, 1:].abs().max() == 0      # padded lattice nodes: no gradient
     assert _lib.prototypes()['nsp_rnnt_lattice'][1][-1] is not None
+
+
+def _lstm_case(seed=7, B=3, n=6, I=16, H=32):
+    torch.manual_seed(seed)
+    ref = torch.nn.LSTM(I, H, 1, batch_first=True)
+    x = torch.randn(B, n, I, requires_grad=True)
+    h0, c0 = torch.randn(B, H, requires_grad=True), torch.randn(B, H, requires_grad=True)
+    params = [ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0]
+    return ref, x, h0, c0, params, (torch.randn(B, n, H), torch.randn(B, H), torch.randn(B, H))
+
+
+def test_lstm_step_kernels_vs_torch(emu):
+    """nsp_lstm_fwd / nsp_lstm_bwd (fp32 MFMA step kernels) through ops.lstm: outputs and every gradient"""
+    ref, x, _, _, params, (wy, _, _) = _lstm_case()
+    yr, _ = ref(x)
+    gr = torch.autograd.grad((yr * wy).sum(), [x] + params)
+    y = emu.lstm(x, *params)
+    g = torch.autograd.grad((y * wy).sum(), [x] + params)
+    assert _rel(y, yr) < 1e-5
+    for a, r in zip(g, gr):
+        assert _rel(a, r) < 1e-5
+
+
+def test_lstm_with_initial_and_final_state(emu):
+    """ops.lstm_state (nsp_lstm_*_range): the step kernels started from (h0, c0), differentiable through the initial and
+    the final state -- what carries the forward direction of the latency-controlled BLSTM from chunk to chunk"""
+    ref, x, h0, c0, params, (wy, wh, wc) = _lstm_case()
+    yr, (hn, cn) = ref(x, (h0[None], c0[None]))
+    gr = torch.autograd.grad((yr * wy).sum() + (hn[0] * wh).sum() + (cn[0] * wc).sum(), [x, h0, c0] + params)
+    y, h, c = emu.lstm_state(x, *params, h0, c0)
+    g = torch.autograd.grad((y * wy).sum() + (h * wh).sum() + (c * wc).sum(), [x, h0, c0] + params)
+    assert _rel(y, yr) < 1e-5 and _rel(h, hn[0]) < 1e-5 and _rel(c, cn[0]) < 1e-5
+    for a, r in zip(g, gr):
+        assert _rel(a, r) < 1e-5
+    # two chained calls == one call over the concatenation (state hand-over, gradients through it)
+    y1, h1, c1 = emu.lstm_state(x[:, :4], *params, h0, c0)
+    y2, h2, c2 = emu.lstm_state(x[:, 4:], *params, h1, c1)
+    g2 = torch.autograd.grad((torch.cat([y1, y2], 1) * wy).sum() + (h2 * wh).sum() + (c2 * wc).sum(), [x, h0, c0] + params)
+    for a, r in zip(g2, gr):
+        assert _rel(a, r) < 1e-5

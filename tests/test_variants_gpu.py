@@ -121,6 +121,31 @@ def test_timit_blstm_ctc_config1_full_size(mode):
         assert not bad, bad
 
 
+@pytest.mark.parametrize('mode,tol', [('f32', 1e-4), ('bf16', 3e-2)])
+def test_lstm_with_initial_and_final_state(mode, tol):
+    """ops.lstm_state (nsp_lstm_*_range) vs torch's nn.LSTM started from (h0, c0): outputs, final state, and the
+    gradients w.r.t. input, initial state and weights when the loss also reads the final state"""
+    from neural_sp_amd import ops
+    torch.manual_seed(5)
+    B, n, I, H = 5, 23, 48, 64
+    dev = torch.device('cuda', 0)
+    ref = torch.nn.LSTM(I, H, 1, batch_first=True)
+    x = torch.randn(B, n, I, requires_grad=True)
+    h0, c0 = torch.randn(B, H, requires_grad=True), torch.randn(B, H, requires_grad=True)
+    wy, wh, wc = torch.randn(B, n, H), torch.randn(B, H), torch.randn(B, H)
+    yr, (hn, cn) = ref(x, (h0[None], c0[None]))
+    params = [ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0]
+    gr = torch.autograd.grad((yr * wy).sum() + (hn[0] * wh).sum() + (cn[0] * wc).sum(), [x, h0, c0] + params)
+    ins = [t.detach().clone().to(dev).requires_grad_(True) for t in [x, h0, c0] + params]
+    with ops.compute_mode(mode):
+        y, h, c = ops.lstm_state(ins[0], *ins[3:], ins[1], ins[2])
+        g = torch.autograd.grad((y * wy.to(dev)).sum() + (h * wh.to(dev)).sum() + (c * wc.to(dev)).sum(), ins)
+    rel = lambda a, r: ((a.cpu() - r).abs().max() / r.abs().max()).item()
+    assert rel(y, yr) < tol and rel(h, hn[0]) < tol and rel(c, cn[0]) < tol
+    for a, r in zip(g, gr):
+        assert rel(a, r) < tol
+
+
 def test_weight_noise_on_device():
     """one multi-tensor add on device parameters; bf16 weight shadows follow the version counters"""
     from neural_sp_amd import ops
