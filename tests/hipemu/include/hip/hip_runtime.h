@@ -7,11 +7,13 @@
 // product build (neural_sp_amd/_lib.py, hipcc --offload-arch=gfx950) never sees this directory, and
 // nothing under neural_sp_amd/ loads the library it produces.
 //
-// Model: one launch = `block` host threads; each thread walks the grid's blocks in order (blocks are
-// serialised, so `__shared__` == function-local static storage is private to the running block);
-// __syncthreads() is a pthread barrier over the block; wave shuffles exchange through a per-wave slot
-// array guarded by a per-wave barrier.  Kernels must be convergent at every barrier / shuffle (no
-// early `return` before one) -- the kernels emulated here are written that way.
+// Model: one launch = one host thread per WAVE; the 64 lanes of a wave are ucontext fibers scheduled round-robin by
+// that thread and switched only at collectives, so wave-level operations (shuffles, MFMA, wave barriers) cost a
+// few user-space context switches and no system call.  Each wave thread walks the grid's blocks in order (blocks are
+// serialised, so `__shared__` == function-local static storage is private to the running block); __syncthreads()
+// = every lane of the wave arrives, the last one joins a pthread barrier over the block's waves, then all are
+// released.  Lanes that have returned no longer take part in collectives (as on the hardware); a whole wave must not
+// exit while other waves of its block still wait at a __syncthreads().
 // Dynamic shared memory: `extern __shared__ T name[];` is rewritten by tests/hipemu/build_emu.py into a pointer to a
 // per-launch buffer (HIPEMU_DYN_SHARED).  The two MFMA builtins of gemm.hip are emulated as wave collectives.
 // Not emulated: inline asm, buffer / LDS-DMA / transposed-LDS-read builtins, streams.
@@ -22,6 +24,8 @@
 #include <sched.h>
 #include <stdint.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <ucontext.h>
 
 #include <thread>
 #include <vector>
@@ -83,20 +87,48 @@ static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 
 namespace hipemu {
-struct Wave {
-  pthread_barrier_t bar;
-  int n;
+struct Launch;
+struct Wave {              // one per host thread
+  Launch* L;
+  int index, n;            // wave number inside the block, lanes in it
+  int cur, alive, arrived; // running lane; lanes not yet returned; lanes waiting at the current collective
+  unsigned gen;            // collective generation (a waiting lane resumes when it changes)
+  ucontext_t sched;
+  ucontext_t ctx[64];
+  bool done[64];
+  char* stacks;            // 64 fiber stacks
+  void (*invoke)(void*);
+  void* closure;
   uint64_t slot[64];
   alignas(16) unsigned char frag[64][32];   // MFMA operand fragments: A (16 B) | B (16 B) per lane
 };
 struct Launch {
   dim3 grid, block;
-  pthread_barrier_t bar;
-  std::vector<Wave> waves;
-  std::vector<double> dyn;  // dynamic shared memory of the running block (8-byte storage: any alignment <= 16 via offset)
+  pthread_barrier_t bar;   // over the block's waves
+  std::vector<double> dyn; // dynamic shared memory of the running block (8-byte storage: any alignment <= 16 via offset)
 };
 extern thread_local Launch* cur;
+extern thread_local Wave* wave;
 extern thread_local int tid_flat;
+static const size_t kFiberStack = 256 * 1024;
+static inline void yield_lane() {
+  Wave* w = wave;
+  swapcontext(&w->ctx[w->cur], &w->sched);
+}
+// every live lane of the wave arrives; `at_release` (may be null) runs once, on the last arriver, before the release
+template <class F>
+static inline void wave_collective(F at_release) {
+  Wave* w = wave;
+  const unsigned g = w->gen;
+  if (++w->arrived >= w->alive) {
+    at_release();
+    w->arrived = 0;
+    ++w->gen;
+  } else {
+    while (w->gen == g) yield_lane();
+  }
+}
+static inline void wave_barrier() { wave_collective([] {}); }
 }  // namespace hipemu
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -105,7 +137,9 @@ static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CS
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
-static inline void __syncthreads() { pthread_barrier_wait(&hipemu::cur->bar); }
+static inline void __syncthreads() {
+  hipemu::wave_collective([] { pthread_barrier_wait(&hipemu::cur->bar); });
+}
 // 16-byte aligned base of the launch's dynamic shared memory
 #define HIPEMU_DYN_SHARED \
   (reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(hipemu::cur->dyn.data()) + 15) & ~uintptr_t(15)))
@@ -113,16 +147,16 @@ static inline void __syncthreads() { pthread_barrier_wait(&hipemu::cur->bar); }
 template <class T>
 static inline T hipemu_shfl(T v, int src_of_lane_fn(int, int), int arg) {
   static_assert(sizeof(T) <= 8, "shuffle of <= 8-byte values only");
-  hipemu::Wave& w = hipemu::cur->waves[hipemu::tid_flat >> 6];
+  hipemu::Wave& w = *hipemu::wave;
   const int lane = hipemu::tid_flat & 63;
   uint64_t raw = 0;
   memcpy(&raw, &v, sizeof(T));
   w.slot[lane] = raw;
-  pthread_barrier_wait(&w.bar);
+  hipemu::wave_barrier();
   int src = src_of_lane_fn(lane, arg);
   if (src < 0 || src >= w.n) src = lane;  // inactive source lane: own value
   raw = w.slot[src];
-  pthread_barrier_wait(&w.bar);
+  hipemu::wave_barrier();
   T r;
   memcpy(&r, &raw, sizeof(T));
   return r;
@@ -142,13 +176,13 @@ template <class T> static inline T __shfl(T v, int i, int = 64) { return hipemu_
 // products are accumulated in k order with fmaf (the f32 form is documented as an exact fmaf chain).
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
-static inline void hipemu_wave_barrier() { pthread_barrier_wait(&hipemu::cur->waves[hipemu::tid_flat >> 6].bar); }
+static inline void hipemu_wave_barrier() { hipemu::wave_barrier(); }
 static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
-  hipemu::Wave& w = hipemu::cur->waves[hipemu::tid_flat >> 6];
+  hipemu::Wave& w = *hipemu::wave;
   const int l = hipemu::tid_flat & 63;
   memcpy(w.frag[l], &a, 4);
   memcpy(w.frag[l] + 16, &b, 4);
-  pthread_barrier_wait(&w.bar);
+  hipemu::wave_barrier();
   const int col = l & 15;
   for (int r = 0; r < 4; ++r) {
     const int row = (l >> 4) * 4 + r;
@@ -161,15 +195,15 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f
     }
     c[r] = acc;
   }
-  pthread_barrier_wait(&w.bar);
+  hipemu::wave_barrier();
   return c;
 }
 static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c, int, int, int) {
-  hipemu::Wave& w = hipemu::cur->waves[hipemu::tid_flat >> 6];
+  hipemu::Wave& w = *hipemu::wave;
   const int l = hipemu::tid_flat & 63;
   memcpy(w.frag[l], &a, 16);
   memcpy(w.frag[l] + 16, &b, 16);
-  pthread_barrier_wait(&w.bar);
+  hipemu::wave_barrier();
   const int col = l & 15;
   for (int r = 0; r < 4; ++r) {
     const int row = (l >> 4) * 4 + r;
@@ -182,7 +216,7 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu
     }
     c[r] = acc;
   }
-  pthread_barrier_wait(&w.bar);
+  hipemu::wave_barrier();
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
@@ -205,6 +239,11 @@ static inline float atomicAdd(float* p, float v) {
 }
 
 namespace hipemu {
+static inline void fiber_entry() {
+  Wave* w = wave;
+  w->invoke(w->closure);
+  w->done[w->cur] = true;   // returns to uc_link = the wave's scheduler
+}
 template <class F>
 static inline void launch(dim3 grid, dim3 block, size_t shmem, F body) {
   Launch L;
@@ -212,34 +251,63 @@ static inline void launch(dim3 grid, dim3 block, size_t shmem, F body) {
   L.block = block;
   L.dyn.assign(shmem / 8 + 4, 0.0);
   const int nthr = (int)(block.x * block.y * block.z);
-  pthread_barrier_init(&L.bar, nullptr, nthr);
   const int nw = (nthr + 63) / 64;
-  L.waves = std::vector<Wave>(nw);
-  for (int w = 0; w < nw; ++w) {
-    L.waves[w].n = (w == nw - 1) ? nthr - 64 * w : 64;
-    pthread_barrier_init(&L.waves[w].bar, nullptr, L.waves[w].n);
-  }
+  pthread_barrier_init(&L.bar, nullptr, nw);
   std::vector<std::thread> th;
-  th.reserve(nthr);
-  for (int t = 0; t < nthr; ++t) {
-    th.emplace_back([&L, t, grid, block, &body]() {
+  th.reserve(nw);
+  for (int wi = 0; wi < nw; ++wi) {
+    th.emplace_back([&L, wi, nw, nthr, grid, block, &body]() {
+      Wave* w = new Wave();
+      w->L = &L;
+      w->index = wi;
+      w->n = (wi == nw - 1) ? nthr - 64 * wi : 64;
+      w->stacks = (char*)mmap(nullptr, 64 * kFiberStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      w->invoke = [](void* c) { (*static_cast<F*>(c))(); };
+      w->closure = (void*)&body;
       cur = &L;
-      tid_flat = t;
+      wave = w;
       blockDim = block;
       gridDim = grid;
-      threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
       for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
           for (unsigned bx = 0; bx < grid.x; ++bx) {
             blockIdx = dim3(bx, by, bz);
-            body();
+            w->alive = w->n;
+            w->arrived = 0;
+            for (int l = 0; l < w->n; ++l) {
+              w->done[l] = false;
+              getcontext(&w->ctx[l]);
+              w->ctx[l].uc_stack.ss_sp = w->stacks + (size_t)l * kFiberStack;
+              w->ctx[l].uc_stack.ss_size = kFiberStack;
+              w->ctx[l].uc_link = &w->sched;
+              makecontext(&w->ctx[l], (void (*)())fiber_entry, 0);
+            }
+            while (w->alive > 0) {
+              for (int l = 0; l < w->n; ++l) {
+                if (w->done[l]) continue;
+                w->cur = l;
+                const int t = wi * 64 + l;
+                tid_flat = t;
+                threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                swapcontext(&w->sched, &w->ctx[l]);
+                if (w->done[l]) {
+                  // a lane that returned no longer takes part in collectives: release the others if they only
+                  // waited for it (wave-level collectives only; see the header comment for __syncthreads)
+                  if (--w->alive > 0 && w->arrived >= w->alive) {
+                    w->arrived = 0;
+                    ++w->gen;
+                  }
+                }
+              }
+            }
             pthread_barrier_wait(&L.bar);  // a block ends before the next one reuses its statics
           }
+      munmap(w->stacks, 64 * kFiberStack);
+      delete w;
     });
   }
   for (auto& t : th) t.join();
   pthread_barrier_destroy(&L.bar);
-  for (auto& w : L.waves) pthread_barrier_destroy(&w.bar);
 }
 }  // namespace hipemu
 

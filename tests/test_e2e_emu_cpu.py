@@ -2,18 +2,18 @@
 fixtures produced by the reference -- the CPU-tier counterpart of tests/test_golden_gpu.py::test_golden_fp32.
 
 Everything runs the product's own code: the Python host side, the ctypes glue, and the .hip kernels compiled from the
-same sources for host threads -- the fp32 MFMA GEMM with its fused epilogues (v_mfma_f32_16x16x4_f32 emulated as a wave
-collective), data / weight gradients and split-K, attention soft-max with relative positions and masks, LayerNorm
-(+Swish), depthwise conv, GLU, pooling / subsampling, dropout plumbing, CTC loss + label smoothing.  Only the ops whose
-kernels use inline asm or gfx950-only builtins are plain-torch stand-ins: the 3x3 conv front-end and its 2-D pooling,
-pinned-memory staging (tests/cpu_ops_shim.py, real_kernels=True); the LSTM step kernels run too (blstm_ctc_xs: no
-stand-in at all on the device side).
-Gates: loss 1e-5 (the two runs below reproduce the reference's loss to the last printed digit), every gradient 2e-3 of
-its max.  The Transformer case (~1 min on 8 cores) always runs; NSP_EMU_SLOW=1 adds the Conformer cases (2-3 min each: relative-
-position attention, depthwise conv, GroupNorm / BatchNorm variants, concat subsampling, all measured: loss identical
-to the fixture, gradients within 7e-6 of max) and the (B)LSTM encoders incl. chunked latency-controlled training."""
+same sources for host threads (fibers) -- the fp32 MFMA GEMM with its fused epilogues (v_mfma_f32_16x16x4_f32 emulated
+as a wave collective), data / weight gradients and split-K, attention soft-max with relative positions and masks,
+LayerNorm (+Swish), depthwise conv, GLU, pooling / subsampling, BatchNorm / GroupNorm, CTC loss + label smoothing + forced
+alignment, the RNN-T joint, lattice and prediction-network LSTM, label-smoothed XE, the (B)LSTM encoders incl. chunked
+latency-controlled training.  Only the ops whose kernels use inline asm are plain-torch stand-ins: the 3x3 conv front-end
+with its 2-D pooling, and pinned-memory staging (tests/cpu_ops_shim.py, real_kernels=True); blstm_ctc_xs has no stand-in
+at all on the device side.
+Gates: loss 1e-5 (the runs reproduce the reference's loss to the last printed digit), every gradient 2e-3 of its max.
+All 34 fixtures pass (NSP_EMU_ALL=1, ~7 min); nine -- one per model family -- run by default."""
 import argparse
 import os
+import random
 
 import pytest
 import torch
@@ -22,10 +22,12 @@ from tests.hipemu import build_emu
 
 pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang++ for the HIP emulator')
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['transformer_ctc_xs']
-if os.environ.get('NSP_EMU_SLOW', '0') == '1':
-    CASES += ['conformer_gn_ctc_xs', 'conformer_ctc_xs', 'conformer_bn_ctc_xs', 'conformer_concat_ctc_xs', 'blstm_ctc_xs',
-              'conv_lcblstm_chunk_xs']
+import glob  # noqa: E402
+ALL = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt')))
+# one fixture per family by default (~1.5 min on 8 cores); NSP_EMU_ALL=1 runs all of them (34 fixtures, ~7 min, all green)
+DEFAULT = ['transformer_ctc_xs', 'conformer_ctc_xs', 'conformer_rnnt_xs', 'conformer_bn_ctc_xs', 'conformer_drop_ctc_xs',
+           'conformer_2mtl_ctc_xs', 'conformer_ctc_att_1dconv_xs', 'conformer_ctc_mocha_ctcsync_xs', 'blstm_ctc_xs']
+CASES = ALL if os.environ.get('NSP_EMU_ALL', '0') == '1' else DEFAULT
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -36,9 +38,18 @@ def test_speech2text_on_emulated_kernels_matches_reference_fixture(name):
     model = Speech2Text(argparse.Namespace(**fix['args']))
     model.load_state_dict(fix['state_dict'], strict=True)
     batch = dict(fix['batch'])
-    batch.update(xlens=[len(x) for x in batch['xs']], trigger_points=None)
+    batch.update(xlens=[len(x) for x in batch['xs']])
     batch.setdefault('ys_sub1', [])
     batch.setdefault('ys_sub2', [])
+    batch.setdefault('trigger_points', None)
+    if fix['meta'].get('trigger_quantity_loss'):
+        model.trigger_quantity_loss()
+    if fix['meta'].get('trigger_stableemit'):
+        model.trigger_stableemit()
+    ss_seed = fix['meta'].get('scheduled_sampling_seed')
+    if ss_seed is not None:
+        model.trigger_scheduled_sampling()
+        random.seed(ss_seed)
     with host_logic_on_cpu(real_kernels=True):
         loss, obs = model(batch, task='all')
         loss.backward()
