@@ -21,6 +21,7 @@ RECIPES = [
     'librispeech/s5/conf/asr/mocha/uni_conformer_kernel7_clamp10_hie_subsample8_mocha_ln_stableemit0.2_qua0.2.yaml',   # config 5
     'aishell/s5/conf/asr/conformer_kernel15_clamp10_hie_subsample8_las_ln_2mtl.yaml',                      # multi-task
     'csj/s5/conf/asr/las/blstm_las.yaml',                                                                  # the BLSTM-LAS family
+    'librispeech/s5/conf/asr/mocha/lcblstm_mocha_chunk4040_ctc_sync.yaml',                                 # streaming LC-BLSTM + MoChA
 ]
 
 
