@@ -350,6 +350,12 @@ int nsp_time_window_gather_fwd(const float* x, float* y, int B, int T, int To, i
 int nsp_time_window_gather_bwd(const float* dy, float* dx, int B, int T, int To, int C, int k,
                                int stride, int pad, void* stream);
 
+/* im2col of a 3x3 / pad 1 / stride 1 convolution on channels-last x [B,T,F,Ci], for input-channel counts the MFMA
+ * conv kernels do not take (conv_in_channel = 3, conv.py:167-175): cols [B*T*F, Kp], Kp >= 9*Ci,
+ * cols[(b,t,f), ci*9 + kh*3 + kw] = x[b, t+kh-1, f+kw-1, ci], zero outside the map and in columns 9*Ci..Kp-1
+ * (= the column order of nn.Conv2d's weight viewed as [Co, Ci*9]); the convolution is then one GEMM. */
+int nsp_im2col3x3(const float* x, float* cols, int B, int T, int F, int Ci, int Kp, void* stream);
+
 /* pack_padded_sequence / pad_packed_sequence around the (B)LSTM layers of    *
  * encoders/rnn.py:534-541, as data movement on [B,T,C] (C % 4 == 0; rows may *
  * be strided: x_ld / y_ld floats per frame, multiples of 4):                *

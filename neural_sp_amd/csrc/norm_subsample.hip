@@ -129,6 +129,32 @@ __global__ __launch_bounds__(256) void window_gather_bwd_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// im2col of a 3x3 / pad 1 / stride 1 convolution on channels-last x [B,T,F,Ci] for input-channel counts the MFMA
+// conv kernels do not take (conv_in_channel = 3: static + delta + delta-delta features of the TIMIT / WSJ recipes,
+// conv.py:167-175): cols[(b,t,f), ci*9 + kh*3 + kw] = x[b, t+kh-1, f+kw-1, ci] (0 outside), columns 9*Ci..Kp-1 = 0,
+// which is the column order of nn.Conv2d's weight viewed as [Co, Ci*9]; the convolution is then one GEMM.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ cols,
+                                                        int B, int T, int F, int Ci, int Kp) {
+  const long long total = (long long)B * T * F * Kp;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gstride) {
+    const int col = (int)(idx % Kp);
+    const long long pix = idx / Kp;
+    const int f = (int)(pix % F);
+    const int t = (int)((pix / F) % T);
+    const long long b = pix / ((long long)F * T);
+    float v = 0.f;
+    if (col < 9 * Ci) {
+      const int ci = col / 9, kh = (col % 9) / 3, kw = col % 3;
+      const int tt = t + kh - 1, ff = f + kw - 1;
+      if (tt >= 0 && tt < T && ff >= 0 && ff < F) v = x[((b * T + tt) * F + ff) * Ci + ci];
+    }
+    cols[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // What pack_padded_sequence / pad_packed_sequence do around a (B)LSTM (encoders/rnn.py:534-541), as data movement:
 //   y[b,t,:] = t < len_b ? x[b, flip ? len_b-1-t : t, :] : 0        (rows of x / y may be strided: x_ld, y_ld)
 // flip = 0 zeroes the frames past each utterance's end (what the padded output of a packed LSTM holds);
@@ -469,6 +495,15 @@ extern "C" int nsp_time_window_gather_bwd(const float* dy, float* dx, int B, int
   if (B == 0) return NSP_OK;
   hipLaunchKernelGGL(window_gather_bwd_kernel, dim3(ew_grid((long long)B * T * (C / 4))), dim3(256), 0,
                      (hipStream_t)stream, dy, dx, B, T, To, C, k, stride, pad);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_im2col3x3(const float* x, float* cols, int B, int T, int F, int Ci, int Kp, void* stream) {
+  if (B < 0 || T < 1 || F < 1 || Ci < 1 || Kp < 9 * Ci) return NSP_EUNSUPPORTED;
+  if (B == 0) return NSP_OK;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(ew_grid((long long)B * T * F * Kp)), dim3(256), 0, (hipStream_t)stream,
+                     x, cols, B, T, F, Ci, Kp);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

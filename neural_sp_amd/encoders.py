@@ -166,8 +166,6 @@ class ConvEncoder(EncoderBase):
             raise NotImplementedError('Conv1dBlock frontend is not on the benchmarked path')
         self.is_1dconv = False
         self.in_channel = in_channel
-        if in_channel != 1:
-            raise NotImplementedError('conv_in_channel = %d (the conv kernels take one input channel)' % in_channel)
         assert input_dim % in_channel == 0
         self.input_freq = input_dim // in_channel
         self.residual = residual
@@ -200,9 +198,11 @@ class ConvEncoder(EncoderBase):
     def forward(self, xs, xlens, lookback=False, lookahead=False):
         """xs `[B,T,F]`, xlens IntTensor (CPU) -> (`[B,T',d]`, xlens)."""
         B, T, F = xs.size()
-        if self.in_channel != 1:
-            raise NotImplementedError('conv_in_channel > 1')
-        xs = xs.reshape(B, T, F, 1)  # channels-last view of [B,1,T,F]
+        if self.in_channel == 1:
+            xs = xs.reshape(B, T, F, 1)  # channels-last view of [B,1,T,F]
+        else:
+            # conv.py:167-175: the feature vector holds the channels one after the other (static | delta | delta-delta)
+            xs = xs.view(B, T, self.in_channel, F // self.in_channel).permute(0, 1, 3, 2).contiguous()
         for i, block in enumerate(self.layers):
             xs, xlens = block(xs, xlens, lookback=lookback, lookahead=lookahead,
                               last=(i == len(self.layers) - 1))

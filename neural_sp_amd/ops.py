@@ -1172,7 +1172,27 @@ class Conv3x3ReLUFn(torch.autograd.Function):
         return dx, dw, db
 
 
+def _conv3x3_relu_im2col(x_cl, weight, bias):
+    """relu(conv2d(x, w, b, padding=1)) for input-channel counts the MFMA conv kernels do not take (conv_in_channel =
+    3: the first layer of the TIMIT / WSJ Transformer recipes): im2col + the GEMM with bias / ReLU in its epilogue.
+    First-layer use only: the input carries no gradient."""
+    assert not x_cl.requires_grad, 'the im2col convolution is built for the input layer (no data gradient)'
+    x = _f32c(x_cl)
+    B, T, F, Ci = x.shape
+    Co = weight.shape[0]
+    K = 9 * Ci
+    Kp = (K + 7) // 8 * 8
+    cols = torch.empty((B * T * F, Kp), device=x.device, dtype=torch.float32)
+    _check(_lib.lib().nsp_im2col3x3(_p(x), _p(cols), B, T, F, Ci, Kp, _stream()), 'nsp_im2col3x3')
+    w2 = weight.reshape(Co, K)
+    if Kp > K:
+        w2 = torch.cat([w2, w2.new_zeros(Co, Kp - K)], dim=1)
+    return linear(cols, w2.contiguous(), bias, act='relu').view(B, T, F, Co)
+
+
 def conv3x3_relu(x_cl, weight, bias):
+    if x_cl.shape[-1] not in (1, 32):
+        return _conv3x3_relu_im2col(x_cl, weight, bias)
     return Conv3x3ReLUFn.apply(x_cl, weight, bias)
 
 

@@ -255,6 +255,11 @@ CASES['conformer_ctc_mocha_ctcsync_xs'] = (_mocha_lat('ctc_sync'), dict(B=4, t_r
 CASES['conformer_ctc_mocha_decot_xs'] = (_mocha_lat('decot', mocha_decot_lookahead=2),
                                          dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=82))
 CTC_ALIGNED = {'conformer_ctc_mocha_ctcsync_xs': 'ctc_sync', 'conformer_ctc_mocha_decot_xs': 'batch'}
+# three input channels (static, delta, delta-delta: `conv_in_channel: 3` of the TIMIT / WSJ Transformer recipes,
+# conv.py:167-175): the first conv layer runs as im2col + GEMM
+CASES['transformer_ctc_3ch_xs'] = (
+    lambda: transformer_ctc_args(n_layers=2, d_model=32, d_ff=64, n_heads=4, vocab=40, conv_in_channel=3, input_dim=120),
+    dict(B=3, t_range=(50, 90), u_range=(2, 8), vocab=40, seed=91))
 TRIGGER_STABLEEMIT = {'conformer_ctc_mocha_stableemit_xs'}
 TRIGGER_SCHEDULED_SAMPLING = {'conformer_ctc_las_ss_xs': 2024}   # name -> random.seed value
 TRIGGER_QUANTITY_LOSS = {'conformer_ctc_mocha_xs', 'conformer_ctc_mocha_stableemit_xs', 'conformer_ctc_mocha_ctcsync_xs',

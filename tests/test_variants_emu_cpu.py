@@ -35,3 +35,7 @@ def test_group_norm_pairs_swish(M, C):
 
 def test_flip_mask_and_bidirectional_merge():
     vc.check_flip_mask_and_merge('emu')
+
+
+def test_three_channel_first_conv_as_im2col_gemm():
+    vc.check_im2col_conv('emu')

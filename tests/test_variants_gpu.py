@@ -55,6 +55,10 @@ def test_flip_mask_and_bidirectional_merge():
     vc.check_flip_mask_and_merge('gpu')
 
 
+def test_three_channel_first_conv_as_im2col_gemm():
+    vc.check_im2col_conv('gpu')
+
+
 @pytest.mark.parametrize('bidir_sum', [False, True])
 def test_blstm_layer_matches_packed_torch_lstm(bidir_sum):
     """RNNEncoder._lstm_layer (two left-to-right runs of the LSTM kernels + nsp_time_flip_mask) against

@@ -194,3 +194,24 @@ def check_flip_mask_and_merge(where):
         n = int(lens[bb])
         assert torch.equal(xf[bb, :n], x[bb, :n].flip(0)) and torch.equal(xm[bb, :n], x[bb, :n])
         assert xf[bb, n:].abs().sum() == 0 and xm[bb, n:].abs().sum() == 0
+
+
+def check_im2col_conv(where):
+    """nsp_im2col3x3 + the [Co, Ci*9] weight view == F.conv2d(padding=1) for 3 input channels (conv.py:167-175,303-307)"""
+    from neural_sp_amd import ops
+    torch.manual_seed(12)
+    B, T, Fq, Ci, Co = 2, 11, 9, 3, 32
+    conv = nn.Conv2d(Ci, Co, 3, padding=1)
+    x = torch.randn(B, T, Fq, Ci)
+    ref = torch.relu(conv(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+    ctx, dev = _env(where)
+    with ctx, ops.compute_mode('f32'):
+        conv.to(dev)
+        y = ops.conv3x3_relu(x.to(dev), conv.weight, conv.bias)
+        w = _weights(ref).to(dev)
+        gw, gb = torch.autograd.grad((y * w).sum(), [conv.weight, conv.bias])
+    conv.cpu()
+    rw, rb = torch.autograd.grad((ref * _weights(ref)).sum(), [conv.weight, conv.bias])
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gw.cpu(), rw, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(gb.cpu(), rb, rtol=1e-3, atol=1e-4)

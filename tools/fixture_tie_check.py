@@ -31,7 +31,8 @@ def near_ties(state_dict, xs_list, poolings, lo=0.0, hi=1e-5, relu_abs=2e-6):
     xs = torch.zeros(len(xl), max(xl), xs_list[0].shape[1], dtype=torch.float64)
     for b, x in enumerate(xs_list):
         xs[b, :len(x)] = torch.as_tensor(x, dtype=torch.float64)
-    x = xs[:, None]
+    ci = sd['enc.conv.layers.0.conv1.weight'].shape[1]      # conv_in_channel (conv.py:167-175)
+    x = xs.view(xs.shape[0], xs.shape[1], ci, xs.shape[2] // ci).transpose(2, 1)
     count, smallest = 0, float('inf')
     n_relu, smallest_pre = 0, float('inf')
     for i, pool in enumerate(poolings):
