@@ -99,7 +99,10 @@ def test_timit_blstm_ctc_config1_full_size(mode):
     """BASELINE configs[0] at its real size (examples/timit/s5/conf/blstm_ctc.yaml): 5 x 256-unit
     BLSTM layers, CTC, 40-dim features, B=16, T~U[150,500], U~U[20,60], ~64 output symbols -- against
     oracle/model_ref.py (pinned to the reference by the blstm fixtures) in fp32 on the host.
-    Gates: fp32 mode loss 1e-4, every gradient 5e-3 of its max; bf16 mode loss 1e-3, cosine >= 0.999 / norm 2 %."""
+    Gates: fp32 mode loss 1e-4, every gradient 5e-3 of its max; bf16 mode loss 1e-3 (the north-star bar), gradients
+    cosine >= 0.99 / norm within 5 % -- wider than the 0.999 / 2 % of the Conformer configurations because the bf16
+    hidden-state shadows feed back through up to 500 recurrent steps in each of 5 layers and 2 directions (a single
+    layer over 23 steps is held to 3e-2 by test_lstm_vs_torch[bf16]); not yet measured on hardware."""
     from tests import test_fullsize_parity_gpu as fs
     from neural_sp_amd.configs import blstm_ctc_args, synthetic_batch
     from neural_sp_amd.speech2text import Speech2Text
@@ -120,7 +123,7 @@ def test_timit_blstm_ctc_config1_full_size(mode):
         assert not bad, bad
     else:
         assert abs(loss - ref) / abs(ref) < 1e-3, (loss, ref)
-        bad, worst, skipped, n = fs._compare_grads(grads, rgrads, 0.999, 0.02)
+        bad, worst, skipped, n = fs._compare_grads(grads, rgrads, 0.99, 0.05)
         print('[config 1 bf16] %d tensors, worst (cos, norm ratio) %s, outside the gate: %s' % (n, worst, bad))
         assert not bad, bad
 
