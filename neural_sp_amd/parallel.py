@@ -22,7 +22,10 @@ this step's shape:
   cannot overlap with anything, so the cap is 48 MB (362 MB of fp32 gradients -> 8 buckets, DDP
   re-orders them by gradient arrival after the first step); optional bf16 compression halves the
   bytes on the links (NSP_DDP_COMPRESS=bf16 or compress='bf16').
-* no per-forward buffer broadcast (the only buffers are constant tables); `no_sync()` on
+* no per-forward buffer broadcast: the buffers are constant tables -- and, with `conformer_normalization:
+  batch_norm`, BatchNorm running statistics, which torch's default (broadcast_buffers=True) would overwrite on every
+  rank with rank 0's before each forward; rank 0's own statistics (the ones checkpoints and rank-0 evaluation see)
+  evolve identically either way, the other ranks simply keep theirs; `no_sync()` on
   accumulation micro-steps is torch DDP's own context manager (train.py reduces every micro-step,
   train.py:414-452; `accumulate(model, is_boundary)` below skips the collective until the boundary).
 """
