@@ -49,10 +49,11 @@ class CPUWrapperASR(nn.Module):
 
 def step_streams(model):
     """The non-default streams the training step of `model` uses (created on demand)."""
-    dec = getattr(model, 'dec_fwd', None)
     out = []
-    if dec is not None and hasattr(dec, 'ensure_streams'):
-        out = [s for s in dec.ensure_streams() if s is not None]
+    for name in ('dec_fwd', 'dec_fwd_sub1', 'dec_fwd_sub2'):      # auxiliary-task decoders may be transducers too
+        dec = getattr(model, name, None)
+        if dec is not None and hasattr(dec, 'ensure_streams'):
+            out += [s for s in dec.ensure_streams() if s is not None]
     return out
 
 
