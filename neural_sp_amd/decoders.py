@@ -481,16 +481,29 @@ class TransformerDecoderBlock(nn.Module):
     Same sub-module / parameter names as the reference block."""
 
     def __init__(self, d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer, layer_norm_eps,
-                 ffn_activation, param_init, ffn_bottleneck_dim=0):
+                 ffn_activation, param_init, ffn_bottleneck_dim=0, atype='scaled_dot', src_tgt_attention=True,
+                 mma=None, dropout_head=0.0):
         super().__init__()
         from neural_sp_amd.modules import MultiheadAttentionMechanism as MHA, PositionwiseFeedForward as FFN
         self.n_heads = n_heads
+        self.atype = atype
+        self.xy_aws = None
         self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
         self.self_attn = MHA(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, n_heads=n_heads,
-                             dropout=dropout_att, param_init=param_init)
-        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
-        self.src_attn = MHA(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, n_heads=n_heads,
-                            dropout=dropout_att, param_init=param_init)
+                             dropout=dropout_att, dropout_head=dropout_head, param_init=param_init)
+        self.src_tgt_attention = src_tgt_attention
+        if not src_tgt_attention:
+            self.src_attn = None          # MMA decoders: the layers below `mocha_first_layer` have no source attention
+        elif 'mocha' in atype:
+            from neural_sp_amd.mma import MMA
+            self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+            self.n_heads = mma['n_heads_mono']
+            self.src_attn = MMA(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, dropout=dropout_att,
+                                dropout_head=dropout_head, param_init=param_init, **mma)
+        else:
+            self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+            self.src_attn = MHA(kdim=d_model, qdim=d_model, adim=d_model, odim=d_model, n_heads=n_heads,
+                                dropout=dropout_att, param_init=param_init)
         self.norm3 = nn.LayerNorm(d_model, eps=layer_norm_eps)
         self.feed_forward = FFN(d_model, d_ff, dropout, ffn_activation, param_init, ffn_bottleneck_dim)
         self.dropout_p = dropout
@@ -503,8 +516,14 @@ class TransformerDecoderBlock(nn.Module):
         p = self.dropout_p
         yn, ys = ops.layer_norm_split(ys, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         out = self.self_attn(yn, yn, yn, mask=yy_mask, residual=ys, out_dropout=p)[0]
-        on, out = ops.layer_norm_split(out, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        out = self.src_attn(xs, xs, on, mask=xy_mask, residual=out, out_dropout=p)[0]
+        self.xy_aws = None
+        if self.src_attn is not None:
+            on, out = ops.layer_norm_split(out, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            if 'mocha' in self.atype:
+                out, self.xy_aws, _ = self.src_attn(xs, xs, on, mask=xy_mask.dense(on.shape[1], xs.shape[1]),
+                                                    residual=out, out_dropout=p)
+            else:
+                out = self.src_attn(xs, xs, on, mask=xy_mask, residual=out, out_dropout=p)[0]
         on, out = ops.layer_norm_split(out, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         return self.feed_forward(on, residual=out, alpha=1.0, out_dropout=p)
 
@@ -519,11 +538,13 @@ class TransformerDecoder(DecoderBase):
     def __init__(self, special_symbols, enc_n_units, attn_type, n_heads, n_layers, d_model, d_ff,
                  ffn_bottleneck_dim, pe_type, layer_norm_eps, ffn_activation, vocab, tie_embedding,
                  dropout, dropout_emb, dropout_att, dropout_layer, lsm_prob, ctc_weight, ctc_lsm_prob,
-                 ctc_fc_list, backward, global_weight, mtl_per_batch, param_init):
+                 ctc_fc_list, backward, global_weight, mtl_per_batch, param_init, dropout_head=0.0, mma=None,
+                 mma_first_layer=1, mma_quantity_loss_weight=0.0):
         super().__init__()
         from neural_sp_amd.modules import PositionalEncoding
-        if attn_type != 'scaled_dot':
-            raise NotImplementedError('transformer_dec_attn_type=%s (MoChA source attention is SURVEY 8f rank 2)' % attn_type)
+        if attn_type not in ('scaled_dot', 'mocha'):
+            raise NotImplementedError('transformer_dec_attn_type=%s' % attn_type)
+        self.quantity_loss_weight, self._quantity_loss_weight = mma_quantity_loss_weight, 0
         self.eos, self.unk = special_symbols['eos'], special_symbols['unk']
         self.pad, self.blank = special_symbols['pad'], special_symbols['blank']
         self.vocab, self.enc_n_units, self.d_model = vocab, enc_n_units, d_model
@@ -543,7 +564,8 @@ class TransformerDecoder(DecoderBase):
             self.pos_enc = PositionalEncoding(d_model, dropout_emb, pe_type, param_init)
             self.layers = nn.ModuleList([copy.deepcopy(TransformerDecoderBlock(
                 d_model, d_ff, n_heads, dropout, dropout_att, dropout_layer, layer_norm_eps, ffn_activation,
-                param_init, ffn_bottleneck_dim)) for _ in range(n_layers)])
+                param_init, ffn_bottleneck_dim, atype=attn_type, src_tgt_attention=lth >= mma_first_layer - 1,
+                mma=mma, dropout_head=dropout_head)) for lth in range(n_layers)])
             self.norm_out = nn.LayerNorm(d_model, eps=layer_norm_eps)
             self.output = nn.Linear(d_model, vocab)
             if tie_embedding:
@@ -564,16 +586,27 @@ class TransformerDecoder(DecoderBase):
             observation['loss_ctc'] = loss_ctc.detach()
             loss = loss + (loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight)
         if self.att_weight > 0 and (task == 'all' or 'ctc' not in task):
-            loss_att, acc_att, ppl_att = self.forward_att(eouts, elens, ys)
+            loss_att, acc_att, ppl_att, loss_quantity = self.forward_att(eouts, elens, ys)
             observation['loss_att'] = loss_att.detach()
             observation['acc_att'] = acc_att
             observation['ppl_att'] = ppl_att
+            if self.attn_type == 'mocha':                 # transformer.py:362-366
+                if self._quantity_loss_weight > 0:
+                    loss_att = loss_att + loss_quantity * self._quantity_loss_weight
+                observation['loss_quantity'] = loss_quantity.detach()
             loss = loss + (loss_att if self.mtl_per_batch else loss_att * self.att_weight)
         observation['loss'] = loss.detach()
         return loss, observation
 
+    def trigger_quantity_loss(self):
+        if self.attn_type == 'mocha':
+            self._quantity_loss_weight = self.quantity_loss_weight
+
+    def trigger_stableemit(self):
+        pass          # decoder_base.py:45-50: "TODO: MMA" in the reference -- nothing is switched for Transformer decoders
+
     def forward_att(self, eouts, elens, ys, trigger_points=None):
-        """transformer.py:373-458 -> (loss [1], acc (device scalar, %), ppl (device scalar))."""
+        """transformer.py:373-458 -> (loss [1], acc (device scalar, %), ppl (device scalar), quantity loss)."""
         from neural_sp_amd.modules import AttnMask
         dev = eouts.device
         B = len(ys)
@@ -595,8 +628,13 @@ class TransformerDecoder(DecoderBase):
         yy_mask = AttnMask(ylens_d, causal=True, lookahead=0)
         xy_mask = AttnMask(elens_d)
         out = self.pos_enc(self.embed(ys_in_d), scale=True)   # scaled + dropout
+        xy_aws_layers = []
         for layer in self.layers:
             out = layer(out, yy_mask, eouts, xy_mask)
+            if layer.xy_aws is not None and self.attn_type == 'mocha':
+                # attention padding (:426-429): target positions past <eos> select nothing
+                tgt_valid = (ys_out_d.view(B, L) != self.pad).view(B, 1, L, 1)
+                xy_aws_layers.append(layer.xy_aws.masked_fill(~tgt_valid, 0))
         out = ops.layer_norm(out, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps)
         logits = ops.linear(out, self.output.weight, self.output.bias)
         lsm = self.lsm_prob if self.training else 0.0         # criterion.py:64
@@ -604,7 +642,14 @@ class TransformerDecoder(DecoderBase):
         n_tokens = float(sum(ylens))
         ppl = torch.exp(loss_rows.sum() / n_tokens)           # criterion.py:66 / :84
         acc = correct.sum().float() * (100.0 / n_tokens)      # torch_utils.py:140-145
-        return loss, acc, ppl
+        loss_quantity = eouts.new_zeros(())
+        if self.attn_type == 'mocha':
+            # :444-452: expected number of selected frames per head, averaged over heads and MMA layers, against the
+            # number of target tokens (<eos> included)
+            n_ref = (ys_out_d.view(B, L) != self.pad).sum(1).float()
+            n_pred = sum(torch.abs(a.sum(3).sum(2).sum(1) / a.size(1)) for a in xy_aws_layers) / len(xy_aws_layers)
+            loss_quantity = torch.mean(torch.abs(n_pred - n_ref))
+        return loss, acc, ppl, loss_quantity
 
     def _plot_attention(self, save_path=None, n_cols=1):
         pass
@@ -615,6 +660,9 @@ class TransformerDecoder(DecoderBase):
 
     def greedy(self, eouts, elens, max_len_ratio, idx2token=None, exclude_eos=False, refs_id=None, utt_ids=None,
                speakers=None, cache_states=True):
+        if self.attn_type == 'mocha':
+            raise NotImplementedError('decoding with monotonic multi-head attention (test-time hard attention) is not '
+                                      'built; evaluate MMA models with the teacher-forced accuracy (--metric accuracy)')
         """decoders/transformer.py:460-566 (validate() with recog_beam_width 1): arg-max decoding, the whole
         prefix re-run through the stack at every step (no state cache: L <= ceil(T * max_len_ratio) short
         steps).  As in the reference the target mask is purely causal and the SOURCE attention is unmasked
@@ -685,7 +733,14 @@ def build_decoder(args, special_symbols, enc_n_units, vocab, ctc_weight, global_
             dropout=args.dropout_dec, dropout_emb=args.dropout_emb, dropout_att=args.dropout_att,
             dropout_layer=args.dropout_dec_layer, lsm_prob=args.lsm_prob, ctc_weight=ctc_weight,
             ctc_lsm_prob=args.ctc_lsm_prob, ctc_fc_list=args.ctc_fc_list, backward=False,
-            global_weight=global_weight, mtl_per_batch=args.mtl_per_batch, param_init=args.transformer_param_init)
+            global_weight=global_weight, mtl_per_batch=args.mtl_per_batch, param_init=args.transformer_param_init,
+            dropout_head=getattr(args, 'dropout_head', 0.0),
+            mma=dict(chunk_size=args.mocha_chunk_size, n_heads_mono=args.mocha_n_heads_mono,
+                     n_heads_chunk=args.mocha_n_heads_chunk, init_r=args.mocha_init_r, eps=args.mocha_eps,
+                     noise_std=args.mocha_std, no_denominator=args.mocha_no_denominator, conv1d=args.mocha_1dconv,
+                     share_chunkwise_attention=getattr(args, 'share_chunkwise_attention', False)),
+            mma_first_layer=getattr(args, 'mocha_first_layer', 1),
+            mma_quantity_loss_weight=args.mocha_quantity_loss_weight)
     if args.dec_type in ('lstm', 'gru'):
         from neural_sp_amd.las import RNNDecoder      # decoders/build.py:88-140 (las.py uses LSTMCell for both)
         return RNNDecoder(

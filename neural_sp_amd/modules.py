@@ -13,6 +13,7 @@ Reference files (relative to the reference root):
 import logging
 import copy
 import math
+import random
 
 import torch
 import torch.nn as nn
@@ -71,6 +72,13 @@ class AttnMask(object):
     def cfg(self):
         return {'causal': self.causal, 'lookahead': self.lookahead,
                 'chunk_nl': self.chunk_nl, 'chunk_nc': self.chunk_nc}
+
+    def dense(self, qlen, klen):
+        """the bool `[B, qlen, klen]` tensor of a plain padding mask (key j < klens[b]), for the host-level
+        monotonic attention of neural_sp_amd.mma"""
+        assert not self.causal and self.chunk_nc == 0
+        j = torch.arange(klen, device=self.klens.device).view(1, 1, klen)
+        return (j < self.klens.view(-1, 1, 1)).expand(-1, qlen, -1)
 
 
 # ---------------------------------------------------------------- FFN
@@ -263,11 +271,10 @@ class MultiheadAttentionMechanism(nn.Module):
         bs, klen = key.shape[:2]
         qlen = query.shape[1]
         H, dk = self.n_heads, self.d_k
-        if self.dropout_head > 0 and self.training:
-            raise NotImplementedError('HeadDrop in the plain MHA encoder path')
+        headdrop = self.dropout_head > 0 and self.training
         d = H * dk
         if (ops.bf16_mode() and key is value and key is query and d % 8 == 0 and dk % 8 == 0
-                and self.w_out.weight.shape[0] == d and key.shape[-1] == d):
+                and self.w_out.weight.shape[0] == d and key.shape[-1] == d and not headdrop):
             cfg = mask.cfg() if mask is not None else {}
             cfg.update(H=H, clamp=-1, dropout=self.dropout_attn_p, training=self.training)
             cv, aw = ops.SelfAttnFn.apply(key, self.w_query.weight, self.w_key.weight, self.w_value.weight,
@@ -282,6 +289,14 @@ class MultiheadAttentionMechanism(nn.Module):
         cfg = mask.cfg() if mask is not None else {}
         cfg.update(clamp=-1, dropout=self.dropout_attn_p, training=self.training)
         cv, aw = ops.AttentionFn.apply(q, None, k, v, None, mask.klens if mask is not None else None, cfg)
+        if headdrop:
+            # HeadDrop (modules/headdrop.py:10-32, multihead_attention.py:147-148): whole heads are zeroed with
+            # probability dropout_head (Python's `random`, one draw per head) and the survivors rescaled; the context
+            # is linear in the attention weights, so the per-head factor is applied to the context vectors
+            keep = [0.0 if random.random() < self.dropout_head else 1.0 for _ in range(H)]
+            n_eff = sum(keep)
+            scale = cv.new_tensor([kk * (H / n_eff if n_eff > 0 else 1.0) for kk in keep]).view(1, 1, H, 1)
+            cv = (cv.view(bs, qlen, H, dk) * scale).view(bs, qlen, H * dk)
         po = out_dropout if self.training else 0.0
         cv = ops.linear(cv, self.w_out.weight, self.w_out.bias, res=residual, dropout_p=po)
         return cv, aw, {}

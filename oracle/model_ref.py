@@ -507,7 +507,18 @@ def transformer_decoder_att(eouts, elens, ys, sd, args, training, p='dec_fwd'):
             out = F.conv1d(out.transpose(2, 1), w, sd[q + '.conv1d.bias'], padding=pad)[:, :, :-pad].transpose(2, 1)
             out = torch.relu(_ln(out, sd, '%s.pos_enc.pe.%d' % (p, 4 * n + 1), args.transformer_layer_norm_eps))
 
-    def mha2(q_in, kv_in, vis, pp):
+    hd = getattr(args, 'dropout_head', 0.0) if (training and getattr(args, 'transformer_dec_attn_type', '') == 'mocha') else 0.0
+
+    def headdrop(aw, nh, head_dim):
+        """modules/headdrop.py:10-32: Python's `random`, one draw per head; survivors rescaled"""
+        import random
+        keep = [0.0 if random.random() < hd else 1.0 for _ in range(nh)]
+        n_eff = sum(keep)
+        shape = [1] * aw.dim()
+        shape[head_dim] = nh
+        return aw * aw.new_tensor([k * (nh / n_eff if n_eff > 0 else 1.0) for k in keep]).view(shape)
+
+    def mha2(q_in, kv_in, vis, pp, drop_heads=False):
         Bq, Lq, _ = q_in.shape
         Tk = kv_in.shape[1]
         dk = d // H
@@ -517,16 +528,81 @@ def transformer_decoder_att(eouts, elens, ys, sd, args, training, p='dec_fwd'):
         e = torch.einsum('bihd,bjhd->bijh', q, k) / math.sqrt(dk)
         e = e.masked_fill(~vis[:, :, :, None], NEG_INF32)
         aw = torch.softmax(e, dim=2)
+        if drop_heads and hd > 0:
+            aw = headdrop(aw, H, 3)
         cv = torch.einsum('bijh,bjhd->bihd', aw, v).reshape(Bq, Lq, d)
         return _lin(cv, sd, pp + '.w_out')
 
+    def mma(q_in, pp):
+        """monotonic multi-head attention, training mode (mocha.py:164-311 with scaled-dot energies, hma_train.py:12-67,
+        mocha_train.py:13-58), no noise / HeadDrop -> (context, alpha [B,H_ma,L,T])"""
+        Hm, Hc, w = args.mocha_n_heads_mono, args.mocha_n_heads_chunk, args.mocha_chunk_size
+        share = getattr(args, 'share_chunkwise_attention', False)
+
+        def energy(pe, nh, r=None):
+            k = _lin(eouts, sd, pe + '.w_key').view(B, T, nh, d // nh)
+            qq = _lin(q_in, sd, pe + '.w_query').view(B, L, nh, d // nh)
+            e = torch.einsum('bihd,bjhd->bhij', qq, k) / math.sqrt(d)
+            if r is not None:
+                e = e + r
+            return e.masked_fill(~src_vis[:, None], NEG_INF32)
+        e_ma = energy(pp + '.monotonic_energy', Hm, sd[pp + '.monotonic_energy.r'])
+        pc = torch.sigmoid(e_ma)
+        x = torch.log(torch.clamp(1 - pc, min=args.mocha_eps, max=1.0))
+        cp = torch.exp(torch.cumsum(torch.cat([x.new_zeros(x.shape[:-1] + (1,)), x[..., :-1]], dim=-1), dim=-1))
+        aw = eouts.new_zeros(B, Hm, 1, T)
+        aw[..., 0] = 1.0
+        alphas = []
+        for i in range(L):
+            den = 1 if args.mocha_no_denominator else torch.clamp(cp[:, :, i:i + 1], min=args.mocha_eps, max=1.0)
+            aw = pc[:, :, i:i + 1] * cp[:, :, i:i + 1] * torch.cumsum(aw / den, dim=-1)
+            alphas.append(aw)
+        alpha = torch.cat(alphas, dim=2)
+        alpha_m = headdrop(alpha, Hm, 1) if hd > 0 else alpha
+        att = alpha_m
+        if w > 1 or w == -1:
+            def msum(z, back, fwd):
+                shp = z.shape
+                y = F.conv1d(F.pad(z.reshape(-1, 1, shp[-1]), [back, fwd]), z.new_ones(1, 1, back + fwd + 1))
+                return y.view(shp[:-1] + (y.shape[-1],))
+            u = energy(pp + '.chunk_energy', Hc if share else Hm * Hc).unsqueeze(1)       # [B,1,(Hm*)Hc,L,T]
+            a = alpha_m.unsqueeze(2).repeat(1, 1, Hc, 1, 1)
+            if Hm > 1 and not share:
+                u = u.view(B, Hm, Hc, L, T)
+            u = u - u.max(dim=-1, keepdim=True)[0]
+            se = torch.clamp(torch.exp(u), min=1e-5)
+            sf = args.attn_sharpening_factor
+            if w == -1:
+                att = se * msum(a * sf / torch.cumsum(se, dim=-1), 0, T - 1)
+            else:
+                att = se * msum(a * sf / msum(se, w - 1, 0), 0, w - 1)
+            att = att.reshape(B, -1, L, T)
+        Ht = Hm * Hc
+        v = _lin(eouts, sd, pp + '.w_value').view(B, T, Ht, d // Ht)
+        cv = torch.einsum('bhlt,bthd->blhd', att, v).reshape(B, L, d)
+        return _lin(cv, sd, pp + '.w_out'), alpha
+
+    is_mma = getattr(args, 'transformer_dec_attn_type', 'scaled_dot') == 'mocha'
+    first = getattr(args, 'mocha_first_layer', 1) if is_mma else 1
+    alphas_all = []
     for l in range(args.dec_n_layers):
         q = '%s.layers.%d' % (p, l)
         yn = _ln(out, sd, q + '.norm1', eps)
-        out = out + mha2(yn, yn, tgt_vis, q + '.self_attn')
-        on = _ln(out, sd, q + '.norm2', eps)
-        out = out + mha2(on, eouts, src_vis, q + '.src_attn')
+        out = out + mha2(yn, yn, tgt_vis, q + '.self_attn', drop_heads=True)
+        if l >= first - 1:                      # transformer.py:168: the layers below mocha_first_layer have no source attention
+            on = _ln(out, sd, q + '.norm2', eps)
+            if is_mma:
+                cvm, al = mma(on, q + '.src_attn')
+                out = out + cvm
+                alphas_all.append(al.masked_fill((ys_out == 3)[:, None, :, None], 0))
+            else:
+                out = out + mha2(on, eouts, src_vis, q + '.src_attn')
         out = out + ffn(_ln(out, sd, q + '.norm3', eps), sd, q + '.feed_forward', args.transformer_ffn_activation)
+    transformer_decoder_att.last_quantity = None
+    if is_mma:                                  # transformer.py:444-452
+        n_ref = (ys_out != 3).sum(1).to(out.dtype)
+        n_pred = sum(torch.abs(a.sum(3).sum(2).sum(1) / a.shape[1]) for a in alphas_all) / len(alphas_all)
+        transformer_decoder_att.last_quantity = torch.mean(torch.abs(n_pred - n_ref))
     logits = _lin(_ln(out, sd, p + '.norm_out', eps), sd, p + '.output')
     V = logits.shape[-1]
     lg, yo = logits.view(-1, V), ys_out.view(-1)
@@ -720,6 +796,9 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quanti
         la, acc, ppl = transformer_decoder_att(eouts, elens, batch['ys'], sd, args, training)
         obs.pop('loss.transducer')
         obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})
+        if transformer_decoder_att.last_quantity is not None:       # transformer.py:362-366
+            obs['loss.quantity'] = transformer_decoder_att.last_quantity.item()
+            la = la + transformer_decoder_att.last_quantity * quantity_weight
         loss = loss + la * (main_w - ctc_w)
     if args.dec_type in ('lstm', 'gru') and main_w - ctc_w > 0:
         la, acc, ppl, lq = rnn_decoder_att(eouts, elens, batch['ys'], sd, args, training, quantity_weight,
