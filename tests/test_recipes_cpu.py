@@ -22,6 +22,7 @@ RECIPES = [
     'aishell/s5/conf/asr/conformer_kernel15_clamp10_hie_subsample8_las_ln_2mtl.yaml',                      # multi-task
     'csj/s5/conf/asr/las/blstm_las.yaml',                                                                  # the BLSTM-LAS family
     'librispeech/s5/conf/asr/mocha/lcblstm_mocha_chunk4040_ctc_sync.yaml',                                 # streaming LC-BLSTM + MoChA
+    'librispeech/s5/conf/asr/mma/streaming/lc_transformer_mma_subsample8_ma4H_ca4H_w16_from4L_512dmodel_8H_64_128_64.yaml',   # MMA
 ]
 
 
