@@ -532,8 +532,9 @@ class TransformerDecoder(DecoderBase):
     """decoders/transformer.py:28-458, training side: hybrid CTC / attention loss of a Transformer
     decoder (BASELINE config 3's loss head family).  forward() = CTC branch
     (:349-357) + forward_att (:373-458): teacher-forced decoder stack on the HIP kernels, output
-    projection, and the fused label-smoothed XE / accuracy kernel (criterion.py:45-86).  MoChA source
-    attention, LM fusion and decoding are not built (NotImplementedError)."""
+    projection, and the fused label-smoothed XE / accuracy kernel (criterion.py:45-86).  Source attention is scaled-dot
+    MHA or monotonic multi-head attention (`attn_type='mocha'`, neural_sp_amd/mma.py, from layer `mma_first_layer` on).
+    LM fusion, beam search and decoding of MMA models are not built (NotImplementedError); greedy decoding is."""
 
     def __init__(self, special_symbols, enc_n_units, attn_type, n_heads, n_layers, d_model, d_ff,
                  ffn_bottleneck_dim, pe_type, layer_norm_eps, ffn_activation, vocab, tie_embedding,
