@@ -45,9 +45,10 @@ class AttentionMechanism(nn.Module):
                  conv_out_channels=10, conv_kernel_size=201, dropout=0., lookahead=2):
         super().__init__()
         assert conv_kernel_size % 2 == 1, "Kernel size should be odd for 'same' conv."
-        if atype not in ('add', 'location'):
-            raise NotImplementedError('attn_type=%s (built: location, add, mocha)' % atype)
+        if atype not in ('add', 'location', 'triggered_attention'):
+            raise NotImplementedError('attn_type=%s (built: location, add, triggered_attention, mocha)' % atype)
         self.atype, self.adim, self.n_heads = atype, adim, 1
+        self.lookahead = lookahead
         self.sharpening_factor = sharpening_factor
         self.sigmoid_smoothing = sigmoid_smoothing
         self.dropout = nn.Dropout(p=dropout)
@@ -82,6 +83,11 @@ class AttentionMechanism(nn.Module):
             conv_feat = ops.linear(win.reshape(bs, klen, k), self.conv.weight.view(-1, k))     # [B,T,ch]
             tmp = tmp + ops.linear(conv_feat, self.w_conv.weight)
         e = (torch.tanh(tmp) * self.v.weight.view(1, 1, -1)).sum(-1).unsqueeze(1)   # v(.) with one output
+        if self.atype == 'triggered_attention':
+            # attention.py:165-169: nothing beyond the token's CTC boundary + `lookahead` frames is attended to
+            assert trigger_points is not None
+            j = torch.arange(klen, device=key.device).view(1, 1, klen)
+            e = e.masked_fill(j > (trigger_points.view(bs, 1, 1).long() + self.lookahead), NEG_INF)
         if self.mask is not None:
             e = e.masked_fill(self.mask == 0, NEG_INF)
         if self.sigmoid_smoothing:
@@ -290,7 +296,7 @@ class RNNDecoder(DecoderBase):
         self.bwd, self.mtl_per_batch = backward, mtl_per_batch
         self.quantity_loss_weight, self._quantity_loss_weight = quantity_loss_weight, 0
         self.latency_metric, self.latency_loss_weight, self._latency_loss_weight = latency_metric, latency_loss_weight, 0
-        if 'ctc_sync' in latency_metric:
+        if 'ctc_sync' in latency_metric or attn_type == 'triggered_attention':
             assert 0 < self.ctc_weight < 1          # las.py:161-162
         self.aws_dict, self.data_dict = {}, {}
         if ctc_weight > 0:
@@ -354,12 +360,14 @@ class RNNDecoder(DecoderBase):
         if self.ctc_weight > 0 and (task == 'all' or 'ctc' in task):
             # CTC-synchronous training (las.py:463-465): the reference boundaries of the latency loss are the
             # forced alignment of this very CTC branch (nsp_ctc_forced_align), recomputed every step
-            loss_ctc, ctc_trigger_points = self.ctc(eouts, elens, ys,
-                                                    forced_align='ctc_sync' in self.latency_metric and self.training)
+            loss_ctc, ctc_trigger_points = self.ctc(
+                eouts, elens, ys, forced_align=('ctc_sync' in self.latency_metric and self.training)
+                or self.attn_type == 'triggered_attention')
             observation['loss_ctc'] = loss_ctc.detach()
             loss = loss + (loss_ctc if self.mtl_per_batch else loss_ctc * self.ctc_weight)
         forced = None
-        if self.latency_metric in ['minlt', 'decot', 'decot_ctc_sync'] and trigger_points is not None:
+        if (self.latency_metric in ['minlt', 'decot', 'decot_ctc_sync'] or self.attn_type == 'triggered_attention') \
+                and trigger_points is not None:
             forced = ops.h2d(np.asarray(trigger_points, dtype=np.int32), eouts.device)      # batch['trigger_points'] (:471-472)
         if self.att_weight > 0 and (task == 'all' or 'ctc' not in task):
             loss_att, acc_att, ppl_att, loss_quantity, loss_latency = self.forward_att(
@@ -510,11 +518,16 @@ class RNNDecoder(DecoderBase):
             ylens = [0] * B
             eos_flags = [False] * B
             ymax = int(math.ceil(T * max_len_ratio))
+            tp = None
+            if self.attn_type == 'triggered_attention':
+                assert trigger_points is not None          # las.py:920-921
+                tp = ops.h2d(np.asarray(trigger_points, dtype=np.int32), dev)
             with ops.compute_mode('f32'):
                 for i in range(ymax):
                     x = torch.cat([self.dropout_emb(self.embed(y)), cv.squeeze(1)], dim=-1)
                     hxs, cxs, dout_score, dout_gen = self._recurrency(x, hxs, cxs)
-                    cv, aw, _ = self.score(eouts, eouts, dout_score.unsqueeze(1), src_mask, aw, cache=True, mode='hard')
+                    cv, aw, _ = self.score(eouts, eouts, dout_score.unsqueeze(1), src_mask, aw, cache=True, mode='hard',
+                                           trigger_points=tp[:, i:i + 1] if tp is not None and i < tp.shape[1] else None)
                     attn_v = torch.tanh(ops.linear(torch.cat([dout_gen, cv.squeeze(1)], dim=-1),
                                                    self.output_bn.weight, self.output_bn.bias))
                     y = ops.argmax_rows(ops.linear(attn_v, self.output.weight, self.output.bias)).long()

@@ -261,7 +261,14 @@ def _mocha_lat(metric, **kw):
 CASES['conformer_ctc_mocha_ctcsync_xs'] = (_mocha_lat('ctc_sync'), dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=81))
 CASES['conformer_ctc_mocha_decot_xs'] = (_mocha_lat('decot', mocha_decot_lookahead=2),
                                          dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=82))
-CTC_ALIGNED = {'conformer_ctc_mocha_ctcsync_xs': 'ctc_sync', 'conformer_ctc_mocha_decot_xs': 'batch'}
+# triggered attention (attention.py:165-169; tedlium blstm_triggered_attention.yaml): additive attention that may not look
+# past the token's CTC boundary (+ 2 frames); boundaries come with the batch, here the model's own CTC alignment
+CASES['conformer_ctc_triggered_xs'] = (
+    lambda: conformer_ctc_las_args('XS', n_layers=2, vocab=43, ctc_weight=0.3, attn_type='triggered_attention',
+                                   ctc_fc_list='', ctc_lsm_prob=0.0, conformer_kernel_size=7),
+    dict(B=4, t_range=(60, 131), u_range=(3, 14), vocab=43, seed=611))
+CTC_ALIGNED = {'conformer_ctc_mocha_ctcsync_xs': 'ctc_sync', 'conformer_ctc_mocha_decot_xs': 'batch',
+               'conformer_ctc_triggered_xs': 'batch'}
 # three input channels (static, delta, delta-delta: `conv_in_channel: 3` of the TIMIT / WSJ Transformer recipes,
 # conv.py:167-175): the first conv layer runs as im2col + GEMM
 CASES['transformer_ctc_3ch_xs'] = (
@@ -335,6 +342,10 @@ def run_case(name):
                                                       batch['ys'], torch.IntTensor([len(y) for y in batch['ys']]))
         if CTC_ALIGNED[name] == 'batch':
             batch['trigger_points'] = ctc_tp.numpy().astype(np.int32)      # what datasets/alignment.py would load
+            if args.attn_type == 'triggered_attention':
+                # attention.py:169 slices with `trigger_points[b] + lookahead + 1`: a 1-element numpy array is no longer
+                # a valid slice bound (numpy >= 2), a 1-element IntTensor is -- the boundaries are handed over as a tensor
+                batch['trigger_points'] = ctc_tp.clone()
     wrapped = CPUWrapperASR(model)
     # taken BEFORE the step: a training-mode forward moves BatchNorm's running statistics (the eval-mode
     # outputs below are computed with the moved ones, as a consumer that loads this state_dict and repeats

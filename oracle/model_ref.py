@@ -732,7 +732,10 @@ def rnn_decoder_att(eouts, elens, ys, sd, args, training, quantity_weight, p='de
                 cw = sd[sc + '.conv.weight']
                 cf = F.conv2d(aw[:, None, None, :], cw, padding=(0, (cw.shape[-1] - 1) // 2)).squeeze(2).transpose(2, 1)
                 tmp = tmp + F.linear(cf, sd[sc + '.w_conv.weight'])
-            e = F.linear(torch.tanh(tmp), sd[sc + '.v.weight']).squeeze(-1).masked_fill(~vis, NEG_INF32)
+            e = F.linear(torch.tanh(tmp), sd[sc + '.v.weight']).squeeze(-1)
+            if args.attn_type == 'triggered_attention':       # attention.py:165-169 (lookahead 2, las.py:233)
+                e = e.masked_fill(torch.arange(T)[None, :] > forced_trigger_points[:, i:i + 1].long() + 2, NEG_INF32)
+            e = e.masked_fill(~vis, NEG_INF32)
             aw = torch.softmax(e * args.attn_sharpening_factor, dim=-1)
             att = aw
         cv = torch.bmm(att[:, None], eouts).squeeze(1)
@@ -806,7 +809,8 @@ def speech2text_loss(sd, args, batch, dtype=torch.float64, training=True, quanti
                                            stableemit=args.mocha_stableemit_weight if stableemit else 0.0,
                                            ctc_trigger_points=ctc_trigger_points if training else None,
                                            forced_trigger_points=(torch.as_tensor(batch['trigger_points']).long()
-                                                                  if batch.get('trigger_points') is not None and getattr(args, 'mocha_latency_metric', '') in ('minlt', 'decot', 'decot_ctc_sync') else None))
+                                                                  if batch.get('trigger_points') is not None and (getattr(args, 'mocha_latency_metric', '') in ('minlt', 'decot', 'decot_ctc_sync')
+                                                                       or args.attn_type == 'triggered_attention') else None))
         obs.pop('loss.transducer')
         obs.update({'loss.att': la.item(), 'acc.att': acc, 'ppl.att': ppl})   # (recorded before the quantity loss is added)
         if lq is not None:

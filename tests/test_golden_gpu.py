@@ -29,7 +29,8 @@ VARIANT_CASES = ['conformer_bn_ctc_xs', 'conformer_gn_ctc_xs', 'transformer_glu_
                  'conformer_2mtl_ctc_xs', 'transformer_3mtl_att_xs', 'blstm_ctc_xs', 'conv_blstm_proj_drop_xs',
                  'conformer_ctc_las_ss_xs', 'conv_blstm_fullcontext_xs',
                  'conformer_ctc_att_1dconv_xs', 'conformer_ctc_mocha_stableemit_xs', 'conformer_ctc_mocha_ctcsync_xs',
-                 'conformer_ctc_mocha_decot_xs', 'conv_lcblstm_chunk_xs', 'transformer_ctc_3ch_xs', 'conformer_ctc_mma_xs', 'conformer_ctc_mma_headdrop_xs']
+                 'conformer_ctc_mocha_decot_xs', 'conv_lcblstm_chunk_xs', 'transformer_ctc_3ch_xs', 'conformer_ctc_mma_xs', 'conformer_ctc_mma_headdrop_xs',
+                 'conformer_ctc_triggered_xs']
 CASES = sorted(set(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*_xs.pt'))) - set(VARIANT_CASES))
 
 
