@@ -243,7 +243,7 @@ class RNNEncoder(EncoderBase):
                 if task == 'ys_sub1':
                     eouts[task]['xs'], eouts[task]['xlens'] = sub1
                     return eouts
-        for lth in range(0 if not chunked else self.n_layers, self.n_layers):
+        for lth in ([] if chunked else range(self.n_layers)):      # full-context variants: layer-major loop
             if self.lc_bidir:
                 full = torch.full((xs.size(0),), xs.size(1), dtype=torch.int32)
                 xs = self._lstm_layer_full_context(xs, ops.h2d(full, xs.device, torch.int32), self.rnn[lth],
