@@ -195,11 +195,10 @@ def _ctc_forced_align(logits, labels, elens, ylens, blank=0):
 
 
 @contextlib.contextmanager
-def host_logic_on_cpu(real_kernels=False):
-    """real_kernels=True: ONLY the ops whose kernels the emulator cannot build (the conv front-end and its 2-D pooling:
-    inline asm; pinned-memory staging) are replaced; GEMMs and the LSTM step kernels (fp32 MFMA emulated as wave
-    collectives), attention soft-max, LayerNorm, CTC, XE, depthwise conv, GLU, pooling over time, dropout, ... all run
-    the real .hip kernels."""
+def host_logic_on_cpu(real_kernels=False, real_conv=True):
+    """real_kernels=True: every op runs the real .hip kernels on the emulator -- the conv front-end and its 2-D pooling,
+    GEMMs and the LSTM step kernels (fp32 MFMA emulated as wave collectives), attention soft-max, LayerNorm, CTC, XE,
+    depthwise conv, GLU, pooling, dropout, ... -- only the pinned-memory H2D staging (which needs a device) is replaced."""
     from neural_sp_amd import ops
     from tests.hipemu.shim import emulated_kernels
     fakes = dict(
@@ -213,12 +212,9 @@ def host_logic_on_cpu(real_kernels=False):
         xe_lsm_loss=_xe_lsm_loss, argmax_rows=lambda x2d: x2d.argmax(-1).int(), ctc_forced_align=_ctc_forced_align,
     )
     if real_kernels:
-        fakes = {k: fakes[k] for k in ('conv3x3_relu', 'maxpool2d', 'h2d_packed')}
-        real_conv = ops.conv3x3_relu
-
-        def conv(x_cl, weight, bias):      # the im2col + GEMM path (other channel counts) has no asm: run it for real
-            return _conv3x3_relu(x_cl, weight, bias) if x_cl.shape[-1] in (1, 32) else real_conv(x_cl, weight, bias)
-        fakes['conv3x3_relu'] = conv
+        # pinned staging needs a device; everything else is real.  real_conv=False keeps the (slow to emulate: thousands of
+        # fp32 MFMAs per tile) conv front-end on its torch stand-in
+        fakes = {k: fakes[k] for k in (('h2d_packed',) if real_conv else ('h2d_packed', 'conv3x3_relu', 'maxpool2d'))}
     saved = {k: getattr(ops, k) for k in fakes}
     mode = ops.get_compute_mode()
     for k, v in fakes.items():

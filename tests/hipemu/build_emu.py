@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, 'neural_sp_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libnsp_emu.so')
 EMULATED_SOURCES = ['norm_subsample.hip', 'elementwise.hip', 'xent.hip', 'decode.hip', 'layernorm.hip', 'ctc.hip',
-                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip', 'lstm.hip']
+                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip', 'lstm.hip', 'conv2d.hip']
 CXX_CANDIDATES = ['/opt/rocm/lib/llvm/bin/clang++', 'clang++']
 
 
@@ -33,7 +33,7 @@ def available():
     return _cxx() is not None
 
 
-_DYN = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w:]*)\s+(\w+)\[\];')
+_DYN = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?((?:unsigned\s+)?[A-Za-z_][\w:]*)\s+(\w+)\[\];')
 
 
 def _rewrite(src, dst):
@@ -42,7 +42,7 @@ def _rewrite(src, dst):
     text = open(src).read()
     text = _DYN.sub(r'\1* \2 = reinterpret_cast<\1*>(HIPEMU_DYN_SHARED);', text)
     text = re.sub(r'asm volatile\("s_waitcnt[^;]*;', '/* s_waitcnt: no-op on the host */;', text)
-    text = text.replace('__attribute__((address_space(1)))', '')
+    text = text.replace('__attribute__((address_space(1)))', '').replace('__attribute__((address_space(3)))', '')
     text = text.replace('#include "common.h"', '#include "%s"' % os.path.join(CSRC, 'common.h'))
     with open(dst, 'w') as fh:
         fh.write(text)

@@ -23,11 +23,14 @@
 #include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <ucontext.h>
 
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #define __global__
@@ -222,6 +225,51 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_bf16x8 a, hipemu
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_f32_16x16x32_bf16
 #define __builtin_amdgcn_wave_barrier hipemu_wave_barrier
+
+// ---- raw buffer access (stride 0): every dword is range-checked against num_records, out-of-range loads give 0,
+// out-of-range stores are dropped -- the property conv2d.hip's predicate-free tile loop relies on ----
+struct hipemu_rsrc { char* base; unsigned num; };
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+template <class P> static inline hipemu_rsrc hipemu_make_rsrc(P* p, short, unsigned num, unsigned) {
+  return hipemu_rsrc{reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(p)), num};
+}
+template <int N, class V> static inline V hipemu_buf_load(hipemu_rsrc r, unsigned voff, unsigned soff) {
+  V v;
+  for (int i = 0; i < N; ++i) {
+    unsigned w = 0;
+    const unsigned long long o = (unsigned long long)voff + soff + 4ull * i;
+    if (o + 4 <= r.num) memcpy(&w, r.base + o, 4);
+    v[i] = w;
+  }
+  return v;
+}
+static inline hipemu_u32x4 hipemu_buf_load_b128(hipemu_rsrc r, unsigned v, unsigned s, int) { return hipemu_buf_load<4, hipemu_u32x4>(r, v, s); }
+static inline hipemu_u32x2 hipemu_buf_load_b64(hipemu_rsrc r, unsigned v, unsigned s, int) { return hipemu_buf_load<2, hipemu_u32x2>(r, v, s); }
+static inline void hipemu_buf_store_b64(hipemu_u32x2 d, hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  for (int i = 0; i < 2; ++i) {
+    const unsigned long long o = (unsigned long long)voff + soff + 4ull * i;
+    unsigned w = d[i];
+    if (o + 4 <= r.num) memcpy(r.base + o, &w, 4);
+  }
+}
+#define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b128 hipemu_buf_load_b128
+#define __builtin_amdgcn_raw_buffer_load_b64 hipemu_buf_load_b64
+#define __builtin_amdgcn_raw_buffer_store_b64 hipemu_buf_store_b64
+#define __builtin_amdgcn_s_barrier __syncthreads
+// transposed LDS reads exist only on the bf16 paths, which the emulator does not run
+typedef __bf16 hipemu_bf16x4 __attribute__((ext_vector_type(4)));
+template <class P> static inline hipemu_bf16x4 hipemu_ds_read_tr16(P) {
+  fprintf(stderr, "hipemu: ds_read_tr16_b64 (bf16-only path) is not emulated\n");
+  abort();
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4bf16 hipemu_ds_read_tr16
+static inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 static inline float atomicAdd(float* p, float v);
 static inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }

@@ -2,15 +2,15 @@
 fixtures produced by the reference -- the CPU-tier counterpart of tests/test_golden_gpu.py::test_golden_fp32.
 
 Everything runs the product's own code: the Python host side, the ctypes glue, and the .hip kernels compiled from the
-same sources for host threads (fibers) -- the fp32 MFMA GEMM with its fused epilogues (v_mfma_f32_16x16x4_f32 emulated
-as a wave collective), data / weight gradients and split-K, attention soft-max with relative positions and masks,
-LayerNorm (+Swish), depthwise conv, GLU, pooling / subsampling, BatchNorm / GroupNorm, CTC loss + label smoothing + forced
-alignment, the RNN-T joint, lattice and prediction-network LSTM, label-smoothed XE, the (B)LSTM encoders incl. chunked
-latency-controlled training.  Only the ops whose kernels use inline asm are plain-torch stand-ins: the 3x3 conv front-end
-with its 2-D pooling, and pinned-memory staging (tests/cpu_ops_shim.py, real_kernels=True); blstm_ctc_xs has no stand-in
-at all on the device side.
+same sources for host threads (fibers) -- the MFMA conv front-end with its fused ReLU masks and 2-D pooling, the fp32 MFMA
+GEMM with its fused epilogues (v_mfma_f32_16x16x4_f32 emulated as a wave collective), data / weight gradients and
+split-K, attention soft-max with relative positions and masks, LayerNorm (+Swish), depthwise conv, GLU, pooling /
+subsampling, BatchNorm / GroupNorm, CTC loss + label smoothing + forced alignment, the RNN-T joint, lattice and
+prediction-network LSTM, label-smoothed XE, the (B)LSTM encoders incl. chunked latency-controlled training, the LAS /
+MoChA / MMA decoders.  The ONLY stand-in is the pinned-memory H2D staging (tests/cpu_ops_shim.py, real_kernels=True).
 Gates: loss 1e-5 (the runs reproduce the reference's loss to the last printed digit), every gradient 2e-3 of its max.
-All 34 fixtures pass (NSP_EMU_ALL=1, ~7 min); nine -- one per model family -- run by default."""
+All 38 fixtures pass in this fully-real mode (NSP_EMU_ALL=1 NSP_EMU_REAL_CONV=1, 27 min).  By default nine fixtures -- one per
+model family -- run, the conv front-end's kernels (the slow ones to emulate) for one of them (~2 min in total)."""
 import argparse
 import os
 import random
@@ -28,6 +28,10 @@ ALL = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*
 DEFAULT = ['transformer_ctc_xs', 'conformer_ctc_xs', 'conformer_rnnt_xs', 'conformer_bn_ctc_xs', 'conformer_drop_ctc_xs',
            'conformer_2mtl_ctc_xs', 'conformer_ctc_att_1dconv_xs', 'conformer_ctc_mocha_ctcsync_xs', 'blstm_ctc_xs']
 CASES = ALL if os.environ.get('NSP_EMU_ALL', '0') == '1' else DEFAULT
+# the conv front-end's kernels are the slow ones to emulate (all 38 fixtures with them: 27 min, all green): by default they
+# run for one fixture, the others keep the front-end on its torch stand-in; NSP_EMU_REAL_CONV=1 runs them everywhere
+REAL_CONV = os.environ.get('NSP_EMU_REAL_CONV', '0') == '1'
+ALWAYS_REAL_CONV = {'transformer_ctc_xs'}
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -50,7 +54,7 @@ def test_speech2text_on_emulated_kernels_matches_reference_fixture(name):
     if ss_seed is not None:
         model.trigger_scheduled_sampling()
         random.seed(ss_seed)
-    with host_logic_on_cpu(real_kernels=True):
+    with host_logic_on_cpu(real_kernels=True, real_conv=REAL_CONV or name in ALWAYS_REAL_CONV):
         loss, obs = model(batch, task='all')
         loss.backward()
     ref = fix['loss'].item()
