@@ -319,8 +319,10 @@ class Speech2Text(nn.Module):
         Returns (nbest_hyps_id `[B][1][L]`, aws None).  Beam search / LM fusion / streaming /
         ensembles are inference-side and raise NotImplementedError."""
         self.eval()
-        if task.split('.')[0] != 'ys':
-            raise NotImplementedError('decode(task=%s): sub-task decoders are not built' % task)
+        base = task.split('.')[0]
+        if base not in ('ys', 'ys_sub1', 'ys_sub2'):
+            raise ValueError(task)
+        dir = {'ys': 'fwd', 'ys_sub1': 'fwd_sub1', 'ys_sub2': 'fwd_sub2'}[base]     # speech2text.py:734-741
         P = self._param
         if P(params, 'recog_streaming_encoding', False) or P(params, 'recog_block_sync', False):
             raise NotImplementedError('streaming encoding / block-synchronous decoding')
@@ -328,8 +330,8 @@ class Speech2Text(nn.Module):
             raise NotImplementedError('ensemble decoding')
         beam = P(params, 'recog_beam_width', 1)
         eout_dict = self.encode(xs, task)
-        eouts, elens = eout_dict[task]['xs'], eout_dict[task]['xlens']
-        dec = self.dec_fwd
+        eouts, elens = eout_dict[base]['xs'], eout_dict[base]['xlens']
+        dec = getattr(self, 'dec_' + dir)
         if (self.fwd_weight == 0 and self.bwd_weight == 0) or \
                 (self.ctc_weight > 0 and P(params, 'recog_ctc_weight', 0) == 1):
             if beam != 1:

@@ -84,3 +84,29 @@ def test_speech2text_host_logic_matches_reference_fixture(name):
         assert bn_out
         for k, v in bn_out.items():
             assert torch.allclose(sd[k].double(), v.double(), rtol=1e-4, atol=1e-5), k
+
+
+def test_decode_of_an_auxiliary_task_matches_the_reference():
+    """Speech2Text.decode(task='ys_sub1') (speech2text.py:734-741): greedy CTC hypotheses of the auxiliary decoder on the
+    encoder's intermediate output -- against the reference's own decode(), live (build container only)."""
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip('reference not present on this machine')
+    from neural_sp_amd.speech2text import Speech2Text
+    from tests.cpu_ops_shim import host_logic_on_cpu
+    ref_import.import_reference()
+    from neural_sp.models.seq2seq.speech2text import Speech2Text as RefS2T
+    fix = torch.load(os.path.join(GOLDEN, 'conformer_2mtl_ctc_xs.pt'), weights_only=False)
+    args = argparse.Namespace(**fix['args'])
+    params = {'recog_beam_width': 1, 'recog_ctc_weight': 0.0, 'recog_streaming_encoding': False,
+              'recog_fwd_bwd_attention': False, 'recog_max_len_ratio': 1.0, 'recog_bwd_attention': False,
+              'recog_batch_size': 1, 'recog_block_sync': False}
+    ref = RefS2T(args)
+    ref.load_state_dict(fix['state_dict'])
+    want = {t: ref.decode(fix['batch']['xs'], dict(params), None, exclude_eos=True, task=t)[0] for t in ('ys', 'ys_sub1')}
+    model = Speech2Text(args)
+    model.load_state_dict(fix['state_dict'], strict=True)
+    with host_logic_on_cpu():
+        for t in ('ys', 'ys_sub1'):
+            got = model.decode(fix['batch']['xs'], dict(params), None, exclude_eos=True, task=t)[0]
+            assert [[int(v) for v in h] for nb in got for h in nb] == [[int(v) for v in h] for nb in want[t] for h in nb], t
