@@ -16,17 +16,6 @@ from tests import variants_common as vc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name', golden.VARIANT_CASES)
-def test_variant_golden_fp32(name):
-    """loss 1e-4, encoder output 2e-4 of max, every gradient 2e-3 of its max against the reference's fixture"""
-    golden.test_golden_fp32(name)
-
-
-@pytest.mark.parametrize('name', golden.VARIANT_CASES)
-def test_variant_golden_bf16(name):
-    golden.test_golden_bf16(name)
-
-
 @pytest.mark.parametrize('T,f,kind', vc.SUM_CASES + [(801, 3, 'drop'), (800, 2, 'add'), (799, 4, 'mean_pool')])
 def test_window_sum_subsamplers(T, f, kind):
     vc.check_window_sum('gpu', T, f, kind)
@@ -94,8 +83,7 @@ def test_blstm_layer_matches_packed_torch_lstm(bidir_sum):
         assert (p.grad.cpu() - q.grad).abs().max() < 1e-3 * q.grad.abs().max() + 1e-5, n
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16'])
-def test_timit_blstm_ctc_config1_full_size(mode):
+def _config1_full_size(mode):
     """BASELINE configs[0] at its real size (examples/timit/s5/conf/blstm_ctc.yaml): 5 x 256-unit
     BLSTM layers, CTC, 40-dim features, B=16, T~U[150,500], U~U[20,60], ~64 output symbols -- against
     oracle/model_ref.py (pinned to the reference by the blstm fixtures) in fp32 on the host.
@@ -128,8 +116,7 @@ def test_timit_blstm_ctc_config1_full_size(mode):
         assert not bad, bad
 
 
-@pytest.mark.parametrize('mode,tol', [('f32', 1e-4), ('bf16', 3e-2)])
-def test_lstm_with_initial_and_final_state(mode, tol):
+def _lstm_state_case(mode, tol):
     """ops.lstm_state (nsp_lstm_*_range) vs torch's nn.LSTM started from (h0, c0): outputs, final state, and the
     gradients w.r.t. input, initial state and weights when the loss also reads the final state"""
     from neural_sp_amd import ops
@@ -153,6 +140,10 @@ def test_lstm_with_initial_and_final_state(mode, tol):
         assert rel(a, r) < tol
 
 
+def test_lstm_with_initial_and_final_state_fp32():
+    _lstm_state_case('f32', 1e-4)
+
+
 def test_weight_noise_on_device():
     """one multi-tensor add on device parameters; bf16 weight shadows follow the version counters"""
     from neural_sp_amd import ops
@@ -167,3 +158,30 @@ def test_weight_noise_on_device():
     delta = (w.detach() - before)
     assert delta.abs().max() > 0 and (delta - delta.flatten()[0]).abs().max() < 1e-6
     assert not torch.equal(ops.weight_bf16(w), shadow0)
+
+
+# ---- model level, in the order "what the emulator has verified" -> "what rests on a simulation": a first-contact
+# failure under `pytest -x` then hides as little as possible
+@pytest.mark.parametrize('name', golden.VARIANT_CASES)
+def test_variant_golden_fp32(name):
+    """loss 1e-4, encoder output 2e-4 of max, every gradient 2e-3 of its max against the reference's fixture"""
+    golden.test_golden_fp32(name)
+
+
+
+def test_timit_blstm_ctc_config1_full_size_fp32():
+    _config1_full_size('f32')
+
+
+@pytest.mark.parametrize('name', golden.VARIANT_CASES)
+def test_variant_golden_bf16(name):
+    golden.test_golden_bf16(name)
+
+
+
+def test_timit_blstm_ctc_config1_full_size_bf16():
+    _config1_full_size('bf16')
+
+
+def test_lstm_with_initial_and_final_state_bf16():
+    _lstm_state_case('bf16', 3e-2)
