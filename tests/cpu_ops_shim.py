@@ -195,7 +195,7 @@ def _ctc_forced_align(logits, labels, elens, ylens, blank=0):
 
 
 @contextlib.contextmanager
-def host_logic_on_cpu(real_kernels=False, real_conv=True):
+def host_logic_on_cpu(real_kernels=False, real_conv=True, mode='f32'):
     """real_kernels=True: every op runs the real .hip kernels on the emulator -- the conv front-end and its 2-D pooling,
     GEMMs and the LSTM step kernels (fp32 MFMA emulated as wave collectives), attention soft-max, LayerNorm, CTC, XE,
     depthwise conv, GLU, pooling, dropout, ... -- only the pinned-memory H2D staging (which needs a device) is replaced."""
@@ -219,7 +219,8 @@ def host_logic_on_cpu(real_kernels=False, real_conv=True):
     mode = ops.get_compute_mode()
     for k, v in fakes.items():
         setattr(ops, k, v)
-    ops.set_compute_mode('f32')
+    assert mode == 'f32' or real_kernels, 'the torch stand-ins are fp32 only'
+    ops.set_compute_mode(mode)
     try:
         with emulated_kernels():
             yield

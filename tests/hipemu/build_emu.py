@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, 'neural_sp_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libnsp_emu.so')
 EMULATED_SOURCES = ['norm_subsample.hip', 'elementwise.hip', 'xent.hip', 'decode.hip', 'layernorm.hip', 'ctc.hip',
-                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip', 'lstm.hip', 'conv2d.hip']
+                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip', 'lstm.hip', 'conv2d.hip', 'gemm_bf16.hip', 'flash_attn.hip']
 CXX_CANDIDATES = ['/opt/rocm/lib/llvm/bin/clang++', 'clang++']
 
 

@@ -82,6 +82,9 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
@@ -259,12 +262,31 @@ static inline void hipemu_buf_store_b64(hipemu_u32x2 d, hipemu_rsrc r, unsigned 
 #define __builtin_amdgcn_raw_buffer_load_b64 hipemu_buf_load_b64
 #define __builtin_amdgcn_raw_buffer_store_b64 hipemu_buf_store_b64
 #define __builtin_amdgcn_s_barrier __syncthreads
-// transposed LDS reads exist only on the bf16 paths, which the emulator does not run
+// ds_read_b64_tr_b16 as a wave collective (lane mapping as probed on gfx950, see the header of gemm_bf16.hip): within
+// a 16-lane group, lane 4a+b supplies the address of row a, columns 4b..4b+3 of a 4x16 bf16 block; lane i receives
+// column i (rows 0..3)
 typedef __bf16 hipemu_bf16x4 __attribute__((ext_vector_type(4)));
-template <class P> static inline hipemu_bf16x4 hipemu_ds_read_tr16(P) {
-  fprintf(stderr, "hipemu: ds_read_tr16_b64 (bf16-only path) is not emulated\n");
-  abort();
+template <class P> static inline hipemu_bf16x4 hipemu_ds_read_tr16(P p) {
+  hipemu::Wave& w = *hipemu::wave;
+  const int l = hipemu::tid_flat & 63;
+  w.slot[l] = (uint64_t)reinterpret_cast<uintptr_t>(p);
+  hipemu::wave_barrier();
+  hipemu_bf16x4 r;
+  const int g = l & ~15, i = l & 15;
+  for (int a = 0; a < 4; ++a) {
+    const __bf16* src = reinterpret_cast<const __bf16*>((uintptr_t)w.slot[g + 4 * a + (i >> 2)]);
+    r[a] = src[i & 3];
+  }
+  hipemu::wave_barrier();
+  return r;
 }
+// global_load_lds (16 B per lane): LDS destination = the wave-uniform base + 16 * lane; executed synchronously
+template <class G, class L> static inline void hipemu_global_load_lds(G* g, L* lds, int size, int, int) {
+  memcpy(reinterpret_cast<char*>(lds) + (size_t)size * (hipemu::tid_flat & 63), reinterpret_cast<const char*>(g), (size_t)size);
+}
+#define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_ds_read_tr16_b64_v4bf16 hipemu_ds_read_tr16
 static inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }

@@ -32,10 +32,10 @@ CASES = ALL if os.environ.get('NSP_EMU_ALL', '0') == '1' else DEFAULT
 # run for one fixture, the others keep the front-end on its torch stand-in; NSP_EMU_REAL_CONV=1 runs them everywhere
 REAL_CONV = os.environ.get('NSP_EMU_REAL_CONV', '0') == '1'
 ALWAYS_REAL_CONV = {'transformer_ctc_xs'}
+BF16_CASES = ALL if os.environ.get('NSP_EMU_ALL', '0') == '1' else DEFAULT
 
 
-@pytest.mark.parametrize('name', CASES)
-def test_speech2text_on_emulated_kernels_matches_reference_fixture(name):
+def _run_fixture(name, mode, real_conv):
     from neural_sp_amd.speech2text import Speech2Text
     from tests.cpu_ops_shim import host_logic_on_cpu
     fix = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
@@ -54,9 +54,15 @@ def test_speech2text_on_emulated_kernels_matches_reference_fixture(name):
     if ss_seed is not None:
         model.trigger_scheduled_sampling()
         random.seed(ss_seed)
-    with host_logic_on_cpu(real_kernels=True, real_conv=REAL_CONV or name in ALWAYS_REAL_CONV):
+    with host_logic_on_cpu(real_kernels=True, real_conv=real_conv, mode=mode):
         loss, obs = model(batch, task='all')
         loss.backward()
+    return fix, model, loss
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_speech2text_on_emulated_kernels_matches_reference_fixture(name):
+    fix, model, loss = _run_fixture(name, 'f32', REAL_CONV or name in ALWAYS_REAL_CONV)
     ref = fix['loss'].item()
     assert abs(loss.item() - ref) / abs(ref) < 1e-5, (loss.item(), ref)
     grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
@@ -68,3 +74,16 @@ def test_speech2text_on_emulated_kernels_matches_reference_fixture(name):
             continue        # true gradient zero (BatchNorm removes the shift): rounding noise on both sides
         err = ((grads[n] - r).abs().max() / max(r.abs().max().item(), 1e-5 * gmax)).item()
         assert err < 2e-3, (n, err)
+
+
+@pytest.mark.parametrize('name', BF16_CASES)
+def test_speech2text_bf16_mode_on_emulated_kernels(name):
+    """the THROUGHPUT mode (bf16 MFMA operands, fp32 accumulation) on the emulator: gemm_bf16.hip (register-staged and
+    LDS-DMA kernels, fused epilogues, transposed LDS reads), the bf16 paths of the attention / LayerNorm / LSTM / RNN-T
+    kernels and every bf16 shadow / dtype hand-over of the host side, held to the SAME gates as the device test
+    (tests/test_golden_gpu.py::test_golden_bf16: loss 1e-3 unless stated per fixture, per-tensor cosine 0.99)"""
+    from tests.test_golden_gpu import assert_bf16_gates
+    fix, model, loss = _run_fixture(name, 'bf16', REAL_CONV or name in ALWAYS_REAL_CONV)
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(fix['grads'])
+    assert_bf16_gates(name, fix, loss.item(), grads, tag='emulated bf16')

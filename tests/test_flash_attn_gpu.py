@@ -8,6 +8,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _dev():
+    return torch.device('cuda:0')
+
+
 def _rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
@@ -41,7 +45,7 @@ def _reference(qkv, QP, klens, H, clamp, scale, causal, lookahead, nl, nc):
 def test_flash_attention_matches_reference(T, with_pos, causal, nc):
     from neural_sp_amd import ops
     torch.manual_seed(T)
-    dev = torch.device('cuda:0')
+    dev = _dev()
     B, H, dk, clamp = 3, 2, 64, 10
     d = H * dk
     R, Rp = clamp + 1, 16
@@ -82,7 +86,7 @@ def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward
     T = 150 (several tiles): keep rate, determinism, and the adjoint identity <dO, O(V)> = <dV, V>
     (O is linear in V for a fixed mask), which ties the backward's regenerated mask to the forward's."""
     from neural_sp_amd import ops
-    dev = torch.device('cuda:0')
+    dev = _dev()
     B, H, dk, clamp, pdrop = 2, 2, 64, 10, 0.25
     d = H * dk
     R, Rp = clamp + 1, 16
@@ -169,7 +173,7 @@ def test_flash_attention_backward_keeps_softmax_shift_invariance(T, H, B):
     (T=800, H=8 is the first-stage shape of Conformer-L.)"""
     from neural_sp_amd import ops
     torch.manual_seed(T + H)
-    dev = torch.device('cuda:0')
+    dev = _dev()
     dk, clamp = 64, 10
     d = H * dk
     R, Rp = clamp + 1, 16

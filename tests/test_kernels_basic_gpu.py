@@ -211,7 +211,7 @@ def test_splitk_slabs_with_an_empty_split_are_fully_written(mode):
     slab must still be written (zeros), or the slab reduction sums garbage left in the buffer."""
     from neural_sp_amd import ops
     torch.manual_seed(0)
-    dev = torch.device('cuda:0')
+    dev = _dev()
     M, N, K, sk = 40, 64, 2091, 8
     a = torch.randn(K, M, device=dev)
     b = torch.randn(K, N, device=dev)
@@ -226,13 +226,13 @@ def test_splitk_slabs_with_an_empty_split_are_fully_written(mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('stages', ['2', '3'])
-def test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch):
+def test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch, shapes=((2048, 640, 512), (1280, 1000, 264), (4096, 512, 2048))):
     """Opt-in RC x RC kernel (NSP_GEMM_RR_RING): unpadded k-major LDS images written by LDS-DMA,
     operands formed by swizzled transposed reads; split-K slabs; ragged M/N edges."""
     from neural_sp_amd import ops
     torch.manual_seed(1)
-    dev = torch.device('cuda:0')
-    for rows, N, K in [(2048, 640, 512), (1280, 1000, 264), (4096, 512, 2048)]:
+    dev = _dev()
+    for rows, N, K in shapes:
         dy = torch.randn(rows, N, device=dev).bfloat16()
         x = torch.randn(rows, K, device=dev).bfloat16()
         ref = dy.float().t() @ x.float()
