@@ -9,12 +9,15 @@ position table, causal / chunk masks, dropout) -- v_mfma_f32_16x16x32_bf16, the 
 are emulated as documented in tests/hipemu/include/hip/hip_runtime.h (the DMA executes synchronously: a missing
 s_waitcnt cannot be detected here, a wrong address or lane mapping is).  Shapes are the small ones of the device tests
 (the large ones take minutes of host time); tolerances are the device tests' own."""
+import os
+
 import pytest
 import torch
 
 from tests.hipemu import build_emu
 
 pytestmark = pytest.mark.skipif(not build_emu.available(), reason='no host clang++ for the HIP emulator')
+SLOW = os.environ.get('NSP_EMU_ALL', '0') == '1'     # + 10 min: three more decoders and train.py's call sequence (all pass)
 
 
 @pytest.fixture
@@ -29,6 +32,15 @@ def basic(monkeypatch):
 @pytest.fixture
 def flash(monkeypatch):
     import tests.test_flash_attn_gpu as mod
+    from tests.hipemu.shim import emulated_kernels
+    monkeypatch.setattr(mod, '_dev', lambda: torch.device('cpu'))
+    with emulated_kernels():
+        yield mod
+
+
+@pytest.fixture
+def convloss(monkeypatch):
+    import tests.test_kernels_conv_loss_gpu as mod
     from tests.hipemu.shim import emulated_kernels
     monkeypatch.setattr(mod, '_dev', lambda: torch.device('cpu'))
     with emulated_kernels():
@@ -75,3 +87,73 @@ def test_flash_attention_matches_reference(flash, T, with_pos, causal, nc):
 
 def test_flash_attention_dropout_mask(flash):
     flash.test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward()
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16maps'])
+@pytest.mark.parametrize('Ci', [1, 32])
+def test_conv3x3_bf16(convloss, mode, Ci, monkeypatch):
+    convloss.test_conv3x3(mode, Ci, monkeypatch)
+
+
+def test_maxpool2d_incl_bf16_maps(convloss):
+    convloss.test_maxpool2d()
+
+
+@pytest.mark.parametrize('U,J,V', [(6, 32, 32), (40, 64, 40)])
+def test_rnnt_joint_loss_bf16_fused_backward(convloss, U, J, V):
+    convloss.test_rnnt_joint_loss_bf16_fused_backward(U, J, V)
+
+
+@pytest.mark.parametrize('B,T,U,J,V', [(3, 21, 6, 32, 29), (4, 37, 40, 64, 43), (2, 9, 0, 64, 130)])
+def test_rnnt_joint_loss_fused_compact(convloss, B, T, U, J, V):
+    convloss.test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V)
+
+
+def test_lstm_vs_torch_bf16(convloss):
+    convloss.test_lstm_vs_torch('bf16', 3e-2)
+
+
+@pytest.mark.parametrize('nl,p_drop,B,L', [(1, 0.0, 5, 9), (2, 0.3, 18, 11)])
+def test_lstm_stack_wavefront_vs_torch(convloss, nl, p_drop, B, L):
+    convloss.test_lstm_stack_wavefront_vs_torch(nl, p_drop, B, L)
+
+
+@pytest.fixture
+def variants(monkeypatch):
+    import tests.test_variants_gpu as mod
+    from tests.hipemu.shim import emulated_kernels
+    monkeypatch.setattr(mod, '_dev', lambda: torch.device('cpu'))
+    with emulated_kernels():
+        yield mod
+
+
+def test_lstm_with_initial_and_final_state_bf16(variants):
+    """nsp_lstm_{fwd,bwd}_range with the bf16 hidden-state shadows (the chunked latency-controlled BLSTM's kernel path)"""
+    variants._lstm_state_case('bf16', 3e-2)
+
+
+@pytest.mark.parametrize('bidir_sum', [False, True])
+def test_blstm_layer_matches_packed_torch_lstm(variants, bidir_sum):
+    variants.test_blstm_layer_matches_packed_torch_lstm(bidir_sum)
+
+
+@pytest.fixture
+def dropin(monkeypatch):
+    import tests.test_dropin_gpu as mod
+    from tests.cpu_ops_shim import host_logic_on_cpu
+    monkeypatch.setattr(mod, '_dev', lambda: torch.device('cpu'))
+    with host_logic_on_cpu(real_kernels=True):      # = emulated kernels + the pinned-staging stand-in (needs a device)
+        yield mod
+
+
+@pytest.mark.parametrize('name', ['conformer_ctc_xs'] + (['conformer_rnnt_xs', 'conformer_ctc_las_xs', 'conformer_ctc_mocha_xs'] if SLOW else []))
+def test_greedy_decode_matches_reference_hypotheses(dropin, name):
+    """bit-exact token sequences from the decode kernels (decode.hip) on the emulated encoder"""
+    dropin.test_greedy_decode_matches_reference_hypotheses(name)
+
+
+@pytest.mark.skipif(not SLOW, reason='4 min of host time: NSP_EMU_ALL=1 runs it (passes)')
+def test_train_py_call_sequence_in_bf16_mode(dropin):
+    """bin/asr/train.py's call sequence (training steps with dropout / SpecAugment / accumulation, dev loss, plot
+    hooks, greedy decode) in the bf16 throughput mode"""
+    dropin.test_train_py_call_sequence_runs_unchanged()

@@ -38,7 +38,14 @@ CASES = sorted(set(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLD
 # (tools/bf16_sensitivity.py: the fp64 oracle with bf16-rounded Linear operands, no GPU involved) already moves the
 # fixture's loss by more: ConcatSubsampler's un-normalised ReLU(Linear(3d -> d)) with torch's default init gives
 # 1.2e-3 .. 1.5e-3 for every seed and batch size tried.
-BF16_LOSS_GATE = {'conformer_concat_ctc_xs': 3e-3}
+BF16_LOSS_GATE = {'conformer_concat_ctc_xs': 3e-3}     # (measured on the emulated kernels: 1.09e-3)
+# bf16-mode cosine gate per tensor family: 0.99 by default.  In conformer_ctc_mma_headdrop_xs HeadDrop removes BOTH
+# monotonic heads of decoder layer 2, so that layer's energies receive gradient only from the quantity loss
+# |sum_j alpha_ij - U| (0.1 .. 0.6 % of the typical gradient size), whose derivative is a SIGN: one (utterance, head)
+# whose expected count is within bf16 rounding of U flips it.  The fp64 oracle with bf16-rounded GEMM operands and
+# gradients (no kernels involved) gives cosine 0.952 .. 0.979 and a norm ratio ~0.8 on exactly these tensors; the
+# emulated kernels 0.974 .. 0.982.
+BF16_COS_GATE = {'conformer_ctc_mma_headdrop_xs': (('dec_fwd.layers.2.norm2.', 'dec_fwd.layers.2.src_attn.monotonic_energy.'), 0.95)}
 # fp32-mode gradient gate (fraction of each tensor's max): 2e-3 for every fixture.  Fixtures may list a wider one here when
 # the REFERENCE's own fp32 gradients (the fixture) sit far from the fp64 oracle (tools/bf16_sensitivity.py, last column)
 # because fp32 rounding decided a max-pool arg-max / ReLU mask in the front-end (tools/fixture_tie_check.py); the
@@ -132,7 +139,13 @@ def assert_bf16_gates(name, fix, loss, grads, tag='golden bf16'):
     # differences of nearly equal neighbouring terms (p_i (delta_ij - p_j)); the 2^-9 rounding of the bf16
     # encoder output that feeds the energies is amplified in it.  Stated gate 0.97 (measured 0.974-0.984; the
     # decoder recurrence itself runs in fp32, and the fp32-mode test holds these tensors to 2e-3 of max).
-    bad = {n: c for n, c in cos.items() if c < (0.97 if '.score.chunk_energy.' in n else 0.99)}
+    fam, fam_gate = BF16_COS_GATE.get(name, ((), 0.99))
+
+    def gate(n):
+        if '.score.chunk_energy.' in n:
+            return 0.97
+        return fam_gate if n.startswith(fam) and fam else 0.99
+    bad = {n: c for n, c in cos.items() if c < gate(n)}
     print('[' + tag + ' %s] loss rel %.2e, min cosine %.5f over %d tensors' % (
         name, abs(loss - ref) / abs(ref), min(cos.values()), len(cos)))
     assert abs(loss - ref) / abs(ref) < BF16_LOSS_GATE.get(name, 1e-3), (loss, ref)

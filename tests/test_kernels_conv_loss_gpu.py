@@ -342,21 +342,25 @@ def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V):
     with ops.compute_mode('bf16'):
         M = sum(t * (u + 1) for t, u in zip(el, yl))
         assert ops.rnnt_joint_fused_supported(J, U + 1, M)
-        torch.cuda.synchronize()
-        torch.cuda.reset_peak_memory_stats()
-        base = torch.cuda.memory_allocated()
+        on_device = _dev().type == 'cuda'      # (the CPU tier runs this body on the emulator, without the memory part)
+        if on_device:
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
         loss, nll = ops.rnnt_joint_loss(e, gq, w, bo, lab.to(_dev()), elens.to(_dev()), ylens.to(_dev()), 0,
                                         elens_host=el, ylens_host=yl)
         assert loss.grad_fn.__class__.__name__.startswith('RNNTJointLossFusedFn')
         grads = torch.autograd.grad(loss, (e, gq, w, bo))
-        torch.cuda.synchronize()
-        peak = torch.cuda.max_memory_allocated() - base
+        if on_device:
+            torch.cuda.synchronize()
+            peak = torch.cuda.max_memory_allocated() - base
     Vp = (V + 63) // 64 * 64
     budget = M * (2 * Vp + 4 * J + 256) + 20 * V * J * 4 + (8 << 20)      # d16 + h + dz + per-node scalars; dW slabs
     padded_old = B * T * (U + 1) * (4 * V + 2 * Vp + 4 * J)
-    assert peak < budget, (peak, budget)
-    if padded_old > (64 << 20):
-        assert peak < 0.6 * padded_old, (peak, padded_old)
+    if on_device:
+        assert peak < budget, (peak, budget)
+        if padded_old > (64 << 20):
+            assert peak < 0.6 * padded_old, (peak, padded_old)
     e64, g64, w64, b64 = [t.detach().cpu().double().requires_grad_() for t in (e, gq, w, bo)]
     logits = torch.tanh(e64[:, :, None] + g64[:, None]) @ w64.t() + b64
     refs = rnnt_loss_ref_diag(torch.log_softmax(logits, -1), lab.long(), elens.long(), ylens.long(), blank=0)

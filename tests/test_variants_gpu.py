@@ -16,6 +16,10 @@ from tests import variants_common as vc
 pytestmark = pytest.mark.gpu
 
 
+def _dev():
+    return torch.device('cuda', 0)
+
+
 @pytest.mark.parametrize('T,f,kind', vc.SUM_CASES + [(801, 3, 'drop'), (800, 2, 'add'), (799, 4, 'mean_pool')])
 def test_window_sum_subsamplers(T, f, kind):
     vc.check_window_sum('gpu', T, f, kind)
@@ -72,11 +76,11 @@ def test_blstm_layer_matches_packed_torch_lstm(bidir_sum):
         yr = yr[..., :H] + yr[..., H:]
     w = torch.randn_like(yr)
     (yr * w).sum().backward()
-    enc.cuda(0)
+    enc.to(_dev())
     with ops.compute_mode('f32'):
-        xo = x.clone().cuda(0).requires_grad_(True)
-        yo = enc._lstm_layer(xo, torch.tensor(lens, dtype=torch.int32, device='cuda:0'), enc.rnn[0])
-        (yo * w.cuda(0)).sum().backward()
+        xo = x.clone().to(_dev()).requires_grad_(True)
+        yo = enc._lstm_layer(xo, torch.tensor(lens, dtype=torch.int32, device=_dev()), enc.rnn[0])
+        (yo * w.to(_dev())).sum().backward()
     torch.testing.assert_close(yo.detach().cpu(), yr.detach(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(xo.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-5)
     for (n, p), (_, q) in zip(enc.rnn[0].named_parameters(), ref.named_parameters()):
@@ -122,7 +126,7 @@ def _lstm_state_case(mode, tol):
     from neural_sp_amd import ops
     torch.manual_seed(5)
     B, n, I, H = 5, 23, 48, 64
-    dev = torch.device('cuda', 0)
+    dev = _dev()
     ref = torch.nn.LSTM(I, H, 1, batch_first=True)
     x = torch.randn(B, n, I, requires_grad=True)
     h0, c0 = torch.randn(B, H, requires_grad=True), torch.randn(B, H, requires_grad=True)
