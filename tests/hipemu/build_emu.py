@@ -1,7 +1,7 @@
 """Build tests/hipemu/_build/libnsp_emu.so: selected csrc/*.hip files compiled by the HOST clang++
 against the emulation header (tests/hipemu/include/hip/hip_runtime.h) -- TEST INFRASTRUCTURE ONLY.
 
-Only sources without inline asm / gfx950 builtins can be emulated; the list below names them.
+All sixteen kernel files build (the header emulates the gfx950 builtins they use; `s_waitcnt` asm is stripped here).
 Nothing under neural_sp_amd/ imports this module or loads the library it builds.
 """
 import hashlib

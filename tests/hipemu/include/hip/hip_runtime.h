@@ -15,8 +15,10 @@
 // released.  Lanes that have returned no longer take part in collectives (as on the hardware); a whole wave must not
 // exit while other waves of its block still wait at a __syncthreads().
 // Dynamic shared memory: `extern __shared__ T name[];` is rewritten by tests/hipemu/build_emu.py into a pointer to a
-// per-launch buffer (HIPEMU_DYN_SHARED).  The two MFMA builtins of gemm.hip are emulated as wave collectives.
-// Not emulated: inline asm, buffer / LDS-DMA / transposed-LDS-read builtins, streams.
+// per-launch buffer (HIPEMU_DYN_SHARED).  Emulated as wave collectives: the fp32 and bf16 MFMA builtins and the
+// transposed LDS read (ds_read_b64_tr_b16); raw buffer loads / stores keep their range check; LDS-DMA
+// (global_load_lds) executes synchronously; s_waitcnt / scheduling barriers are no-ops (build_emu.py strips the asm).
+// Not emulated: other inline asm, streams, cooperative launches (the occupancy query fails, launchers fall back).
 #pragma once
 #include <float.h>
 #include <math.h>

@@ -2,8 +2,8 @@
 
 `with emulated_kernels():` swaps the loader's `lib()` for the emulator library, lets `_p()` pass CPU
 addresses and makes `_stream()` a null stream, so the *real* ctypes glue and autograd Functions of
-ops.py run unchanged on CPU tensors for the kernels the emulator can build (EMULATED_SOURCES).  Any
-other symbol is absent from the emulator library and raises AttributeError: nothing silently falls back.
+ops.py run unchanged on CPU tensors (every kernel file is in EMULATED_SOURCES).  A symbol absent from the
+emulator library raises AttributeError: nothing silently falls back.
 """
 import contextlib
 import ctypes

@@ -157,3 +157,23 @@ def test_train_py_call_sequence_in_bf16_mode(dropin):
     """bin/asr/train.py's call sequence (training steps with dropout / SpecAugment / accumulation, dev loss, plot
     hooks, greedy decode) in the bf16 throughput mode"""
     dropin.test_train_py_call_sequence_runs_unchanged()
+
+
+@pytest.mark.parametrize('rows,d', [(5, 256), (33, 1024), (64, 144)])
+def test_layernorm_with_bf16_shadow(basic, rows, d):
+    basic.test_layernorm(rows, d)
+
+
+@pytest.mark.parametrize('clamp,causal,nc', [(10, False, 0), (-1, False, 0), (10, True, 0), (4, False, 8)])
+def test_attn_softmax(basic, clamp, causal, nc):
+    basic.test_attn_softmax(clamp, causal, nc)
+
+
+def test_elementwise_and_batched_gemm(basic):
+    basic.test_elementwise()
+    basic.test_gemm_batched_strided()
+
+
+@pytest.mark.skipif(not SLOW, reason='minutes of host time (M = 16389 rows x ~20 GEMMs): NSP_EMU_ALL=1 runs it')
+def test_specialised_epilogues_on_the_single_stage_kernel(basic):
+    basic.test_specialised_epilogues_on_the_single_stage_kernel(16389, 768, 64)

@@ -6,7 +6,8 @@ tests/test_golden_gpu.py.
 NOTE (round 2): written after the round's GPU minutes were (almost) spent.  The kernel tests of this file (window / flip /
 group_norm / batch_norm: 32 cases) passed on an MI355X at first contact in the round's last call
 (profiles/r02d_variants_kernels_gpu.log); the model-level tests (test_variant_golden_*, config 1 at full size, the BLSTM
-layer, weight noise) had only run through the CPU shim / emulator when they were committed."""
+layer, weight noise) had only run through the CPU shim / emulator when they were committed -- in BOTH compute modes
+since the emulator learned the bf16 kernels (tests/test_e2e_emu_cpu.py, profiles/r02e_bf16_mode_emulated.log)."""
 import pytest
 import torch
 
