@@ -216,7 +216,7 @@ def host_logic_on_cpu(real_kernels=False, real_conv=True, mode='f32'):
         # fp32 MFMAs per tile) conv front-end on its torch stand-in
         fakes = {k: fakes[k] for k in (('h2d_packed',) if real_conv else ('h2d_packed', 'conv3x3_relu', 'maxpool2d'))}
     saved = {k: getattr(ops, k) for k in fakes}
-    mode = ops.get_compute_mode()
+    saved_mode = ops.get_compute_mode()
     for k, v in fakes.items():
         setattr(ops, k, v)
     assert mode == 'f32' or real_kernels, 'the torch stand-ins are fp32 only'
@@ -227,4 +227,4 @@ def host_logic_on_cpu(real_kernels=False, real_conv=True, mode='f32'):
     finally:
         for k, v in saved.items():
             setattr(ops, k, v)
-        ops.set_compute_mode(mode)
+        ops.set_compute_mode(saved_mode)

@@ -12,7 +12,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'neural_sp_amd', 'csrc')
-OUT = os.path.join(HERE, '_build')
+# NSP_EMU_ASAN=1: the same build with AddressSanitizer (every global / LDS access of every kernel is bounds-checked
+# against the real allocation: torch's CPU tensors, the static __shared__ arrays, the dynamic shared buffer).  Run as
+#   NSP_EMU_ASAN=1 LD_PRELOAD=$(python tests/hipemu/build_emu.py --asan-runtime) ASAN_OPTIONS=detect_leaks=0 python -m pytest ...
+ASAN = os.environ.get('NSP_EMU_ASAN', '0') == '1'
+OUT = os.path.join(HERE, '_build_asan' if ASAN else '_build')
 LIB = os.path.join(OUT, 'libnsp_emu.so')
 EMULATED_SOURCES = ['norm_subsample.hip', 'elementwise.hip', 'xent.hip', 'decode.hip', 'layernorm.hip', 'ctc.hip',
                     'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip', 'lstm.hip', 'conv2d.hip', 'gemm_bf16.hip', 'flash_attn.hip']
@@ -68,7 +72,8 @@ def build():
         dst = os.path.join(OUT, os.path.basename(src).replace('.hip', '_emu.cpp'))
         _rewrite(src, dst)
         gen.append(dst)
-    cmd = [cxx, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unused-value', '-Wno-unused-result',
+    cmd = [cxx, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unused-value', '-Wno-unused-result'] + (
+        ['-g', '-fsanitize=address', '-shared-libasan', '-fno-omit-frame-pointer'] if ASAN else []) + [
            '-Wl,-Bsymbolic',   # libnsp_hip.so (RTLD_GLOBAL) may already be loaded: bind our own nsp_* references locally
            '-I', os.path.join(HERE, 'include'), '-x', 'c++'] + gen + [srcs[-1]] + ['-o', LIB]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -81,3 +86,14 @@ def build():
 
 if __name__ == '__main__':
     print(build())
+
+
+def asan_runtime():
+    """path of the shared ASan runtime of the host clang (to LD_PRELOAD into python)"""
+    out = subprocess.run([_cxx(), '-print-file-name=libclang_rt.asan-x86_64.so'], stdout=subprocess.PIPE).stdout.decode().strip()
+    return out
+
+
+if __name__ == '__main__':
+    import sys
+    print(asan_runtime() if '--asan-runtime' in sys.argv else build())

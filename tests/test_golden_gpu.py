@@ -53,6 +53,10 @@ BF16_COS_GATE = {'conformer_ctc_mma_headdrop_xs': (('dec_fwd.layers.2.norm2.', '
 FP32_GRAD_GATE = {}
 
 
+def _dev():
+    return torch.device('cuda', 0)      # (tests/test_e2e_emu_cpu.py points this at the CPU and runs the same bodies on the emulator)
+
+
 def _load(name):
     return torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
 
@@ -63,7 +67,7 @@ def _run(fix, mode):
     args = argparse.Namespace(**fix['args'])
     model = Speech2Text(args)
     model.load_state_dict(fix['state_dict'], strict=True)
-    model.cuda(0)
+    model.to(_dev())
     if fix['meta'].get('trigger_quantity_loss'):
         model.trigger_quantity_loss()        # train.py's curriculum switch (MoChA quantity loss)
     ss_seed = fix['meta'].get('scheduled_sampling_seed')
