@@ -45,7 +45,9 @@ def _rewrite(src, dst):
     the include of common.h is redirected to the real csrc directory"""
     text = open(src).read()
     text = _DYN.sub(r'\1* \2 = reinterpret_cast<\1*>(HIPEMU_DYN_SHARED);', text)
-    text = re.sub(r'asm volatile\("s_waitcnt[^;]*;', '/* s_waitcnt: no-op on the host */;', text)
+    text = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)"\s*::\s*"n"\((.*?)\)\s*:\s*"memory"\);', r'hipemu_waitcnt_vm(\1);', text)
+    text = re.sub(r'asm volatile\("s_waitcnt vmcnt\((\d+)\)"\s*:::\s*"memory"\);', r'hipemu_waitcnt_vm(\1);', text)
+    text = re.sub(r'asm volatile\("s_waitcnt[^;]*;', '/* s_waitcnt (lgkmcnt): no-op on the host */;', text)
     text = text.replace('__attribute__((address_space(1)))', '').replace('__attribute__((address_space(3)))', '')
     text = text.replace('#include "common.h"', '#include "%s"' % os.path.join(CSRC, 'common.h'))
     with open(dst, 'w') as fh:

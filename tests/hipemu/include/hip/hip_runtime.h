@@ -17,7 +17,8 @@
 // Dynamic shared memory: `extern __shared__ T name[];` is rewritten by tests/hipemu/build_emu.py into a pointer to a
 // per-launch buffer (HIPEMU_DYN_SHARED).  Emulated as wave collectives: the fp32 and bf16 MFMA builtins and the
 // transposed LDS read (ds_read_b64_tr_b16); raw buffer loads / stores keep their range check; LDS-DMA
-// (global_load_lds) executes synchronously; s_waitcnt / scheduling barriers are no-ops (build_emu.py strips the asm).
+// (global_load_lds) lands at the s_waitcnt vmcnt(n) that retires it (build_emu.py turns that asm into hipemu_waitcnt_vm(n));
+// lgkmcnt waits and scheduling barriers are no-ops.
 // Not emulated: other inline asm, streams, cooperative launches (the occupancy query fails, launchers fall back).
 #pragma once
 #include <float.h>
@@ -109,6 +110,10 @@ struct Wave {              // one per host thread
   void* closure;
   uint64_t slot[64];
   alignas(16) unsigned char frag[64][32];   // MFMA operand fragments: A (16 B) | B (16 B) per lane
+  // LDS-DMA (global_load_lds) in flight, per lane, oldest first: the LDS write lands only when a s_waitcnt vmcnt(n)
+  // retires it (or at a __syncthreads, whose fence waits for everything) -- the latest moment the hardware allows
+  struct Dma { char* dst; int size; unsigned char data[16]; };
+  std::vector<Dma> dma[64];
 };
 struct Launch {
   dim3 grid, block;
@@ -145,8 +150,19 @@ static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CS
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
-static inline void __syncthreads() {
+static inline void hipemu_waitcnt_vm(int n) {     // s_waitcnt vmcnt(n): all but the n most recent LDS-DMA loads of this lane land
+  std::vector<hipemu::Wave::Dma>& q = hipemu::wave->dma[hipemu::tid_flat & 63];
+  const int retire = (int)q.size() - n;
+  if (retire <= 0) return;
+  for (int i = 0; i < retire; ++i) memcpy(q[i].dst, q[i].data, (size_t)q[i].size);
+  q.erase(q.begin(), q.begin() + retire);
+}
+static inline void hipemu_raw_barrier() {         // s_barrier alone: no memory wait
   hipemu::wave_collective([] { pthread_barrier_wait(&hipemu::cur->bar); });
+}
+static inline void __syncthreads() {              // HIP's __syncthreads = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
+  hipemu_waitcnt_vm(0);
+  hipemu_raw_barrier();
 }
 // 16-byte aligned base of the launch's dynamic shared memory
 #define HIPEMU_DYN_SHARED \
@@ -263,7 +279,7 @@ static inline void hipemu_buf_store_b64(hipemu_u32x2 d, hipemu_rsrc r, unsigned 
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_buf_load_b128
 #define __builtin_amdgcn_raw_buffer_load_b64 hipemu_buf_load_b64
 #define __builtin_amdgcn_raw_buffer_store_b64 hipemu_buf_store_b64
-#define __builtin_amdgcn_s_barrier __syncthreads
+#define __builtin_amdgcn_s_barrier hipemu_raw_barrier
 // ds_read_b64_tr_b16 as a wave collective (lane mapping as probed on gfx950, see the header of gemm_bf16.hip): within
 // a 16-lane group, lane 4a+b supplies the address of row a, columns 4b..4b+3 of a 4x16 bf16 block; lane i receives
 // column i (rows 0..3)
@@ -282,9 +298,16 @@ template <class P> static inline hipemu_bf16x4 hipemu_ds_read_tr16(P p) {
   hipemu::wave_barrier();
   return r;
 }
-// global_load_lds (16 B per lane): LDS destination = the wave-uniform base + 16 * lane; executed synchronously
+// global_load_lds (16 B per lane): LDS destination = the wave-uniform base + 16 * lane.  The data is captured at issue
+// (kernel inputs do not change during a launch) and written to LDS when a s_waitcnt retires it (hipemu_waitcnt_vm):
+// a consumer that reads the tile without the wait (+ barrier) sees stale LDS, as it may on the hardware
 template <class G, class L> static inline void hipemu_global_load_lds(G* g, L* lds, int size, int, int) {
-  memcpy(reinterpret_cast<char*>(lds) + (size_t)size * (hipemu::tid_flat & 63), reinterpret_cast<const char*>(g), (size_t)size);
+  const int lane = hipemu::tid_flat & 63;
+  hipemu::Wave::Dma d;
+  d.dst = reinterpret_cast<char*>(lds) + (size_t)size * lane;
+  d.size = size;
+  memcpy(d.data, reinterpret_cast<const char*>(g), (size_t)size);
+  hipemu::wave->dma[lane].push_back(d);
 }
 #define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
@@ -314,6 +337,7 @@ namespace hipemu {
 static inline void fiber_entry() {
   Wave* w = wave;
   w->invoke(w->closure);
+  w->dma[w->cur].clear();   // LDS dies with the block
   w->done[w->cur] = true;   // returns to uc_link = the wave's scheduler
 }
 template <class F>

@@ -6,8 +6,8 @@ What this executes on the CPU tier: gemm_bf16.hip (register-staged KC / RC loade
 kernels with `global_load_lds`, transposed LDS reads `ds_read_b64_tr_b16`, XOR-swizzled tiles, split-K slabs, the
 persistent kernel with its deferred epilogue, every fused epilogue) and flash_attn.hip (forward, backward, relative
 position table, causal / chunk masks, dropout) -- v_mfma_f32_16x16x32_bf16, the transposed read and the LDS-DMA load
-are emulated as documented in tests/hipemu/include/hip/hip_runtime.h (the DMA executes synchronously: a missing
-s_waitcnt cannot be detected here, a wrong address or lane mapping is).  Shapes are the small ones of the device tests
+are emulated as documented in tests/hipemu/include/hip/hip_runtime.h (an LDS-DMA load lands only at the s_waitcnt that
+retires it, so a too-weak counted wait fails these tests as well as a wrong address or lane mapping).  Shapes are the small ones of the device tests
 (the large ones take minutes of host time); tolerances are the device tests' own."""
 import os
 
