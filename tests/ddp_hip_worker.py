@@ -8,13 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def global_batch(vocab):
+def global_batch(vocab, t_range=(120, 180)):
     """4 utterances; ranks take [0,2] / [1,3] (rank-strided, sampler.py:96).  Utterances 0 and 1
     both have the maximum length, so each rank pads to the same T_max as the single-process run on
     all four (padding is live data in this model)."""
     import numpy as np
     from neural_sp_amd.configs import synthetic_batch
-    b = synthetic_batch(B=4, t_range=(120, 180), u_range=(5, 12), vocab=vocab, seed=31)
+    b = synthetic_batch(B=4, t_range=t_range, u_range=(5, 12), vocab=vocab, seed=31)
     rng = np.random.RandomState(5)
     b['xs'][1] = rng.randn(len(b['xs'][0]), 80).astype('float32')
     b['xlens'][1] = len(b['xs'][1])
@@ -28,8 +28,13 @@ def sub_batch(b, idx):
     return out
 
 
-def model_args():
+def model_args(small=False):
     from neural_sp_amd.configs import conformer_rnnt_args
+    if small:       # the CPU tier (emulated kernels): same structure -- d_k = 64 flash attention, 2-layer LSTM stack, CTC + RNN-T
+        return conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=0.3, ctc_fc_list='', ctc_lsm_prob=0.0,
+                                   transformer_enc_d_model=64, transformer_enc_n_heads=1, transformer_enc_d_ff=128,
+                                   conformer_kernel_size=7, dec_n_units=64, dec_n_layers=2, emb_dim=32,
+                                   dec_bottleneck_dim=32)
     # d_k = 64 -> flash attention; 2x256 LSTM -> persistent stack; CTC + RNN-T -> all three streams
     return conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=0.3, ctc_fc_list='', ctc_lsm_prob=0.0,
                                transformer_enc_d_model=128, transformer_enc_n_heads=2, transformer_enc_d_ff=256,
@@ -37,34 +42,55 @@ def model_args():
                                dec_bottleneck_dim=32)
 
 
-def run(rank, world, port, out_path, compress):
+def run(rank, world, port, out_path, compress, device='cuda'):
+    """device='cpu': the same two-rank run on the host-emulated kernels (tests/test_ddp_gloo_cpu.py) -- CPU tensors, gloo
+    all-reduce through the CPU branch of the comm hook, no streams"""
+    if device == 'cpu':
+        import torch
+        torch.set_num_threads(2)
+        from tests.cpu_ops_shim import host_logic_on_cpu
+        with host_logic_on_cpu(real_kernels=True, real_conv=False, mode='bf16'):
+            return _run(rank, world, port, out_path, compress, device)
+    return _run(rank, world, port, out_path, compress, device)
+
+
+def _run(rank, world, port, out_path, compress, device):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
     from neural_sp_amd import ops, parallel
     from neural_sp_amd.speech2text import Speech2Text
-    torch.cuda.set_device(0)
+    on_gpu = device == 'cuda'
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    if on_gpu:
+        torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    args = model_args()
+    args = model_args(small=not on_gpu)
     torch.manual_seed(7)
-    model = Speech2Text(args).cuda(0)
+    model = Speech2Text(args)
+    if on_gpu:
+        model.cuda(0)
     with torch.no_grad():
         for p in model.parameters():
             if p.dim() == 1:
                 p.add_(torch.empty_like(p).uniform_(-0.1, 0.1))
-    full = global_batch(args.vocab)
+    full = global_batch(args.vocab) if on_gpu else global_batch(args.vocab, t_range=(60, 90))
     ops.set_compute_mode('bf16')
     result = {}
     if rank == 0:
         model.zero_grad(set_to_none=True)
         loss, _ = model(full, task='all')
         loss.backward()
-        torch.cuda.synchronize()
+        sync()
         result['single'] = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
         result['single_loss'] = loss.item()
         model.zero_grad(set_to_none=True)
-    ddp = parallel.wrap_ddp(model, 0, bucket_cap_mb=1, compress=compress)   # 1 MB: several buckets even at XS size
-    assert len(model._nsp_grad_accumulators) > 0
+    if on_gpu:
+        ddp = parallel.wrap_ddp(model, 0, bucket_cap_mb=1, compress=compress)   # 1 MB: several buckets even at XS size
+        assert len(model._nsp_grad_accumulators) > 0
+    else:
+        ddp = parallel.wrap_ddp(model, None, bucket_cap_mb=0.05)               # 50 kB buckets: several at this size
+        ddp.register_comm_hook(None, parallel.make_comm_hook(parallel.step_streams(model), compress))
     local = sub_batch(full, list(range(rank, 4, world)))
     losses = []
     for it in range(2):                      # 2nd iteration runs on DDP's rebuilt (arrival-ordered) buckets
@@ -73,7 +99,7 @@ def run(rank, world, port, out_path, compress):
         loss = loss * world                  # train.py:423-424
         loss.backward()
         losses.append(loss.item())
-    torch.cuda.synchronize()
+    sync()
     ops.lstm_check()
     grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
     # every rank must hold the same averaged gradient

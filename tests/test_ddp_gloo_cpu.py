@@ -1,8 +1,9 @@
 """world_size=2 gloo test of the data-parallel plumbing (neural_sp_amd/parallel.py) on CPU.
 
-The HIP model itself cannot run without a GPU, so a small stand-in module exercises exactly
-the logic the N>1 path adds around it: DDP wrapping with our settings, rank-strided batch
-sharding, the train.py loss pre-scaling, and bench.py's max-time / sum-units aggregation."""
+Two tiers: a small stand-in module exercises exactly the logic the N>1 path adds around the model (DDP wrapping with
+our settings, rank-strided batch sharding, the train.py loss pre-scaling, bench.py's max-time / sum-units
+aggregation); and the PRODUCT model itself runs as two gloo ranks on the host-emulated HIP kernels (the worker of the
+device test tests/test_ddp_hip_gpu.py with device='cpu') against the single-process gradient."""
 import os
 import socket
 
@@ -67,3 +68,38 @@ def test_ddp_gloo_world2_matches_single_process():
         for a, b in zip(grads, ref):
             assert torch.allclose(torch.tensor(a), b, atol=1e-6), rank
         assert dt == 2.0 and units == 300.0
+
+
+def test_two_rank_ddp_on_the_real_model_with_emulated_kernels():
+    """The N>1 path with the PRODUCT model: tests/ddp_hip_worker.py -- the worker of the device test
+    tests/test_ddp_hip_gpu.py -- with device='cpu': two gloo ranks, each running neural_sp_amd.Speech2Text (Conformer
+    with d_k = 64 fused attention, CTC + RNN-T with its 2-layer prediction network) in bf16 mode on the host-emulated HIP
+    kernels, gradients all-reduced by parallel.make_comm_hook in 50 kB buckets (rebuilt by arrival order in the second
+    iteration), against the single-process gradient on the concatenated batch (train.py:263,423-424)."""
+    import tempfile
+
+    import pytest
+    from tests.hipemu import build_emu
+    if not build_emu.available():
+        pytest.skip('no host clang++ for the HIP emulator')
+    build_emu.build()                       # once, before the ranks start
+    from tests import ddp_hip_worker
+    world = 2
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'res.pt')
+        mp.spawn(ddp_hip_worker.run, args=(world, _free_port(), out, None, 'cpu'), nprocs=world, join=True)
+        res = torch.load(out, weights_only=False)
+    assert all(res['same']), 'ranks disagree on the reduced gradient'
+    assert set(res['ddp']) == set(res['single'])
+    gmax = sorted(g.abs().max().item() for g in res['single'].values())
+    floor = 1e-4 * gmax[int(0.9 * (len(gmax) - 1))]
+    worst, wn = 0.0, ''
+    for n, g in res['single'].items():
+        want = g * world
+        e = ((res['ddp'][n] - want).abs().max() / max(want.abs().max().item(), floor)).item()
+        if e > worst:
+            worst, wn = e, n
+    print('[ddp 2 ranks on emulated kernels] worst per-tensor gradient error vs single process: %.2e (%s)' % (worst, wn))
+    assert worst < 1e-3, (worst, wn)          # the device test's gate
+    mean_local = sum(l[0] for l in res['losses']) / world / world
+    assert abs(mean_local - res['single_loss']) / abs(res['single_loss']) < 1e-3
