@@ -52,3 +52,17 @@ def test_cpu_tensor_is_rejected_loudly():
     from neural_sp_amd import ops
     with pytest.raises((AssertionError, RuntimeError)):
         ops.linear(torch.randn(4, 8), torch.randn(3, 8))
+
+
+def test_smoke_body_runs_on_the_emulated_kernels():
+    """__graft_entry__.smoke() -- the check the driver runs on cuda:0 before the bench -- with its device pointed at the
+    CPU and the C-ABI calls routed to the host emulator of the kernels: loss and every gradient against the oracle in
+    fp32 mode, the loss again in bf16 mode (the smoke's own gates)."""
+    import pytest
+    from tests.hipemu import build_emu
+    if not build_emu.available():
+        pytest.skip('no host clang++ for the HIP emulator')
+    import __graft_entry__ as entry
+    from tests.cpu_ops_shim import host_logic_on_cpu
+    with host_logic_on_cpu(real_kernels=True, real_conv=False):
+        entry.smoke(device='cpu')

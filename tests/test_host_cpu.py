@@ -230,3 +230,20 @@ def test_ctc_alignment_files_round_trip(tmp_path):
     n = alignment.align_batches(FakeModel(), [{'xs': [0, 1], 'ys': ys, 'speakers': ['s', 's'], 'utt_ids': ['a', 'b']}],
                                 str(tmp_path / 'out'), lambda ids, return_list=True: ['t%d' % i for i in ids])
     assert n == 2 and alignment.load_ctc_alignment(str(tmp_path / 'out'), 's', 'a').tolist() == [3, 9, 17, 40]
+
+
+def test_bench_cpu_baseline_leg_runs_with_dropout_as_configured():
+    """bench.py's cpu_baseline() -- the oracle port timed on a bounded sample -- at the XS size: the leg the driver's
+    round-end bench runs on the GPU box's host cores (dropout 0.1 as bench configures it, full step incl. Adam)"""
+    import argparse
+    import bench
+    from neural_sp_amd.configs import conformer_rnnt_args
+    a = argparse.Namespace(size='XS', tmin=60, tmax=90, umin=5, umax=9, cpu_batch=2)
+    margs = conformer_rnnt_args('XS', n_layers=2, vocab=40, dropout=0.1, ctc_weight=0.3)
+    threads = torch.get_num_threads()
+    try:
+        out = bench.cpu_baseline(a, margs, 4)
+    finally:
+        torch.set_num_threads(threads)
+    assert out['kind'] == 'port' and out['unit'] == 'frames/s' and out['value'] > 0 and out['cores'] == 4
+    assert 'full training step' in out['sample'] or 'probe' in out['sample']
