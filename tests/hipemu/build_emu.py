@@ -75,7 +75,7 @@ def build():
         _rewrite(src, dst)
         gen.append(dst)
     cmd = [cxx, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unused-value', '-Wno-unused-result'] + (
-        ['-g', '-fsanitize=address', '-shared-libasan', '-fno-omit-frame-pointer'] if ASAN else []) + [
+        ['-g', '-fsanitize=address', '-shared-libasan', '-fno-omit-frame-pointer', '-DHIPEMU_UCONTEXT=1'] if ASAN else []) + [
            '-Wl,-Bsymbolic',   # libnsp_hip.so (RTLD_GLOBAL) may already be loaded: bind our own nsp_* references locally
            '-I', os.path.join(HERE, 'include'), '-x', 'c++'] + gen + [srcs[-1]] + ['-o', LIB]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
