@@ -56,7 +56,7 @@ def test_gemm_layout_asymmetric(basic):
     basic.test_gemm_layout_asymmetric()
 
 
-@pytest.mark.parametrize('M,N,K', [(256, 128, 96)] + ([(531, 1000, 512)] if SLOW else []))
+@pytest.mark.parametrize('M,N,K', [(256, 128, 96), (531, 1000, 512)])
 def test_gemm_dgrad_wgrad_bf16(basic, M, N, K):
     basic.test_gemm_dgrad_wgrad('bf16', 2e-2, M, N, K)
 
@@ -70,12 +70,12 @@ def test_splitk_slabs_with_an_empty_split(basic):
     basic.test_splitk_slabs_with_an_empty_split_are_fully_written('bf16')
 
 
-@pytest.mark.parametrize('stages', ['2', '3'] if SLOW else ['3'])
+@pytest.mark.parametrize('stages', ['2', '3'])
 def test_weight_gradient_gemm_on_the_lds_dma_ring(basic, stages, monkeypatch):
     basic.test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch, shapes=[(1280, 1000, 264)])
 
 
-@pytest.mark.parametrize('M,N,K', [(1000, 384, 128)] + ([(700, 2048, 64)] if SLOW else []))
+@pytest.mark.parametrize('M,N,K', [(1000, 384, 128), (700, 2048, 64)])
 def test_persistent_gemm_with_deferred_epilogue(basic, M, N, K, monkeypatch):
     basic.test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch)
 
@@ -146,7 +146,7 @@ def dropin(monkeypatch):
         yield mod
 
 
-@pytest.mark.parametrize('name', ['conformer_ctc_xs'] + (['conformer_rnnt_xs', 'conformer_ctc_las_xs', 'conformer_ctc_mocha_xs'] if SLOW else []))
+@pytest.mark.parametrize('name', ['conformer_ctc_xs', 'conformer_rnnt_xs'] + (['conformer_ctc_las_xs', 'conformer_ctc_mocha_xs'] if SLOW else []))
 def test_greedy_decode_matches_reference_hypotheses(dropin, name):
     """bit-exact token sequences from the decode kernels (decode.hip) on the emulated encoder"""
     dropin.test_greedy_decode_matches_reference_hypotheses(name)

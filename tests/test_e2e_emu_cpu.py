@@ -14,7 +14,7 @@ model family -- run, the conv front-end's kernels (the slow ones to emulate) for
 
 The bf16 THROUGHPUT mode runs as well (the emulator executes gemm_bf16.hip / flash_attn.hip and every bf16 path of the
 other kernels): the body of the device test tests/test_golden_gpu.py::test_golden_bf16 itself, its device pointed at
-the CPU -- three fixtures by default, all 38 with NSP_EMU_ALL=1 (all pass; profiles/r02e_bf16_mode_emulated.log)."""
+the CPU -- six fixtures by default, all 38 with NSP_EMU_ALL=1 (all pass; profiles/r02e_bf16_mode_emulated.log)."""
 import argparse
 import os
 import random
@@ -36,9 +36,9 @@ CASES = ALL if os.environ.get('NSP_EMU_ALL', '0') == '1' else DEFAULT
 # run for one fixture, the others keep the front-end on its torch stand-in; NSP_EMU_REAL_CONV=1 runs them everywhere
 REAL_CONV = os.environ.get('NSP_EMU_REAL_CONV', '0') == '1'
 ALWAYS_REAL_CONV = {'transformer_ctc_xs'}
-# bf16 mode: three families by default (~1 min); NSP_EMU_ALL=1 all 38 (11 min, all pass: profiles/r02e_bf16_mode_emulated.log)
+# bf16 mode: six fixtures by default (~2 min); NSP_EMU_ALL=1 all 38 (11 min, all pass: profiles/r02e_bf16_mode_emulated.log)
 BF16_CASES = ALL if os.environ.get('NSP_EMU_ALL', '0') == '1' else [
-    'conformer_ctc_xs', 'conformer_rnnt_xs', 'conformer_bn_ctc_xs']
+    n for n in DEFAULT if n not in ('blstm_ctc_xs', 'conformer_2mtl_ctc_xs', 'conformer_drop_ctc_xs')]   # (113 s, 20 s, 18 s)
 
 
 def _run_fixture(name, mode, real_conv):
@@ -92,5 +92,5 @@ def test_speech2text_bf16_mode_on_emulated_kernels(name, monkeypatch):
     from tests import test_golden_gpu as golden
     from tests.cpu_ops_shim import host_logic_on_cpu
     monkeypatch.setattr(golden, '_dev', lambda: torch.device('cpu'))
-    with host_logic_on_cpu(real_kernels=True, real_conv=REAL_CONV, mode='bf16'):
+    with host_logic_on_cpu(real_kernels=True, real_conv=REAL_CONV or name in ALWAYS_REAL_CONV, mode='bf16'):
         golden.test_golden_bf16(name)
