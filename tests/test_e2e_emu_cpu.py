@@ -36,7 +36,7 @@ CASES = ALL if os.environ.get('NSP_EMU_ALL', '0') == '1' else DEFAULT
 # run for one fixture, the others keep the front-end on its torch stand-in; NSP_EMU_REAL_CONV=1 runs them everywhere
 REAL_CONV = os.environ.get('NSP_EMU_REAL_CONV', '0') == '1'
 ALWAYS_REAL_CONV = {'transformer_ctc_xs'}
-# bf16 mode: six fixtures by default (~2 min); NSP_EMU_ALL=1 all 38 (11 min, all pass: profiles/r02e_bf16_mode_emulated.log)
+# bf16 mode: six fixtures by default (~2 min); NSP_EMU_ALL=1 all 38 (16 min through the device test's body, all pass: profiles/r02e_bf16_mode_emulated.log)
 BF16_CASES = ALL if os.environ.get('NSP_EMU_ALL', '0') == '1' else [
     n for n in DEFAULT if n not in ('blstm_ctc_xs', 'conformer_2mtl_ctc_xs', 'conformer_drop_ctc_xs')]   # (113 s, 20 s, 18 s)
 
