@@ -661,14 +661,14 @@ class TransformerDecoder(DecoderBase):
 
     def greedy(self, eouts, elens, max_len_ratio, idx2token=None, exclude_eos=False, refs_id=None, utt_ids=None,
                speakers=None, cache_states=True):
-        if self.attn_type == 'mocha':
-            raise NotImplementedError('decoding with monotonic multi-head attention (test-time hard attention) is not '
-                                      'built; evaluate MMA models with the teacher-forced accuracy (--metric accuracy)')
         """decoders/transformer.py:460-566 (validate() with recog_beam_width 1): arg-max decoding, the whole
         prefix re-run through the stack at every step (no state cache: L <= ceil(T * max_len_ratio) short
         steps).  As in the reference the target mask is purely causal and the SOURCE attention is unmasked
         (`layer(out, causal_mask, eouts, None, ...)`, :500: padded encoder frames are attended to).
         -> (hyps: list of int arrays, None); attention-weight plots are not produced."""
+        if self.attn_type == 'mocha':
+            raise NotImplementedError('decoding with monotonic multi-head attention (test-time hard attention) is not '
+                                      'built; evaluate MMA models with the teacher-forced accuracy (--metric accuracy)')
         from neural_sp_amd.modules import AttnMask
         dev = eouts.device
         B, T = eouts.shape[:2]

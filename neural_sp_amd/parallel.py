@@ -120,7 +120,11 @@ def make_comm_hook(streams, compress=None):
 def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
     """DDP(model) with the settings above; local_rank=None wraps a CPU module (gloo tests)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    kw = dict(broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+    # constant tables need no per-forward broadcast; BatchNorm running statistics do (torch DDP's default, which
+    # the reference relies on: every rank evaluates / checkpoints rank 0's statistics)
+    has_bn = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) or type(m).__name__.startswith('BatchNorm')
+                 for m in model.modules())
+    kw = dict(broadcast_buffers=has_bn, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
     if local_rank is None:
         return DDP(model, **kw)
     pin_grad_streams(model)

@@ -12,6 +12,7 @@ import logging
 import random
 
 import copy
+import inspect
 import os
 
 import numpy as np
@@ -339,8 +340,11 @@ class Speech2Text(nn.Module):
             return dec.ctc.greedy(eouts, elens), None
         if beam != 1 or P(params, 'recog_fwd_bwd_attention', False):
             dec.beam_search()
+        kw = {}
+        if 'trigger_points' in inspect.signature(dec.greedy).parameters:
+            kw['trigger_points'] = trigger_points        # triggered attention decodes from the CTC alignment
         best_hyps_id, aws = dec.greedy(eouts, elens, P(params, 'recog_max_len_ratio', 1.0), idx2token,
-                                       exclude_eos, refs_id, utt_ids, speakers)
+                                       exclude_eos, refs_id, utt_ids, speakers, **kw)
         return [[hyp] for hyp in best_hyps_id], aws
 
     # ---- hot path
@@ -384,7 +388,6 @@ class Speech2Text(nn.Module):
                 observation['loss.mbr'] = obs_fwd['loss_mbr']
                 observation['loss.quantity'] = obs_fwd.get('loss_quantity')
                 observation['loss.latency'] = obs_fwd.get('loss_latency')
-                observation = {k: v for k, v in observation.items()}
             observation['loss.ctc'] = obs_fwd['loss_ctc']
         # only forward decoders for the auxiliary tasks (speech2text.py:326-343)
         for sub in ['sub1', 'sub2']:
@@ -447,6 +450,11 @@ class Speech2Text(nn.Module):
             xs = self.specaug(xs)
         if self.weight_noise_std > 0 and self.training:
             self.add_weight_noise(std=self.weight_noise_std)
+            # the prediction network's side stream waits for the step-start event only: move that event behind
+            # the in-place noise add, or it would read (and shadow) weights while they change
+            dec = getattr(self, 'dec_fwd', None)
+            if getattr(dec, '_step_start_event', None) is not None:
+                dec.mark_step_start()
         if self.input_noise_std > 0 and self.training:
             noise = torch.normal(xs.new_zeros(xs.shape[-1]), self.input_noise_std)  # input_noise.py
             xs = ops.scale_add_bcast(xs, noise, 1.0)

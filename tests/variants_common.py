@@ -3,6 +3,7 @@ kernels of csrc/norm_subsample.hip through the real ctypes glue / autograd Funct
 torch-CPU restatements of the reference modules (encoders/subsampling.py, conformer_convolution.py:58-66,119-124).
 `where`: 'emu' = host-emulated kernels on CPU tensors, 'gpu' = libnsp_hip.so on cuda:0."""
 import contextlib
+import copy
 import math
 
 import torch
@@ -204,14 +205,15 @@ def check_im2col_conv(where):
     conv = nn.Conv2d(Ci, Co, 3, padding=1)
     x = torch.randn(B, T, Fq, Ci)
     ref = torch.relu(conv(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+    # reference gradients first: Module.to(cuda) replaces the Parameter objects, so the device side
+    # runs on its own copy of the module
+    rw, rb = torch.autograd.grad((ref * _weights(ref)).sum(), [conv.weight, conv.bias])
     ctx, dev = _env(where)
     with ctx, ops.compute_mode('f32'):
-        conv.to(dev)
-        y = ops.conv3x3_relu(x.to(dev), conv.weight, conv.bias)
+        dconv = copy.deepcopy(conv).to(dev)
+        y = ops.conv3x3_relu(x.to(dev), dconv.weight, dconv.bias)
         w = _weights(ref).to(dev)
-        gw, gb = torch.autograd.grad((y * w).sum(), [conv.weight, conv.bias])
-    conv.cpu()
-    rw, rb = torch.autograd.grad((ref * _weights(ref)).sum(), [conv.weight, conv.bias])
+        gw, gb = torch.autograd.grad((y * w).sum(), [dconv.weight, dconv.bias])
     torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(gw.cpu(), rw, rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(gb.cpu(), rb, rtol=1e-3, atol=1e-4)
