@@ -113,6 +113,9 @@ typedef struct {
 #define NSP_EPI_RNNT_LSE 1
 #define NSP_EPI_RNNT_DLOGITS 2
 
+/* reduction splits for the weight gradient dW[N, K] = dY[rows, N]^T X[rows, K] with bf16 operands (slab mode, c_ss),
+ * sized for the 256 x 256 kernel (tiles x splits ~ one workgroup per CU); 0 = shape not eligible, caller's rule */
+int nsp_wgrad_splitk(long long N, long long K, long long rows);
 /* out[i] = sum_s part[s*n + i] (i < n): the deterministic reduction of split-K slabs */
 int nsp_splitk_reduce(const float* part, float* out, int splits, long long n, void* stream);
 

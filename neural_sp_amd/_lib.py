@@ -139,7 +139,10 @@ def lib():
     if _lib is None:
         import torch  # noqa: F401  -- loads the process-wide HIP runtime (libamdhip64.so.7) first
         path = LIBPATH
-        if os.path.exists(HIPCC):
+        if os.environ.get('NSP_LIB_OVERRIDE'):
+            # development only (tools/*_ab.py): A/B a previously built library against the tree's in one gpurun call
+            path = os.environ['NSP_LIB_OVERRIDE']
+        elif os.path.exists(HIPCC):
             path = build()
         elif not os.path.exists(path):
             raise RuntimeError('libnsp_hip.so missing and no hipcc to build it: the HIP path is '

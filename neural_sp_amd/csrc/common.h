@@ -5,6 +5,15 @@
 #include <float.h>
 #include "../../include/nsp_hip.h"
 
+// "these values exist in registers HERE": an empty asm that makes its operands opaque at this point of the program,
+// so that the compiler can neither sink the arithmetic that produced them below it nor keep their inputs alive past
+// it (CDNA guide 5.7 item 3).  No instruction is emitted.
+#ifdef NSP_HOST_EMULATION
+#define NSP_PIN4(a, b, c, d) ((void)0)
+#else
+#define NSP_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#endif
+
 #define NSP_LAUNCH_CHECK()                         \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

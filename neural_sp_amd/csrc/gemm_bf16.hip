@@ -105,6 +105,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + slot;
 }
 
+// (tile, split, batch) of a workgroup.  Split-K launches of ONE problem use a flat grid (gridDim.z == 1):
+// workgroup -> v = xcd_remap(id) -> split = v / ntiles, tile = v % ntiles, so that an XCD (id % 8) works
+// on whole reduction splits: all tiles of a split read the same k-rows of both operands, and with the
+// tiles of one split spread over eight private L2s (the old z-major grid) every operand panel was
+// fetched from HBM / Infinity Cache once per XCD -- measured in round 2: the weight-gradient kernels
+// read 1.76x (2048 x 512 outputs) to 5x (512 x 512 outputs) their operand bytes.
+struct TileCoord { int tile, split, z1, z2; };
+__device__ __forceinline__ TileCoord tile_coord(const nsp_gemm_params& p, int ntiles) {
+  TileCoord c;
+  if (gridDim.z == 1 && p.splitk > 1) {
+    const int v = xcd_remap(blockIdx.x, ntiles * p.splitk);
+    c.split = v / ntiles;
+    c.tile = v - c.split * ntiles;
+    c.z1 = c.z2 = 0;
+    return c;
+  }
+  c.tile = xcd_remap(blockIdx.x, ntiles);
+  int z = blockIdx.z;
+  c.split = z % p.splitk;
+  z /= p.splitk;
+  c.z2 = z % p.batch2;
+  c.z1 = z / p.batch2;
+  return c;
+}
+
 __device__ __forceinline__ void store4(void* base, int dtype, long long off, const float* v, int nv,
                                        bool vec) {
   if (dtype == NSP_DT_BF16) {
@@ -317,9 +342,19 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   const long long off0 = coff + (long long)(mrow0 + er) * p.ldc + n;
   const long long ldc4 = 4ll * p.ldc;
   float b4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias && colok) {
-    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-    b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
+  {
+    if (p.bias && colok) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
+    }
+    // The bias must have LANDED before the row loop, and the compiler must know it.  The row groups below are
+    // predicated blocks (only rows < M store); hipcc's wait insertion does not carry "this load was waited
+    // for" out of a conditional block, so it re-waited for the bias in EVERY row group -- as s_waitcnt
+    // vmcnt(0), which on gfx9 (one in-order counter for loads and stores) also waits for every store of the
+    // previous row groups: 16 store round trips per tile in the epilogues that have a bias but no side
+    // operand (FFN first linear, pointwise conv 1, every plain Linear).  This builtin is a wait the
+    // compiler's scoreboard sees: afterwards only lgkmcnt waits remain inside the loop (round 3, .s audit).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
   }
   const uint32_t keep_thr = (uint32_t)(p.dropout_p * 65536.f);
   const float keep_inv = nsp_rcp(1.f - p.dropout_p);
@@ -348,6 +383,70 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
     for (int j = 0; j < 4; ++j) request(0, j, raw[j]);
   }
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  // one row group (rows er + 4j of block mi, this lane's four columns): staged accumulators -> stores
+  auto row_group = [&](int mi, int j) {
+    float v[4];
+    const int row = er + 4 * j;
+    const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
+    const int m = mrow0 + mi * 16 + row;
+    const bool ok = m < p.M && colok;              // only the stores are predicated
+    const long long off = off0 + (long long)(mi * 4 + j) * ldc4;
+    const uint4 sd = raw[j];
+    if (has_side && mi + 1 < MI) request(mi + 1, j, raw[j]);
+    v[0] = a4.x + b4[0]; v[1] = a4.y + b4[1]; v[2] = a4.z + b4[2]; v[3] = a4.w + b4[3];
+    if (has_pre && ok) store4(p.pre_out, pre_dt, off, v, 4, true);
+    if (act != NSP_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], act);
+    }
+    if (has_dact) {
+      float d[4];
+      if (side16) {
+        d[0] = __uint_as_float(sd.x << 16); d[1] = __uint_as_float(sd.x & 0xFFFF0000u);
+        d[2] = __uint_as_float(sd.y << 16); d[3] = __uint_as_float(sd.y & 0xFFFF0000u);
+      } else {
+        d[0] = __uint_as_float(sd.x); d[1] = __uint_as_float(sd.y);
+        d[2] = __uint_as_float(sd.z); d[3] = __uint_as_float(sd.w);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], dact);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    if (drop) {
+      float kp[4];
+      if constexpr (S::kStatic) {
+        // (p.offset + off) is even here (the dispatcher checks p.offset): the two-mixes-per-four form of
+        // nsp_keep_scale4 without its per-lane parity branch
+        const unsigned long long base = (p.offset + (unsigned long long)off) >> 1;
+        const uint32_t h0 = nsp_hash_u32(p.seed, base), h1 = nsp_hash_u32(p.seed, base + 1ull);
+        kp[0] = (h0 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
+        kp[1] = (h0 >> 16) < keep_thr ? 0.f : keep_inv;
+        kp[2] = (h1 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
+        kp[3] = (h1 >> 16) < keep_thr ? 0.f : keep_inv;
+      } else {
+        nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= kp[e];
+    }
+    if (has_res) {
+      v[0] += __uint_as_float(sd.x); v[1] += __uint_as_float(sd.y);
+      v[2] += __uint_as_float(sd.z); v[3] += __uint_as_float(sd.w);
+    }
+    if (ok) {
+      store4(p.C, c_dt, off, v, 4, true);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += v[e];
+    }
+  };
+  // MEASURED AND REMOVED (round 3): finishing row groups in pairs with a DPP lane swap so that every bf16 image
+  // is written with dwordx4 instead of dwordx2 stores (CDNA guide T21) changed nothing (x0.98-1.00 on all ten
+  // GEMM configurations of the step, profiles/r03f_gemm_step_ab.log): this epilogue is not store-issue-bound.
+  // 102400 x 2048 x 512 with two bf16 images = 840 MB written in the ~265 us the epilogue adds to the main loop =
+  // 3.2 TB/s of pure writes, i.e. the chip-wide write phase runs near what HBM3E sustains for writes (a copy's
+  // 6.3 TB/s is half reads) while the MFMA pipes idle; the lever is overlapping that phase with other tiles'
+  // main loops, not the store width.
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -358,59 +457,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       __builtin_amdgcn_sched_barrier(0);   // one row group at a time: interleaving four of them costs ~24 VGPRs
-      const int row = er + 4 * j;
-      const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
-      const int m = mrow0 + mi * 16 + row;
-      const bool ok = m < p.M && colok;              // only the stores are predicated
-      const long long off = off0 + (long long)(mi * 4 + j) * ldc4;
-      const uint4 sd = raw[j];
-      if (has_side && mi + 1 < MI) request(mi + 1, j, raw[j]);
-      float v[4] = {a4.x + b4[0], a4.y + b4[1], a4.z + b4[2], a4.w + b4[3]};
-      if (has_pre && ok) store4(p.pre_out, pre_dt, off, v, 4, true);
-      if (act != NSP_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], act);
-      }
-      if (has_dact) {
-        float d[4];
-        if (side16) {
-          d[0] = __uint_as_float(sd.x << 16); d[1] = __uint_as_float(sd.x & 0xFFFF0000u);
-          d[2] = __uint_as_float(sd.y << 16); d[3] = __uint_as_float(sd.y & 0xFFFF0000u);
-        } else {
-          d[0] = __uint_as_float(sd.x); d[1] = __uint_as_float(sd.y);
-          d[2] = __uint_as_float(sd.z); d[3] = __uint_as_float(sd.w);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], dact);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-      if (drop) {
-        float kp[4];
-        if constexpr (S::kStatic) {
-          // (p.offset + off) is even here (the dispatcher checks p.offset): the two-mixes-per-four form of
-          // nsp_keep_scale4 without its per-lane parity branch
-          const unsigned long long base = (p.offset + (unsigned long long)off) >> 1;
-          const uint32_t h0 = nsp_hash_u32(p.seed, base), h1 = nsp_hash_u32(p.seed, base + 1ull);
-          kp[0] = (h0 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
-          kp[1] = (h0 >> 16) < keep_thr ? 0.f : keep_inv;
-          kp[2] = (h1 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
-          kp[3] = (h1 >> 16) < keep_thr ? 0.f : keep_inv;
-        } else {
-          nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= kp[e];
-      }
-      if (has_res) {
-        v[0] += __uint_as_float(sd.x); v[1] += __uint_as_float(sd.y);
-        v[2] += __uint_as_float(sd.z); v[3] += __uint_as_float(sd.w);
-      }
-      if (ok) {
-        store4(p.C, c_dt, off, v, 4, true);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) csum[e] += v[e];
-      }
+      row_group(mi, j);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -430,7 +477,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
 // kernel on the run-time version only (compile time / code size of the kernels that rarely see big grids)
 template <int MI, bool SPECIALISE>
 __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
-                                                            int mrow0, int n, int lane, long long coff) {
+                                                            int mrow0, int nbase, int lane, long long coff) {
+  const int n = nbase + (lane & 15) * 4;
 #define NSP_EPI(...) do { gemm_epilogue_fast<MI, EpiSpec<__VA_ARGS__>>(p, acc, stage, mrow0, n, lane, coff); return; } while (0)
   if constexpr (SPECIALISE) {
     const bool c16 = p.c_dtype == NSP_DT_BF16;
@@ -481,7 +529,7 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
   constexpr int SP = 68;  // floats per staged row (64 + 4 pad)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   if (!GENERIC || (c_vec && (p.N & 3) == 0 && !atomic && !(p.res && p.dact_src))) {
-    gemm_epilogue_fast_dispatch<MI, SPEC>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64 + (lane & 15) * 4, lane, coff);
+    gemm_epilogue_fast_dispatch<MI, SPEC>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64, lane, coff);
     return;
   }
   if constexpr (!GENERIC) return;
@@ -573,14 +621,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const nsp_gemm_para
   unsigned char* smB = smem + TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const TileCoord tc = tile_coord(p, tiles_m * tiles_n);
+  const int tile = tc.tile, split = tc.split, z1 = tc.z1, z2 = tc.z2;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-
-  int z = blockIdx.z;
-  const int split = z % p.splitk;
-  z /= p.splitk;
-  const int z2 = z % p.batch2, z1 = z / p.batch2;
   const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
   const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
   const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
@@ -657,13 +701,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const ns
   unsigned char* smB = smem + 128 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const TileCoord tc = tile_coord(p, tiles_m * tiles_n);
+  const int tile = tc.tile, split = tc.split, z1 = tc.z1, z2 = tc.z2;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  int z = blockIdx.z;
-  const int split = z % p.splitk;
-  z /= p.splitk;
-  const int z2 = z % p.batch2, z1 = z / p.batch2;
   const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
   const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
   const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
@@ -755,13 +796,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
   constexpr int NLOAD = NA + 4;           // loads per lane per k-tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const TileCoord tc = tile_coord(p, tiles_m * tiles_n);
+  const int tile = tc.tile, split = tc.split, z1 = tc.z1, z2 = tc.z2;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM_, n0 = tn * BN;
-  int z = blockIdx.z;
-  const int split = z % p.splitk;
-  z /= p.splitk;
-  const int z2 = z % p.batch2, z1 = z / p.batch2;
   const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
   const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
   const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
@@ -1280,13 +1318,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_rr_ring_kernel(const nsp_g
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // NS x (A image 16 KB | B image 16 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const TileCoord tc = tile_coord(p, tiles_m * tiles_n);
+  const int tile = tc.tile, split = tc.split, z1 = tc.z1, z2 = tc.z2;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  int z = blockIdx.z;
-  const int split = z % p.splitk;
-  z /= p.splitk;
-  const int z2 = z % p.batch2, z1 = z / p.batch2;
   const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
   const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
   const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
@@ -1374,13 +1409,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_rr_glds_kernel(const ns
   __shared__ __attribute__((aligned(16))) unsigned char ring[32768];   // A image 16 KB | B image 16 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const TileCoord tc = tile_coord(p, tiles_m * tiles_n);
+  const int tile = tc.tile, split = tc.split, z1 = tc.z1, z2 = tc.z2;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  int z = blockIdx.z;
-  const int split = z % p.splitk;
-  z /= p.splitk;
-  const int z2 = z % p.batch2, z1 = z / p.batch2;
   const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
   const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
   const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
@@ -1447,6 +1479,121 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_rr_glds_kernel(const ns
   gemm_epilogue<4, false>(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);   // fast path only (launcher: fast_epi)
 }
 
+// ---- RC x RC on 256 x 256 tiles: the weight gradients dW[N, K'] = dY[M, N]^T X[M, K'] of the training step
+// (reduction over M = 25..100 k rows; outputs 512 x 512 .. 2048 x 512, the RNN-T output layer 1000 x 512 over
+// ~3.6 M lattice nodes).  Why a second tile size: at 128 x 128 with 64 x 64 wave tiles a k-tile costs 32 KB
+// of L2 -> LDS fill and 16 KB of LDS fragment reads per wave for 32 MFMAs -- at MFMA rate that is the whole
+// LDS read bandwidth (8 waves x 16 KB per 544 MFMA cycles = 235 of 256 B/clk) and ~16 TB/s of L2 fill per
+// PFLOP/s.  Here: 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 (24 KB of fragment reads per 64 MFMAs: 0.75x),
+// 64 KB of fill per 8.4 MFLOP (0.5x), one workgroup per CU, two waves per SIMD covering each other's LDS
+// reads and waits.  Images as in the ring kernel above, per operand two half-images [64 k][128 cols]
+// (unpadded 256-B rows, LDS-DMA, source-side XOR swizzle, transposed reads); two stages of 64 KB; the DMA
+// of k-tile t+1 is in flight while tile t is multiplied.
+// Split-K over a FLAT grid (tile_coord): the launcher sizes splitk so that tiles x splitk ~ 256 = one
+// workgroup per CU, and an XCD's 32 workgroups are whole splits: each operand panel crosses the fabric once.
+// Ragged reduction length (K % 64 != 0: the compacted RNN-T lattice): rows >= K of the LAST k-tile are read
+// from row K - 1 (finite) for A and from a zero line for B, so their products vanish.
+__device__ __attribute__((aligned(256))) unsigned int nsp_zero_line[64];   // 256 B of zeros (static storage)
+
+__global__ __launch_bounds__(512) void gemm_bf16_rr256_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
+                                                              int c_vec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A lo | A hi | B lo | B hi), 16 KB each
+  constexpr int STAGE = 65536, HALF = 16384;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const TileCoord tc = tile_coord(p, tiles_m * tiles_n);
+  const int tm = tc.tile / tiles_n, tn = tc.tile % tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int split = tc.split;
+  const __bf16* A = reinterpret_cast<const __bf16*>(p.A);
+  const __bf16* B = reinterpret_cast<const __bf16*>(p.B);
+  const long long coff = p.c_ss ? (long long)split * p.c_ss : 0;
+  const long long lda = p.a_cs, ldb = p.b_ks;   // row pitch of the k-major operands
+  const int nkt_all = (p.K + BK - 1) / BK;
+  int ktbeg = 0, ktend = nkt_all;
+  if (p.splitk > 1) {
+    const int per = (nkt_all + p.splitk - 1) / p.splitk;
+    ktbeg = min(split * per, nkt_all);
+    ktend = min((split + 1) * per, nkt_all);
+    if (ktbeg >= ktend && !p.c_ss) return;   // atomic accumulation: nothing to add (slab mode writes its zeros)
+  }
+  const int nkt = ktend - ktbeg;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // DMA piece pi = 4 * wave + i (0..31) of an operand: half-image pi >> 4, k-rows 4 * (pi & 15) .. + 3;
+  // lane = (k-row & 3, 16-B chunk).  Per-lane element offsets of k-tile 0 of this split:
+  const int lk = lane >> 4, lp = lane & 15;
+  long long aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pi = wave * 4 + i, half = pi >> 4, krow = (pi & 15) * 4 + lk;
+    const int csrc = lp ^ rr_swz(krow);
+    // chunks beyond M / N re-read the tile's first chunk: they only feed outputs that are never stored
+    const int ma = (m0 + half * 128 + csrc * 8 < p.M) ? m0 + half * 128 + csrc * 8 : m0;
+    const int nb = (n0 + half * 128 + csrc * 8 < p.N) ? n0 + half * 128 + csrc * 8 : n0;
+    aoff[i] = (long long)(ktbeg * BK + krow) * lda + ma;
+    boff[i] = (long long)(ktbeg * BK + krow) * ldb + nb;
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const bool ragged = (p.K % BK) != 0;
+  auto issue = [&](int kt) {
+    unsigned char* st = ring + (kt & 1) * STAGE;
+    const long long ka = (long long)kt * BK * lda, kb = (long long)kt * BK * ldb;
+    const bool tail = ragged && (ktbeg + kt == nkt_all - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pi = wave * 4 + i;
+      const __bf16* sa = A + aoff[i] + ka;
+      const __bf16* sb = B + boff[i] + kb;
+      if (tail) {
+        const int krow = (pi & 15) * 4 + lk;
+        const int kg = (ktbeg + kt) * BK + krow;
+        if (kg >= p.K) {
+          sa -= (long long)(kg - (p.K - 1)) * lda;
+          sb = reinterpret_cast<const __bf16*>(nsp_zero_line) + ((lp ^ rr_swz(krow)) & 15) * 8;
+        }
+      }
+      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(st + (pi >> 4) * HALF + (pi & 15) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(st + 2 * HALF + (pi >> 4) * HALF + (pi & 15) * 1024), 16, 0, 0);
+    }
+  };
+  const int fr = lane & 15, fg = lane >> 4;
+  if (nkt > 0) issue(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    // this wave's pieces of k-tile kt have landed; behind the barrier everybody's have, and every wave has
+    // finished reading the other stage (k-tile kt - 1), which is re-armed right away
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nkt) issue(kt + 1);
+    const unsigned char* smA = ring + (kt & 1) * STAGE + wm * HALF;
+    const unsigned char* smB = ring + (kt & 1) * STAGE + 2 * HALF + (wn >> 1) * HALF;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[8], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bf[i] = rr_frag(smB, (wn & 1) * 64 + i * 16, s, fr, fg);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = rr_frag(smA, i * 16, s, fr, fg);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  __syncthreads();  // the epilogue stages through the ring
+  // two 64-row halves through the MI = 4 epilogue (as gemm_bf16_kk256_kernel): rows m0 + wm*128 (+ 64) ..
+  gemm_epilogue<4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), ring, m0 + wm * 64, n0, wm, wn, lane, wave, coff, c_vec);
+  gemm_epilogue<4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), ring, m0 + wm * 64 + 64, n0, wm, wn, lane, wave, coff, c_vec);
+}
+
 // fp32 [rows, cols] (row stride ld_in) -> bf16 [rows, ld_out] with zero fill; 8 elements per lane
 __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long long rows,
                                  int cols, long long ld_in, long long ld_out, int vec_in) {
@@ -1486,6 +1633,21 @@ inline int rr_ring_min_tiles() {
   return e ? atoi(e) : 24;
 }
 
+// 256 x 256 weight-gradient kernel.  MEASURED (round 3, interleaved A/B, profiles/r03b_wgrad_ab.log): with its
+// one-barrier-per-k-tile loop it is 0.6-0.9x the 128 x 128 kernels (which gained 10-35 % from the flat grid
+// alone: 700-840 TFLOP/s) at the encoder's shapes (25-100 k rows, 256 workgroups of 25-100 k-tiles each: the
+// single workgroup per CU has nothing to hide its prologue / slab epilogue behind), and 1.10x on the RNN-T
+// output layer (3.6 M rows: 829 vs 751 TFLOP/s).  So by default it takes the long reductions only
+// (>= 2^19 rows); NSP_GEMM_RR256 = 1 forces it for every eligible shape, 0 switches it off (read on every call
+// so that tests can flip it).
+inline bool rr256_shape_ok(long long M, long long N, long long K) {
+  if (!(M % 8 == 0 && N % 8 == 0 && M > 128 && N > 128 && K >= 2 * BK)) return false;
+  const char* e = getenv("NSP_GEMM_RR256");
+  if (e) return atoi(e) != 0;
+  return K >= (1ll << 19);
+}
+inline bool rr256_enabled() { return true; }
+
 }  // namespace
 
 // called from nsp_gemm (gemm.hip) when both operands are bf16
@@ -1511,7 +1673,9 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   if (p.dact_src && reinterpret_cast<uintptr_t>(p.dact_src) % 16) c_vec = 0;
   if (p.res && !aligned16(p.res)) c_vec = 0;
   if (p.bias && !aligned16(p.bias)) c_vec = 0;
-  dim3 grid(tiles_m * tiles_n, 1, p.batch1 * p.batch2 * p.splitk), block(NTHREADS);
+  // split-K of one problem: flat grid, whole splits per XCD (tile_coord)
+  const int flat = (p.batch1 * p.batch2 == 1 && p.splitk > 1) ? p.splitk : 1;
+  dim3 grid(tiles_m * tiles_n * flat, 1, flat > 1 ? 1 : p.batch1 * p.batch2 * p.splitk), block(NTHREADS);
   const bool fast_epi = c_vec && p.N % 4 == 0 && !(p.splitk > 1 && p.c_ss == 0) && !(p.res && p.dact_src);
   if (a_kc && b_kc && p.K % BK == 0 && p.K >= BK) {
     // how many workgroups would share a CU decides how the load latency gets hidden
@@ -1564,7 +1728,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     }
     if (ring_env && wgs < 192 && p.M > 64 && nkt >= 4 && p.epi_mode == NSP_EPI_NONE) {
       tiles_m = nsp_cdiv(p.M, 64);
-      grid.x = tiles_m * tiles_n;
+      grid.x = tiles_m * tiles_n * flat;
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 2>), grid, block, 4 * 24576, st, p, tiles_m, tiles_n, c_vec);
     } else if (ring_env && wgs <= 288 && nkt >= 4)
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 4>), grid, block, 4 * 32768, st, p, tiles_m, tiles_n, c_vec);
@@ -1578,6 +1742,15 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel<0>, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
     else   // odd widths / unaligned outputs / atomic split-K on a large grid: the generic epilogue lives in the ring kernels
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
+  }
+  else if (!a_kc && !b_kc && p.batch1 * p.batch2 == 1 && rr256_enabled() && rr256_shape_ok(p.M, p.N, p.K)) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_rr256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr = true;
+    }
+    const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
+    hipLaunchKernelGGL(gemm_bf16_rr256_kernel, dim3(tm256 * tn256 * p.splitk), dim3(512), 131072, st, p, tm256, tn256, c_vec);
   }
   else if (!a_kc && !b_kc && p.K % BK == 0 && p.K >= 2 * BK && p.M % 8 == 0 && p.N % 8 == 0 &&
            tiles_m * tiles_n >= rr_ring_min_tiles() && rr_ring_stages() > 0) {
@@ -1603,6 +1776,19 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
+}
+
+// reduction splits of a weight gradient dW[N, K] = dY[rows, N]^T X[rows, K] in bf16 mode, or 0 when the caller's
+// own rule applies (the 128 x 128 kernels).  256 x 256 tiles x splits ~ 256 workgroups = one per CU.
+extern "C" int nsp_wgrad_splitk(long long N, long long K, long long rows) {
+  if (!rr256_enabled() || !rr256_shape_ok(N, K, rows)) return 0;
+  const long long tiles = (long long)nsp_cdiv((int)N, 256) * nsp_cdiv((int)K, 256);
+  const long long nkt = (rows + BK - 1) / BK;
+  long long sk = 256 / tiles;
+  if (sk < 1) sk = 1;
+  if (sk > nkt / 2) sk = nkt / 2 > 0 ? nkt / 2 : 1;
+  const long long per = (nkt + sk - 1) / sk;      // no empty splits
+  return (int)((nkt + per - 1) / per);
 }
 
 extern "C" int nsp_cast_bf16(const float* x, void* out, long long rows, int cols, long long ld_in,

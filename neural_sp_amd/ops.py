@@ -207,6 +207,16 @@ def _pick_splitk(M, N, K, batch=1):
     return -(-nkt // per)
 
 
+def _wgrad_splitk(N, K, rows, bf16):
+    """Reduction splits of dW[N, K] = dY[rows, N]^T X[rows, K]: the library's plan for its 256 x 256 weight-gradient
+    kernel (tiles x splits ~ one workgroup per CU) when the shape is eligible, else the 128-tile rule above."""
+    if bf16:
+        sk = _lib.lib().nsp_wgrad_splitk(N, K, rows)
+        if sk > 0:
+            return sk
+    return _pick_splitk(N, K, rows)
+
+
 def linear_fwd(x2d, weight, bias=None, act=0, res=None, alpha=1.0, pre_out=None, out=None,
                dropout_p=0.0, seed=0, offset=0, out_bf16=False):
     """y[M,N] = res + dropout(alpha*act(x2d[M,K] @ weight[N,K]^T + bias)).  In bf16 mode the
@@ -266,7 +276,7 @@ def linear_wgrad(dy2d, x2d, alpha=1.0):
         ga, xa = dy2d, x2d
     if ga.dtype != xa.dtype:
         ga, xa = ga.float(), xa.float()
-    sk = _pick_splitk(N, K, M)
+    sk = _wgrad_splitk(N, K, M, ga.dtype == torch.bfloat16)
     if sk > 1 and (N * K) % 4 == 0:
         # split slabs + deterministic reduction (no atomics, no zero fill)
         part = torch.empty((sk, N, K), device=dy2d.device, dtype=torch.float32)
@@ -1382,7 +1392,7 @@ class RNNTJointLossFn(torch.autograd.Function):
         h2d = h.view(-1, J)
         if use16:
             # operands are already bf16 images: call the GEMMs directly (pitch Vp on dlogits)
-            sk = _pick_splitk(V, J, n)
+            sk = _wgrad_splitk(V, J, n, True)
             part = torch.empty((sk, V, J), device=h.device, dtype=torch.float32)
             gemm_raw(V, J, n, d16, 1, Vp, h2d, J, 1, part, J, splitk=sk, c_ss=V * J)
             dw = torch.empty((V, J), device=h.device, dtype=torch.float32)
@@ -1528,7 +1538,7 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
                'nsp_rnnt_joint_gemm(dlogits)')
         db = colsum(dbpart)[:V] if ctx.has_bias else None
         # dW = dlogits^T h  (split over the M rows, deterministic slab reduction)
-        sk = _pick_splitk(V, J, M)
+        sk = _wgrad_splitk(V, J, M, True)
         part = torch.empty((sk, V, J), device=dev, dtype=torch.float32)
         gemm_raw(V, J, M, d16, 1, Vp, h16, J, 1, part, J, splitk=sk, c_ss=V * J)
         dw = torch.empty((V, J), device=dev, dtype=torch.float32)

@@ -21,6 +21,7 @@
 // lgkmcnt waits and scheduling barriers are no-ops.
 // Not emulated: other inline asm, streams, cooperative launches (the occupancy query fails, launchers fall back).
 #pragma once
+#define NSP_HOST_EMULATION 1   /* csrc/common.h: register-pinning asm statements become no-ops */
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
@@ -212,6 +213,11 @@ template <class T> static inline T __shfl_xor(T v, int m, int = 64) { return hip
 template <class T> static inline T __shfl_down(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_down, d); }
 template <class T> static inline T __shfl_up(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_up, d); }
 template <class T> static inline T __shfl(T v, int i, int = 64) { return hipemu_shfl(v, hipemu_src_idx, i); }
+// DPP quad_perm (dpp_ctrl < 0x100: lane l reads lane (l & ~3) | ((ctrl >> 2 (l & 3)) & 3)); all rows / banks enabled
+static inline int hipemu_src_quad(int lane, int ctrl) { return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3); }
+static inline int __builtin_amdgcn_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+  return hipemu_shfl(src, hipemu_src_quad, ctrl);
+}
 
 // ---- MFMA as a wave collective (register layouts: cdna_hip_programming.md, "Fragment layout") ----
 //   v_mfma_f32_16x16x4_f32 : lane l holds A[l&15][k=l>>4], B[k=l>>4][l&15]; D/C reg r: row (l>>4)*4+r, col l&15
@@ -330,6 +336,10 @@ template <class G, class L> static inline void hipemu_global_load_lds(G* g, L* l
 }
 #define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)        /* scheduling hint only */
+/* s_waitcnt as a builtin (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4) */
+#define __builtin_amdgcn_s_waitcnt(imm) hipemu_waitcnt_vm(((imm) & 15) | ((((imm) >> 14) & 3) << 4))
+#define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_ds_read_tr16_b64_v4bf16 hipemu_ds_read_tr16
 static inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }

@@ -75,6 +75,11 @@ def test_weight_gradient_gemm_on_the_lds_dma_ring(basic, stages, monkeypatch):
     basic.test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch, shapes=[(1280, 1000, 264)])
 
 
+@pytest.mark.parametrize('rows,N,K', [(1291, 1000, 264), (333, 136, 1280), (130, 256, 256)])
+def test_weight_gradient_gemm_on_256_tiles(basic, rows, N, K, monkeypatch):
+    basic.test_weight_gradient_gemm_on_256_tiles(rows, N, K, monkeypatch)
+
+
 @pytest.mark.parametrize('M,N,K', [(1000, 384, 128), (700, 2048, 64)])
 def test_persistent_gemm_with_deferred_epilogue(basic, M, N, K, monkeypatch):
     basic.test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch)

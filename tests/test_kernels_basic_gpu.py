@@ -236,6 +236,7 @@ def test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch, shapes=((
         dy = torch.randn(rows, N, device=dev).bfloat16()
         x = torch.randn(rows, K, device=dev).bfloat16()
         ref = dy.float().t() @ x.float()
+        monkeypatch.setenv('NSP_GEMM_RR256', '0')     # (the 256 x 256 kernel has its own test below)
         with ops.compute_mode('bf16'):
             monkeypatch.setenv('NSP_GEMM_RR_RING', '0')
             base = ops.linear_wgrad(dy, x)
@@ -244,6 +245,38 @@ def test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch, shapes=((
         scale = ref.abs().max()
         assert ((base - ref).abs().max() / scale).item() < 1e-4
         assert ((dw - ref).abs().max() / scale).item() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,N,K', [(2048, 640, 512), (1291, 1000, 264), (4096, 512, 2048), (333, 136, 1280), (130, 256, 256)])
+def test_weight_gradient_gemm_on_256_tiles(rows, N, K, monkeypatch):
+    """gemm_bf16_rr256_kernel (default for weight gradients with both output extents > 128): flat split-K grid with
+    whole splits per XCD, split count from nsp_wgrad_splitk, ragged output edges (1000, 264, 136), a reduction
+    length that is not a multiple of the 64-row k-tile (1291, 333, 130: the tail rows must contribute exactly
+    nothing -- the B operand reads a zero line there), and the single-k-tile / two-k-tile corner (130 rows)."""
+    from neural_sp_amd import ops, _lib
+    torch.manual_seed(rows)
+    dev = _dev()
+    dy = torch.randn(rows, N, device=dev).bfloat16()
+    x = torch.randn(rows, K, device=dev).bfloat16()
+    ref = dy.float().t() @ x.float()
+    monkeypatch.setenv('NSP_GEMM_RR256', '1')     # (default: reductions of >= 2^19 rows only)
+    assert _lib.lib().nsp_wgrad_splitk(N, K, rows) > 0
+    with ops.compute_mode('bf16'):
+        dw = ops.linear_wgrad(dy, x)
+        monkeypatch.setenv('NSP_GEMM_RR256', '0')
+        assert _lib.lib().nsp_wgrad_splitk(N, K, rows) == 0
+        base = ops.linear_wgrad(dy, x)
+    scale = ref.abs().max()
+    assert ((base - ref).abs().max() / scale).item() < 1e-4
+    assert ((dw - ref).abs().max() / scale).item() < 1e-4
+    # explicit split counts, incl. more splits than k-tiles need (empty splits write zero slabs)
+    with ops.compute_mode('bf16'):
+        monkeypatch.setenv('NSP_GEMM_RR256', '1')
+        for sk in (1, 3, 8):
+            part = torch.full((sk, N, K), float('nan'), device=dev)
+            ops.gemm_raw(N, K, rows, dy, 1, N, x, K, 1, part, K, splitk=sk, c_ss=N * K)
+            assert ((part.sum(0) - ref).abs().max() / scale).item() < 1e-4, sk
 
 
 @pytest.mark.gpu
