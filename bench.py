@@ -8,8 +8,12 @@ A step = one full training step (neural_sp/bin/asr/train.py:414-452): H2D of a s
 batch, Conformer encoder fwd, CTC + RNN-T loss, backward (RCCL gradient all-reduce under
 DDP when N>1), grad clipping, Adam.  Workload = BASELINE.json configs[3] per GPU:
 Conformer-L (d=512, d_ff=2048, H=8, k=15, 12 layers, x8 subsampling) + CTC(0.3) + RNN-T
-(2x1024 LSTM prediction net, joint 512, V=1000), B=16 utterances of T~U[1200,1600] 80-dim
-frames, U~U[120,200] labels, dropout 0.1, bf16 MFMA operands / fp32 accumulate.
+(2x1024 LSTM prediction net, joint 512, V=1000), 128 utterances per GPU by default (the same step at 64 and at
+16 -- the per-GPU batch SURVEY.md section 8(d) names -- is measured and reported beside it, the 16 entry with its
+own roofline object) of T~U[1200,1600] 80-dim frames, U~U[120,200] labels, dropout 0.1, bf16 MFMA operands / fp32
+accumulate.  Beside the GEMM-class roofline the line carries the north-star number itself: `encoder_mfu` = encoder
+forward + backward time on the main stream against 161.5 MFLOP per valid input frame and the 2.5 PFLOP/s
+dense bf16 peak, and the node's MEASURED peaks (library bf16 GEMM, streaming copy) next to the vendor peaks.
 Weak scaling: every rank owns its own batch (seed = rank); value = valid frames of all
 ranks / wall time (max over ranks).
 """
@@ -211,7 +215,19 @@ def main():
     # encoder forward | loss heads forward | backward (+ DDP reduction) | clip + Adam
     phase_ev = []
     enc_done = [None]
-    model.enc.register_forward_hook(lambda *_: enc_done.__setitem__(0, _ev()) if _PH['on'] else None)
+    enc_bwd_start = [None]
+
+    def _enc_fwd_hook(_m, _inp, out):
+        if not _PH['on']:
+            return
+        enc_done[0] = _ev()
+        # the encoder's backward starts when the gradient of its output is complete (CTC + RNN-T branches summed)
+        xs = out['ys']['xs'] if isinstance(out, dict) else None
+        if torch.is_tensor(xs) and xs.requires_grad:
+            xs.register_hook(lambda g: enc_bwd_start.__setitem__(0, _ev()))
+    model.enc.register_forward_hook(_enc_fwd_hook)
+    comm = getattr(train_model, 'comm_stats', None)
+    comm_log = []
 
     def step(i):
         batch = batches[i % len(batches)]
@@ -221,8 +237,12 @@ def main():
         e1 = _ev() if ph else None
         if distributed:
             loss = loss * world  # train.py:423-424
+        if comm is not None:
+            comm.reset()
         loss.backward()
-        e2 = _ev() if ph else None
+        e2 = _ev() if (ph or comm is not None) else None
+        if comm is not None and comm.last_ready is not None:
+            comm_log.append((comm.last_ready, e2, comm.buckets, comm.bytes, comm.waited_side))
         # the previous step's loss values are read here, one step late: reading step i's values
         # right after its own forward (the reference's .item() calls) or at the end of the step
         # drains the HIP queue and lets the GPU idle through the next step's host-bound forward
@@ -232,7 +252,8 @@ def main():
         opt.step()
         opt.zero_grad(set_to_none=True)
         if ph:
-            phase_ev.append((e0, enc_done[0], e1, e2, _ev()))
+            phase_ev.append((e0, enc_done[0], e1, e2, _ev(), enc_bwd_start[0], sum(batch['xlens']),
+                             len(batch['xlens']) * max(batch['xlens'])))
         return sum(batch['xlens']), len(batch['xlens']) * max(batch['xlens'])
 
     def sync():
@@ -267,13 +288,29 @@ def main():
     phases = None
     if phase_ev:
         torch.cuda.synchronize()
-        acc = [0.0, 0.0, 0.0, 0.0]
-        for e0, ee, e1, e2, e3 in phase_ev:
+        acc = [0.0, 0.0, 0.0, 0.0, 0.0]
+        fr_valid = fr_padded = 0
+        for e0, ee, e1, e2, e3, eb, nv, npad in phase_ev:
             acc[0] += e0.elapsed_time(ee); acc[1] += ee.elapsed_time(e1)
             acc[2] += e1.elapsed_time(e2); acc[3] += e2.elapsed_time(e3)
+            acc[4] += eb.elapsed_time(e2) if eb is not None else 0.0
+            fr_valid += nv; fr_padded += npad
         phases = {k: round(v / len(phase_ev), 2) for k, v in zip(
-            ('encoder_fwd_ms', 'loss_fwd_ms', 'backward_ms', 'clip_adam_ms'), acc)}
+            ('encoder_fwd_ms', 'loss_fwd_ms', 'backward_ms', 'clip_adam_ms', 'encoder_bwd_ms'), acc)}
         phases['steps_sampled'] = len(phase_ev)
+        enc_ms = acc[0] + acc[4]
+        if enc_ms > 0 and a.size == 'L' and acc[4] > 0:
+            # the north-star number: Conformer-L encoder forward + backward against the dense bf16 MFMA peak.
+            # 161.5 MFLOP per input frame = SURVEY.md section 8(d) (conv front-end + bridge + 12 blocks at T/2, T/4, T/8,
+            # forward x 3); valid = unpadded frames (headline), padded = what the kernels actually multiply.
+            # encoder_bwd_ms runs from "gradient of the encoder output complete" to the end of backward on the main
+            # stream (the prediction network's backward on its side stream overlaps it and is not encoder work).
+            phases['encoder_mfu'] = {
+                'definition': '161.5 MFLOP x input frames / (encoder_fwd_ms + encoder_bwd_ms) / peak',
+                'flop_per_frame': 161.5e6, 'peak_tflops': 2500.0 if a.mode == 'bf16' else 157.3,
+                'valid_frames': round(161.5e6 * fr_valid / (enc_ms * 1e-3) / 1e12 / (2500.0 if a.mode == 'bf16' else 157.3), 4),
+                'padded_frames': round(161.5e6 * fr_padded / (enc_ms * 1e-3) / 1e12 / (2500.0 if a.mode == 'bf16' else 157.3), 4),
+                'encoder_tflops_padded': round(161.5e6 * fr_padded / (enc_ms * 1e-3) / 1e12, 1)}
 
     # Secondary measurements (single GPU only, outside the timed region above): the same step at 64 utterances
     # per GPU (the round-1/2 default) and at 16 (the upper end of the per-GPU batch SURVEY.md section 8(d)
@@ -290,15 +327,65 @@ def main():
                 step(i)
             report_pending()
             sync()
+            with_events = b_also == 16 and not a.no_kernel_events
+            if with_events:
+                ops.kernel_events_start()
             t1 = time.perf_counter()
             f_also = 0
             for i in range(12):
+                if with_events:
+                    ops.kernel_events_enable(i % 4 == 0)
                 f_also += step(4 + i)[0]
             report_pending()
             sync()
             dt_also = time.perf_counter() - t1
-            also.append({'per_gpu_batch': b_also, 'value': round(f_also / dt_also, 1), 'unit': 'frames/s', 'steps': 12,
-                         'ms_per_step': round(dt_also / 12 * 1e3, 2)})
+            ent = {'per_gpu_batch': b_also, 'value': round(f_also / dt_also, 1), 'unit': 'frames/s', 'steps': 12,
+                   'ms_per_step': round(dt_also / 12 * 1e3, 2)}
+            if with_events:
+                k16 = ops.kernel_events_stop()
+                if k16['launches'] > 0:
+                    ach16 = k16['flops'] / (k16['ms'] * 1e-3) / 1e12
+                    pk = 2500.0 if a.mode == 'bf16' else 157.3
+                    ent['roofline'] = {'kernel': 'the same GEMM class (main-stream launches of 3 of the 12 steps)', 'bound': 'mfma',
+                                       'achieved': round(ach16, 2), 'peak': pk, 'unit': 'TFLOP/s', 'frac': round(ach16 / pk, 4),
+                                       'traffic': None, 'gemm_launches_per_step': round(k16['launches'] / 3.0, 1),
+                                       'avg_launch_us': round(k16['ms'] * 1e3 / k16['launches'], 2),
+                                       'gemm_share_of_step': round(k16['ms'] / 3.0 / (dt_also / 12 * 1e3), 3)}
+            also.append(ent)
+
+    # measured peak denominators of THIS node ("state both"): a library bf16 GEMM (hipBLASLt behind
+    # torch.matmul, 8192^3, random operands) and a streaming device copy (1 GiB, read + write counted)
+    peaks = None
+    if rank == 0 and not a.no_kernel_events:
+        def _timed(fn, reps):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            q0.record()
+            for _ in range(reps):
+                fn()
+            q1.record()
+            torch.cuda.synchronize()
+            return q0.elapsed_time(q1) / reps * 1e-3
+        try:
+            n = 8192
+            xa = torch.randn(n, n, device=dev).bfloat16()
+            xb = torch.randn(n, n, device=dev).bfloat16()
+            t_lib = _timed(lambda: torch.matmul(xa, xb.t()), 5)
+            xc = torch.empty(n, n, device=dev, dtype=torch.bfloat16)
+            t_own = _timed(lambda: ops._gemm_raw_untimed(n, n, n, xa, n, 1, xb, 1, n, xc, n), 5)
+            del xa, xb, xc
+            src = torch.empty(1 << 30, device=dev, dtype=torch.uint8)
+            dst = torch.empty_like(src)
+            t_cp = _timed(lambda: dst.copy_(src), 5)
+            del src, dst
+            peaks = {'library_gemm_bf16_8192_tflops': round(2.0 * n ** 3 / t_lib / 1e12, 1),
+                     'nsp_gemm_bf16_8192_tflops': round(2.0 * n ** 3 / t_own / 1e12, 1),
+                     'stream_copy_tb_per_s': round(2.0 * (1 << 30) / t_cp / 1e12, 2),
+                     'vendor': {'mfma_bf16_dense_tflops': 2500.0, 'hbm_tb_per_s': 8.0}}
+        except Exception as e:      # never lose the headline line to the side measurement
+            peaks = {'error': repr(e)[:200]}
 
     tot = torch.tensor([dt, float(frames), float(padded)], device=dev, dtype=torch.float64)
     padded_all = float(padded)
@@ -357,6 +444,20 @@ def main():
                        'parallelism': 'dp%d' % world, 'phases': phases},
             'roofline': roof,
         }
+        if roof is not None and peaks is not None:
+            roof['peaks_measured'] = peaks
+            if 'library_gemm_bf16_8192_tflops' in peaks:
+                roof['frac_of_measured_library_gemm'] = round(roof['achieved'] / peaks['library_gemm_bf16_8192_tflops'], 4)
+        if phases is not None and 'encoder_mfu' in phases:
+            out['encoder_mfu'] = phases['encoder_mfu']['valid_frames']     # the north-star figure (target 0.40)
+        if distributed and comm_log:
+            torch.cuda.synchronize()
+            ex = [r.elapsed_time(e) for r, e, _, _, _ in comm_log[a.warmup:]] or [r.elapsed_time(e) for r, e, _, _, _ in comm_log]
+            out['comm'] = {'backend': a.dist_backend, 'buckets_per_step': comm_log[-1][2], 'bytes_per_step': comm_log[-1][3],
+                           'side_stream_waits_per_step': comm_log[-1][4],
+                           'exposed_ms_per_step': round(sum(ex) / len(ex), 3),
+                           'definition': 'main-stream time from "last bucket ready" (all of backward enqueued) to the point '
+                                         'behind DDP\'s wait for every collective, mean over the timed steps, rank 0'}
         if also is not None:
             out['also'] = also
         if not a.no_cpu_baseline and world == 1:

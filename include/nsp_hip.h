@@ -254,11 +254,12 @@ int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
  *   QP   fp32 [B,T,H,r_pitch] position scores (NULL for plain MHA); needs    *
  *        clamp > 0 and R <= 16                                              *
  *   O    bf16 [B*T, d] context (operand of the output projection);          *
- *   O32  fp32 [B*T, d] the same context un-rounded (may be NULL in inference): *
- *        backward forms D_i = dO_i . O_i from it -- the probabilities enter   *
- *        P V as a bf16 hi+lo pair so that D matches sum_j P_ij dP_ij of the   *
- *        recomputed P to ~2^-17 (softmax shift invariance, see flash_attn.hip) *
- *   LSE  fp32 [2,B,H,T]: row max (log2 domain) and 1/row-sum                  *
+ *   O32  fp32 [B*T, d] the same context un-rounded (may be NULL in inference):  *
+ *        backward forms D_i = dO_i . O_i from it; the running row maximum is kept  *
+ *        integer-valued (log2 domain) so that the bf16 probabilities of P V are    *
+ *        reproduced bit for bit by backward (softmax shift invariance of dS, see   *
+ *        flash_attn.hip)                                                           *
+ *   LSE  fp32 [2,B,H,T]: ceil(row max) (log2 domain) and 1/row-sum of exp2(. - it) *
  * Backward: dqkv bf16 [B*T,3d] receives dK (block d) and dV (block 2d);      *
  * dq32 fp32 [B*T,d] and dQP [B,T,H,r_pitch] are written (no zero-init);      *
  * D is scratch [B,H,T].  Masks / dropout as in nsp_attn_softmax_*.          *

@@ -11,7 +11,7 @@
 //             V is consumed through ds_read_b64_tr_b16 transpose reads.
 //             e(i,j) = (q_i.k_j + QP[i, min(|i-j|, clamp)]) * scale with the reference's mask
 //             semantics (masked = -FLT_MAX, finite) and counter-based dropout.
-//             Saves the row max and 1/sum (LSE[0], LSE[1], each [B,H,T]) for backward.
+//             Saves the (integer-valued, log2-domain) row max and 1/sum (LSE[0], LSE[1], each [B,H,T]) for backward.
 //   backward: per (64-key tile, head, utterance) workgroup looping over query tiles: recomputes
 //             P from LSE, dP^T = V dO^T, dS = P (dP - D) scale; dV += P_drop^T dO and
 //             dK += dS^T Q over the workgroup's keys (accumulated in registers, the P / dS
@@ -19,18 +19,25 @@
 //             kernel recomputes dS and produces dQ = dS K and the relative-table gradient dQP
 //             with no global atomics.
 // The 11-entry (clamp_len = 10) position table per query lives in LDS.
-// LSE[0] holds the row maximum in the LOG2 domain (logit * log2 e), LSE[1] the reciprocal row sum.
+// LSE[0] holds the CEILING of the row maximum in the LOG2 domain (logit * log2 e), LSE[1] the reciprocal row sum.
+//
+// Round 3 (measured at B = 64, H = 8, T = 800, key lengths 600..800; profiles/r03i_flash_bench.log):
+// forward 327 -> 228 us (368 TFLOP/s; with dropout 368 -> 263 us), backward 1182 -> 1113 us.
+//   * key tiles beyond an utterance's length are skipped (their probabilities are exactly 0), the three tiles
+//     around the diagonal take a straight-line position lookup instead of the general masked path;
+//   * ONE bf16 probability operand instead of the hi + lo pair: the running maximum is integer-valued, so every
+//     rescale is a power of two and backward reproduces forward's P bit for bit (see the forward kernel);
+//   * K / V (dK/dV kernel: Q / dO) tiles by LDS-DMA into unpadded swizzled images: no staging registers, no
+//     ds_write pass (ablation: prefetch + restage was 32 % of the forward, profiles/r03h_flash_fwd_ablation.log);
+//   * cross-lane max / sum with v_permlane16/32_swap instead of ds_bpermute, the row sum combined once at the end.
+// What remains is VALU issue: ~13 (forward) to ~25 (backward with dropout) vector instructions per score against
+// 256 MFMA flops -- the ablation's "everything removed but fragment reads, max, rescale and conversions" build
+// still takes 42 % of the forward.
 #include "common.h"
 
 namespace {
 
 constexpr int DK = 64;
-// LDS row pitch in bytes for [rows][64] bf16 tiles: 128 + 32 pad.  With 16 bytes of padding (the first
-// version) BOTH read patterns of these kernels ran at half rate: a ds_read_b128 row-per-lane fragment took 8
-// LDS cycles instead of 4 and a ds_read_b64_tr_b16 fragment 4 instead of 2 (lane groups of
-// MI355X_MICROARCH.md "LDS", simulated per instruction; rocprofv3 measured SQ_LDS_BANK_CONFLICT /
-// SQ_LDS_IDX_ACTIVE = 31-36 % on the three kernels).  160 is conflict-free for both.
-constexpr int KP = 160;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -47,37 +54,6 @@ __device__ __forceinline__ bool fa_visible(const nsp_attn_mask_params& p, int kl
   }
   return ok;
 }
-
-// MFMA X operand (rows = `rbase + r`, k = 8 consecutive at 32*s + 8*g) from a KC tile
-__device__ __forceinline__ bf16x8 frag_kc(const unsigned char* tile, int rbase, int s, int r, int g) {
-  return *reinterpret_cast<const bf16x8*>(tile + (rbase + r) * KP + (s * 4 + g) * 16);
-}
-
-// MFMA operand whose rows are COLUMNS cbase..cbase+15 of a k-major tile [k rows][64 cols] and whose
-// 8 k-values are tile rows {k0 + 0..3} and {k1 + 0..3}: two transpose reads
-__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int cbase, int k0, int k1, int r) {
-  const int a = r >> 2, b = r & 3;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + (k0 + a) * KP + (cbase + 4 * b) * 2));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + (k1 + a) * KP + (cbase + 4 * b) * 2));
-  bf16x8 o;
-  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-  return o;
-}
-
-// stage 64 rows x 64 bf16 (rows row0.., clipped to T -> zero rows) of a [B*T, ld] matrix column block
-__device__ __forceinline__ void stage_tile(unsigned char* tile, const __bf16* __restrict__ src, long long ld,
-                                           long long brow0, int row0, int T) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = threadIdx.x + i * 256;
-    const int j = idx >> 3, c = idx & 7;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row0 + j < T) v = *reinterpret_cast<const u32x4*>(src + (brow0 + row0 + j) * ld + c * 8);
-    *reinterpret_cast<u32x4*>(tile + j * KP + c * 16) = v;
-  }
-}
-
 
 // ---- per-element work of a (query tile, key tile) pair.  With d_k = 64 the softmax arithmetic,
 // not the MFMA, bounds these kernels (16 logits per lane per tile against 16 MFMAs per wave), so
@@ -133,6 +109,49 @@ __device__ __forceinline__ unsigned fa_logits(const f32x4 (&s_acc)[4], float (&e
   return vis;
 }
 
+// NEAR tile: no mask predicate (plain) but inside the clamp band, so the relative term differs from key to key:
+// straight-line |i - j| -> min(., clamp) -> one LDS word per score, no branches.  (Round 2 sent these tiles through
+// fa_logits with its per-score visibility / causal / chunk predicates: with 64-query and 64-key tiles the three
+// tiles around the diagonal are "near", and together with the key tiles beyond an utterance's length -- now skipped
+// altogether -- ~45 % of all tiles ran that branchy path at several times the cost of a uniform tile.)
+__device__ __forceinline__ void fa_logits_near(const f32x4 (&s_acc)[4], float (&ev)[4][4], const float* qrow, float sl2,
+                                               int qi, int k0, int g, int clamp) {
+#pragma unroll
+  for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int dlt = qi - (k0 + kf * 16 + 4 * g + e);
+      const int rel = min(dlt < 0 ? -dlt : dlt, clamp);
+      ev[kf][e] = fmaf(s_acc[kf][e], sl2, qrow[rel]);
+    }
+}
+
+// max / sum over the four lanes that share lane & 15 (xor 16, xor 32): v_permlane16_swap / v_permlane32_swap exchange
+// 16- resp. 32-lane halves between two registers in one VALU instruction each -- the ds_bpermute behind
+// __shfl_xor is an LDS-crossbar round trip (~100+ cycles of latency on the softmax's critical path, x4 per tile).
+__device__ __forceinline__ float fa_xmax4(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float fa_xsum4(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// number of key tiles that can contribute: keys >= klen are masked with -FLT_MAX in the reference
+// (relative_multihead_attention.py:203-204), and with at least one visible key in the row exp(-FLT_MAX - max) is
+// exactly 0 -- whole tiles beyond the utterance's length add nothing to any sum.  Only without causal / chunk
+// masks (with them a row can be fully masked, where the reference's softmax is uniform over ALL keys).
+__device__ __forceinline__ int fa_key_tiles(const nsp_attn_mask_params& p, int T, int klen) {
+  const int nkt = (T + 63) / 64;
+  if (p.causal || p.chunk_nc > 0 || klen < 1) return nkt;
+  return min(nkt, (min(klen, T) + 63) / 64);
+}
+
 __device__ __forceinline__ void fa_keep(float (&kp)[4][4], unsigned rowhash, int k0, int g, unsigned thr16, float inv_keep) {
   // one 32-bit value per PAIR of adjacent keys (16 bits per decision), from full-rate integer ops only:
   // a 24-bit multiply-add of the pair index folded into the per-row hash, one xorshift round and a
@@ -154,28 +173,46 @@ __device__ __forceinline__ unsigned fa_rowhash(const nsp_attn_mask_params& p, in
   return nsp_hash_u32(p.seed, p.offset + (unsigned long long)(((long long)b * p.H + h) * T + qi));
 }
 
-// 16 B per thread, 2 per tile: global -> registers now, registers -> LDS later (the loads are issued
-// before a tile's arithmetic and written after it, so their latency hides behind the MFMA / softmax
-// work of the current tile: the CDNA guide's "async-STAGE split")
-struct TileRegs { u32x4 v[2]; };
-__device__ __forceinline__ void tile_load(TileRegs& t, const __bf16* __restrict__ src, long long ld, long long brow0,
-                                          int row0, int T) {
+// ---- K / V tiles staged by LDS-DMA (global_load_lds_dwordx4) in the forward and dq kernels.  The ablation of the
+// register-staged forward (profiles/r03h_flash_fwd_ablation.log: T = 800, B = 64) put 32 % of the kernel into the
+// next tile's prefetch + restage (4 predicated 16-B loads, 4 ds_write_b128 and their address arithmetic per
+// thread and key tile, 16 staging VGPRs) and 24 % behind the barrier that follows it.  The DMA writes a wave's 64
+// x 16 B lane-linear, so rows are unpadded 128 B ([64 keys][64 d_k] bf16 = 8 KB per tile) and the bank spreading
+// moves into an XOR of the 16-B chunk index on the SOURCE address, mirrored by the reads (CDNA guide rule 21):
+//   chunk ^= row & 7 (the GEMM tiles' swizzle): conflict-free both for the ds_read_b128 row fragments (16 rows at one
+//   chunk) and for the ds_read_b64_tr_b16 transposed fragments (a 32-lane pass = 8 rows x 32 B -> 8 distinct 32-B
+//   slots of the 256-B bank row) -- tools/lds_bank_sim.py: 4 and 2 LDS cycles, the ideal -- so ONE image serves
+//   tiles that are read both ways (K in the dq kernel, Q / dO in the dK/dV kernel).
+// Rows beyond T re-read row T - 1 (finite values): their scores are masked as tile padding and their
+// probabilities are 0, so no zero fill is needed.
+constexpr int KD = 128;   // DMA tile row pitch (bytes)
+typedef __attribute__((address_space(3))) void fa_lds_void;
+typedef const __attribute__((address_space(1))) void fa_glb_void;
+__device__ __forceinline__ void tile_dma(unsigned char* tile, const __bf16* __restrict__ src, long long ld, long long brow0,
+                                         int row0, int T, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int idx = threadIdx.x + i * 256;
-    const int j = idx >> 3, c = idx & 7;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row0 + j < T) v = *reinterpret_cast<const u32x4*>(src + (brow0 + row0 + j) * ld + c * 8);
-    t.v[i] = v;
+    const int ii = wave * 2 + i;                    // 1-KB piece: rows 8 ii .. 8 ii + 7
+    const int row = ii * 8 + (lane >> 3), c = lane & 7;
+    const int sc = c ^ (row & 7);
+    const __bf16* g = src + (brow0 + min(row0 + row, T - 1)) * ld + sc * 8;
+    __builtin_amdgcn_global_load_lds((fa_glb_void*)g, (fa_lds_void*)(tile + ii * 1024), 16, 0, 0);
   }
 }
-__device__ __forceinline__ void tile_store(unsigned char* tile, const TileRegs& t) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = threadIdx.x + i * 256;
-    const int j = idx >> 3, c = idx & 7;
-    *reinterpret_cast<u32x4*>(tile + j * KP + c * 16) = t.v[i];
-  }
+__device__ __forceinline__ bf16x8 frag_kc_dma(const unsigned char* tile, int rbase, int s, int r, int g) {
+  const int row = rbase + r;
+  return *reinterpret_cast<const bf16x8*>(tile + row * KD + (((s * 4 + g) ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ bf16x8 frag_tr_dma(const unsigned char* tile, int cbase, int k0, int k1, int r) {
+  const int a = r >> 2, b = r & 3;
+  const int ch = (cbase >> 3) + (b >> 1), sub = (b & 1) * 8;
+  const int r0 = k0 + a, r1 = k1 + a;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * KD + ((ch ^ (r0 & 7)) << 4) + sub));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * KD + ((ch ^ (r1 & 7)) << 4) + sub));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
 }
 
 // forward: one workgroup per (128-query tile, head, utterance); 4 waves x 32 queries (two 16-query
@@ -189,9 +226,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
                                                         __bf16* __restrict__ O, float* __restrict__ O32,
                                                         float* __restrict__ LSE,
                                                         const nsp_attn_mask_params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char Vs[2][64 * KP];
-  __shared__ float QPs[64 * NQ][17];
+  __shared__ __attribute__((aligned(16))) unsigned char KV[4 * 64 * KD + 64 * NQ * 17 * 4];   // ONE LDS object (a second one makes
+  unsigned char (*Ks)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV);             //  hipcc wait vmcnt(0) per LDS read
+  unsigned char (*Vs)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV + 2 * 64 * KD); //  while a DMA is in flight)
+  float (*QPs)[17] = reinterpret_cast<float (*)[17]>(KV + 4 * 64 * KD);
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -202,11 +240,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
   const float sl2 = p.scale * LOG2E;
   const __bf16* kbase = qkv + d + h * DK;
   const __bf16* vbase = qkv + 2 * d + h * DK;
-  TileRegs kr, vr;
-  // NOTE the order: Q / QP loads are issued BEFORE tile 0's loads.  vmcnt retires in issue order, so
-  // the wait in front of the first tile_store then covers them too and the k-loop is entered with
-  // nothing pending; issued after, hipcc has to keep a vmcnt(0) in front of the loop's first MFMA
-  // (Q is its operand), which drains every iteration's prefetch as soon as it is issued.
+  // NOTE the order: Q / QP loads are issued BEFORE tile 0's DMA.  vmcnt retires in issue order, so the wait in
+  // front of the first barrier then covers them too and the k-loop is entered with nothing pending.
   int qi[NQ];
   bf16x8 Qf[NQ][2];
 #pragma unroll
@@ -237,18 +272,17 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
   float m_run[NQ], l_run[NQ];
 #pragma unroll
   for (int f = 0; f < NQ; ++f) { m_run[f] = -INFINITY; l_run[f] = 0.f; }
-  tile_load(kr, kbase, ld3, brow0, 0, T);
-  tile_load(vr, vbase, ld3, brow0, 0, T);
-  tile_store(Ks[0], kr);
-  tile_store(Vs[0], vr);
+  tile_dma(Ks[0], kbase, ld3, brow0, 0, T, wave, lane);
+  tile_dma(Vs[0], vbase, ld3, brow0, 0, T, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int nkt = (T + 63) / 64;
+  const int nkt = fa_key_tiles(p, T, klen);
   for (int kt = 0; kt < nkt; ++kt) {
     const unsigned char* Kc = Ks[kt & 1];
     const unsigned char* Vc = Vs[kt & 1];
-    if (kt + 1 < nkt) {
-      tile_load(kr, kbase, ld3, brow0, (kt + 1) * 64, T);
-      tile_load(vr, vbase, ld3, brow0, (kt + 1) * 64, T);
+    if (kt + 1 < nkt) {     // the other buffer was last read in iteration kt - 1, behind that iteration's barrier
+      tile_dma(Ks[(kt + 1) & 1], kbase, ld3, brow0, (kt + 1) * 64, T, wave, lane);
+      tile_dma(Vs[(kt + 1) & 1], vbase, ld3, brow0, (kt + 1) * 64, T, wave, lane);
     }
     f32x4 s_acc[NQ][4];
 #pragma unroll
@@ -257,13 +291,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
       for (int f = 0; f < NQ; ++f) s_acc[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 kfrag = frag_kc(Kc, kf * 16, s, r, g);
+        const bf16x8 kfrag = frag_kc_dma(Kc, kf * 16, s, r, g);
 #pragma unroll
         for (int f = 0; f < NQ; ++f)
           s_acc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, Qf[f][s], s_acc[f][kf], 0, 0, 0);
       }
     }
-    bf16x8 Pf[NQ][2], Pl[NQ][2];
+    bf16x8 Pf[NQ][2];
 #pragma unroll
     for (int f = 0; f < NQ; ++f) {
       // lane: query qi[f], keys kt*64 + kf*16 + 4g + e
@@ -281,6 +315,12 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
         for (int kf = 0; kf < 4; ++kf)
           mx = fmaxf(mx, fmaxf(fmaxf(s_acc[f][kf][0], s_acc[f][kf][1]), fmaxf(s_acc[f][kf][2], s_acc[f][kf][3])));
         mx = fmaf(mx, sl2, addc);           // sl2 > 0: max commutes with the affine map
+      } else if (tl.plain) {
+        fa_logits_near(s_acc[f], ev, qrow, sl2, qi[f], kt * 64, g, p.clamp);
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mx = fmaxf(mx, ev[kf][e]);
       } else {
         fa_logits(s_acc[f], ev, p, qrow, sl2, qi[f], kt * 64, g, klen, tl);
         if (!tl.plain && kt * 64 + 63 >= T) {
@@ -295,18 +335,24 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
 #pragma unroll
           for (int e = 0; e < 4; ++e) mx = fmaxf(mx, ev[kf][e]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[f], mx);
+      // The running maximum is kept INTEGER-valued (log2 domain: ceil of the true maximum), so every rescale
+      // factor alpha = 2^(m_old - m_new) is a power of two.  Why: backward's D_i = dO_i . O_i must equal
+      // sum_j Pd_ij dP_ij of the probabilities backward RECOMPUTES far better than bf16 precision -- dS =
+      // P (dP - D) sums to zero over keys only then, and any residue multiplies the component common to all
+      // keys / queries (large once biases are non-zero), which the softmax's shift invariance removes from the
+      // true gradient (measured in round 2: w_query / w_key gradients of the upper Conformer-L blocks at cosine
+      // 0.45 with a single bf16 P against fp32-recomputed P).  Round 2 fixed it with a bf16 hi + lo pair (two
+      // P V MFMAs per fragment, ~4 extra VALU per score: 18 % of this kernel, profiles/r03h).  With power-of-
+      // two rescales the value that enters P V, bf16(exp2(t - m_tile) keep) * 2^(m_tile - m_final), equals
+      // bf16(exp2(t - m_final) keep) BIT FOR BIT (rounding commutes with a power-of-two scale), which is what
+      // backward forms from the saved m_final: O is then exactly the sum backward pairs with dP, with ONE bf16
+      // probability operand.  (exp2's argument differs by one fp32 rounding of t - m between the two:
+      // ~1e-6 relative, a bf16 flip once in ~3000 elements -- below fp32 accumulation noise in D.)
+      mx = fa_xmax4(mx);
+      const float m_new = fmaxf(m_run[f], ceilf(mx));
       const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // m_run = -inf on the first tile -> 0
       const float c0 = addc - m_new;
       float rs = 0.f;
-      // The probabilities enter P V as a bf16 PAIR hi + lo (two MFMAs): O then carries P to ~2^-17
-      // instead of 2^-9.  Backward's D_i = dO_i . O_i must equal sum_j P_ij dP_ij of the RECOMPUTED fp32
-      // P to far better than bf16 precision: dS = P (dP - D) sums to zero over keys only then, and any
-      // residue multiplies the component common to all keys / queries (large once biases are non-zero),
-      // which the softmax's shift invariance removes from the true gradient (measured: w_query / w_key
-      // gradients of the upper Conformer-L blocks at cosine 0.45 with a single bf16 P).
       float kp[4][4];
       if (drop) fa_keep(kp, rowhash[f], kt * 64, g, thr16, inv_keep);
 #pragma unroll
@@ -324,14 +370,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
             pr[q] = v;
           }
           const bf16x2 hi = __builtin_convertvector(pr, bf16x2);
-          const bf16x2 lo = __builtin_convertvector(pr - __builtin_convertvector(hi, f32x2), bf16x2);
           Pf[f][kf >> 1][(kf & 1) * 4 + e2] = hi[0];
           Pf[f][kf >> 1][(kf & 1) * 4 + e2 + 1] = hi[1];
-          Pl[f][kf >> 1][(kf & 1) * 4 + e2] = lo[0];
-          Pl[f][kf >> 1][(kf & 1) * 4 + e2 + 1] = lo[1];
         }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
+      // l_run is this LANE's partial row sum (its 16 keys per tile); alpha is common to the four lanes of a
+      // query, so the partials are combined once, after the last tile
       l_run[f] = l_run[f] * alpha + rs;
       m_run[f] = m_new;
 #pragma unroll
@@ -344,23 +387,20 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
     for (int ddf = 0; ddf < 4; ++ddf)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 vT = frag_tr(Vc, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r);
+        const bf16x8 vT = frag_tr_dma(Vc, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r);
 #pragma unroll
         for (int f = 0; f < NQ; ++f) {
           o_acc[f][ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pf[f][s], o_acc[f][ddf], 0, 0, 0);
-          o_acc[f][ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pl[f][s], o_acc[f][ddf], 0, 0, 0);
         }
       }
-    if (kt + 1 < nkt) {
-      tile_store(Ks[(kt + 1) & 1], kr);
-      tile_store(Vs[(kt + 1) & 1], vr);
-    }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 have landed ...
+    __syncthreads();                                     // ... everybody's have; tile kt's buffers are free
   }
 #pragma unroll
   for (int f = 0; f < NQ; ++f) {
+    const float l_row = fa_xsum4(l_run[f]);
     if (qi[f] < T) {
-      const float inv = nsp_rcp(l_run[f]);
+      const float inv = nsp_rcp(l_row);
       __bf16* op = O + (brow0 + qi[f]) * d + h * DK;
       float* op32 = O32 ? O32 + (brow0 + qi[f]) * d + h * DK : nullptr;
 #pragma unroll
@@ -419,14 +459,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, __bf16* __restrict__ dqkv,
     const nsp_attn_mask_params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char Qs[2][64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char dOs[2][64 * KP];
-  __shared__ __attribute__((aligned(16))) float QPs[2][64][16];
-  __shared__ __attribute__((aligned(16))) float st_c0[2][64];    // far score * sl2 - row max (uniform tiles)
-  __shared__ __attribute__((aligned(16))) float st_max[2][64];   // row max (log2 domain)
-  __shared__ __attribute__((aligned(16))) float st_inv[2][64];   // 1 / row sum (0 for rows >= T)
-  __shared__ __attribute__((aligned(16))) float st_d[2][64];     // D_i = dO_i . O_i
-  __shared__ __attribute__((aligned(16))) unsigned st_hash[2][64];
+  // one LDS object (see the forward kernel): Q | dO tiles (DMA images), position rows, per-query statistics
+  __shared__ __attribute__((aligned(16))) unsigned char SM[4 * 64 * KD + 2 * 64 * 16 * 4 + 5 * 2 * 64 * 4];
+  unsigned char (*Qs)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(SM);
+  unsigned char (*dOs)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(SM + 2 * 64 * KD);
+  float (*QPs)[64][16] = reinterpret_cast<float (*)[64][16]>(SM + 4 * 64 * KD);
+  float (*st_c0)[64] = reinterpret_cast<float (*)[64]>(SM + 4 * 64 * KD + 2 * 64 * 16 * 4);   // far score * sl2 - row max (uniform tiles)
+  float (*st_max)[64] = st_c0 + 2;       // row max (log2 domain)
+  float (*st_inv)[64] = st_c0 + 4;       // 1 / row sum (0 for rows >= T)
+  float (*st_d)[64] = st_c0 + 6;         // D_i = dO_i . O_i
+  unsigned (*st_hash)[64] = reinterpret_cast<unsigned (*)[64]>(st_c0 + 8);
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -440,6 +482,19 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
   const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
   const int rp = p.r_pitch;
+  if (!p.causal && p.chunk_nc == 0 && klen >= 1 && k0 >= klen) {
+    // every probability of these keys is exactly 0 (see fa_key_tiles): dK = dV = 0
+    for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+      const int kk = k0 + (idx >> 4), c = (idx & 15) * 4;
+      if (kk < T) {
+        const long long rowoff = (brow0 + kk) * ld3 + h * DK + c;
+        const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        *reinterpret_cast<bf16x4*>(dqkv + rowoff + d) = z;
+        *reinterpret_cast<bf16x4*>(dqkv + rowoff + 2 * d) = z;
+      }
+    }
+    return;
+  }
   const int key = k0 + wave * 16 + r;                 // this lane's key
   // K / V fragments of the wave's 16 keys (Y operands: row = key r, k-chunk (s, g))
   bf16x8 Kf[2], Vf[2];
@@ -500,18 +555,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
   auto qp_store = [&](int buf, const float4& v) {
     *reinterpret_cast<float4*>(&QPs[buf][threadIdx.x >> 2][(threadIdx.x & 3) * 4]) = v;
   };
-  TileRegs qr, dor;
-  tile_load(qr, qbase, ld3, brow0, 0, T);
-  tile_load(dor, dobase, d, brow0, 0, T);
   float4 qpr = qp_load(0);
   Stat str = stat_load(0);
+  tile_dma(Qs[0], qbase, ld3, brow0, 0, T, wave, lane);
+  tile_dma(dOs[0], dobase, d, brow0, 0, T, wave, lane);
   f32x4 dk_acc[4], dv_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dk_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  tile_store(Qs[0], qr);
-  tile_store(dOs[0], dor);
   qp_store(0, qpr);
   stat_store(0, str);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // dropout: the pair-of-keys part of the hash is constant for the lane (its key is fixed)
   const unsigned pair = (unsigned)key >> 1;
@@ -522,10 +575,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
     const int q0 = qt * 64;
     const int cur = qt & 1;
     if (qt + 1 < nqt) {
-      tile_load(qr, qbase, ld3, brow0, q0 + 64, T);
-      tile_load(dor, dobase, d, brow0, q0 + 64, T);
+      // (the register loads first: a wait for them then does not have to cover the DMA issued after them)
       qpr = qp_load(q0 + 64);
       str = stat_load(q0 + 64);
+      tile_dma(Qs[cur ^ 1], qbase, ld3, brow0, q0 + 64, T, wave, lane);
+      tile_dma(dOs[cur ^ 1], dobase, d, brow0, q0 + 64, T, wave, lane);
     }
     // S[query][key], dP[query][key] for the 4 query blocks: lane = key r, queries qb*16 + 4g + e
     f32x4 s_acc[4], dp_acc[4];
@@ -535,8 +589,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
       dp_acc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        s_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Qs[cur], qb * 16, s2, r, g), Kf[s2], s_acc[qb], 0, 0, 0);
-        dp_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(dOs[cur], qb * 16, s2, r, g), Vf[s2], dp_acc[qb], 0, 0, 0);
+        s_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc_dma(Qs[cur], qb * 16, s2, r, g), Kf[s2], s_acc[qb], 0, 0, 0);
+        dp_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc_dma(dOs[cur], qb * 16, s2, r, g), Vf[s2], dp_acc[qb], 0, 0, 0);
       }
     }
     const FaTile tl = fa_tile(p, QP != nullptr, q0, k0, T, klen);
@@ -562,6 +616,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
         bool vis = true;
         if (uni) {
           ex = __builtin_amdgcn_exp2f(fmaf(s_acc[qb][e], sl2, c0a[e]));
+        } else if (tl.plain) {          // near the diagonal, no mask predicate (fa_logits_near)
+          const int dlt = q0 + ql - key;
+          const int rel = min(dlt < 0 ? -dlt : dlt, p.clamp);
+          ex = __builtin_amdgcn_exp2f(fmaf(s_acc[qb][e], sl2, QPs[cur][ql][rel]) - mxa[e]);
         } else {
           const int qi = q0 + ql;
           float v = s_acc[qb][e] * sl2;
@@ -582,10 +640,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
           y = __umul24(y >> 8, 0x85EBCBu) ^ y;
           keep = ((y >> half_shift) & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
         }
-        const float pr = ex * ina[e];
-        float ds = pr * p.scale * fmaf(dp_acc[qb][e], keep, -dda[e]);
+        // pdr = the value forward fed into P V, bit for bit (integer row max: see the forward kernel); the first
+        // term pairs it with dP so that sum_j of it equals D_i = dO_i . O_i, the second uses the fp32
+        // probability that sums to one with the saved 1 / l
+        const float pdr = (float)(__bf16)(ex * keep);
+        float ds = ina[e] * p.scale * fmaf(pdr, dp_acc[qb][e], -ex * dda[e]);
         if (!vis) ds = 0.f;
-        Pt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)(pr * keep);
+        Pt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)(pdr * ina[e]);
         dSt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)ds;
       }
     }
@@ -594,17 +655,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        const bf16x8 doT = frag_tr(dOs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
-        const bf16x8 qT = frag_tr(Qs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
+        const bf16x8 doT = frag_tr_dma(dOs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
+        const bf16x8 qT = frag_tr_dma(Qs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
         dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pt[s2], doT, dv_acc[df], 0, 0, 0);
         dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dSt[s2], qT, dk_acc[df], 0, 0, 0);
       }
     if (qt + 1 < nqt) {
-      tile_store(Qs[cur ^ 1], qr);
-      tile_store(dOs[cur ^ 1], dor);
       qp_store(cur ^ 1, qpr);
       stat_store(cur ^ 1, str);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // next tile's buffers visible; this tile's free
   }
   // D[i = key (4g+e)][j = lane&15 = channel within fragment df]
@@ -630,10 +690,11 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, float* __restrict__ dq32,
     float* __restrict__ dQP, const nsp_attn_mask_params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][64 * KP];
-  __shared__ __attribute__((aligned(16))) unsigned char Vs[2][64 * KP];
-  __shared__ float QPs[64][17];
-  __shared__ float dQPs[64][17];
+  __shared__ __attribute__((aligned(16))) unsigned char KV[4 * 64 * KD + 2 * 64 * 17 * 4];   // one LDS object (see the forward kernel)
+  unsigned char (*Ks)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV);
+  unsigned char (*Vs)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV + 2 * 64 * KD);
+  float (*QPs)[17] = reinterpret_cast<float (*)[17]>(KV + 4 * 64 * KD);
+  float (*dQPs)[17] = reinterpret_cast<float (*)[17]>(KV + 4 * 64 * KD + 64 * 17 * 4);
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -673,23 +734,21 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
   const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
   const __bf16* kbase = qkv + d + h * DK;
   const __bf16* vbase = qkv + 2 * d + h * DK;
-  TileRegs kr, vr;
-  tile_load(kr, kbase, ld3, brow0, 0, T);
-  tile_load(vr, vbase, ld3, brow0, 0, T);
+  tile_dma(Ks[0], kbase, ld3, brow0, 0, T, wave, lane);
+  tile_dma(Vs[0], vbase, ld3, brow0, 0, T, wave, lane);
   f32x4 dq_acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) dq_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float far = 0.f;
-  tile_store(Ks[0], kr);
-  tile_store(Vs[0], vr);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int nkt = (T + 63) / 64;
+  const int nkt = fa_key_tiles(p, T, klen);
   for (int kt = 0; kt < nkt; ++kt) {
     const unsigned char* Kc = Ks[kt & 1];
     const unsigned char* Vc = Vs[kt & 1];
     if (kt + 1 < nkt) {
-      tile_load(kr, kbase, ld3, brow0, (kt + 1) * 64, T);
-      tile_load(vr, vbase, ld3, brow0, (kt + 1) * 64, T);
+      tile_dma(Ks[(kt + 1) & 1], kbase, ld3, brow0, (kt + 1) * 64, T, wave, lane);
+      tile_dma(Vs[(kt + 1) & 1], vbase, ld3, brow0, (kt + 1) * 64, T, wave, lane);
     }
     f32x4 s_acc[4], dp_acc[4];
 #pragma unroll
@@ -698,8 +757,8 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
       dp_acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Kc, kf * 16, s, r, g), Qf[s], s_acc[kf], 0, 0, 0);
-        dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(Vc, kf * 16, s, r, g), dOf[s], dp_acc[kf], 0, 0, 0);
+        s_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc_dma(Kc, kf * 16, s, r, g), Qf[s], s_acc[kf], 0, 0, 0);
+        dp_acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc_dma(Vc, kf * 16, s, r, g), dOf[s], dp_acc[kf], 0, 0, 0);
       }
     }
     bf16x8 dSf[2];
@@ -710,7 +769,10 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     const float rs_ = rinv * p.scale;
     float ev[4][4], kp[4][4];
     unsigned vis = 0xFFFFu;
-    if (!uni) vis = fa_logits(s_acc, ev, p, qrow, sl2, qi, kt * 64, g, klen, tl);
+    if (!uni) {
+      if (tl.plain) fa_logits_near(s_acc, ev, qrow, sl2, qi, kt * 64, g, p.clamp);
+      else vis = fa_logits(s_acc, ev, p, qrow, sl2, qi, kt * 64, g, klen, tl);
+    }
     if (drop) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf)
@@ -720,7 +782,8 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
         float ex = uni ? __builtin_amdgcn_exp2f(fmaf(s_acc[kf][e], sl2, c0)) : __builtin_amdgcn_exp2f(ev[kf][e] - rmax);
         if (!tl.plain && key >= T) ex = 0.f;
         const float keep = drop ? kp[kf][e] : 1.f;
-        float ds = ex * rs_ * fmaf(dp_acc[kf][e], keep, -dsum);
+        const float pdr = (float)(__bf16)(ex * keep);       // forward's P V operand, bit for bit (see flash_bwd_dkv_kernel)
+        float ds = rs_ * fmaf(pdr, dp_acc[kf][e], -ex * dsum);
         if (!tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
         dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
         if (QP) {
@@ -740,11 +803,8 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
 #pragma unroll
       for (int s = 0; s < 2; ++s)
         dq_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            frag_tr(Kc, df * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), dSf[s], dq_acc[df], 0, 0, 0);
-    if (kt + 1 < nkt) {
-      tile_store(Ks[(kt + 1) & 1], kr);
-      tile_store(Vs[(kt + 1) & 1], vr);
-    }
+            frag_tr_dma(Kc, df * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), dSf[s], dq_acc[df], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   if (qi < T) {
@@ -779,7 +839,8 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
     return NSP_EUNSUPPORTED;
   if (p.r_pitch < p.R) p.r_pitch = p.R;
   const char* e = getenv("NSP_FLASH_NQ");
-  const int nq = e ? atoi(e) : 1;   // 16 queries per wave measured faster than 32 (occupancy 3 vs 2)
+  const int nq = e ? atoi(e) : 1;   // 16 queries per wave measured faster than 32 (occupancy 3 vs 2; round 3: 228 vs 311 us at T = 800, B = 64)
+  // (forcing 4 waves per SIMD -- 128 VGPRs, 8 dwords spilled -- measured equal to the 137-VGPR / 3-wave build)
   if (nq == 1) {
     dim3 grid(((p.Tq + 63) / 64) * p.H, p.B);
     hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream,

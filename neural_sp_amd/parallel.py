@@ -82,9 +82,47 @@ def pin_grad_streams(model):
     return keep
 
 
-def make_comm_hook(streams, compress=None):
-    """DDP communication hook: all-reduce(mean) of one bucket, launched from a gather stream that
-    waits for every stream of the step (see the module docstring); `compress='bf16'` sends bf16."""
+class CommStats(object):
+    """What bench.py reports about the collective under DDP: per backward pass the number of buckets, their bytes,
+    and the event recorded on the hook's stream when the LAST bucket became ready (= backward's compute is fully
+    enqueued); `exposed_ms(after)` = time from that point to `after` (an event recorded once backward() has returned,
+    i.e. behind DDP's wait for every collective) = communication that backward could not hide."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.buckets, self.bytes, self.last_ready, self.waited_side = 0, 0, None, 0
+
+    def exposed_ms(self, after):
+        return None if self.last_ready is None else self.last_ready.elapsed_time(after)
+
+
+def param_streams(model):
+    """{id(parameter): stream} for the parameters whose gradients are produced on a side stream of the step
+    (prediction network -> its side stream, CTC head -> the CTC stream); everything else is the main stream's."""
+    out = {}
+    for name in ('dec_fwd', 'dec_fwd_sub1', 'dec_fwd_sub2'):
+        dec = getattr(model, name, None)
+        if dec is None or not hasattr(dec, 'ensure_streams') or not next(model.parameters()).is_cuda:
+            continue
+        side, ctc = dec.ensure_streams()
+        if side is not None:
+            for p in dec.prediction_network_parameters():
+                out[id(p)] = side
+            if ctc is not None and getattr(dec, 'ctc', None) is not None:
+                for p in dec.ctc.parameters():
+                    out[id(p)] = ctc
+    return out
+
+
+def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_stream=None):
+    """DDP communication hook: all-reduce(mean) of one bucket, launched from a gather stream.  The gather stream
+    waits for the hook's (main) stream and for the side streams that produced gradients OF THIS BUCKET
+    (`pstreams` = param_streams(model)): a bucket of encoder parameters no longer waits for the prediction
+    network's LSTM backward (8 ms per 64 utterances on its side stream), so the early buckets' collectives start
+    while it is still running.  Without `pstreams` every bucket waits for every stream of the step.
+    `compress='bf16'` sends bf16; `stats` (CommStats) collects what bench.py prints."""
     import torch.distributed as dist
     gather = {}
 
@@ -98,9 +136,27 @@ def make_comm_hook(streams, compress=None):
         g = gather.get(dev)
         if g is None:
             g = gather[dev] = torch.cuda.Stream(device=dev)
-        g.wait_stream(torch.cuda.current_stream(dev))
-        for s in streams:
+        cur = torch.cuda.current_stream(dev)      # the stream of the gradient that completed the bucket
+        g.wait_stream(cur)
+        if main_stream is not None and main_stream != cur:
+            g.wait_stream(main_stream)             # (the other gradients of the bucket may be the main stream's)
+        if pstreams is None:
+            need = list(streams)
+        else:
+            need = []
+            for p in bucket.parameters():
+                s = pstreams.get(id(p))
+                if s is not None and s not in need:
+                    need.append(s)
+        for s in need:
             g.wait_stream(s)
+        if stats is not None:
+            stats.buckets += 1
+            stats.bytes += buf.numel() * buf.element_size()
+            stats.waited_side += len(need)
+            if bucket.is_last():
+                stats.last_ready = torch.cuda.Event(enable_timing=True)
+                stats.last_ready.record(cur)
         buf.record_stream(g)
         with torch.cuda.stream(g):
             if compress == 'bf16':
@@ -130,7 +186,10 @@ def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
     pin_grad_streams(model)
     ddp = DDP(model, device_ids=[local_rank], **kw)
     compress = compress if compress is not None else (os.environ.get('NSP_DDP_COMPRESS') or None)
-    ddp.register_comm_hook(None, make_comm_hook(step_streams(model), compress))
+    ddp.comm_stats = CommStats()
+    pstreams = param_streams(model) if os.environ.get('NSP_DDP_WAIT_ALL_STREAMS', '0') != '1' else None
+    ddp.register_comm_hook(None, make_comm_hook(step_streams(model), compress, pstreams, ddp.comm_stats,
+                                                torch.cuda.current_stream(torch.device('cuda', local_rank))))
     return ddp
 
 

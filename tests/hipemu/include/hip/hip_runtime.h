@@ -213,6 +213,23 @@ template <class T> static inline T __shfl_xor(T v, int m, int = 64) { return hip
 template <class T> static inline T __shfl_down(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_down, d); }
 template <class T> static inline T __shfl_up(T v, int d, int = 64) { return hipemu_shfl(v, hipemu_src_up, d); }
 template <class T> static inline T __shfl(T v, int i, int = 64) { return hipemu_shfl(v, hipemu_src_idx, i); }
+// v_permlane16_swap / v_permlane32_swap (vdst, src): odd 16-lane rows (upper 32-lane half) of vdst <-> even rows (lower
+// half) of src; returns {vdst', src'}
+struct hipemu_swap_pair { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+static inline int hipemu_src_same(int lane, int) { return lane; }
+static inline hipemu_swap_pair hipemu_permlane_swap(unsigned a, unsigned b, int width) {
+  const int lane = hipemu::tid_flat & 63;
+  const bool upper = (lane / width) & 1;
+  // lane in an upper block of vdst receives src's lane - width; lane in a lower block of src receives vdst's lane + width
+  const unsigned b_from_lo = hipemu_shfl(b, hipemu_src_up, width);     // value of b at lane - width
+  const unsigned a_from_hi = hipemu_shfl(a, hipemu_src_down, width);   // value of a at lane + width
+  hipemu_swap_pair r;
+  r.v[0] = upper ? b_from_lo : a;
+  r.v[1] = upper ? b : a_from_hi;
+  return r;
+}
+static inline hipemu_swap_pair __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) { return hipemu_permlane_swap(a, b, 16); }
+static inline hipemu_swap_pair __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) { return hipemu_permlane_swap(a, b, 32); }
 // DPP quad_perm (dpp_ctrl < 0x100: lane l reads lane (l & ~3) | ((ctrl >> 2 (l & 3)) & 3)); all rows / banks enabled
 static inline int hipemu_src_quad(int lane, int ctrl) { return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3); }
 static inline int __builtin_amdgcn_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {

@@ -45,3 +45,27 @@ def test_two_rank_ddp_gradients_equal_single_process(compress):
     # world x mean over ranks of the local means == world x the global mean (equal shard sizes)
     mean_local = sum(l[0] for l in res['losses']) / world / world
     assert abs(mean_local - res['single_loss']) / abs(res['single_loss']) < 1e-3
+
+
+def test_bench_two_ranks_same_device_reports_comm_fields():
+    """`bench.py --gpus 2` through its own launcher path (self-spawn via torch.distributed.run on 127.0.0.1), two
+    ranks on cuda:0 over gloo (RCCL refuses two ranks per device): the spawn path the driver's scaling run uses, the
+    per-bucket stream waits of the comm hook and the exposed-communication fields, on a small model."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--same-device', '--dist-backend', 'gloo',
+           '--steps', '3', '--warmup', '2', '--batch', '4', '--size', 'XS', '--tmin', '200', '--tmax', '320',
+           '--umin', '10', '--umax', '24', '--no-cpu-baseline', '--no-b16']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 0
+    c = d['comm']
+    assert c['buckets_per_step'] >= 1 and c['bytes_per_step'] > 0 and c['exposed_ms_per_step'] >= 0.0
+    print('[bench 2 ranks / gloo / one device] %.0f frames/s, comm %s' % (d['value'], {k: c[k] for k in c if k != 'definition'}))

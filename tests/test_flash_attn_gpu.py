@@ -41,7 +41,8 @@ def _reference(qkv, QP, klens, H, clamp, scale, causal, lookahead, nl, nc):
 
 
 @pytest.mark.parametrize('T,with_pos,causal,nc', [(130, True, False, 0), (64, False, False, 0),
-                                                  (200, True, True, 0), (96, True, False, 16)])
+                                                  (200, True, True, 0), (96, True, False, 16),
+                                                  (330, True, False, 0), (330, False, False, 0)])
 def test_flash_attention_matches_reference(T, with_pos, causal, nc):
     from neural_sp_amd import ops
     torch.manual_seed(T)
@@ -64,7 +65,7 @@ def test_flash_attention_matches_reference(T, with_pos, causal, nc):
                           nl, nc, r_pitch=Rp if with_pos else 0)
     qkv2 = qkv.view(B * T, 3 * d)
     O, O32, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP if with_pos else None, mp)
-    assert _rel(O32.view(B, T, d), Oref.detach()) < 1e-4      # hi+lo P: fp32-grade context
+    assert _rel(O32.view(B, T, d), Oref.detach()) < 4e-3      # one bf16 probability operand (integer row max: backward reproduces it bit for bit)
     assert _rel(O.float().view(B, T, d), Oref.detach()) < 1.5e-2
     lse = LSE[0] * math.log(2.0) - torch.log(LSE[1])   # LSE[0]: row max in the log2 domain
     ok = LSEref.detach() > -1e30  # fully masked rows: max + log(sum) is not representable in fp32

@@ -22,7 +22,7 @@ for T in (800, 400, 200):
         def fwd(): ops.flash_attn_fwd_raw(qkv, d, QP, mp)
         def bwd(): ops.flash_attn_bwd_raw(qkv, d, QP, dO, O32, LSE, mp, dqkv)
         res = []
-        for nq in ('2', '1'):
+        for nq, occ in (('2', ''), ('1', '')):
             os.environ['NSP_FLASH_NQ'] = nq
             for _ in range(2): fwd()
             torch.cuda.synchronize()
@@ -30,7 +30,7 @@ for T in (800, 400, 200):
             e0.record()
             for _ in range(10): fwd()
             e1.record(); torch.cuda.synchronize()
-            print('   NQ=%s fwd %7.1f us' % (nq, e0.elapsed_time(e1) * 100), flush=True)
+            print('   NQ=%s OCC=%s fwd %7.1f us' % (nq, occ or 'default', e0.elapsed_time(e1) * 100), flush=True)
         for fn in (fwd, bwd):
             for _ in range(2): fn()
             torch.cuda.synchronize()
