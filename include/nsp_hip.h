@@ -629,6 +629,51 @@ int nsp_lstm_cell_step(const float* gates, const float* h_prev, const float* c_p
                        const int* update /*device [B] or NULL*/, float* h_out, float* c_out,
                        int B, int H, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Monotonic (chunkwise) attention training scans (MoChA / MMA), fp32, `rows`  *
+ * independent rows of klen encoder frames, one wave per row (mocha.hip).      *
+ * hma_train.py:12-67: p = (1 - stableemit) sigmoid(e); c = exclusive cumprod  *
+ *   of clamp(1 - p, eps, 1) in log space; alpha = p c cumsum(aw_prev / den),   *
+ *   den = clamp(c, eps, 1) (1 when no_denom).  p_choose / cprod are saved for  *
+ *   the backward, which returns d e and d aw_prev.                              *
+ * mocha_train.py:13-83: ex = max(exp(u - max u), 1e-5); den_j = sum of ex over  *
+ *   the w frames ending at j; beta_i = ex_i sum_{j=i}^{i+w-1} alpha_j sf / den_j *
+ *   (w = -1: MILk, den = prefix sum, outer sum to the end of the row; w <= 64). *
+ * ------------------------------------------------------------------------ */
+int nsp_mono_alpha_fwd(const float* e, const float* aw_prev, float* alpha, float* p_choose, float* cprod,
+                       int rows, int klen, float eps, int no_denom, float stableemit, void* stream);
+int nsp_mono_alpha_bwd(const float* d_alpha, const float* p_choose, const float* cprod, const float* aw_prev,
+                       float* d_e, float* d_aw_prev, int rows, int klen, float eps, int no_denom,
+                       float stableemit, void* stream);
+int nsp_chunk_beta_fwd(const float* u, const float* alpha, float* beta, int rows, int klen, int w, float sf,
+                       void* stream);
+int nsp_chunk_beta_bwd(const float* d_beta, const float* u, const float* alpha, float* d_u, float* d_alpha,
+                       int rows, int klen, int w, float sf, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Per-step pieces of the attention-based LSTM decoder (decoder_step.hip),   *
+ * fp32.  las.py:667-776, modules/attention.py:148-176, monotonic_energy.py:  *
+ * 137-146, chunk_energy.py.                                                 *
+ *  add_energy: e[b,t] = sum_a v[a] act(K[b,t,a] + Q[b,a] (+ C[b,t,a]));     *
+ *    act = NSP_ACT_TANH | NSP_ACT_RELU; C may be NULL.  bwd: dtmp [B,T,A] =  *
+ *    de v act' (gradient of K and of C), dQ [B,A] = sum_t dtmp, dv_part      *
+ *    [B,A] = sum_t de act(tmp) (dv = its sum over b).                        *
+ *  row_softmax: aw = softmax(sharp * e) over frames with mask != 0 (mask    *
+ *    uint8 [rows,T] or NULL); masked frames get no gradient.                 *
+ *  lstm_cell: gates [B,4H] pre-activation, PyTorch order (i,f,g,o).          *
+ * ------------------------------------------------------------------------ */
+int nsp_add_energy_fwd(const float* K, const float* Q, const float* C, const float* v, float* e, int B, int T,
+                       int A, int act, void* stream);
+int nsp_add_energy_bwd(const float* de, const float* K, const float* Q, const float* C, const float* v,
+                       float* dtmp, float* dQ, float* dv_part, int B, int T, int A, int act, void* stream);
+int nsp_row_softmax_fwd(const float* e, const unsigned char* mask, float* aw, int rows, int T, float sharp,
+                        void* stream);
+int nsp_row_softmax_bwd(const float* aw, const float* daw, const unsigned char* mask, float* de, int rows, int T,
+                        float sharp, void* stream);
+int nsp_lstm_cell_fwd(const float* gates, const float* c_prev, float* h, float* c, int B, int H, void* stream);
+int nsp_lstm_cell_bwd(const float* dh, const float* dc_next, const float* gates, const float* c_prev, const float* c,
+                      float* dgates, float* dc_prev, int B, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

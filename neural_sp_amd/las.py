@@ -8,16 +8,15 @@ las.py:735-745).  Parameter names and shapes are the reference's (checked agains
 reference-generated fixtures), so checkpoints are interchangeable.
 
 How it is built.  The decoder is a teacher-forced loop over target positions (`for i in range(ymax)`,
-las.py:667) whose step is a handful of [B, .]-sized operations.  SURVEY 8f keeps that loop in
-PyTorch tensor operations; here the GEMM-shaped parts go through this package's kernels
-(`ops.linear`: key / query / location projections, LSTM gate GEMMs, bottleneck, output layer), the
-label-smoothed XE + accuracy is the fused `ops.xe_lsm_loss` kernel and the CTC branch is `CTC`
-(ctc.hip); the per-step glue -- LSTM cell non-linearities, tanh/softmax of the energies, the
-cumulative sums / products of the monotonic recurrences -- are plain torch tensor ops on the device
-(with autograd).  That is deliberate for this round: the decoder is not on the benchmarked path;
-fused step kernels (energy + softmax + context; alpha recurrence as a wavefront scan) are the next
-step.  Everything that does not feed back into the recurrence is hoisted out of the loop: the
-key projections are computed once, the bottleneck + tanh + output layer run once over all steps.
+las.py:667) whose step is a handful of [B, .]-sized operations: that loop stays a host loop.  Every piece of
+arithmetic inside it is a kernel of libnsp_hip.so: `ops.linear` (key / query / location projections, LSTM gate GEMMs,
+bottleneck, output layer), `ops.add_energy` (v . tanh / relu of the summed projections in one pass),
+`ops.row_softmax` (masked, sharpened), `ops.head_context` (batched GEMM), `ops.lstm_cell`, and for MoChA the scan
+kernels `ops.mono_alpha` / `ops.chunk_beta` (csrc/mocha.hip); the label-smoothed XE + accuracy is the fused
+`ops.xe_lsm_loss` kernel and the CTC branch is `CTC` (ctc.hip).  What remains in torch is glue (concatenations,
+the Gaussian noise on the monotonic energies, the scalar quantity / latency losses) and the test-time (hard) MoChA
+path used by greedy decoding.  Everything that does not feed back into the recurrence is hoisted out of the loop:
+the key projections are computed once, the bottleneck + tanh + output layer run once over all steps.
 
 Not built (NotImplementedError): LM fusion / initialisation, MBR training,
 multi-head / GMM / dot-family attention, MoChA with several heads, 1-d conv, DeCoT / latency losses,
@@ -74,29 +73,33 @@ class AttentionMechanism(nn.Module):
         if self.key is None or not cache:
             self.key = ops.linear(key, self.w_key.weight, self.w_key.bias)          # [B,T,adim], once per batch
             self.mask = mask
-        tmp = self.key + ops.linear(query, self.w_query.weight)                      # [B,T,adim] + [B,1,adim]
+        q_proj = ops.linear(query, self.w_query.weight)                              # [B,1,adim]
+        loc = None
         if self.atype == 'location':
             # Conv2d(1 -> ch, (1,k), 'same') over the previous attention weights as a GEMM on the k-wide
             # windows of the zero-padded signal: [B*T, k] x [k, ch] (attention.py:142-145)
             k = self.conv.weight.shape[-1]
             win = nn.functional.pad(aw_prev, ((k - 1) // 2, (k - 1) // 2)).unfold(-1, k, 1)   # [B,1,T,k]
             conv_feat = ops.linear(win.reshape(bs, klen, k), self.conv.weight.view(-1, k))     # [B,T,ch]
-            tmp = tmp + ops.linear(conv_feat, self.w_conv.weight)
-        e = (torch.tanh(tmp) * self.v.weight.view(1, 1, -1)).sum(-1).unsqueeze(1)   # v(.) with one output
+            loc = ops.linear(conv_feat, self.w_conv.weight)                           # [B,T,adim]
+        # e = v . tanh(key + query (+ location)): one pass over the key projection (nsp_add_energy_fwd)
+        e = ops.add_energy(self.key, q_proj, self.v.weight, 'tanh', loc).unsqueeze(1)  # [B,1,T]
+        mask_ = self.mask
         if self.atype == 'triggered_attention':
             # attention.py:165-169: nothing beyond the token's CTC boundary + `lookahead` frames is attended to
             assert trigger_points is not None
             j = torch.arange(klen, device=key.device).view(1, 1, klen)
-            e = e.masked_fill(j > (trigger_points.view(bs, 1, 1).long() + self.lookahead), NEG_INF)
-        if self.mask is not None:
-            e = e.masked_fill(self.mask == 0, NEG_INF)
+            reach = j <= (trigger_points.view(bs, 1, 1).long() + self.lookahead)
+            mask_ = reach if mask_ is None else (reach & (mask_ != 0))
         if self.sigmoid_smoothing:
+            if mask_ is not None:
+                e = e.masked_fill(mask_ == 0, NEG_INF)
             s = torch.sigmoid(e)
             aw = s / s.sum(-1, keepdim=True)
         else:
-            aw = torch.softmax(e * self.sharpening_factor, dim=-1)
+            aw = ops.row_softmax(e, mask_, self.sharpening_factor)                    # masked, sharpened soft-max: one kernel
         aw = self.dropout(aw)
-        cv = torch.bmm(aw, value)
+        cv = ops.head_context(aw.unsqueeze(1), value.unsqueeze(2)).view(bs, 1, value.shape[-1])
         return cv, aw.unsqueeze(1), {}
 
 
@@ -135,30 +138,12 @@ class _AddEnergy(nn.Module):
         if self.key is None or not cache:
             self.key = ops.linear(key, self.w_key.weight, self.w_key.bias)
             self.mask = mask
-        tmp = torch.relu(self.key + ops.linear(query, self.w_query.weight))          # [B,T,adim]
-        e = (tmp * self.v_weight().view(1, 1, -1)).sum(-1).unsqueeze(1)             # [B,1,T]
+        e = ops.add_energy(self.key, ops.linear(query, self.w_query.weight), self.v_weight(), 'relu').unsqueeze(1)  # [B,1,T]
         if self.monotonic:
             e = e + self.r
         if self.mask is not None:
             e = e.masked_fill(self.mask == 0, NEG_INF)
         return e.unsqueeze(1)
-
-
-def _exclusive_cumsum(x):
-    return torch.cumsum(torch.cat([x.new_zeros(x.shape[:-1] + (1,)), x[..., :-1]], dim=-1), dim=-1)
-
-
-def _safe_cumprod(x, eps):
-    """hma_train.py:80-89: exclusive cumulative product in log space."""
-    return torch.exp(_exclusive_cumsum(torch.log(torch.clamp(x, min=eps, max=1.0))))
-
-
-def _moving_sum(x, back, forward):
-    """mocha_train.py:60-83 (a ones-filter conv1d there): sum_{k=j-back}^{j+forward} x[k] with zero padding,
-    here as a difference of two cumulative sums."""
-    klen = x.shape[-1]
-    cs = torch.cumsum(nn.functional.pad(x, (back + 1, forward)), dim=-1)
-    return cs[..., back + 1 + forward: back + 1 + forward + klen] - cs[..., :klen]
 
 
 class MoChA(nn.Module):
@@ -206,12 +191,9 @@ class MoChA(nn.Module):
         # parallel_monotonic_attention (hma_train.py:12-67) for qlen = 1
         if self.noise_std > 0:                                                        # (training AND eval, as the reference)
             e_ma = e_ma + torch.zeros_like(e_ma).normal_(std=self.noise_std)
-        p_choose = torch.sigmoid(e_ma)
-        if self._stableemit_weight > 0:                                               # StableEmit (hma_train.py:43-44)
-            p_choose = (1 - self._stableemit_weight) * p_choose
-        cumprod_1mp = _safe_cumprod(1 - p_choose, self.eps)
-        denom = 1 if self.no_denom else torch.clamp(cumprod_1mp, min=self.eps, max=1.0)
-        alpha = p_choose * cumprod_1mp * torch.cumsum(aw_prev / denom, dim=-1)
+        # p_choose (StableEmit scaling, hma_train.py:43-44) -> exclusive cumprod in log space -> alpha recurrence:
+        # ONE scan kernel per direction (csrc/mocha.hip) instead of ~12 tensor ops
+        alpha, p_choose = ops.mono_alpha(e_ma, aw_prev, self.eps, self.no_denom, self._stableemit_weight)
         if self.decot:
             # delay-constrained training (hma_train.py:59-63): nothing may be selected more than `decot_delta`
             # frames after the token's reference boundary
@@ -222,16 +204,12 @@ class MoChA(nn.Module):
         if self.chunk_energy is not None:
             # soft_chunkwise_attention (mocha_train.py:13-58)
             u = self.chunk_energy(key, query, mask, cache)
-            u = u - torch.max(u, dim=-1, keepdim=True)[0]
-            softmax_exp = torch.clamp(torch.exp(u), min=1e-5)
-            if self.milk:
-                den = torch.cumsum(softmax_exp, dim=-1)
-                beta = softmax_exp * _moving_sum(alpha * self.sharpening_factor / den, back=0, forward=klen - 1)
-            else:
-                den = _moving_sum(softmax_exp, back=self.w - 1, forward=0)
-                beta = softmax_exp * _moving_sum(alpha * self.sharpening_factor / den, back=0, forward=self.w - 1)
+            if not ops.chunk_beta_supported(self.w):
+                raise NotImplementedError('MoChA chunk sizes above 64 frames (nsp_chunk_beta_fwd sums the window directly)')
+            beta = ops.chunk_beta(u, alpha, self.w, self.sharpening_factor)     # clamped exp, window sums, beta: one kernel
             beta = self.dropout_attn(beta)
-        cv = torch.bmm((alpha if self.w == 1 else beta).squeeze(1), value)
+        aw = alpha if self.w == 1 else beta                                      # [B,1,1,T]
+        cv = ops.head_context(aw, value.unsqueeze(2)).view(bs, 1, value.shape[-1])  # batched MFMA GEMM (was torch.bmm)
         return cv, alpha, {'beta': beta, 'p_choose': p_choose}
 
 
@@ -394,9 +372,7 @@ class RNNDecoder(DecoderBase):
         dout_score = None
         for l, cell in enumerate(self.rnn):
             gates = ops.linear(dout, cell.weight_ih, cell.bias_ih) + ops.linear(hxs[l], cell.weight_hh, cell.bias_hh)
-            gi, gf, gg, go = gates.chunk(4, dim=1)
-            c = torch.sigmoid(gf) * cxs[l] + torch.sigmoid(gi) * torch.tanh(gg)
-            h = torch.sigmoid(go) * torch.tanh(c)
+            h, c = ops.lstm_cell(gates, cxs[l])        # gate non-linearities + cell update: one kernel per direction
             new_h.append(h)
             new_c.append(c)
             dout = self.dropout(h)

@@ -7,8 +7,9 @@ H_ma monotonic heads each select frames with the expected-alignment recurrence o
 (alpha_i from alpha_{i-1}: a loop over the L target positions, vectorised over batch, heads and frames); every
 monotonic head feeds H_ca chunkwise heads that soft-max over the w frames ending at the selected one (moving sums as
 1-d convolutions with ones); the H_ma * H_ca context vectors are concatenated and projected (w_value / w_out).
-The four projections are the MFMA GEMMs of ops.linear; the per-position recurrence and the moving sums are torch
-tensor ops on the device, as for the LAS / MoChA decoder (las.py).  Parameter names follow the reference
+The four projections are the MFMA GEMMs of ops.linear, the energies and the context batched nsp_gemm calls
+(ops.head_scores / ops.head_context); the alpha recurrence and the chunkwise beta are the scan kernels of csrc/mocha.hip
+(ops.mono_alpha once per target position, ops.chunk_beta once for all positions).  Parameter names follow the reference
 (`src_attn.monotonic_energy.{w_key,w_query,r}`, `src_attn.chunk_energy.{w_key,w_query}`, `src_attn.{w_value,w_out}`).
 
 Not built: test-time (hard) attention -- decoding an MMA model raises; additive energies, the 1-d conv on the keys,
@@ -19,7 +20,6 @@ import random
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from neural_sp_amd import ops
 
@@ -51,28 +51,12 @@ class _ScaledDotEnergy(nn.Module):
         qlen = query.shape[1]
         k = ops.linear(key, self.w_key.weight, self.w_key.bias).view(bs, klen, self.n_heads, self.d_k)
         q = ops.linear(query, self.w_query.weight, self.w_query.bias).view(bs, qlen, self.n_heads, self.d_k)
-        e = torch.einsum('bihd,bjhd->bhij', q, k) / self.scale
+        e = ops.head_scores(q, k, 1.0 / self.scale)                                  # batched MFMA GEMM (was torch.einsum)
         if self.r is not None:
             e = e + self.r
         if mask is not None:
             e = e.masked_fill(~mask.unsqueeze(1), NEG_INF)
         return e
-
-
-def _safe_cumprod(x, eps):
-    """hma_train.py:87-106: exclusive cumulative product in log space"""
-    return torch.exp(_exclusive_cumsum(torch.log(torch.clamp(x, min=eps, max=1.0))))
-
-
-def _exclusive_cumsum(x):
-    return torch.cumsum(torch.cat([x.new_zeros(x.shape[:-1] + (1,)), x[..., :-1]], dim=-1), dim=-1)
-
-
-def _moving_sum(x, back, forward):
-    """mocha_train.py:61-83 on [..., klen]"""
-    shape = x.shape
-    y = F.conv1d(F.pad(x.reshape(-1, 1, shape[-1]), [back, forward]), x.new_ones(1, 1, back + forward + 1))
-    return y.view(shape[:-1] + (y.shape[-1],))
 
 
 class MMA(nn.Module):
@@ -132,18 +116,17 @@ class MMA(nn.Module):
         # parallel_monotonic_attention (hma_train.py:12-67)
         if self.noise_std > 0:
             e_ma = e_ma + torch.zeros_like(e_ma).normal_(std=self.noise_std)
-        p_choose = torch.sigmoid(e_ma)
-        if self._stableemit_weight > 0:
-            p_choose = (1 - self._stableemit_weight) * p_choose
-        cumprod_1mp = _safe_cumprod(1 - p_choose, self.eps)
+        # p_choose -> exclusive cumprod -> alpha_i from alpha_{i-1}: one scan kernel per target position and direction
+        # (csrc/mocha.hip, rows = batch x monotonic heads); the recurrence over positions stays a host loop
         aw_prev = key.new_zeros(bs, self.H_ma, 1, klen)
         aw_prev[:, :, :, 0] = 1.0
-        alphas = []
+        alphas, pcs = [], []
         for i in range(qlen):
-            denom = 1 if self.no_denom else torch.clamp(cumprod_1mp[:, :, i:i + 1], min=self.eps, max=1.0)
-            aw_prev = p_choose[:, :, i:i + 1] * cumprod_1mp[:, :, i:i + 1] * torch.cumsum(aw_prev / denom, dim=-1)
+            aw_prev, pc = ops.mono_alpha(e_ma[:, :, i:i + 1], aw_prev, self.eps, self.no_denom, self._stableemit_weight)
             alphas.append(aw_prev)
+            pcs.append(pc)
         alpha = torch.cat(alphas, dim=2)                                             # [B,H_ma,L,T]
+        p_choose = torch.cat(pcs, dim=2)
         alpha_masked = alpha
         if self.dropout_head > 0 and self.training:                                  # HeadDrop (headdrop.py:10-32)
             keep = [0.0 if random.random() < self.dropout_head else 1.0 for _ in range(self.H_ma)]
@@ -162,23 +145,19 @@ class MMA(nn.Module):
             u = u.unsqueeze(1)                                                       # [B,1,(H_ma*)H_ca,L,T]
             if self.H_ma > 1 and not self.share_ca:
                 u = u.view(bs, self.H_ma, self.H_ca, qlen, klen)
-            u = u - torch.max(u, dim=-1, keepdim=True)[0]
-            softmax_exp = torch.clamp(torch.exp(u), min=1e-5)
-            if self.milk:
-                den = torch.cumsum(softmax_exp, dim=-1)
-                beta = softmax_exp * _moving_sum(a * self.sharpening_factor / den, back=0, forward=klen - 1)
-            else:
-                den = _moving_sum(softmax_exp, back=self.w - 1, forward=0)
-                beta = softmax_exp * _moving_sum(a * self.sharpening_factor / den, back=0, forward=self.w - 1)
+            if not ops.chunk_beta_supported(self.w):
+                raise NotImplementedError('MMA chunk sizes above 64 frames (nsp_chunk_beta_fwd sums the window directly)')
+            full = (bs, self.H_ma, self.H_ca, qlen, klen)
+            beta = ops.chunk_beta(u.expand(full), a.expand(full), self.w, self.sharpening_factor)
             beta = self.dropout_attn(beta.reshape(bs, -1, qlen, klen))               # [B,H_ma*H_ca,L,T]
         po = out_dropout if self.training else 0.0
         if self.H_total > 1:
             v = ops.linear(value, self.w_value.weight, self.w_value.bias).view(bs, klen, self.H_total, self.d_k)
             aw = alpha_masked if self.w == 1 else beta                               # [B,H_total,L,T]
-            cv = torch.einsum('bhlt,bthd->blhd', aw, v).reshape(bs, qlen, self.H_total * self.d_k)
+            cv = ops.head_context(aw, v).reshape(bs, qlen, self.H_total * self.d_k)     # batched MFMA GEMM (was torch.einsum)
             cv = ops.linear(cv, self.w_out.weight, self.w_out.bias, res=residual, dropout_p=po)
         else:
-            cv = torch.bmm((alpha_masked if self.w == 1 else beta).squeeze(1), value)
+            cv = ops.head_context(alpha_masked if self.w == 1 else beta, value.unsqueeze(2)).view(bs, qlen, value.shape[-1])
             if residual is not None:
                 cv = residual + ops.dropout(cv, po, self.training)
         return cv, alpha, {'beta': beta, 'p_choose': p_choose}

@@ -1668,6 +1668,244 @@ def lstm_cell_step(gates, h_prev, c_prev, update=None):
 
 
 # --------------------------------------------------------------------------
+# monotonic (chunkwise) attention training: the scans of MoChA / MMA (csrc/mocha.hip)
+# --------------------------------------------------------------------------
+class MonoAlphaFn(torch.autograd.Function):
+    """alpha [..., klen] of parallel_monotonic_attention (hma_train.py:12-67) for one target position:
+    p_choose = (1 - stableemit) sigmoid(e), cumprod in log space, alpha = p c cumsum(aw_prev / den).
+    -> (alpha, p_choose); p_choose is returned for the caller's bookkeeping only (not differentiable here)."""
+
+    @staticmethod
+    def forward(ctx, e, aw_prev, eps, no_denom, stableemit):
+        klen = e.shape[-1]
+        e2, a2 = _f32c(e).reshape(-1, klen), _f32c(aw_prev.expand_as(e)).reshape(-1, klen)
+        rows = e2.shape[0]
+        alpha, pch, cp = torch.empty_like(e2), torch.empty_like(e2), torch.empty_like(e2)
+        _check(_lib.lib().nsp_mono_alpha_fwd(_p(e2), _p(a2), _p(alpha), _p(pch), _p(cp), rows, klen, float(eps),
+                                             int(bool(no_denom)), float(stableemit), _stream()), 'nsp_mono_alpha_fwd')
+        ctx.save_for_backward(pch, cp, a2)
+        ctx.cfg = (rows, klen, float(eps), int(bool(no_denom)), float(stableemit), e.shape, aw_prev.shape)
+        pch_out = pch.view(e.shape)
+        ctx.mark_non_differentiable(pch_out)
+        return alpha.view(e.shape), pch_out
+
+    @staticmethod
+    def backward(ctx, dalpha, _dp):
+        pch, cp, a2 = ctx.saved_tensors
+        rows, klen, eps, no_denom, lam, eshape, ashape = ctx.cfg
+        da_ = _f32c(dalpha).reshape(rows, klen)
+        de, daw = torch.empty_like(da_), torch.empty_like(da_)
+        _check(_lib.lib().nsp_mono_alpha_bwd(_p(da_), _p(pch), _p(cp), _p(a2), _p(de), _p(daw), rows, klen, eps, no_denom,
+                                             lam, _stream()), 'nsp_mono_alpha_bwd')
+        daw = daw.view(eshape)
+        if tuple(ashape) != tuple(eshape):
+            daw = daw.sum_to_size(ashape)
+        return de.view(eshape), daw, None, None, None
+
+
+def mono_alpha(e, aw_prev, eps, no_denom=False, stableemit=0.0):
+    return MonoAlphaFn.apply(e, aw_prev, eps, no_denom, stableemit)
+
+
+class ChunkBetaFn(torch.autograd.Function):
+    """beta [..., klen] of soft_chunkwise_attention (mocha_train.py:13-58) from chunk energies u and alpha (same
+    shape); w = chunk size (1 < w <= 64) or -1 (MILk)."""
+
+    @staticmethod
+    def forward(ctx, u, alpha, w, sf):
+        klen = u.shape[-1]
+        u2, a2 = _f32c(u).reshape(-1, klen), _f32c(alpha).reshape(-1, klen)
+        beta = torch.empty_like(u2)
+        _check(_lib.lib().nsp_chunk_beta_fwd(_p(u2), _p(a2), _p(beta), u2.shape[0], klen, int(w), float(sf), _stream()),
+               'nsp_chunk_beta_fwd')
+        ctx.save_for_backward(u2, a2)
+        ctx.cfg = (int(w), float(sf), u.shape)
+        return beta.view(u.shape)
+
+    @staticmethod
+    def backward(ctx, dbeta):
+        u2, a2 = ctx.saved_tensors
+        w, sf, shape = ctx.cfg
+        db = _f32c(dbeta).reshape(u2.shape)
+        du, da_ = torch.empty_like(u2), torch.empty_like(u2)
+        _check(_lib.lib().nsp_chunk_beta_bwd(_p(db), _p(u2), _p(a2), _p(du), _p(da_), u2.shape[0], u2.shape[1], w, sf,
+                                             _stream()), 'nsp_chunk_beta_bwd')
+        return du.view(shape), da_.view(shape), None, None
+
+
+def chunk_beta(u, alpha, w, sf=1.0):
+    return ChunkBetaFn.apply(u, alpha, w, sf)
+
+
+def chunk_beta_supported(w):
+    return w == -1 or 1 < w <= 64
+
+
+class AddEnergyFn(torch.autograd.Function):
+    """e [B,T] = sum_a v_a act(K[b,t,a] + Q[b,a] (+ C[b,t,a])): additive attention energies (attention.py:148-156 with
+    tanh, monotonic_energy.py / chunk_energy.py with relu) in one pass over the key projection."""
+
+    @staticmethod
+    def forward(ctx, K, Q, C, v, act):
+        B, T, A = K.shape
+        K, Q, v = _f32c(K), _f32c(Q).reshape(B, A), _f32c(v).reshape(A)
+        C = _f32c(C) if C is not None else None
+        e = torch.empty((B, T), device=K.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_add_energy_fwd(_p(K), _p(Q), _p(C), _p(v), _p(e), B, T, A, ACT[act], _stream()), 'nsp_add_energy_fwd')
+        ctx.save_for_backward(K, Q, C, v)
+        ctx.act = ACT[act]
+        ctx.qshape, ctx.vshape = None, None
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        K, Q, C, v = ctx.saved_tensors
+        B, T, A = K.shape
+        de = _f32c(de)
+        dtmp = torch.empty_like(K)
+        dQ = torch.empty((B, A), device=K.device, dtype=torch.float32)
+        dvp = torch.empty((B, A), device=K.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_add_energy_bwd(_p(de), _p(K), _p(Q), _p(C), _p(v), _p(dtmp), _p(dQ), _p(dvp), B, T, A, ctx.act,
+                                             _stream()), 'nsp_add_energy_bwd')
+        return dtmp, dQ, (dtmp if C is not None else None), colsum(dvp), None
+
+
+def add_energy(K, Q, v, act, C=None):
+    """K [B,T,A], Q [B,1,A] or [B,A], v [A] or [1,A] -> e [B,T]"""
+    B, T, A = K.shape
+    return AddEnergyFn.apply(K, Q.reshape(B, A), C, v.reshape(A), act)
+
+
+class RowSoftmaxFn(torch.autograd.Function):
+    """softmax(sharp * e) over the last dim with masked_fill(mask == 0, NEG_INF) semantics (attention.py:170-176)"""
+
+    @staticmethod
+    def forward(ctx, e, mask, sharp):
+        T = e.shape[-1]
+        e2 = _f32c(e).reshape(-1, T)
+        m2 = None
+        if mask is not None:
+            m2 = mask.expand_as(e).reshape(-1, T).to(torch.uint8).contiguous()
+        aw = torch.empty_like(e2)
+        _check(_lib.lib().nsp_row_softmax_fwd(_p(e2), _p(m2), _p(aw), e2.shape[0], T, float(sharp), _stream()), 'nsp_row_softmax_fwd')
+        ctx.save_for_backward(aw, m2)
+        ctx.cfg = (float(sharp), e.shape)
+        return aw.view(e.shape)
+
+    @staticmethod
+    def backward(ctx, daw):
+        aw, m2 = ctx.saved_tensors
+        sharp, shape = ctx.cfg
+        d2 = _f32c(daw).reshape(aw.shape)
+        de = torch.empty_like(aw)
+        _check(_lib.lib().nsp_row_softmax_bwd(_p(aw), _p(d2), _p(m2), _p(de), aw.shape[0], aw.shape[1], sharp, _stream()),
+               'nsp_row_softmax_bwd')
+        return de.view(shape), None, None
+
+
+def row_softmax(e, mask=None, sharp=1.0):
+    return RowSoftmaxFn.apply(e, mask, sharp)
+
+
+class LSTMCellFn(torch.autograd.Function):
+    """(h, c) = LSTMCell non-linearity on pre-activation gates [B,4H] (i, f, g, o) and c_prev [B,H] (las.py:860-866)"""
+
+    @staticmethod
+    def forward(ctx, gates, c_prev):
+        B, H4 = gates.shape
+        H = H4 // 4
+        gates, c_prev = _f32c(gates), _f32c(c_prev)
+        h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+        _check(_lib.lib().nsp_lstm_cell_fwd(_p(gates), _p(c_prev), _p(h), _p(c), B, H, _stream()), 'nsp_lstm_cell_fwd')
+        ctx.save_for_backward(gates, c_prev, c)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c_prev, c = ctx.saved_tensors
+        B, H = c.shape
+        dh = _f32c(dh) if dh is not None else None
+        dc = _f32c(dc) if dc is not None else None
+        dg, dcp = torch.empty_like(gates), torch.empty_like(c)
+        _check(_lib.lib().nsp_lstm_cell_bwd(_p(dh), _p(dc), _p(gates), _p(c_prev), _p(c), _p(dg), _p(dcp), B, H, _stream()),
+               'nsp_lstm_cell_bwd')
+        return dg, dcp
+
+
+def lstm_cell(gates, c_prev):
+    return LSTMCellFn.apply(gates, c_prev)
+
+
+class HeadScoresFn(torch.autograd.Function):
+    """S[b,h,i,j] = alpha * q[b,i,h,:] . k[b,j,h,:] on [B,L,H,dk] x [B,T,H,dk] (monotonic_energy.py / chunk_energy.py
+    'scaled_dot'): the batched nsp_gemm of AttentionFn without its softmax."""
+
+    @staticmethod
+    def forward(ctx, q, k, alpha):
+        B, L, H, dk = q.shape
+        T = k.shape[1]
+        d = H * dk
+        q, k = _f32c(q), _f32c(k)
+        S = torch.empty((B, H, L, T), device=q.device, dtype=torch.float32)
+        gemm_raw(L, T, dk, q, d, 1, k, 1, d, S, T, batch=(B, H), a_b=(L * d, dk), b_b=(T * d, dk),
+                 c_b=(H * L * T, L * T), alpha=alpha)
+        ctx.save_for_backward(q, k)
+        ctx.alpha = alpha
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        q, k = ctx.saved_tensors
+        B, L, H, dk = q.shape
+        T = k.shape[1]
+        d = H * dk
+        dS = _f32c(dS)
+        dQ = torch.empty_like(q)
+        gemm_raw(L, dk, T, dS, T, 1, k, d, 1, dQ, d, batch=(B, H), a_b=(H * L * T, L * T), b_b=(T * d, dk),
+                 c_b=(L * d, dk), alpha=ctx.alpha)
+        dK = torch.empty_like(k)
+        gemm_raw(T, dk, L, dS, 1, T, q, d, 1, dK, d, batch=(B, H), a_b=(H * L * T, L * T), b_b=(L * d, dk),
+                 c_b=(T * d, dk), alpha=ctx.alpha)
+        return dQ, dK, None
+
+
+def head_scores(q, k, alpha=1.0):
+    return HeadScoresFn.apply(q, k, alpha)
+
+
+class HeadContextFn(torch.autograd.Function):
+    """cv[b,i,h,:] = sum_j aw[b,h,i,j] v[b,j,h,:]  ([B,H,L,T] x [B,T,H,dk] -> [B,L,H,dk])"""
+
+    @staticmethod
+    def forward(ctx, aw, v):
+        B, H, L, T = aw.shape
+        dk = v.shape[-1]
+        d = H * dk
+        aw, v = _f32c(aw), _f32c(v)
+        O = torch.empty((B, L, H, dk), device=aw.device, dtype=torch.float32)
+        gemm_raw(L, dk, T, aw, T, 1, v, d, 1, O, d, batch=(B, H), a_b=(H * L * T, L * T), b_b=(T * d, dk), c_b=(L * d, dk))
+        ctx.save_for_backward(aw, v)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        aw, v = ctx.saved_tensors
+        B, H, L, T = aw.shape
+        dk = v.shape[-1]
+        d = H * dk
+        dO = _f32c(dO)
+        dA = torch.empty_like(aw)
+        gemm_raw(L, T, dk, dO, d, 1, v, 1, d, dA, T, batch=(B, H), a_b=(L * d, dk), b_b=(T * d, dk), c_b=(H * L * T, L * T))
+        dV = torch.empty_like(v)
+        gemm_raw(T, dk, L, aw, 1, T, dO, d, 1, dV, d, batch=(B, H), a_b=(H * L * T, L * T), b_b=(L * d, dk), c_b=(T * d, dk))
+        return dA, dV
+
+
+def head_context(aw, v):
+    return HeadContextFn.apply(aw, v)
+
+
+# --------------------------------------------------------------------------
 # per-launch timing of the GEMM kernel with HIP events (bench.py roofline)
 # --------------------------------------------------------------------------
 _KEV = {'on': False, 'events': [], 'flops': 0.0, 'side_events': [], 'side_flops': 0.0}

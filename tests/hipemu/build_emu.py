@@ -19,7 +19,7 @@ ASAN = os.environ.get('NSP_EMU_ASAN', '0') == '1'
 OUT = os.path.join(HERE, '_build_asan' if ASAN else '_build')
 LIB = os.path.join(OUT, 'libnsp_emu.so')
 EMULATED_SOURCES = ['norm_subsample.hip', 'elementwise.hip', 'xent.hip', 'decode.hip', 'layernorm.hip', 'ctc.hip',
-                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip', 'lstm.hip', 'conv2d.hip', 'gemm_bf16.hip', 'flash_attn.hip']
+                    'dwconv.hip', 'rnnt.hip', 'rnnt_fused.hip', 'gemm.hip', 'attention.hip', 'lstm.hip', 'conv2d.hip', 'gemm_bf16.hip', 'flash_attn.hip', 'mocha.hip', 'decoder_step.hip']
 CXX_CANDIDATES = ['/opt/rocm/lib/llvm/bin/clang++', 'clang++']
 
 

@@ -39,3 +39,13 @@ def test_flip_mask_and_bidirectional_merge():
 
 def test_three_channel_first_conv_as_im2col_gemm():
     vc.check_im2col_conv('emu')
+
+
+@pytest.mark.parametrize('rows,klen,w,no_denom,lam', vc.MOCHA_CASES)
+def test_mocha_alpha_and_beta_scans(rows, klen, w, no_denom, lam):
+    vc.check_mocha_scans('emu', rows, klen, w, no_denom, lam)
+
+
+@pytest.mark.parametrize('act,with_loc', [('tanh', True), ('relu', False)])
+def test_decoder_step_kernels(act, with_loc):
+    vc.check_decoder_step_kernels('emu', act, with_loc)

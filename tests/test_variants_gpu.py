@@ -53,6 +53,16 @@ def test_three_channel_first_conv_as_im2col_gemm():
     vc.check_im2col_conv('gpu')
 
 
+@pytest.mark.parametrize('rows,klen,w,no_denom,lam', vc.MOCHA_CASES)
+def test_mocha_alpha_and_beta_scans(rows, klen, w, no_denom, lam):
+    vc.check_mocha_scans('gpu', rows, klen, w, no_denom, lam)
+
+
+@pytest.mark.parametrize('act,with_loc', [('tanh', True), ('relu', False)])
+def test_decoder_step_kernels(act, with_loc):
+    vc.check_decoder_step_kernels('gpu', act, with_loc)
+
+
 @pytest.mark.parametrize('bidir_sum', [False, True])
 def test_blstm_layer_matches_packed_torch_lstm(bidir_sum):
     """RNNEncoder._lstm_layer (two left-to-right runs of the LSTM kernels + nsp_time_flip_mask) against

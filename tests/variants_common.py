@@ -217,3 +217,119 @@ def check_im2col_conv(where):
     torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(gw.cpu(), rw, rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(gb.cpu(), rb, rtol=1e-3, atol=1e-4)
+
+
+# ---- MoChA / MMA training scans (csrc/mocha.hip) against the torch-op restatement of hma_train.py:12-67 and
+# mocha_train.py:13-83 (the form the reference itself uses: clamp / log / cumsum / exp, ones-filter conv1d)
+def _ref_mono_alpha(e, aw_prev, eps, no_denom, lam):
+    p = (1 - lam) * torch.sigmoid(e)
+    x = torch.log(torch.clamp(1 - p, min=eps, max=1.0))
+    excl = torch.cumsum(torch.cat([x.new_zeros(x.shape[:-1] + (1,)), x[..., :-1]], dim=-1), dim=-1)
+    c = torch.exp(excl)
+    den = 1 if no_denom else torch.clamp(c, min=eps, max=1.0)
+    return p * c * torch.cumsum(aw_prev / den, dim=-1), p
+
+
+def _ref_moving_sum(x, back, forward):
+    shape = x.shape
+    y = F.conv1d(F.pad(x.reshape(-1, 1, shape[-1]), [back, forward]), x.new_ones(1, 1, back + forward + 1))
+    return y.view(shape[:-1] + (y.shape[-1],))
+
+
+def _ref_chunk_beta(u, alpha, w, sf):
+    klen = u.shape[-1]
+    u = u - torch.max(u, dim=-1, keepdim=True)[0]
+    ex = torch.clamp(torch.exp(u), min=1e-5)
+    if w == -1:
+        den = torch.cumsum(ex, dim=-1)
+        return ex * _ref_moving_sum(alpha * sf / den, back=0, forward=klen - 1)
+    den = _ref_moving_sum(ex, back=w - 1, forward=0)
+    return ex * _ref_moving_sum(alpha * sf / den, back=0, forward=w - 1)
+
+
+MOCHA_CASES = [(3, 50, 4, False, 0.0), (2, 200, 8, False, 0.1), (5, 1, 2, True, 0.0), (4, 129, -1, False, 0.0),
+               (2, 333, 16, True, 0.2)]
+
+
+def check_mocha_scans(where, rows, klen, w, no_denom, lam):
+    from neural_sp_amd import ops
+    torch.manual_seed(rows * 1000 + klen)
+    NEG = float(torch.finfo(torch.float32).min)
+    e = torch.randn(rows, klen) * 2 - 1.0
+    u = torch.randn(rows, klen) * 3
+    if klen > 8:                                     # padded frames: masked energies, as the decoders pass them
+        e[0, klen - 5:] = NEG
+        u[0, klen - 5:] = NEG
+        u[1, 3] = u[1].max() + 0.5                   # a unique maximum away from index 0
+    aw = torch.softmax(torch.randn(rows, klen), -1)
+    if rows > 1:
+        aw[1] = 0
+        aw[1, 0] = 1.0                               # the decoders' first step: [1, 0, 0, ...]
+    eps = 1e-6
+    er, awr, ur = e.clone().requires_grad_(True), aw.clone().requires_grad_(True), u.clone().requires_grad_(True)
+    a_ref, p_ref = _ref_mono_alpha(er, awr, eps, no_denom, lam)
+    b_ref = _ref_chunk_beta(ur, a_ref, w, 1.3)
+    wa, wb = _weights(a_ref.detach()), _weights(b_ref.detach()) * 0.7
+    (a_ref * wa).sum().backward(retain_graph=True)
+    ge_a, gaw_a = er.grad.clone(), awr.grad.clone()
+    er.grad = None; awr.grad = None
+    (b_ref * wb).sum().backward()
+    ctx, dev = _env(where)
+    with ctx:
+        ed, awd, ud = [t.clone().to(dev).requires_grad_(True) for t in (e, aw, u)]
+        a, p = ops.mono_alpha(ed, awd, eps, no_denom, lam)
+        (a * wa.to(dev)).sum().backward(retain_graph=True)
+        ge, gaw = ed.grad.clone().cpu(), awd.grad.clone().cpu()
+        ed.grad = None; awd.grad = None
+        b = ops.chunk_beta(ud, a, w, 1.3)
+        (b * wb.to(dev)).sum().backward()
+        got = [t.detach().cpu() for t in (a, p, b, ed.grad, awd.grad, ud.grad)]
+
+    def close(x, y, what, tol=2e-5):
+        scale = max(y.abs().max().item(), 1e-30)
+        err = (x - y).abs().max().item() / scale
+        assert err < tol, (what, err)
+    close(got[0], a_ref.detach(), 'alpha'); close(got[1], p_ref.detach(), 'p_choose'); close(ge, ge_a, 'd e (alpha only)', 2e-4)
+    close(gaw, gaw_a, 'd aw_prev (alpha only)', 2e-4)
+    close(got[2], b_ref.detach(), 'beta', 1e-4)
+    close(got[3], er.grad, 'd e through beta', 5e-4); close(got[4], awr.grad, 'd aw_prev through beta', 5e-4)
+    close(got[5], ur.grad, 'd u', 5e-4)
+
+
+# ---- decoder-step kernels (csrc/decoder_step.hip) against their torch-op forms
+def check_decoder_step_kernels(where, act='tanh', with_loc=True):
+    from neural_sp_amd import ops
+    torch.manual_seed(5)
+    B, T, A, H = 3, 37, 70, 24
+    K, Q, v = torch.randn(B, T, A), torch.randn(B, 1, A), torch.randn(1, A) * 0.3
+    C = torch.randn(B, T, A) * 0.5 if with_loc else None
+    mask = torch.ones(B, 1, T, dtype=torch.bool)
+    mask[1, 0, 20:] = False
+    mask[2, 0, 5:] = False
+    gates, cp = torch.randn(B, 4 * H), torch.randn(B, H)
+    f = torch.tanh if act == 'tanh' else torch.relu
+    leaves = [t.clone().requires_grad_(True) for t in (K, Q, v, gates, cp)] + ([C.clone().requires_grad_(True)] if with_loc else [])
+    Kr, Qr, vr, gr, cr = leaves[:5]
+    Cr = leaves[5] if with_loc else None
+    e_ref = (f(Kr + Qr + (Cr if with_loc else 0)) * vr.view(1, 1, -1)).sum(-1).unsqueeze(1)
+    aw_ref = torch.softmax(e_ref.masked_fill(mask == 0, float(torch.finfo(torch.float32).min)) * 1.7, dim=-1)
+    gi, gf, gg, go = gr.chunk(4, dim=1)
+    c_ref = torch.sigmoid(gf) * cr + torch.sigmoid(gi) * torch.tanh(gg)
+    h_ref = torch.sigmoid(go) * torch.tanh(c_ref)
+    w1, w2, w3 = _weights(aw_ref.detach()), _weights(h_ref.detach()), _weights(c_ref.detach()) * 0.5
+    ((aw_ref * w1).sum() + (h_ref * w2).sum() + (c_ref * w3).sum()).backward()
+    ctx, dev = _env(where)
+    with ctx:
+        dl = [t.clone().to(dev).requires_grad_(True) for t in ([K, Q, v, gates, cp] + ([C] if with_loc else []))]
+        e = ops.add_energy(dl[0], dl[1], dl[2], act, dl[5] if with_loc else None).unsqueeze(1)
+        aw = ops.row_softmax(e, mask.to(dev), 1.7)
+        h, c = ops.lstm_cell(dl[3], dl[4])
+        ((aw * w1.to(dev)).sum() + (h * w2.to(dev)).sum() + (c * w3.to(dev)).sum()).backward()
+        outs = [t.detach().cpu() for t in (e, aw, h, c)]
+        grads = [t.grad.detach().cpu() for t in dl]
+    for got, ref, what in zip(outs, (e_ref, aw_ref, h_ref, c_ref), ('e', 'aw', 'h', 'c')):
+        torch.testing.assert_close(got, ref.detach(), rtol=2e-5, atol=2e-6, msg=lambda m, w=what: w + ': ' + m)
+    for got, leaf, what in zip(grads, leaves, ('dK', 'dQ', 'dv', 'dgates', 'dc_prev', 'dC')):
+        scale = leaf.grad.abs().max().item()
+        assert ((got - leaf.grad).abs().max().item() / scale) < 2e-5, what
+    assert aw[1, 0, 20:].abs().sum() == 0 and grads[0][2, 5:].abs().sum() == 0     # masked frames: no weight, no gradient
