@@ -54,22 +54,31 @@ __global__ __launch_bounds__(256) void add_energy_bwd_kernel(const float* __rest
   }
 }
 
-// dQ[b,a] = sum_t dtmp[b,t,a];  dvp[b,a] = sum_t de[b,t] act(tmp[b,t,a])  (dv = sum_b dvp): grid (B, ceil(A / 256))
+// dQ[b,a] = sum_t dtmp[b,t,a];  dvp[b,a] = sum_t de[b,t] act(tmp[b,t,a])  (dv = sum_b dvp): grid (B, ceil(A / 64)),
+// the four waves of a block take every fourth frame of the block's 64 columns (256-B coalesced reads), LDS combine
 __global__ __launch_bounds__(256) void add_energy_bwd_reduce_kernel(const float* __restrict__ de, const float* __restrict__ K,
                                                                     const float* __restrict__ Q, const float* __restrict__ C,
                                                                     const float* __restrict__ dtmp, float* __restrict__ dQ,
                                                                     float* __restrict__ dvp, int T, int A, int act) {
-  const int b = blockIdx.x, a = blockIdx.y * 256 + threadIdx.x;
-  if (a >= A) return;
-  const float q = Q[(long long)b * A + a];
+  __shared__ float part[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x, a = blockIdx.y * 64 + lane;
   float sq = 0.f, sv = 0.f;
-  for (int t = 0; t < T; ++t) {
-    const long long i = ((long long)b * T + t) * A + a;
-    sq += dtmp[i];
-    sv += de[(long long)b * T + t] * step_act(K[i] + q + (C ? C[i] : 0.f), act);
+  if (a < A) {
+    const float q = Q[(long long)b * A + a];
+    for (int t = w; t < T; t += 4) {
+      const long long i = ((long long)b * T + t) * A + a;
+      sq += dtmp[i];
+      sv += de[(long long)b * T + t] * step_act(K[i] + q + (C ? C[i] : 0.f), act);
+    }
   }
-  dQ[(long long)b * A + a] = sq;
-  dvp[(long long)b * A + a] = sv;
+  part[0][w][lane] = sq;
+  part[1][w][lane] = sv;
+  __syncthreads();
+  if (w == 0 && a < A) {
+    dQ[(long long)b * A + a] = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+    dvp[(long long)b * A + a] = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
+  }
 }
 
 // aw = softmax(sharp * e) over the frames with mask != 0 (masked frames: e := -FLT_MAX, as masked_fill(NEG_INF));
@@ -158,7 +167,7 @@ extern "C" int nsp_add_energy_bwd(const float* de, const float* K, const float* 
   if (!de || !K || !Q || !v || !dtmp || !dQ || !dv_part || (act != NSP_ACT_TANH && act != NSP_ACT_RELU)) return NSP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(add_energy_bwd_kernel, dim3(nsp_cdiv(B * T, 4)), dim3(256), 0, st, de, K, Q, C, v, dtmp, B * T, T, A, act);
-  hipLaunchKernelGGL(add_energy_bwd_reduce_kernel, dim3(B, nsp_cdiv(A, 256)), dim3(256), 0, st, de, K, Q, C, dtmp, dQ, dv_part,
+  hipLaunchKernelGGL(add_energy_bwd_reduce_kernel, dim3(B, nsp_cdiv(A, 64)), dim3(256), 0, st, de, K, Q, C, dtmp, dQ, dv_part,
                      T, A, act);
   NSP_LAUNCH_CHECK();
   return NSP_OK;

@@ -371,7 +371,8 @@ class RNNDecoder(DecoderBase):
         dout = x
         dout_score = None
         for l, cell in enumerate(self.rnn):
-            gates = ops.linear(dout, cell.weight_ih, cell.bias_ih) + ops.linear(hxs[l], cell.weight_hh, cell.bias_hh)
+            # (the sum of the two gate GEMMs is the residual epilogue of the second one, not a separate add)
+            gates = ops.linear(hxs[l], cell.weight_hh, cell.bias_hh, res=ops.linear(dout, cell.weight_ih, cell.bias_ih))
             h, c = ops.lstm_cell(gates, cxs[l])        # gate non-linearities + cell update: one kernel per direction
             new_h.append(h)
             new_c.append(c)
