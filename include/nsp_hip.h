@@ -116,6 +116,11 @@ typedef struct {
 /* reduction splits for the weight gradient dW[N, K] = dY[rows, N]^T X[rows, K] with bf16 operands (slab mode, c_ss),
  * sized for the 256 x 256 kernel (tiles x splits ~ one workgroup per CU); 0 = shape not eligible, caller's rule */
 int nsp_wgrad_splitk(long long N, long long K, long long rows);
+/* refresh many bf16 weight shadows in ONE launch.  table (device): n_entries rows of 8 x int64
+ * {src fp32 pointer, dst bf16 pointer, rows, cols, src_ld, dst_ld, transpose, first tile}: dst(r,c) = transpose ?
+ * src[c*src_ld + r] : src[r*src_ld + c] for r < rows, c < cols; entries sorted by first tile, an entry owns
+ * ceil(rows/64) * ceil(cols/64) tiles; total_tiles = their sum.  Pad elements of dst are not touched. */
+int nsp_shadow_refresh(const long long* table, int n_entries, int total_tiles, void* stream);
 /* out[i] = sum_s part[s*n + i] (i < n): the deterministic reduction of split-K slabs */
 int nsp_splitk_reduce(const float* part, float* out, int splits, long long n, void* stream);
 

@@ -506,3 +506,58 @@ extern "C" int nsp_pad_batch(const float* packed, const long long* offsets, cons
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
+
+// ---- one launch that refreshes EVERY bf16 weight shadow of the model (plain casts, transposed casts, pieces of stacked /
+// concatenated shadows).  After an optimizer step all ~190 shadows of Conformer-L + RNN-T are stale; rebuilding them one
+// by one cost ~190 launches (cast_bf16 x 90, transposing copies x 49, torch.cat ...) = ~3 ms of HOST time per step, which
+// is what bounds the step at 16 utterances per GPU (26 ms of enqueue time for ~1500 launches, tools/b16_probe.py).
+// table: n rows of 8 x int64 {src (fp32), dst (bf16), rows, cols, src_ld, dst_ld, transpose, first tile}; dst(r, c) =
+// transpose ? src[c * src_ld + r] : src[r * src_ld + c] for r < rows, c < cols; 64 x 64 tiles, one per workgroup.
+namespace {
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const long long* __restrict__ table, int n) {
+  __shared__ float tile[64][65];
+  // entry of this workgroup: the last one whose first tile is <= blockIdx.x
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 8 + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* e = table + lo * 8;
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  __bf16* dst = reinterpret_cast<__bf16*>(e[1]);
+  const int rows = (int)e[2], cols = (int)e[3];
+  const long long src_ld = e[4], dst_ld = e[5];
+  const bool tr = e[6] != 0;
+  const int t = blockIdx.x - (int)e[7];
+  const int tiles_c = (cols + 63) >> 6;
+  const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if (!tr) {
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + i * 4 + ty, c = c0 + tx;
+      if (r < rows && c < cols) dst[(long long)r * dst_ld + c] = (__bf16)src[(long long)r * src_ld + c];
+    }
+  } else {
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {        // read along the source's contiguous index (= dst row index r)
+      const int c = c0 + i * 4 + ty, r = r0 + tx;
+      tile[i * 4 + ty][tx] = (r < rows && c < cols) ? src[(long long)c * src_ld + r] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + i * 4 + ty, c = c0 + tx;
+      if (r < rows && c < cols) dst[(long long)r * dst_ld + c] = (__bf16)tile[tx][i * 4 + ty];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int nsp_shadow_refresh(const long long* table, int n_entries, int total_tiles, void* stream) {
+  if (n_entries <= 0 || total_tiles <= 0) return NSP_OK;
+  if (!table) return NSP_EINVAL;
+  hipLaunchKernelGGL(shadow_refresh_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table, n_entries);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

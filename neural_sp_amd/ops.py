@@ -179,16 +179,98 @@ def to_bf16(x2d, pad_to=8):
     return out
 
 
+# ---- registry of bf16 weight shadows: all stale shadows are rebuilt by ONE kernel launch per optimizer step
+# (nsp_shadow_refresh) instead of one cast / transpose / cat per shadow at first use.  Every shadow getter below
+# registers what it built: the destination tensor and its parts (source parameter, sub-block, transposed or not).
+import weakref  # noqa: E402
+
+_SHADOWS = {}          # (id(owner), attr) -> record
+_SHADOW_TABLE = {'key': None, 'table': None, 'n': 0, 'tiles': 0}
+_WEIGHT_EPOCH = [0]
+
+
+def _wkey(w):
+    """Cache key of everything derived from parameter `w`: (Parameter._version, weight epoch).  The version counter alone
+    is NOT enough: torch.optim.Adam(fused=True) (and any other fused / multi-tensor update that writes through raw
+    pointers) leaves _version untouched while the values change -- measured on the MI355X box in round 3, where it meant
+    that bench.py's steps 2.. had been multiplying with the bf16 weights of step 1.  The epoch is bumped by
+    refresh_weight_shadows(force=True), which every TRAINING forward calls: all derived copies are then either
+    refreshed by its one launch (registered bf16 shadows) or rebuilt at first use (everything else)."""
+    return (w._version, _WEIGHT_EPOCH[0])
+
+
+
+def _shadow_register(owner, attr, dst, parts, make_entry):
+    """parts: [(src_param, dst_row0, dst_col0, rows, cols, transpose)] with src viewed as [N, K] row-major;
+    make_entry(): the tuple the getter caches on `owner.attr` for the CURRENT parameter versions."""
+    try:
+        rec = {'owner': weakref.ref(owner), 'attr': attr, 'dst': dst, 'make': make_entry,
+               'parts': [(weakref.ref(sp), int(r0), int(c0), int(rows), int(cols), bool(tr)) for sp, r0, c0, rows, cols, tr in parts]}
+    except TypeError:
+        return
+    _SHADOWS[(id(owner), attr)] = rec
+    _SHADOW_TABLE['key'] = None
+
+
+def refresh_weight_shadows(force=False):
+    """Bring every registered bf16 shadow whose source parameters have moved on (optimizer step, load_state_dict, weight
+    noise) up to date with ONE launch on the current stream.  Called at the top of a training / evaluation step;
+    the per-weight getters then find their caches fresh.  Shadows not yet registered are built at first use.
+    force=True (training steps): start a new weight epoch first -- every derived copy counts as stale whatever the
+    parameters' version counters say (see _wkey)."""
+    if force:
+        _WEIGHT_EPOCH[0] += 1
+    if not _SHADOWS or not bf16_mode():
+        return
+    stale, dead = [], []
+    for k, rec in _SHADOWS.items():
+        owner = rec['owner']()
+        if owner is None or any(sp() is None for sp, *_ in rec['parts']):
+            dead.append(k)
+            continue
+        ent = getattr(owner, rec['attr'], None)
+        if ent is None or ent[1] is not rec['dst']:
+            dead.append(k)                      # invalidated or rebuilt elsewhere: the getter re-registers
+            continue
+        if ent[0] != rec['make']()[0]:
+            stale.append(rec)
+    for k in dead:
+        del _SHADOWS[k]
+    if not stale:
+        return
+    key = tuple((id(rec), rec['dst'].data_ptr()) + tuple(sp().data_ptr() for sp, *_ in rec['parts']) for rec in stale)
+    if _SHADOW_TABLE['key'] != key:
+        rows_, tiles = [], 0
+        for rec in stale:
+            dst = rec['dst']
+            for sp, r0, c0, rows, cols, tr in rec['parts']:
+                w = sp()
+                K = w[0].numel()
+                rows_.append([w.data_ptr(), dst.data_ptr() + 2 * (r0 * dst.stride(0) + c0), rows, cols, K, dst.stride(0),
+                              1 if tr else 0, tiles])
+                tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+        dev = stale[0]['dst'].device
+        _SHADOW_TABLE.update(key=key, table=h2d(torch.tensor(rows_, dtype=torch.int64), dev), n=len(rows_), tiles=tiles)
+    _check(_lib.lib().nsp_shadow_refresh(_p(_SHADOW_TABLE['table']), _SHADOW_TABLE['n'], _SHADOW_TABLE['tiles'], _stream()),
+           'nsp_shadow_refresh')
+    for rec in stale:
+        try:
+            setattr(rec['owner'](), rec['attr'], rec['make']())
+        except Exception:
+            pass
+
+
 def weight_bf16(w):
     """bf16 shadow [N, roundup8(K)] of a parameter (any dim >= 2, flattened to 2-D), cached ON
     the parameter object and refreshed when its version counter moves (one cast per optimizer
     step).  Callers must pass the Parameter itself, not a temporary view of it."""
     ent = getattr(w, '_nsp_bf16', None)
-    if ent is not None and ent[0] == w._version and ent[1].device == w.device:
+    if ent is not None and ent[0] == _wkey(w) and ent[1].device == w.device:
         return ent[1]
     wb = to_bf16(w.detach().reshape(w.shape[0], -1))
     try:
-        w._nsp_bf16 = (w._version, wb)
+        w._nsp_bf16 = (_wkey(w), wb)
+        _shadow_register(w, '_nsp_bf16', wb, [(w, 0, 0, w.shape[0], w[0].numel(), False)], lambda w=w, wb=wb: (_wkey(w), wb))
     except Exception:
         pass
     return wb
@@ -747,18 +829,20 @@ def next_dropout_seed():
 
 
 def invalidate_weight_shadows(module):
-    """Drop every cached bf16 / transposed / stacked weight shadow of `module`'s parameters.  The
-    caches are keyed by Parameter._version, which optimizers bump -- but in-place writes through
-    `.data` (p.data.add_, EMA / weight-noise code, manual checkpoint surgery) do NOT; call this
-    after such an update (load_state_dict and torch.optim steps need no call)."""
+    """Drop every cached bf16 / transposed / stacked weight shadow of `module`'s parameters.  The caches are keyed by
+    (Parameter._version, weight epoch) -- see _wkey: a training forward starts a new epoch by itself; in-place writes
+    through `.data` OUTSIDE training steps (EMA code, manual checkpoint surgery before an evaluation) change neither,
+    call this after such an update."""
     for p in module.parameters():
         for name in ('_nsp_bf16', '_nsp_t16', '_nsp_t32', '_nsp_stack16', '_nsp_stackt16',
-                     '_nsp_lstm_cat', '_nsp_lstm_catT'):
+                     '_nsp_lstm_cat', '_nsp_lstm_catT', '_nsp_rowpad16'):
             if hasattr(p, name):
                 try:
                     delattr(p, name)
                 except AttributeError:
                     pass
+            _SHADOWS.pop((id(p), name), None)
+    _SHADOW_TABLE['key'] = None
 
 
 # --------------------------------------------------------------------------
@@ -1435,12 +1519,13 @@ def _rows_padded_bf16(w, mult):
     if Np == N:
         return wb
     ent = getattr(w, '_nsp_rowpad16', None)
-    if ent is not None and ent[0] == w._version and ent[1].device == w.device and ent[1].shape[0] == Np:
+    if ent is not None and ent[0] == _wkey(w) and ent[1].device == w.device and ent[1].shape[0] == Np:
         return ent[1]
     out = torch.zeros((Np, wb.shape[1]), device=wb.device, dtype=torch.bfloat16)
     out[:N] = wb
     try:
-        w._nsp_rowpad16 = (w._version, out)
+        w._nsp_rowpad16 = (_wkey(w), out)
+        _shadow_register(w, '_nsp_rowpad16', out, [(w, 0, 0, N, w[0].numel(), False)], lambda w=w, out=out: (_wkey(w), out))
     except Exception:
         pass
     return out
@@ -1451,12 +1536,12 @@ def _vec_padded(b, n, device):
     if b is None:
         return torch.zeros((n,), device=device, dtype=torch.float32)
     ent = getattr(b, '_nsp_vecpad', None)
-    if ent is not None and ent[0] == b._version and ent[1].device == b.device and ent[1].numel() == n:
+    if ent is not None and ent[0] == _wkey(b) and ent[1].device == b.device and ent[1].numel() == n:
         return ent[1]
     out = torch.zeros((n,), device=b.device, dtype=torch.float32)
     out[:b.numel()] = b.detach()
     try:
-        b._nsp_vecpad = (b._version, out)
+        b._nsp_vecpad = (_wkey(b), out)
     except Exception:
         pass
     return out
@@ -1982,13 +2067,15 @@ def _weight_t_shadow(w, bf16):
     """W^T [K, N] (bf16 or fp32) cached on the parameter like weight_bf16."""
     name = '_nsp_t16' if bf16 else '_nsp_t32'
     ent = getattr(w, name, None)
-    if ent is not None and ent[0] == w._version and ent[1].device == w.device:
+    if ent is not None and ent[0] == _wkey(w) and ent[1].device == w.device:
         return ent[1]
     wt = w.detach().reshape(w.shape[0], -1).t().contiguous()   # [K, N]
     if bf16:
         wt = to_bf16(wt, pad_to=64)                              # [K, roundup64(N)], zero padded
     try:
-        setattr(w, name, (w._version, wt))
+        setattr(w, name, (_wkey(w), wt))
+        if bf16:
+            _shadow_register(w, name, wt, [(w, 0, 0, w[0].numel(), w.shape[0], True)], lambda w=w, wt=wt: (_wkey(w), wt))
     except Exception:
         pass
     return wt
@@ -2121,15 +2208,18 @@ def lstm_state(x, w_ih, w_hh, b_ih, b_hh, h0, c0):
     return LSTMStateFn.apply(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
 
 
-def _cat_cached(owner, name, parts, build):
-    """torch.cat of derived weight shadows, cached on `owner` and keyed by the versions of `parts`."""
-    key = tuple(p._version for p in parts)
+def _cat_cached(owner, name, parts, build, layout=None):
+    """torch.cat of derived weight shadows, cached on `owner` and keyed by the versions of `parts`.
+    layout(t) -> the shadow-registry parts of the result (see _shadow_register), when it is a bf16 shadow."""
+    key = tuple(_wkey(p) for p in parts)
     ent = getattr(owner, name, None)
     if ent is not None and ent[0] == key and ent[1].device == owner.device:
         return ent[1]
     t = build()
     try:
         setattr(owner, name, (key, t))
+        if layout is not None and t.dtype == torch.bfloat16:
+            _shadow_register(owner, name, t, layout(t), lambda parts=tuple(parts), t=t: (tuple(_wkey(p) for p in parts), t))
     except Exception:
         pass
     return t
@@ -2241,7 +2331,9 @@ class LSTMStackFn(torch.autograd.Function):
                 wl = weight_bf16(w_hh)
             else:
                 wl = _cat_cached(w_hh, '_nsp_lstm_cat', (w_ih, w_hh),
-                                 lambda a=w_ih, b=w_hh: torch.cat([weight_bf16(a), weight_bf16(b)], dim=1).contiguous())
+                                 lambda a=w_ih, b=w_hh: torch.cat([weight_bf16(a), weight_bf16(b)], dim=1).contiguous(),
+                                 lambda t, a=w_ih, b=w_hh: [(a, 0, 0, a.shape[0], a.shape[1], False),
+                                                            (b, 0, _r8(a.shape[1]), b.shape[0], b.shape[1], False)])
                 bl = axpby(b_ih, b_hh, 1.0, 1.0)
                 P.bias[l] = bl.data_ptr()
                 keep.append(bl)
@@ -2288,7 +2380,9 @@ class LSTMStackFn(torch.autograd.Function):
                 wt = _cat_cached(w_hh, '_nsp_lstm_catT', (w_ih_up, w_hh),
                                  lambda a=w_ih_up, b=w_hh: torch.cat(
                                      [_weight_t_shadow(a, True)[:, :4 * H], _weight_t_shadow(b, True)[:, :4 * H]],
-                                     dim=1).contiguous())                         # [H, 8H]
+                                     dim=1).contiguous(),                         # [H, 8H]
+                                 lambda t, a=w_ih_up, b=w_hh: [(a, 0, 0, a.shape[1], a.shape[0], True),
+                                                               (b, 0, 4 * H, b.shape[1], b.shape[0], True)])
                 P.seed[l], P.offset[l] = seeds[l]
             keep.append(wt)
             P.w[l] = wt.data_ptr()
@@ -2452,13 +2546,19 @@ def ffn(x, w1, b1, w2, b2, act, p_h=0.0, res=None, alpha=1.0, p_o=0.0):
 # --------------------------------------------------------------------------
 def _stacked_weight_bf16(ws):
     """bf16 [sum N_i, K] stack of several [N_i, K] parameters (e.g. W_q;W_k;W_v), cached on the first."""
-    ver = tuple(w._version for w in ws)
+    ver = tuple(_wkey(w) for w in ws)
     ent = getattr(ws[0], '_nsp_stack16', None)
     if ent is not None and ent[0] == ver and ent[1].device == ws[0].device and ent[2] == len(ws):
         return ent[1]
     wb = torch.cat([weight_bf16(w) for w in ws], dim=0).contiguous()
     try:
         ws[0]._nsp_stack16 = (ver, wb, len(ws))
+        parts, r0 = [], 0
+        for w in ws:
+            parts.append((w, r0, 0, w.shape[0], w[0].numel(), False))
+            r0 += w.shape[0]
+        _shadow_register(ws[0], '_nsp_stack16', wb, parts,
+                         lambda ws=tuple(ws), wb=wb: (tuple(_wkey(w) for w in ws), wb, len(ws)))
     except Exception:
         pass
     return wb
@@ -2466,13 +2566,19 @@ def _stacked_weight_bf16(ws):
 
 def _stacked_weight_t_bf16(ws):
     """bf16 [K, sum N_i] = [W_1^T | W_2^T | ...] (the data-gradient operand of a stacked projection)."""
-    ver = tuple(w._version for w in ws)
+    ver = tuple(_wkey(w) for w in ws)
     ent = getattr(ws[0], '_nsp_stackt16', None)
     if ent is not None and ent[0] == ver and ent[1].device == ws[0].device and ent[2] == len(ws):
         return ent[1]
     wt = to_bf16(torch.cat([w.detach().reshape(w.shape[0], -1).t() for w in ws], dim=1).contiguous())
     try:
         ws[0]._nsp_stackt16 = (ver, wt, len(ws))
+        parts, c0 = [], 0
+        for w in ws:
+            parts.append((w, 0, c0, w[0].numel(), w.shape[0], True))
+            c0 += w.shape[0]
+        _shadow_register(ws[0], '_nsp_stackt16', wt, parts,
+                         lambda ws=tuple(ws), wt=wt: (tuple(_wkey(w) for w in ws), wt, len(ws)))
     except Exception:
         pass
     return wt

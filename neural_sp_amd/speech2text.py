@@ -320,6 +320,7 @@ class Speech2Text(nn.Module):
         Returns (nbest_hyps_id `[B][1][L]`, aws None).  Beam search / LM fusion / streaming /
         ensembles are inference-side and raise NotImplementedError."""
         self.eval()
+        ops.refresh_weight_shadows(force=True)
         base = task.split('.')[0]
         if base not in ('ys', 'ys_sub1', 'ys_sub2'):
             raise ValueError(task)
@@ -361,6 +362,10 @@ class Speech2Text(nn.Module):
         return loss, observation
 
     def _forward(self, batch, task):
+        # every bf16 weight shadow that the last optimizer step made stale: one launch (before the side stream's
+        # step-start event, so that the prediction network reads the refreshed images)
+        # (forced in evaluation too: the last optimizer step of a fused optimizer leaves no trace in the version counters)
+        ops.refresh_weight_shadows(force=True)
         if isinstance(getattr(self, 'dec_fwd', None), RNNT) and task in ('all', 'ys'):
             # the prediction network overlaps with the encoder on a side stream; it is enqueued
             # right after the encoder's front-end so that neither stream starts the step idle
@@ -452,6 +457,7 @@ class Speech2Text(nn.Module):
             self.add_weight_noise(std=self.weight_noise_std)
             # the prediction network's side stream waits for the step-start event only: move that event behind
             # the in-place noise add, or it would read (and shadow) weights while they change
+            ops.refresh_weight_shadows(force=True)          # the noise moved every parameter: one launch again
             dec = getattr(self, 'dec_fwd', None)
             if getattr(dec, '_step_start_event', None) is not None:
                 dec.mark_step_start()
@@ -463,6 +469,7 @@ class Speech2Text(nn.Module):
     def ctc_forced_align(self, xs, ys, task='ys'):
         """speech2text.py:470-492: CTC forced alignment -> trigger points `[B,L+1]` (np.int32)."""
         self.eval()
+        ops.refresh_weight_shadows(force=True)
         with torch.no_grad():
             eout_dict = self.encode(xs, 'ys')
             ctc = self.dec_fwd.ctc

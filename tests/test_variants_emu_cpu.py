@@ -49,3 +49,13 @@ def test_mocha_alpha_and_beta_scans(rows, klen, w, no_denom, lam):
 @pytest.mark.parametrize('act,with_loc', [('tanh', True), ('relu', False)])
 def test_decoder_step_kernels(act, with_loc):
     vc.check_decoder_step_kernels('emu', act, with_loc)
+
+
+def test_all_weight_shadows_refreshed_by_one_launch():
+    vc.check_shadow_refresh('emu')
+
+
+def test_weight_copies_follow_updates_that_do_not_bump_the_version_counter():
+    from tests.cpu_ops_shim import host_logic_on_cpu
+    with host_logic_on_cpu(real_kernels=True, real_conv=False, mode='bf16'):
+        vc.check_weights_changed_without_version_bump('emu')

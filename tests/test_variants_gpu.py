@@ -63,6 +63,50 @@ def test_decoder_step_kernels(act, with_loc):
     vc.check_decoder_step_kernels('gpu', act, with_loc)
 
 
+def test_all_weight_shadows_refreshed_by_one_launch():
+    vc.check_shadow_refresh('gpu')
+
+
+def test_weight_copies_follow_updates_that_do_not_bump_the_version_counter():
+    vc.check_weights_changed_without_version_bump('gpu')
+
+
+def test_fused_adam_training_matches_plain_adam():
+    """torch.optim.Adam(fused=True) leaves Parameter._version alone (measured here, asserted below so that a torch
+    upgrade that changes it is noticed): three bf16-mode training steps with it must track the same steps with the
+    foreach implementation -- they did not before round 3, when the bf16 weight shadows were keyed by the version
+    counter alone and every step after the first multiplied with step 1's weights."""
+    import copy
+    from neural_sp_amd import ops
+    from neural_sp_amd.configs import conformer_rnnt_args, synthetic_batch
+    from neural_sp_amd.speech2text import Speech2Text
+    args = conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=0.3, ctc_fc_list='32', dropout=0.0)
+    batch = synthetic_batch(B=3, t_range=(40, 64), u_range=(2, 6), vocab=40, seed=0)
+    torch.manual_seed(0)
+    base = Speech2Text(args).to('cuda:0')
+    losses = {}
+    with ops.compute_mode('bf16'):
+        for fused in (True, False):
+            model = copy.deepcopy(base)
+            opt = torch.optim.Adam(model.parameters(), lr=2e-3, fused=fused)
+            v0 = next(model.parameters())._version
+            ls = []
+            for _ in range(4):
+                loss, _ = model(batch, task='all')
+                loss.backward()
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                ls.append(loss.item())
+            losses[fused] = ls
+            if fused:
+                assert next(model.parameters())._version == v0, 'fused Adam now bumps _version: fine, but re-read ops._wkey'
+    print('[fused vs foreach Adam, bf16 mode] losses', losses)
+    assert losses[True][0] == losses[False][0]
+    assert abs(losses[True][3] - losses[True][0]) / abs(losses[True][0]) > 1e-3, 'the loss does not move: stale weights?'
+    for a, b in zip(losses[True], losses[False]):
+        assert abs(a - b) / abs(b) < 2e-3, losses
+
+
 @pytest.mark.parametrize('bidir_sum', [False, True])
 def test_blstm_layer_matches_packed_torch_lstm(bidir_sum):
     """RNNEncoder._lstm_layer (two left-to-right runs of the LSTM kernels + nsp_time_flip_mask) against

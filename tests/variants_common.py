@@ -333,3 +333,80 @@ def check_decoder_step_kernels(where, act='tanh', with_loc=True):
         scale = leaf.grad.abs().max().item()
         assert ((got - leaf.grad).abs().max().item() / scale) < 2e-5, what
     assert aw[1, 0, 20:].abs().sum() == 0 and grads[0][2, 5:].abs().sum() == 0     # masked frames: no weight, no gradient
+
+
+# ---- one-launch refresh of all bf16 weight shadows (ops.refresh_weight_shadows / nsp_shadow_refresh)
+def check_shadow_refresh(where):
+    from neural_sp_amd import ops
+    torch.manual_seed(3)
+    ctx, dev = _env(where)
+    with ctx, ops.compute_mode('bf16'):
+        P = lambda *s: nn.Parameter(torch.randn(*s, device=dev))
+        w1, w2, w3 = P(70, 24), P(130, 24), P(33, 24)           # stacked projections (ragged row counts)
+        wq = P(100, 72)                                           # plain + transposed (N % 64 != 0: zero padded)
+        wo = P(43, 40)                                            # rows padded to 64
+        a, b, a2 = P(96, 20), P(96, 24), P(96, 24)               # LSTM-style concatenations (20 % 8 != 0: padded gap)
+
+        def get():
+            return dict(
+                plain=ops.weight_bf16(wq), t=ops._weight_t_shadow(wq, True), stack=ops._stacked_weight_bf16([w1, w2, w3]),
+                stackt=ops._stacked_weight_t_bf16([w1, w2, w3]), rowpad=ops._rows_padded_bf16(wo, 64),
+                cat=ops._cat_cached(b, '_nsp_lstm_cat', (a, b), lambda: torch.cat([ops.weight_bf16(a), ops.weight_bf16(b)], dim=1).contiguous(),
+                                    lambda t: [(a, 0, 0, a.shape[0], a.shape[1], False), (b, 0, ops._r8(a.shape[1]), b.shape[0], b.shape[1], False)]),
+                catT=ops._cat_cached(b, '_nsp_lstm_catT', (a2, b), lambda: torch.cat(
+                    [ops._weight_t_shadow(a2, True)[:, :96], ops._weight_t_shadow(b, True)[:, :96]], dim=1).contiguous(),
+                    lambda t: [(a2, 0, 0, a2.shape[1], a2.shape[0], True), (b, 0, 96, b.shape[1], b.shape[0], True)]))
+        first = get()
+        ref_first = {k: v.clone() for k, v in first.items()}
+        with torch.no_grad():
+            for p in (w1, w2, w3, wq, wo, a, b, a2):
+                p.add_(torch.randn_like(p))                       # bumps ._version like an optimizer step
+        ops.refresh_weight_shadows()
+        second = get()
+        for k in first:
+            assert second[k] is first[k], k + ': the getter rebuilt a shadow the refresh should have updated in place'
+            assert not torch.equal(second[k], ref_first[k]), k
+        # against shadows built from scratch
+        ops.invalidate_weight_shadows(nn.ParameterList([w1, w2, w3, wq, wo, a, b, a2]))
+        third = get()
+        for k in first:
+            assert third[k] is not first[k]
+            assert torch.equal(third[k].cpu(), second[k].cpu()), k
+
+
+def check_weights_changed_without_version_bump(where):
+    """A fused optimizer (torch.optim.Adam(fused=True) on the device) rewrites the parameters WITHOUT touching
+    Parameter._version; every bf16 / transposed weight copy must follow all the same.  Emulated here with .data writes:
+    the second forward must see the new weights (= a freshly built model holding them)."""
+    import argparse
+    from neural_sp_amd import ops
+    from neural_sp_amd.configs import conformer_rnnt_args, synthetic_batch
+    from neural_sp_amd.speech2text import Speech2Text
+    args = conformer_rnnt_args('XS', n_layers=2, vocab=40, ctc_weight=0.3, ctc_fc_list='32', dropout=0.0)
+    batch = synthetic_batch(B=2, t_range=(40, 48), u_range=(2, 4), vocab=40, seed=0)
+    ctx, dev = _env(where)
+    torch.manual_seed(0)
+    model = Speech2Text(args)
+    with ctx, ops.compute_mode('bf16'):
+        if where == 'gpu':
+            model = model.to(dev)
+        l0 = model(batch, task='all')[0].item()
+        versions = [p._version for p in model.parameters()]
+        with torch.no_grad():
+            for p in model.parameters():
+                p.data.mul_(1.25)                     # values change, version counters do not
+        assert versions == [p._version for p in model.parameters()]
+        l1 = model(batch, task='all')[0].item()
+        fresh = Speech2Text(args)
+        fresh.load_state_dict(model.state_dict())
+        if where == 'gpu':
+            fresh = fresh.to(dev)
+        l2 = fresh(batch, task='all')[0].item()
+        model.eval()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.data.mul_(0.8)                      # back to the original weights, evaluation mode
+        l3 = model(batch, task='all', is_eval=True)[0].item()
+    assert abs(l1 - l0) / abs(l0) > 1e-3, 'the modified weights did not reach the kernels'
+    assert abs(l1 - l2) / abs(l2) < 1e-5, (l1, l2)
+    assert abs(l3 - l0) / abs(l0) < 2e-3, (l3, l0)    # (0.8 * 1.25 = 1 up to rounding)
