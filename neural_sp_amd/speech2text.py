@@ -96,6 +96,10 @@ class LazyObservation(dict):
             self._pending = None
             if ev is not None:
                 ev.synchronize()
+                # the step's loss values are on the host: the forward's persistent-LSTM launches have finished too (the
+                # loss depends on them), so a grid-barrier time-out is reported with THIS step's values, not one
+                # launch later (the backward's launches are checked at the next step's first read)
+                ops._lstm_poll_dead()
             for k, v in zip(keys, host.tolist()):
                 dict.__setitem__(self, k, v)
         return self
