@@ -130,6 +130,21 @@ __device__ __forceinline__ TileCoord tile_coord(const nsp_gemm_params& p, int nt
   return c;
 }
 
+// Epilogue cache policy.  The outputs of the step's GEMMs are 100-800 MB images that nobody re-reads before they have
+// left the 4-MB L2 of their XCD anyway; written with plain stores they push the weight / activation panels that the
+// OTHER tiles of the launch are about to re-read out of it (PMC, round 3: gemm_bf16_kk_glds_kernel<0> read 1.5x its
+// algorithmic bytes).  NSP_EPI_STORE: 0 = plain stores, 1 = non-temporal (default), 2 = fp32 images with sc1 (write-
+// through) and bf16 images non-temporal; NSP_EPI_SIDE_NT: the residual / act' side operand (read exactly once) with
+// non-temporal loads.  Measured interleaved at M = 102400 (profiles/r03q*_store_policy_ab.log): non-temporal stores
+// x1.15 on the FFN first linear and the stacked QKV projection (bf16 images), x1.48 on the fp32-output GEMMs without a
+// side operand (pointwise conv 1, d x d data gradients), neutral on the K >= 1536 shapes; sc1 buys nothing over plain;
+// non-temporal side loads +4-5 % on the residual epilogues.  Full step: 130.2 -> 128.6 ms.
+#ifndef NSP_EPI_STORE
+#define NSP_EPI_STORE 1
+#endif
+#ifndef NSP_EPI_SIDE_NT
+#define NSP_EPI_SIDE_NT 1
+#endif
 __device__ __forceinline__ void store4(void* base, int dtype, long long off, const float* v, int nv,
                                        bool vec) {
   if (dtype == NSP_DT_BF16) {
@@ -137,7 +152,11 @@ __device__ __forceinline__ void store4(void* base, int dtype, long long off, con
     if (vec) {
       bf16x4 h;
       h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+#if NSP_EPI_STORE >= 1
+      __builtin_nontemporal_store(h, reinterpret_cast<bf16x4*>(o));
+#else
       *reinterpret_cast<bf16x4*>(o) = h;
+#endif
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (e < nv) o[e] = (__bf16)v[e];
@@ -145,7 +164,17 @@ __device__ __forceinline__ void store4(void* base, int dtype, long long off, con
   } else {
     float* o = reinterpret_cast<float*>(base) + off;
     if (vec) {
+#if NSP_EPI_STORE == 1
+      typedef __attribute__((ext_vector_type(4))) float f32x4_;
+      f32x4_ q = {v[0], v[1], v[2], v[3]};
+      __builtin_nontemporal_store(q, reinterpret_cast<f32x4_*>(o));
+#elif NSP_EPI_STORE == 2
+      typedef __attribute__((ext_vector_type(4))) float f32x4_;
+      f32x4_ q = {v[0], v[1], v[2], v[3]};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(o), "v"(q) : "memory");
+#else
       *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (e < nv) o[e] = v[e];
@@ -273,7 +302,7 @@ __device__ __forceinline__ void rnnt_epilogue_mode(const nsp_gemm_params& p, f32
         o[0] = (__bf16)g[0]; o[1] = (__bf16)g[1]; o[2] = (__bf16)g[2]; o[3] = (__bf16)g[3];
 #pragma unroll
         for (int e = 0; e < 4; ++e) csum[e] += g[e];
-        if (rowok) *reinterpret_cast<bf16x4*>(cbase + (long long)(mi * 4 + j) * ldc4) = o;
+        if (rowok) __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(cbase + (long long)(mi * 4 + j) * ldc4));   // 7.6 GB image: streams past L2 (see store4)
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -372,10 +401,21 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
     const int mcl = min(mrow0 + mi * 16 + er + 4 * j, p.M - 1);
     const long long off = coff + (long long)mcl * p.ldc + ncl;
     if (side16) {
+#if NSP_EPI_SIDE_NT
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_;
+      const u32x2_ h = __builtin_nontemporal_load(reinterpret_cast<const u32x2_*>(side + off * 2));
+      buf.x = h[0]; buf.y = h[1];
+#else
       const uint2 h = *reinterpret_cast<const uint2*>(side + off * 2);
       buf.x = h.x; buf.y = h.y;
+#endif
     } else {
+#if NSP_EPI_SIDE_NT
+      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(side + off * 4));
+      buf = make_uint4(q[0], q[1], q[2], q[3]);
+#else
       buf = *reinterpret_cast<const uint4*>(side + off * 4);
+#endif
     }
   };
   if (has_side) {

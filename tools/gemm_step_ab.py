@@ -49,20 +49,26 @@ if __name__ == '__main__':
     if os.environ.get('GEMM_AB_CHILD'):
         child()
         sys.exit(0)
-    prev = os.path.join(ROOT, 'tools', 'probe', 'ab', 'libnsp_hip_prev.so')
-    runs = {'prev': [], 'tree': []}
+    # arms: "tree" (the in-tree library) plus GEMM_AB_LIBS="name=path,..." (default: prev = tools/probe/ab/libnsp_hip_prev.so)
+    arms = [('tree', None)]
+    spec = os.environ.get('GEMM_AB_LIBS', 'prev=' + os.path.join(ROOT, 'tools', 'probe', 'ab', 'libnsp_hip_prev.so'))
+    for item in spec.split(','):
+        n, pth = item.split('=')
+        arms.insert(0, (n, pth if os.path.isabs(pth) else os.path.join(ROOT, pth)))
+    runs = {n: [] for n, _ in arms}
     for rnd in range(3):
-        for which in ('prev', 'tree'):
+        for which, pth in arms:
             env = dict(os.environ, GEMM_AB_CHILD='1')
-            if which == 'prev':
-                env['NSP_LIB_OVERRIDE'] = prev
+            if pth:
+                env['NSP_LIB_OVERRIDE'] = pth
             out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
             if out.returncode != 0:
                 print(which, 'failed:', out.stderr[-2000:])
                 sys.exit(1)
             runs[which].append(json.loads(out.stdout.strip().splitlines()[-1]))
     names = list(runs['tree'][0])
-    print('%-64s %10s %8s | %10s %8s | %s' % ('GEMM (M = %s rows)' % os.environ.get('GM', '102400'), 'prev us', 'TF/s', 'tree us', 'TF/s', 'speed-up'))
+    print('GEMM (M = %s rows): min us over 3 interleaved rounds' % os.environ.get('GM', '102400'))
+    print('%-64s ' % '' + ' '.join('%10s' % n for n, _ in arms))
     for n in names:
-        a = min(r[n][0] for r in runs['prev']); b = min(r[n][0] for r in runs['tree']); fl = runs['tree'][0][n][1]
-        print('%-64s %10.1f %8.1f | %10.1f %8.1f | x%.3f' % (n, a, fl / a / 1e6, b, fl / b / 1e6, a / b))
+        row = [min(r[n][0] for r in runs[a]) for a, _ in arms]
+        print('%-64s ' % n + ' '.join('%10.1f' % v for v in row) + '   | vs tree: ' + ' '.join('x%.3f' % (row[-1] / v) for v in row[:-1]))
