@@ -576,6 +576,7 @@ typedef struct {
   float* dc[NSP_LSTM_MAX_LAYERS];
   unsigned long long seed[NSP_LSTM_MAX_LAYERS];
   unsigned long long offset[NSP_LSTM_MAX_LAYERS];
+  void* xchg[NSP_LSTM_MAX_LAYERS];   /* persistent launches only: per-layer exchange scratch, see below */
 } nsp_lstm_stack_params;
 int nsp_lstm_stack_fwd(const nsp_lstm_stack_params* p, void* stream);
 int nsp_lstm_stack_bwd(const nsp_lstm_stack_params* p, void* stream);
@@ -585,6 +586,8 @@ int nsp_lstm_stack_bwd(const nsp_lstm_stack_params* p, void* stream);
  * monotonic device counter; h / dgates handed over with write-through stores + agent acquire). *
  * Requires B <= 64 (batch blocks of 16 are looped inside a stage), H % 256 == 0, H <= 1024,     *
  * nl * H/16 co-resident workgroups (<= 256).                                                   *
+ * p->xchg[l] = scratch for the fragment-major hand-over between stages (csrc/lstm.hip):        *
+ *   forward 2 * L * 64 * H bf16 elements per layer, backward L * 64 * 4H.                        *
  * `sync` = 2 zero-initialised 32-bit words owned by this call (barrier counter, abort flag):   *
  * spins are bounded; on expiry the flag is set and y_top[0] / dg16[0][0] become NaN instead of *
  * the call hanging.  Returns NSP_EUNSUPPORTED when the shape does not qualify.                 */

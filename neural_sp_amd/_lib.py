@@ -127,6 +127,7 @@ class LstmStackParams(ctypes.Structure):
         ('c_all', ctypes.c_void_p * LSTM_MAX_LAYERS), ('gates', ctypes.c_void_p * LSTM_MAX_LAYERS),
         ('dg16', ctypes.c_void_p * LSTM_MAX_LAYERS), ('dc', ctypes.c_void_p * LSTM_MAX_LAYERS),
         ('seed', ctypes.c_ulonglong * LSTM_MAX_LAYERS), ('offset', ctypes.c_ulonglong * LSTM_MAX_LAYERS),
+        ('xchg', ctypes.c_void_p * LSTM_MAX_LAYERS),
     ]
 
 

@@ -338,6 +338,17 @@ __global__ __launch_bounds__(1024) void lstm_stack_bwd_kernel(const nsp_lstm_sta
 
 // ---------------------------------------------------------------------------------------------
 // Persistent variants: weights in registers for the whole sequence, grid barrier per stage.
+#ifndef NSP_LSTM_FWD_DEPTH
+#define NSP_LSTM_FWD_DEPTH 8
+#endif
+#ifndef NSP_LSTM_BWD_DEPTH
+#define NSP_LSTM_BWD_DEPTH 12
+#endif
+#ifndef NSP_LSTM_ABL
+#define NSP_LSTM_ABL 0   // development ablations (tools/lstm_ablate.sh), 0 in the product: 1 no operand loads, 4 no forward
+                         // state stores, 8 no grid barrier, 16 no publishing stores, 32 no backward dgates image, 64 no
+                         // prefetch of the saved forward state
+#endif
 typedef __attribute__((address_space(1))) unsigned int gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
@@ -373,13 +384,44 @@ __device__ __forceinline__ bool grid_wait(unsigned int* sync, unsigned int targe
   return *dead_sh == 0;
 }
 
-// forward.  grid: (H/16, nl); block 512.  Workgroup (ub, l) owns hidden units 16*ub.. of layer l:
-// wave w holds, for each of the 4 gates, the 16 W rows of those units restricted to its 1/8 of the
-// reduction (layer 0: K = H; layers >= 1: K = 2H over [W_ih | W_hh]) as MFMA B-fragments.
-// NB = ceil(B/16) batch blocks share a stage: all their partial products go to LDS first (their
-// operand loads are independent, so the latencies overlap), ONE workgroup barrier, then the two
-// halves of the workgroup run the cell updates of alternating blocks, one barrier, publish.
-template <int NB>
+// ---- persistent kernels, second version (round 3).  What the first version's stage time was made of, measured at
+// B = 64, 2 x 1024, L = 200 by compiling pieces out (profiles/r03t_lstm_*_ablation.log; microseconds per stage):
+//   forward  17.1 = operand loads 6.0 + grid barrier 6.0 + state stores 2.3 + MFMA 1.1 + the rest 1.7
+//   backward 43   = operand loads 27.7 + grid barrier 5.9 + MFMA 1.5 + the rest ~8
+// Now 8.5 and ~21 (profiles/r03ae_lstm_v3_bwd_ablation.log), from four changes:
+//   * the exchange buffers below: the loads were never latency-bound -- more of them in flight, another row stride,
+//     another unit -> XCD map, a rotated sweep order, no L2 invalidate all measured nothing -- but bound by the vector
+//     L1's line lookups;
+//   * a layer's operand from the layer BELOW / ABOVE (forward: dropout(h_{l-1}) at the same step; backward: the
+//     dgates of layer l+1 at the same step) is consumed one stage late (layer l lags its neighbour by TWO stages
+//     instead of one): its loads and MFMAs run between the workgroup's arrival at the barrier and the end of its
+//     wait and leave their partial sums in the LDS slots of the reduction; only the recurrent half is in front of
+//     the cell update;
+//   * no register spills: a rolling ring of 8 (forward) / 12 (backward, now 8 waves x 256 VGPRs instead of 16 x 128)
+//     fragment loads with (uniform base + 32-bit lane offset + immediate) addresses.  A spilled build of the same
+//     source (deeper ring, 30 - 90 dwords of scratch) is 1.7 - 2.5x slower per stage: scratch reloads are memory round
+//     trips on the critical path;
+//   * the forward's saved state (c, activated gates, y) and the [B, L, .] images for the GEMMs are stored at the END
+//     of the stage, behind the arrival and the early half's loads (vmcnt is in-order).
+// Rows beyond B carry garbage through the exchange (their MFMA rows are independent and never stored).
+
+// Exchange buffers.  An MFMA operand fragment read straight from a [B, L, K] image puts 16 DIFFERENT rows (utterances)
+// into every quarter-wave, 16 bytes each: the vector L1 looks up 16 lines per quarter-wave and such loads crawl at
+// ~16 B/clk per CU (40 GB/s: 6 us for the forward's 256 KB, 27 us for the backward's 1 MB per stage -- whatever the
+// number of loads in flight, the row stride, the XCD mapping or the sweep order; profiles/r03*_lstm_*.log).  So the
+// recurrent hand-over goes through a FRAGMENT-MAJOR image per layer,
+//   lstm_xchg_index(tau, bk, k, b) = (((tau * NB + bk) * K/8 + k/8) * 16 + b) * 8 + k%8      (bf16 elements),
+// step tau, batch block bk of 16 utterances b, column k of K (H forward, 4H backward): the 16 utterances of one
+// 8-column group are 256 contiguous bytes, a wave-wide fragment load is 1 KB contiguous, and a workgroup publishes
+// its 16 units as whole 256-byte pieces.  The [B, L, K] images the weight-gradient GEMMs need are written as well,
+// by plain stores after the arrival at the barrier (off the critical path).  p.xchg[l]: forward 2 x L x NB x H x 16
+// elements (h, then dropout(h)), backward L x NB x 4H x 16; the caller sizes them for NB = 4.
+//
+// forward.  grid: (H/16, nl); block 512.  Workgroup (ub, l) owns hidden units 16*ub.. of layer l: wave w holds, for
+// each of the 4 gates, the 16 W rows of those units restricted to its 1/8 of the recurrent reduction (brec) and,
+// for layers >= 1, of the input reduction (bin) as MFMA B-fragments.  NF = H / 256 fragments per wave and half.
+// Stage s runs step t = s - 2 l of layer l.
+template <int NB, int NF>
 __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const nsp_lstm_stack_params p,
                                                                         unsigned int* sync) {
   extern __shared__ __attribute__((aligned(16))) float fdyn[];
@@ -389,35 +431,84 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
   hs_t* hs = reinterpret_cast<hs_t*>(fdyn + NB * (8 * 4 * 16 * 17));                // [NB]
   __shared__ int dead_sh;
   constexpr int NU = (NB + 1) / 2;   // blocks per cell-update thread (thread group tg: blocks tg, tg+2)
+  constexpr int Q = NB * NF;         // operand fragments per wave and half: all in flight at once
   const int l = blockIdx.y;
   const int H = p.H, L = p.L, B = p.B, top = p.nl - 1;
   const int nwg = gridDim.x * gridDim.y;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int u0 = blockIdx.x * 16;
-  const int Ktot = l == 0 ? H : 2 * H;
-  const int Kw = Ktot >> 3;
-  const int nf = Kw >> 5;  // 32-wide k-fragments per wave: <= 8
-  const int kbeg = w * Kw;
-  bf16x8 bfrag[4][8];
+  const bool has_in = l > 0;
+  const int Ktot = has_in ? 2 * H : H;
+  const int koff = w * (NF * 32) + g * 8;   // the lane's first column inside a half
+  bf16x8 bin[4][NF], brec[4][NF];
   {
     const __bf16* W = reinterpret_cast<const __bf16*>(p.w[l]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      const __bf16* wr = W + (long long)(j * H + u0 + r) * Ktot + koff;
 #pragma unroll
-      for (int f = 0; f < 8; ++f)
-        if (f < nf)
-          bfrag[j][f] = *reinterpret_cast<const bf16x8*>(W + (long long)(j * H + u0 + r) * Ktot + kbeg + f * 32 + g * 8);
+      for (int f = 0; f < NF; ++f) {
+        brec[j][f] = *reinterpret_cast<const bf16x8*>(wr + (has_in ? H : 0) + f * 32);
+        bin[j][f] = *reinterpret_cast<const bf16x8*>(wr + f * 32);   // layer 0: never used
+      }
+    }
   }
-  const __bf16* abase0;
-  bool a_rec;  // the wave's k-slice lies in the recurrent half
-  if (l == 0 || kbeg >= H) {
-    abase0 = reinterpret_cast<const __bf16*>(p.hp16[l]) + (l == 0 ? kbeg : kbeg - H);
-    a_rec = true;
-  } else {
-    abase0 = reinterpret_cast<const __bf16*>(p.yd16[l - 1]) + kbeg;
-    a_rec = false;
-  }
+  // exchange buffers (see lstm_xchg_index): slot tau of hx holds h_tau, of ydx dropout(h_tau)
+  __bf16* hx = reinterpret_cast<__bf16*>(p.xchg[l]);
+  __bf16* ydx = hx + (long long)L * NB * H * 16;
+  const __bf16* inx = has_in ? reinterpret_cast<const __bf16*>(p.xchg[l - 1]) + (long long)L * NB * H * 16 : hx;
+  const int lane_off = ((koff >> 3) * 16 + r) * 8;
+
+  // acc(block) = init + A(16 utterances x this wave's k-slice) . W^T -> the wave's LDS slot
+  // acc(block) = init + A(16 utterances x this wave's k-slice of exchange slot `slot`) . W^T -> the wave's LDS slot.
+  // Addresses are (uniform slot / block base) + (32-bit lane offset) + (immediate fragment offset): one VGPR for all.
+  auto dot_half = [&](const __bf16* xbuf, int slot, const bf16x8 (&bw)[4][NF], bool init_from_slot, bool live) {
+    constexpr int D = Q < NSP_LSTM_FWD_DEPTH ? Q : NSP_LSTM_FWD_DEPTH;   // fragment loads in flight per wave
+    bf16x8 ring[D];
+    const __bf16* blk0 = xbuf + (long long)slot * NB * H * 16;
+    auto frag = [&](int q) {
+#if NSP_LSTM_ABL & 1
+      return bw[q % 4][q % NF];
+#else
+      return *reinterpret_cast<const bf16x8*>(blk0 + (long long)(q / NF) * H * 16 + (lane_off + (q % NF) * 512));
+#endif
+    };
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < D; ++q) ring[q] = frag(q);
+    }
+#pragma unroll
+    for (int bk = 0; bk < NB; ++bk) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (init_from_slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[j][e] = part[bk][w][j][g * 4 + e][r];
+      }
+      if (live) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int q = bk * NF + f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[q % D], bw[j][f], acc[j], 0, 0, 0);
+          if (q + D < Q) ring[q % D] = frag(q + D);
+        }
+      }
+      // D[i = batch][j = unit]: lane holds unit r, batches 4g..4g+3
+      if (live || !init_from_slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part[bk][w][j][g * 4 + e][r] = acc[j][e];
+      }
+    }
+  };
+
   // cell-update thread (block group tg, b within block, unit)
   const int tg = threadIdx.x >> 8, bb = (threadIdx.x >> 4) & 15, uu = threadIdx.x & 15;
   const int u = u0 + uu;
@@ -434,43 +525,14 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
       if (upd) gin[i][q] = l > 0 ? p.bias[l][q * H + u] : p.gi0[((long long)(bk * 16 + bb) * L) * 4 * H + q * H + u];
     }
   }
-  const int nstage = L + p.nl - 1;
+  const int nstage = L + 2 * top;
   bool alive = true;
   for (int s = 0; s < nstage; ++s) {
-    const int t = s - l;
-    if (t >= 0 && t < L) {
-#pragma unroll
-      for (int bk = 0; bk < NB; ++bk) {
-        const int b0 = bk * 16;
-        const bool a_valid = b0 + r < B;
-        const long long arow0 = (long long)min(b0 + r, B - 1) * L;
-        f32x4 acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!a_rec || t > 0) {
-          const __bf16* ap = abase0 + (arow0 + t) * H + g * 8;
-          bf16x8 af[8];
-#pragma unroll
-          for (int f = 0; f < 8; ++f) {
-            bf16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-            af[f] = (f < nf && a_valid) ? *reinterpret_cast<const bf16x8*>(ap + f * 32) : z;
-          }
-#pragma unroll
-          for (int f = 0; f < 8; ++f)
-            if (f < nf) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfrag[j][f], acc[j], 0, 0, 0);
-            }
-        }
-        // D[i = batch][j = unit]: lane holds unit r, batches 4g..4g+3
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) part[bk][w][j][g * 4 + e][r] = acc[j][e];
-      }
+    const int t = s - 2 * l;
+    const bool active = t >= 0 && t < L;
+    float st_i[NU], st_f[NU], st_g[NU], st_o[NU], st_h[NU];   // this step's state, stored after the arrival
+    if (active) {
+      dot_half(hx, t - 1, brec, has_in, t > 0);
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
@@ -485,19 +547,15 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
             for (int ww = 0; ww < 8; ++ww) v += part[bk][ww][q][bb][uu];
             pre[q] = v;
           }
-          const float ig = nsp_sigmoid(pre[0]);
-          const float fg = nsp_sigmoid(pre[1]);
-          const float gg = nsp_tanh(pre[2]);
-          const float og = nsp_sigmoid(pre[3]);
-          c_reg[i] = fg * c_reg[i] + ig * gg;
-          const float h = og * nsp_tanh(c_reg[i]);
-          p.c_all[l][row * H + u] = c_reg[i];
-          float* gs = p.gates[l] + row * 4 * H;
-          gs[u] = ig; gs[H + u] = fg; gs[2 * H + u] = gg; gs[3 * H + u] = og;
+          st_i[i] = nsp_sigmoid(pre[0]);
+          st_f[i] = nsp_sigmoid(pre[1]);
+          st_g[i] = nsp_tanh(pre[2]);
+          st_o[i] = nsp_sigmoid(pre[3]);
+          c_reg[i] = st_f[i] * c_reg[i] + st_i[i] * st_g[i];
+          const float h = st_o[i] * nsp_tanh(c_reg[i]);
+          st_h[i] = h;
           hs[bk][0][bb][uu] = (__bf16)h;
-          if (l == top) {
-            p.y_top[row * H + u] = h;
-          } else {
+          if (l < top) {
             float hd = h;
             if (p.dropout_p > 0.f)
               hd *= nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
@@ -511,46 +569,81 @@ __global__ __launch_bounds__(512) void lstm_stack_fwd_persistent_kernel(const ns
         }
       }
       __syncthreads();
-      // publish h (shifted by one step) and dropout(h) with 8-byte write-through stores
+      // publish h and dropout(h) into the exchange buffers with 8-byte write-through stores: a workgroup's 16 units
+      // are two whole 256-byte pieces (16 utterances x 8 units) per batch block
+      if (threadIdx.x < 64 * NB && !(NSP_LSTM_ABL & 16)) {
+        const int bk = threadIdx.x >> 6, pb = (threadIdx.x >> 2) & 15, pq = threadIdx.x & 3;
+        const long long xo = (long long)(t * NB + bk) * H * 16 + (((u0 >> 3) + (pq >> 1)) * 16 + pb) * 8 + (pq & 1) * 4;
+        if (t + 1 < L)
+          __hip_atomic_store((gu64*)(hx + xo), *reinterpret_cast<const unsigned long long*>(&hs[bk][0][pb][pq * 4]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (l < top)
+          __hip_atomic_store((gu64*)(ydx + xo), *reinterpret_cast<const unsigned long long*>(&hs[bk][1][pb][pq * 4]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    const bool more = s + 1 < nstage;
+#if !(NSP_LSTM_ABL & 8)
+    if (more) grid_arrive(sync);
+#endif
+    // the NEXT step's input half: dropout(h_{l-1}) at t + 1 was published one stage ago
+    if (has_in && more && t + 1 >= 0 && t + 1 < L) dot_half(inx, t + 1, bin, false, true);
+    if (active && !(NSP_LSTM_ABL & 4)) {
+      // this step's saved state, after the arrival and after the input half's loads (vmcnt is in-order: in front of the
+      // barrier's drain, or of those loads, ~20 KB of scattered 4-byte stores cost 2 - 6 us per stage)
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int bk = tg + 2 * i;
+        if (bk < NB && bk * 16 + bb < B) {
+          const long long row = (long long)(bk * 16 + bb) * L + t;
+          p.c_all[l][row * H + u] = c_reg[i];
+          float* gs = p.gates[l] + row * 4 * H;
+          gs[u] = st_i[i]; gs[H + u] = st_f[i]; gs[2 * H + u] = st_g[i]; gs[3 * H + u] = st_o[i];
+          if (l == top) p.y_top[row * H + u] = st_h[i];
+        }
+      }
+      // the [B, L, H] images the weight-gradient GEMMs read after this kernel (hs is not touched again before the
+      // next stage's cell update)
       if (threadIdx.x < 64 * NB) {
         const int bk = threadIdx.x >> 6, pb = (threadIdx.x >> 2) & 15, pq = threadIdx.x & 3;
         if (bk * 16 + pb < B) {
           const long long prow = (long long)(bk * 16 + pb) * L + t;
           if (t + 1 < L)
-            __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.hp16[l]) + (prow + 1) * H + u0 + pq * 4),
-                               *reinterpret_cast<const unsigned long long*>(&hs[bk][0][pb][pq * 4]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<unsigned long long*>(reinterpret_cast<__bf16*>(p.hp16[l]) + (prow + 1) * H + u0 + pq * 4) =
+                *reinterpret_cast<const unsigned long long*>(&hs[bk][0][pb][pq * 4]);
           if (t == 0)
             *reinterpret_cast<unsigned long long*>(reinterpret_cast<__bf16*>(p.hp16[l]) + prow * H + u0 + pq * 4) = 0ull;
           if (l < top)
-            __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.yd16[l]) + prow * H + u0 + pq * 4),
-                               *reinterpret_cast<const unsigned long long*>(&hs[bk][1][pb][pq * 4]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<unsigned long long*>(reinterpret_cast<__bf16*>(p.yd16[l]) + prow * H + u0 + pq * 4) =
+                *reinterpret_cast<const unsigned long long*>(&hs[bk][1][pb][pq * 4]);
         }
       }
     }
-    if (s + 1 < nstage) {
-      grid_arrive(sync);
-      if (alive) alive = grid_wait(sync, (unsigned int)(s + 1) * nwg, &dead_sh);
-    }
+#if !(NSP_LSTM_ABL & 8)
+    if (more && alive) alive = grid_wait(sync, (unsigned int)(s + 1) * nwg, &dead_sh);
+#else
+    __syncthreads();
+#endif
   }
   if (!alive && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.y_top[0] = __builtin_nanf("");
 }
 
-// backward.  grid: (H/16, nl); block 1024 = 16 waves, each holding its 1/16 of the reduction of the
-// workgroup's 16 rows of W_hh^T (top layer, K = 4H) or [W_ih_{l+1}^T | W_hh_l^T] (K = 8H).
-// NB <= 4 batch blocks per stage: the dot products of all blocks go to LDS, then thread group
-// tg = tid/256 runs the cell update of block tg (so every update thread owns ONE (block, b, unit)
-// for the whole sequence: dc and the prefetched inputs of the next stage stay in registers).
-template <int NB>
-__global__ __launch_bounds__(1024) void lstm_stack_bwd_persistent_kernel(const nsp_lstm_stack_params p,
-                                                                         unsigned int* sync) {
+// backward.  grid: (H/16, nl); block 512 = 8 waves, each holding its 1/8 of the reduction over the workgroup's 16
+// rows of W_hh^T (brec, K = 4H) and, below the top layer, of W_ih_{l+1}^T (bext, K = 4H): NF = H / 64 fragments per
+// wave and half.  Stage s runs step t = L - 1 - (s - 2 (top - l)) of layer l.  LDS slots per batch block: 0..7 the
+// waves' "ext" partial sums (written one stage early, see above), 8..15 the recurrent ones.
+template <int NB, int NF>
+__global__ __launch_bounds__(512) void lstm_stack_bwd_persistent_kernel(const nsp_lstm_stack_params p,
+                                                                        unsigned int* sync) {
   extern __shared__ __attribute__((aligned(16))) float bdyn[];
   typedef float part_t[16][16][17];
   part_t* part = reinterpret_cast<part_t*>(bdyn);                                  // [NB]
   typedef __bf16 dss_t[4][16][16];
   dss_t* dss = reinterpret_cast<dss_t*>(bdyn + NB * (16 * 16 * 17));               // [NB]
   __shared__ int dead_sh;
+  constexpr int NU = (NB + 1) / 2;
+  constexpr int Q = NB * NF;
+  constexpr int D = Q < NSP_LSTM_BWD_DEPTH ? Q : NSP_LSTM_BWD_DEPTH;   // operand fragments in flight per wave
   const int top = p.nl - 1;
   const int l = blockIdx.y;
   const int H = p.H, L = p.L, B = p.B;
@@ -561,104 +654,152 @@ __global__ __launch_bounds__(1024) void lstm_stack_bwd_persistent_kernel(const n
   const int K4 = 4 * H;
   const bool has_ext = l < top;
   const int Ktot = has_ext ? 2 * K4 : K4;
-  const int Kw = Ktot >> 4;
-  const int nf = Kw >> 5;  // <= 16
-  const int kbeg = w * Kw;
-  bf16x8 bfrag[16];
+  const int koff = w * (NF * 32) + g * 8;
+  bf16x8 bext[NF], brec[NF];
   {
-    const __bf16* W = reinterpret_cast<const __bf16*>(p.w[l]) + (long long)(u0 + r) * Ktot + kbeg + g * 8;
+    const __bf16* wr = reinterpret_cast<const __bf16*>(p.w[l]) + (long long)(u0 + r) * Ktot + koff;
 #pragma unroll
-    for (int f = 0; f < 16; ++f)
-      if (f < nf) bfrag[f] = *reinterpret_cast<const bf16x8*>(W + f * 32);
+    for (int f = 0; f < NF; ++f) {
+      brec[f] = *reinterpret_cast<const bf16x8*>(wr + (has_ext ? K4 : 0) + f * 32);
+      bext[f] = *reinterpret_cast<const bf16x8*>(wr + f * 32);   // top layer: never used
+    }
   }
-  const bool a_ext = has_ext && kbeg < K4;
-  const __bf16* abase0 = a_ext ? reinterpret_cast<const __bf16*>(p.dg16[l + 1]) + kbeg
-                               : reinterpret_cast<const __bf16*>(p.dg16[l]) + (has_ext ? kbeg - K4 : kbeg);
+  // exchange buffer of layer l: slot tau holds its dgates at step tau (see lstm_xchg_index)
+  __bf16* dgx = reinterpret_cast<__bf16*>(p.xchg[l]);
+  const __bf16* extx = has_ext ? reinterpret_cast<const __bf16*>(p.xchg[l + 1]) : dgx;
+  const int lane_off = ((koff >> 3) * 16 + r) * 8;
+
+  // part[block][slot0 + w] = A(16 utterances x this wave's k-slice at time row trow) . W^T, a rolling ring of D loads
+  auto dot_half = [&](const __bf16* xbuf, int trow, const bf16x8 (&bw)[NF], int slot0, bool live) {
+    bf16x8 ring[D];
+    const __bf16* blk0 = xbuf + (long long)trow * NB * K4 * 16;   // uniform; + block * K4 * 16 + 32-bit lane offset + immediate
+    auto frag = [&](int q) {
+#if NSP_LSTM_ABL & 1
+      return bw[q % NF];
+#else
+      return *reinterpret_cast<const bf16x8*>(blk0 + (long long)(q / NF) * K4 * 16 + (lane_off + (q % NF) * 512));
+#endif
+    };
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < D; ++q) ring[q] = frag(q);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (live) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[q % D], bw[q % NF], acc, 0, 0, 0);
+        if (q + D < Q) ring[q % D] = frag(q + D);
+      }
+      if (q % NF == NF - 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[q / NF][slot0 + w][g * 4 + e][r] = acc[e];
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
   const int tg = threadIdx.x >> 8, bb = (threadIdx.x >> 4) & 15, uu = threadIdx.x & 15;
   const int u = u0 + uu;
-  const bool upd = tg < NB && tg * 16 + bb < B;
-  const long long brow = (long long)(tg * 16 + bb) * L;
-  float dc_reg = 0.f;
-  const int nstage = L + p.nl - 1;
-  bool alive = true;
-  // the cell-update inputs of the NEXT stage (saved by the forward pass: plain data) are fetched
-  // before the grid barrier, so their latency hides behind it
-  float n_dy = 0.f, n_ig = 0.f, n_fg = 0.f, n_gg = 0.f, n_og = 0.f, n_cp = 0.f, n_c = 0.f;
+  bool upd[NU];
+  long long brow[NU];
+  float dc_reg[NU];
+  // the cell-update inputs of the NEXT stage (saved by the forward pass: plain data) are fetched a stage ahead
+  float n_dy[NU], n_ig[NU], n_fg[NU], n_gg[NU], n_og[NU], n_cp[NU], n_c[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const int bk = tg + 2 * i;
+    upd[i] = bk < NB && bk * 16 + bb < B;
+    brow[i] = (long long)(bk * 16 + bb) * L;
+    dc_reg[i] = 0.f;
+    n_dy[i] = n_ig[i] = n_fg[i] = n_gg[i] = n_og[i] = n_cp[i] = n_c[i] = 0.f;
+    if (upd[i]) n_c[i] = p.c_all[l][(brow[i] + L - 1) * H + u];
+  }
   auto fetch = [&](int tn) {
-    if (!upd || tn < 0) return;
-    const long long rown = brow + tn;
-    const float* gs = p.gates[l] + rown * K4;
-    if (!has_ext) n_dy = p.dy_top[rown * H + u];
-    n_ig = gs[u]; n_fg = gs[H + u]; n_gg = gs[2 * H + u]; n_og = gs[3 * H + u];
-    n_cp = tn > 0 ? p.c_all[l][(rown - 1) * H + u] : 0.f;
+    if (tn < 0 || (NSP_LSTM_ABL & 64)) return;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      if (!upd[i]) continue;
+      const long long rown = brow[i] + tn;
+      const float* gs = p.gates[l] + rown * K4;
+      if (!has_ext) n_dy[i] = p.dy_top[rown * H + u];
+      n_ig[i] = gs[u]; n_fg[i] = gs[H + u]; n_gg[i] = gs[2 * H + u]; n_og[i] = gs[3 * H + u];
+      n_cp[i] = tn > 0 ? p.c_all[l][(rown - 1) * H + u] : 0.f;
+    }
   };
-  if (upd) n_c = p.c_all[l][(brow + L - 1) * H + u];
   fetch(L - 1);
+  const int lag = 2 * (top - l);
+  const int nstage = L + 2 * top;
+  bool alive = true;
   for (int s = 0; s < nstage; ++s) {
-    const int t = L - 1 - (s - (top - l));
-    if (t >= 0 && t < L) {
-      const long long row = brow + t;
-      const float dyv = n_dy, ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, cp = n_cp, c = n_c;
-      float keep = 1.f;
-      if (upd && has_ext && p.dropout_p > 0.f)
-        keep = nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)(row * H + u), p.dropout_p);
-      n_c = cp;          // c_{t-1} is this step's c_prev
+    const int t = L - 1 - (s - lag);
+    const bool active = t >= 0 && t < L;
+    if (active) {
+      float dyv[NU], ig[NU], fg[NU], gg[NU], og[NU], cp[NU], c[NU], keep[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        dyv[i] = n_dy[i]; ig[i] = n_ig[i]; fg[i] = n_fg[i]; gg[i] = n_gg[i]; og[i] = n_og[i]; cp[i] = n_cp[i]; c[i] = n_c[i];
+        keep[i] = 1.f;
+        if (upd[i] && has_ext && p.dropout_p > 0.f)
+          keep[i] = nsp_keep_scale(p.seed[l], p.offset[l] + (unsigned long long)((brow[i] + t) * H + u), p.dropout_p);
+        n_c[i] = cp[i];          // c_{t-1} is this step's c_prev
+      }
       fetch(t - 1);
+      dot_half(dgx, t + 1, brec, 8, t + 1 < L);
+      __syncthreads();
 #pragma unroll
-      for (int bk = 0; bk < NB; ++bk) {
-        const bool a_valid = bk * 16 + r < B;
-        const long long arow0 = (long long)min(bk * 16 + r, B - 1) * L;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (a_ext || t + 1 < L) {
-          const __bf16* ap = abase0 + (arow0 + t + (a_ext ? 0 : 1)) * K4 + g * 8;
-          // four rounds of 4 fragments: 4 waves per SIMD leave 128 VGPRs per wave, 64 hold weights
+      for (int i = 0; i < NU; ++i) {
+        if (!upd[i]) continue;
+        const int bk = tg + 2 * i;
+        float ext = 0.f, rec = 0.f;
+        if (has_ext) {
 #pragma unroll
-          for (int h2 = 0; h2 < 4; ++h2) {
-            bf16x8 af[4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-              bf16x8 z;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-              af[f] = (h2 * 4 + f < nf && a_valid) ? *reinterpret_cast<const bf16x8*>(ap + (h2 * 4 + f) * 32) : z;
-            }
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-              if (h2 * 4 + f < nf) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfrag[h2 * 4 + f], acc, 0, 0, 0);
-          }
+          for (int q = 0; q < 8; ++q) ext += part[bk][q][bb][uu];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) part[bk][w][g * 4 + e][r] = acc[e];
+        for (int q = 8; q < 16; ++q) rec += part[bk][q][bb][uu];
+        const float dh = has_ext ? keep[i] * ext + rec : dyv[i] + rec;
+        const float tc = nsp_tanh(c[i]);
+        const float dct = dc_reg[i] + dh * og[i] * (1.f - tc * tc);
+        dss[bk][3][bb][uu] = (__bf16)(dh * tc * og[i] * (1.f - og[i]));
+        dss[bk][0][bb][uu] = (__bf16)(dct * gg[i] * ig[i] * (1.f - ig[i]));
+        dss[bk][1][bb][uu] = (__bf16)(dct * cp[i] * fg[i] * (1.f - fg[i]));
+        dss[bk][2][bb][uu] = (__bf16)(dct * ig[i] * (1.f - gg[i] * gg[i]));
+        dc_reg[i] = dct * fg[i];
       }
       __syncthreads();
-      if (upd) {
-        float ext = 0.f, rec = 0.f;
+      // (block, gate q, batch pb, 4-unit group pq): one 8-byte write-through store
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ext += part[tg][q][bb][uu];
-#pragma unroll
-        for (int q = 8; q < 16; ++q) rec += part[tg][q][bb][uu];
-        const float dh = has_ext ? keep * ext + rec : dyv + ext + rec;
-        const float tc = nsp_tanh(c);
-        const float dct = dc_reg + dh * og * (1.f - tc * tc);
-        dss[tg][3][bb][uu] = (__bf16)(dh * tc * og * (1.f - og));
-        dss[tg][0][bb][uu] = (__bf16)(dct * gg * ig * (1.f - ig));
-        dss[tg][1][bb][uu] = (__bf16)(dct * cp * fg * (1.f - fg));
-        dss[tg][2][bb][uu] = (__bf16)(dct * ig * (1.f - gg * gg));
-        dc_reg = dct * fg;
-      }
-      __syncthreads();
-      {   // (block tg, gate q, batch pb, 4-unit group pq): one 8-byte write-through store
-        const int q = (threadIdx.x >> 6) & 3, pb = (threadIdx.x >> 2) & 15, pq = threadIdx.x & 3;
-        if (tg < NB && tg * 16 + pb < B)
-          __hip_atomic_store((gu64*)(reinterpret_cast<__bf16*>(p.dg16[l]) + ((long long)(tg * 16 + pb) * L + t) * K4 + q * H + u0 + pq * 4),
-                             *reinterpret_cast<const unsigned long long*>(&dss[tg][q][pb][pq * 4]), __ATOMIC_RELAXED,
+      for (int k = 0; k < (NB * 256 + 511) / 512; ++k) {
+        const int idx = threadIdx.x + 512 * k;
+        const int bk = idx >> 8, q = (idx >> 6) & 3, pb = (idx >> 2) & 15, pq = idx & 3;
+        if (bk < NB && !(NSP_LSTM_ABL & 16))
+          __hip_atomic_store((gu64*)(dgx + (long long)(t * NB + bk) * K4 * 16 + ((((q * H + u0) >> 3) + (pq >> 1)) * 16 + pb) * 8 + (pq & 1) * 4),
+                             *reinterpret_cast<const unsigned long long*>(&dss[bk][q][pb][pq * 4]), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (s + 1 < nstage) {
-      grid_arrive(sync);
-      if (alive) alive = grid_wait(sync, (unsigned int)(s + 1) * nwg, &dead_sh);
+    const bool more = s + 1 < nstage;
+#if !(NSP_LSTM_ABL & 8)
+    if (more) grid_arrive(sync);
+#endif
+    if (active && !(NSP_LSTM_ABL & 32)) {   // the [B, L, 4H] image the weight / input gradient GEMMs read after this kernel
+#pragma unroll
+      for (int k = 0; k < (NB * 256 + 511) / 512; ++k) {
+        const int idx = threadIdx.x + 512 * k;
+        const int bk = idx >> 8, q = (idx >> 6) & 3, pb = (idx >> 2) & 15, pq = idx & 3;
+        if (bk < NB && bk * 16 + pb < B)
+          *reinterpret_cast<unsigned long long*>(reinterpret_cast<__bf16*>(p.dg16[l]) + ((long long)(bk * 16 + pb) * L + t) * K4 + q * H + u0 + pq * 4) =
+              *reinterpret_cast<const unsigned long long*>(&dss[bk][q][pb][pq * 4]);
+      }
     }
+    // the NEXT step's "ext" half: layer l+1's dgates at t - 1 were published one stage ago
+    if (has_ext && more && t - 1 >= 0 && t - 1 < L) dot_half(extx, t - 1, bext, 0, true);
+#if !(NSP_LSTM_ABL & 8)
+    if (more && alive) alive = grid_wait(sync, (unsigned int)(s + 1) * nwg, &dead_sh);
+#else
+    __syncthreads();
+#endif
   }
   if (!alive && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     reinterpret_cast<__bf16*>(p.dg16[0])[0] = (__bf16)__builtin_nanf("");
@@ -757,6 +898,7 @@ static int lstm_persistent_check(const nsp_lstm_stack_params* p) {
   int rc = lstm_stack_check(p);
   if (rc != NSP_OK) return rc;
   if (p->B > 64 || p->H % 256 || p->H > 1024 || p->nl * (p->H / 16) > 256) return NSP_EUNSUPPORTED;
+  if ((long long)p->B * p->L * 4 * p->H >= (1ll << 31)) return NSP_EUNSUPPORTED;   // 32-bit operand offsets
   return NSP_OK;
 }
 
@@ -780,29 +922,41 @@ static bool lstm_grid_fits(const void* kernel, int block, size_t shmem, int nwg)
   return cap >= nwg;
 }
 
+template <typename KernelT>
+static int lstm_launch_persistent(KernelT kernel, dim3 grid, int block, size_t shmem, const nsp_lstm_stack_params* p,
+                                  unsigned int* sync, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (!lstm_grid_fits((const void*)kernel, block, shmem, grid.x * grid.y)) return NSP_EUNSUPPORTED;
+  hipLaunchKernelGGL(kernel, grid, dim3(block), shmem, st, *p, sync);
+  return NSP_OK;
+}
+
+// NB in {1, 2, 4} batch blocks (3 runs as 4: rows beyond B repeat row B - 1 and are never stored), HB = H / 256
+#define LSTM_P_CASE(KERNEL, NBT, HB, FMUL)                                                                   \
+  case NBT * 8 + HB:                                                                                          \
+    rc = lstm_launch_persistent(KERNEL<NBT, HB * FMUL>, grid, 512, (size_t)NBT * shmem_per_block, p, sync, st); \
+    break;
+#define LSTM_P_DISPATCH(KERNEL, FMUL)                                                                         \
+  do {                                                                                                        \
+    const int nb_ = nsp_cdiv(p->B, 16), nbt = nb_ <= 1 ? 1 : (nb_ == 2 ? 2 : 4);                              \
+    switch (nbt * 8 + p->H / 256) {                                                                           \
+      LSTM_P_CASE(KERNEL, 1, 1, FMUL) LSTM_P_CASE(KERNEL, 1, 2, FMUL) LSTM_P_CASE(KERNEL, 1, 3, FMUL)         \
+      LSTM_P_CASE(KERNEL, 1, 4, FMUL) LSTM_P_CASE(KERNEL, 2, 1, FMUL) LSTM_P_CASE(KERNEL, 2, 2, FMUL)         \
+      LSTM_P_CASE(KERNEL, 2, 3, FMUL) LSTM_P_CASE(KERNEL, 2, 4, FMUL) LSTM_P_CASE(KERNEL, 4, 1, FMUL)         \
+      LSTM_P_CASE(KERNEL, 4, 2, FMUL) LSTM_P_CASE(KERNEL, 4, 3, FMUL) LSTM_P_CASE(KERNEL, 4, 4, FMUL)         \
+      default: rc = NSP_EUNSUPPORTED;                                                                         \
+    }                                                                                                         \
+  } while (0)
+
 extern "C" int nsp_lstm_stack_fwd_persistent(const nsp_lstm_stack_params* p, unsigned int* sync, void* stream) {
   int rc = lstm_persistent_check(p);
   if (rc != NSP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(sync, 0, 2 * sizeof(unsigned int), st);
   const dim3 grid(p->H / 16, p->nl);
-  const int nb = nsp_cdiv(p->B, 16);
-  const size_t shmem = (size_t)nb * (sizeof(float) * 8 * 4 * 16 * 17 + 2 * 16 * 16 * 2);
-#define LSTM_FWD_P(N)                                                                                         \
-  do {                                                                                                        \
-    (void)hipFuncSetAttribute((const void*)lstm_stack_fwd_persistent_kernel<N>,                               \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                        \
-    if (!lstm_grid_fits((const void*)lstm_stack_fwd_persistent_kernel<N>, 512, shmem, grid.x * grid.y))       \
-      return NSP_EUNSUPPORTED;                                                                                \
-    hipLaunchKernelGGL((lstm_stack_fwd_persistent_kernel<N>), grid, dim3(512), shmem, st, *p, sync);          \
-  } while (0)
-  switch (nb) {
-    case 1: LSTM_FWD_P(1); break;
-    case 2: LSTM_FWD_P(2); break;
-    case 3: LSTM_FWD_P(3); break;
-    default: LSTM_FWD_P(4); break;
-  }
-#undef LSTM_FWD_P
+  const size_t shmem_per_block = sizeof(float) * 8 * 4 * 16 * 17 + 2 * 16 * 16 * 2;
+  LSTM_P_DISPATCH(lstm_stack_fwd_persistent_kernel, 1);
+  if (rc != NSP_OK) return rc;
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
@@ -813,23 +967,11 @@ extern "C" int nsp_lstm_stack_bwd_persistent(const nsp_lstm_stack_params* p, uns
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(sync, 0, 2 * sizeof(unsigned int), st);
   const dim3 grid(p->H / 16, p->nl);
-  const int nb = nsp_cdiv(p->B, 16);
-  const size_t shmem = (size_t)nb * (sizeof(float) * 16 * 16 * 17 + 4 * 16 * 16 * 2);
-#define LSTM_BWD_P(N)                                                                                         \
-  do {                                                                                                        \
-    (void)hipFuncSetAttribute((const void*)lstm_stack_bwd_persistent_kernel<N>,                               \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                        \
-    if (!lstm_grid_fits((const void*)lstm_stack_bwd_persistent_kernel<N>, 1024, shmem, grid.x * grid.y))      \
-      return NSP_EUNSUPPORTED;                                                                                \
-    hipLaunchKernelGGL((lstm_stack_bwd_persistent_kernel<N>), grid, dim3(1024), shmem, st, *p, sync);         \
-  } while (0)
-  switch (nb) {
-    case 1: LSTM_BWD_P(1); break;
-    case 2: LSTM_BWD_P(2); break;
-    case 3: LSTM_BWD_P(3); break;
-    default: LSTM_BWD_P(4); break;
-  }
-#undef LSTM_BWD_P
+  const size_t shmem_per_block = sizeof(float) * 16 * 16 * 17 + 4 * 16 * 16 * 2;
+  LSTM_P_DISPATCH(lstm_stack_bwd_persistent_kernel, 4);
+  if (rc != NSP_OK) return rc;
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
+#undef LSTM_P_DISPATCH
+#undef LSTM_P_CASE

@@ -2245,6 +2245,15 @@ def _lstm_poll_dead(block=False):
     _LSTM_DEAD_CHECKS[:] = keep
 
 
+def _lstm_xchg(P, cols, dev):
+    """Scratch for the persistent kernels' fragment-major hand-over (csrc/lstm.hip): L x 64 x cols bf16 per layer
+    (cols = 2H forward: h and dropout(h); 4H backward); slabs of a larger batch reuse it one after the other."""
+    bufs = [torch.empty((P.L * 64 * cols,), device=dev, dtype=torch.bfloat16) for _ in range(P.nl)]
+    for l, b in enumerate(bufs):
+        P.xchg[l] = b.data_ptr()
+    return bufs
+
+
 def _lstm_stack_launch(which, P, dev):
     """Persistent single-launch recurrence when the shape qualifies (H % 256 == 0, H <= 1024;
     NSP_LSTM_PERSISTENT=0 disables) AND the device can hold the whole grid (the C side checks
@@ -2349,7 +2358,9 @@ class LSTMStackFn(torch.autograd.Function):
                 sd = next_dropout_seed() if p_drop > 0 else (0, 0)
                 seeds.append(sd)
                 P.seed[l], P.offset[l] = sd
+        xchg = _lstm_xchg(P, 2 * H, dev)
         _lstm_stack_launch('fwd', P, dev)
+        del xchg
         ctx.save_for_backward(xa, *ws, *hp16, *yd16, *c_all, *gates)
         ctx.cfg = (nl, B, L, I, H, float(p_drop), seeds)
         return y_top
@@ -2391,7 +2402,9 @@ class LSTMStackFn(torch.autograd.Function):
             keep.append(dc)
             P.dg16[l], P.dc[l] = dg16[l].data_ptr(), dc.data_ptr()
             P.c_all[l], P.gates[l] = c_all[l].data_ptr(), gates[l].data_ptr()
+        xchg = _lstm_xchg(P, 4 * H, dev)
         _lstm_stack_launch('bwd', P, dev)
+        del xchg
         grads = []
         dx = None
         for l in range(nl):

@@ -15,5 +15,6 @@ db=$(find $out -name '*.db' | head -1)
 } > $root/gpurun_out/${tag}_kernel_stats.txt
 python $root/tools/trace_overlap.py $db > $root/gpurun_out/${tag}_overlap.txt 2>&1
 tail -1 $out/bench.out | cut -c1-400
+python $root/tools/rocpd_lstm_shadow.py $db > $root/gpurun_out/${tag}_lstm_shadow.txt 2>&1
 [ -n "$AROUND" ] && python $root/tools/rocpd_around.py $db "$AROUND" > $root/gpurun_out/${tag}_around.txt 2>&1
 rm -rf $out   # the database is tens of MB
