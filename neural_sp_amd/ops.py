@@ -2245,6 +2245,15 @@ def _lstm_poll_dead(block=False):
     _LSTM_DEAD_CHECKS[:] = keep
 
 
+def _lstm_layerwise(B, H):
+    """Run a multi-layer stack layer by layer (see LSTMStackFn._forward_layerwise)?  OPT-IN (NSP_LSTM_LAYERWISE=1), only
+    where the persistent kernels apply (H % 256 == 0, H <= 1024).  Measured at 2 x 1024, B = 128, L = 200
+    (profiles/r03ag_lstm_layerwise.log): 20.9 ms on 64 CUs against the wavefront's 13.8 ms on 128 -- 25 % fewer
+    CU-milliseconds, but the bench step does not move (126.2 vs 125.4 ms), so the wavefront stays the default."""
+    return (os.environ.get('NSP_LSTM_LAYERWISE', '0') == '1' and os.environ.get('NSP_LSTM_PERSISTENT', '1') != '0'
+            and H % 256 == 0 and H <= 1024)
+
+
 def _lstm_xchg(P, cols, dev):
     """Scratch for the persistent kernels' fragment-major hand-over (csrc/lstm.hip): L x 64 x cols bf16 per layer
     (cols = 2H forward: h and dropout(h); 4H backward); slabs of a larger batch reuse it one after the other."""
@@ -2327,6 +2336,8 @@ class LSTMStackFn(torch.autograd.Function):
         x2d = _f32c(x).reshape(B * L, I)
         xa = to_bf16(x2d) if I % 8 == 0 else x2d
         gi0 = linear_fwd(xa, ws[0], axpby(ws[2], ws[3], 1.0, 1.0))                # [B*L, 4H] fp32
+        if nl > 1 and _lstm_layerwise(B, H):
+            return LSTMStackFn._forward_layerwise(ctx, xa, gi0, p_drop, ws, (nl, B, L, I, H), dev)
         P = _lib.LstmStackParams()
         P.nl, P.B, P.L, P.H, P.dropout_p = nl, B, L, H, float(p_drop)
         P.gi0 = gi0.data_ptr()
@@ -2366,6 +2377,44 @@ class LSTMStackFn(torch.autograd.Function):
         return y_top
 
     @staticmethod
+    def _forward_layerwise(ctx, xa, gi0, p_drop, ws, dims, dev):
+        """One persistent launch PER LAYER (H/16 workgroups each) with the next layer's input projection as one GEMM
+        over all steps in between, instead of the (layer, time) wavefront on nl * H/16 workgroups.  The wavefront
+        minimises latency; but the recurrence runs on a side stream beside the encoder, where what it costs the step
+        is the CUs it holds times how long it holds them ("The persistent LSTM in round 3"): a stage of the
+        single-layer kernel reads only its own h (the neighbour's half is a GEMM at full speed).  See _lstm_layerwise
+        for what it measured."""
+        nl, B, L, I, H = dims
+        hp16, yd16, c_all, gates, seeds = [], [], [], [], []
+        gi, y = gi0, None
+        for l in range(nl):
+            w_ih, w_hh, b_ih, b_hh = ws[4 * l:4 * l + 4]
+            if l > 0:
+                gi = linear_fwd(yd16[l - 1].view(B * L, H), w_ih, axpby(b_ih, b_hh, 1.0, 1.0))
+            P = _lib.LstmStackParams()
+            P.nl, P.B, P.L, P.H, P.dropout_p = 1, B, L, H, 0.0
+            P.gi0 = gi.data_ptr()
+            y = torch.empty((B, L, H), device=dev, dtype=torch.float32)
+            P.y_top = y.data_ptr()
+            wl = weight_bf16(w_hh)
+            P.w[0] = wl.data_ptr()
+            hp16.append(torch.empty((B, L, H), device=dev, dtype=torch.bfloat16))
+            c_all.append(torch.empty((B, L, H), device=dev, dtype=torch.float32))
+            gates.append(torch.empty((B, L, 4 * H), device=dev, dtype=torch.float32))
+            P.hp16[0], P.c_all[0], P.gates[0] = hp16[l].data_ptr(), c_all[l].data_ptr(), gates[l].data_ptr()
+            xchg = _lstm_xchg(P, 2 * H, dev)
+            _lstm_stack_launch('fwd', P, dev)
+            del xchg, wl
+            if l < nl - 1:
+                sd = next_dropout_seed() if p_drop > 0 else (0, 0)
+                seeds.append(sd)
+                yd = dropout_raw(y, p_drop, sd[0], sd[1]) if p_drop > 0 else y
+                yd16.append(to_bf16(yd.view(B * L, H)).view(B, L, H))
+        ctx.save_for_backward(xa, *ws, *hp16, *yd16, *c_all, *gates)
+        ctx.cfg = (nl, B, L, I, H, float(p_drop), seeds)
+        return y
+
+    @staticmethod
     def backward(ctx, dy):
         nl, B, L, I, H, p_drop, seeds = ctx.cfg
         sv = ctx.saved_tensors
@@ -2378,11 +2427,33 @@ class LSTMStackFn(torch.autograd.Function):
         gates = sv[o:o + nl]
         dev = dy.device
         dy = _f32c(dy)
+        keep, dg16 = [], []
+        layerwise = nl > 1 and _lstm_layerwise(B, H)
+        if layerwise:
+            dg16 = [None] * nl
+            dyl = dy
+            for l in range(nl - 1, -1, -1):
+                P = _lib.LstmStackParams()
+                P.nl, P.B, P.L, P.H, P.dropout_p = 1, B, L, H, 0.0
+                P.dy_top = dyl.data_ptr()
+                wt = _weight_t_shadow(ws[4 * l + 1], True)                        # [H, 4H]
+                P.w[0] = wt.data_ptr()
+                dg16[l] = torch.empty((B, L, 4 * H), device=dev, dtype=torch.bfloat16)
+                dc = torch.empty((B, H), device=dev, dtype=torch.float32)
+                P.dg16[0], P.dc[0] = dg16[l].data_ptr(), dc.data_ptr()
+                P.c_all[0], P.gates[0] = c_all[l].data_ptr(), gates[l].data_ptr()
+                xchg = _lstm_xchg(P, 4 * H, dev)
+                _lstm_stack_launch('bwd', P, dev)
+                del xchg
+                if l > 0:   # gradient of layer l's input = dropout(h_{l-1}): one GEMM over all steps, then the mask
+                    dyl = linear_dgrad(dg16[l].view(B * L, 4 * H), ws[4 * l])[:, :H]
+                    dyl = dyl if dyl.is_contiguous() else dyl.contiguous()
+                    if p_drop > 0:
+                        dyl = dropout_raw(dyl, p_drop, seeds[l - 1][0], seeds[l - 1][1])
         P = _lib.LstmStackParams()
         P.nl, P.B, P.L, P.H, P.dropout_p = nl, B, L, H, p_drop
         P.dy_top = dy.data_ptr()
-        keep, dg16 = [], []
-        for l in range(nl):
+        for l in range(0 if layerwise else nl):
             w_hh = ws[4 * l + 1]
             if l == nl - 1:
                 wt = _weight_t_shadow(w_hh, True)                                 # [H, 4H]
@@ -2402,9 +2473,10 @@ class LSTMStackFn(torch.autograd.Function):
             keep.append(dc)
             P.dg16[l], P.dc[l] = dg16[l].data_ptr(), dc.data_ptr()
             P.c_all[l], P.gates[l] = c_all[l].data_ptr(), gates[l].data_ptr()
-        xchg = _lstm_xchg(P, 4 * H, dev)
-        _lstm_stack_launch('bwd', P, dev)
-        del xchg
+        if not layerwise:
+            xchg = _lstm_xchg(P, 4 * H, dev)
+            _lstm_stack_launch('bwd', P, dev)
+            del xchg
         grads = []
         dx = None
         for l in range(nl):

@@ -123,6 +123,14 @@ def test_lstm_stack_wavefront_vs_torch(convloss, nl, p_drop, B, L):
     convloss.test_lstm_stack_wavefront_vs_torch(nl, p_drop, B, L)
 
 
+@pytest.mark.parametrize('nl,p_drop,B,L,H', [(2, 0.25, 7, 6, 256), (3, 0.0, 3, 4, 256)])
+def test_lstm_stack_layer_by_layer_matches_wavefront(convloss, nl, p_drop, B, L, H, monkeypatch):
+    """the layer-by-layer orchestration (one recurrence per layer, input projections and their gradients as GEMMs,
+    dropout masks by the elementwise kernel) against the (layer, time) wavefront: same masks, same results.  (On the
+    emulator both run the per-stage kernels -- a grid barrier needs co-resident workgroups.)"""
+    convloss.test_lstm_stack_persistent_matches_wavefront(nl, p_drop, B, L, H, monkeypatch)
+
+
 @pytest.fixture
 def variants(monkeypatch):
     import tests.test_variants_gpu as mod

@@ -304,15 +304,18 @@ def test_lstm_stack_persistent_matches_wavefront(nl, p_drop, B, L, H, monkeypatc
     layers = [(r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0) for r in refs]
     flat = [t for lay in layers for t in lay]
     outs = {}
-    for flag in ('1', '0'):
+    # persistent launches layer by layer (opt-in), the persistent (layer, time) wavefront (default), per-stage launches
+    for mode, (flag, layerwise) in {'layers': ('1', '1'), 'wavefront': ('1', '0'), 'stages': ('0', '0')}.items():
         monkeypatch.setenv('NSP_LSTM_PERSISTENT', flag)
+        monkeypatch.setenv('NSP_LSTM_LAYERWISE', layerwise)
         ops._DROPOUT_STATE['counter'] = 77
         with ops.compute_mode('bf16'):
             y = ops.lstm_stack(x, layers, p_drop)
-            outs[flag] = [y] + list(torch.autograd.grad(y, [x] + flat, dy))
-    for a, b in zip(outs['1'], outs['0']):
-        assert torch.isfinite(a).all()
-        assert _rel(a, b) < 2e-3
+            outs[mode] = [y] + list(torch.autograd.grad(y, [x] + flat, dy))
+    for mode in ('layers', 'wavefront'):
+        for a, b in zip(outs[mode], outs['stages']):
+            assert torch.isfinite(a).all()
+            assert _rel(a, b) < 2e-3, mode
 
 
 @pytest.mark.gpu
