@@ -898,7 +898,8 @@ static int lstm_persistent_check(const nsp_lstm_stack_params* p) {
   int rc = lstm_stack_check(p);
   if (rc != NSP_OK) return rc;
   if (p->B > 64 || p->H % 256 || p->H > 1024 || p->nl * (p->H / 16) > 256) return NSP_EUNSUPPORTED;
-  if ((long long)p->B * p->L * 4 * p->H >= (1ll << 31)) return NSP_EUNSUPPORTED;   // 32-bit operand offsets
+  for (int l = 0; l < p->nl; ++l)
+    if (!p->xchg[l]) return NSP_EINVAL;   // the hand-over scratch is the caller's (sizes: include/nsp_hip.h)
   return NSP_OK;
 }
 
