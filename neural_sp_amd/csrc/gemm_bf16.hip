@@ -111,6 +111,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // tiles of one split spread over eight private L2s (the old z-major grid) every operand panel was
 // fetched from HBM / Infinity Cache once per XCD -- measured in round 2: the weight-gradient kernels
 // read 1.76x (2048 x 512 outputs) to 5x (512 x 512 outputs) their operand bytes.
+#ifndef NSP_GEMM_TRACE
+#define NSP_GEMM_TRACE 0   // development (tools/gemm_wg_trace.py): per-workgroup timestamps of gemm_bf16_kk_glds_kernel<0>
+#endif
+#if NSP_GEMM_TRACE
+__device__ unsigned long long nsp_gemm_trace_buf[4 * 16384];
+#define NSP_TRACE_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) nsp_gemm_trace_buf[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NSP_TRACE_MARK(i) do { } while (0)
+#endif
 struct TileCoord { int tile, split, z1, z2; };
 __device__ __forceinline__ TileCoord tile_coord(const nsp_gemm_params& p, int ntiles) {
   TileCoord c;
@@ -783,6 +792,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const ns
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
 
+  if (EPI == 0) NSP_TRACE_MARK(0);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -793,6 +803,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const ns
         __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + k0), (lds_void*)(smB + (wave * 4 + i) * 1024), 16, 0, 0);
     }
     __syncthreads();
+    if (EPI == 0 && k0 == kbeg) NSP_TRACE_MARK(1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[4], bf[4];
@@ -810,9 +821,16 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const ns
     }
     __syncthreads();
   }
+  if (EPI == 0) NSP_TRACE_MARK(2);
   if constexpr (EPI == 1) rnnt_epilogue_mode<4, true>(p, acc, smem, m0, n0, wm, wn, lane, wave);
   else if constexpr (EPI == 2) rnnt_epilogue_mode<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave);
   else gemm_epilogue<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+#if NSP_GEMM_TRACE
+  if (EPI == 0) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // the stores have left (vmcnt(0)) before the last mark
+    NSP_TRACE_MARK(3);
+  }
+#endif
 }
 
 // ---- the same KC x KC tile with an NS-stage LDS ring.  The single-stage kernel above hides the
@@ -1844,3 +1862,10 @@ extern "C" int nsp_cast_bf16(const float* x, void* out, long long rows, int cols
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
+
+#if NSP_GEMM_TRACE
+extern "C" int nsp_gemm_trace_read(unsigned long long* out, int n_wg) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nsp_gemm_trace_buf), sizeof(unsigned long long) * 4 * (size_t)n_wg) == hipSuccess ? 0 : -1;
+}
+#endif
