@@ -358,10 +358,16 @@ struct EpiSpec {
   static constexpr bool C16 = C16_, PRE16 = PRE16_, RES = RES_, DROP = DROP_;
 };
 
-template <int MI, class S>
+// SWZ: the per-wave staging slab is 16 rows x 64 floats UNPADDED (4 KB) with the 16-B chunk index XOR-ed with
+// (row & 7) instead of 68-float rows (the 8-wave kernel: 8 x 4 KB next to a 128-KB ring = the whole 160-KB LDS);
+// conflict-free for the ds_write_b128 of a fragment (8 consecutive rows, one chunk) and for the row-major read-back.
+template <bool SWZ>
+__device__ __forceinline__ int stage_idx(int row, int chunk) {
+  return SWZ ? row * 64 + ((chunk ^ (row & 7)) << 2) : row * 68 + (chunk << 2);
+}
+template <int MI, class S, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
                                                    int mrow0, int n, int lane, long long coff) {
-  constexpr int SP = 68;
   const int fr = lane & 15, fg = lane >> 4;
   const int er = lane >> 4, ec = (lane & 15) * 4;
   const bool colok = n < p.N;                       // N % 4 == 0: all four columns or none
@@ -436,11 +442,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   auto row_group = [&](int mi, int j) {
     float v[4];
     const int row = er + 4 * j;
-    const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
+    const float4 a4 = *reinterpret_cast<const float4*>(stage + stage_idx<SWZ>(row, lane & 15));
     const int m = mrow0 + mi * 16 + row;
     const bool ok = m < p.M && colok;              // only the stores are predicated
     const long long off = off0 + (long long)(mi * 4 + j) * ldc4;
     const uint4 sd = raw[j];
+#ifndef NSP_HOST_EMULATION
+    // the side operand is CONSUMED on every path: hipcc sinks its only uses into the predicated store block, and a
+    // wave whose rows are all beyond M would otherwise leave the load on the scoreboard -- in a persistent kernel that
+    // becomes an s_waitcnt vmcnt(0) (= every store of the epilogue, gfx9 retires in order) at the top of the next tile
+    if (SWZ && has_side) asm volatile("" :: "v"(sd.x), "v"(sd.y), "v"(sd.z), "v"(sd.w));
+#endif
     if (has_side && mi + 1 < MI) request(mi + 1, j, raw[j]);
     v[0] = a4.x + b4[0]; v[1] = a4.y + b4[1]; v[2] = a4.z + b4[2]; v[3] = a4.w + b4[3];
     if (has_pre && ok) store4(p.pre_out, pre_dt, off, v, 4, true);
@@ -500,7 +512,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
-      *reinterpret_cast<float4*>(stage + fr * SP + ni * 16 + fg * 4) =
+      *reinterpret_cast<float4*>(stage + stage_idx<SWZ>(fr, ni * 4 + fg)) =
           make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -520,15 +532,20 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
       *reinterpret_cast<float4*>(p.epi_f3 + (long long)(mrow0 / (16 * MI)) * p.N + n) =
           make_float4(csum[0], csum[1], csum[2], csum[3]);
   }
+  // The run-time version can leave a (conditional, never consumed) side-operand load on the compiler's scoreboard.  In a
+  // PERSISTENT caller all epilogue variants merge at the tile loop's back edge, and the merged state made hipcc put an
+  // s_waitcnt vmcnt(0) -- which on gfx9 also waits for every store of the epilogue -- in front of the next tile's
+  // first register write.  Resolving it here keeps that wait on the rare path.
+  if constexpr (!S::kStatic && SWZ) __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
 // picks the specialisation for the epilogues of the training step (bf16 mode); SPECIALISE = false keeps a
 // kernel on the run-time version only (compile time / code size of the kernels that rarely see big grids)
-template <int MI, bool SPECIALISE>
+template <int MI, bool SPECIALISE, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
                                                             int mrow0, int nbase, int lane, long long coff) {
   const int n = nbase + (lane & 15) * 4;
-#define NSP_EPI(...) do { gemm_epilogue_fast<MI, EpiSpec<__VA_ARGS__>>(p, acc, stage, mrow0, n, lane, coff); return; } while (0)
+#define NSP_EPI(...) do { gemm_epilogue_fast<MI, EpiSpec<__VA_ARGS__>, SWZ>(p, acc, stage, mrow0, n, lane, coff); return; } while (0)
   if constexpr (SPECIALISE) {
     const bool c16 = p.c_dtype == NSP_DT_BF16;
     const bool drop = p.dropout_p > 0.f;
@@ -551,7 +568,7 @@ __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_param
     }
   }
 #undef NSP_EPI
-  gemm_epilogue_fast<MI, EpiRuntime>(p, acc, stage, mrow0, n, lane, coff);
+  gemm_epilogue_fast<MI, EpiRuntime, SWZ>(p, acc, stage, mrow0, n, lane, coff);
 }
 
 // ---- shared epilogue (see the comment inside): acc[mi][ni] -> global with full-line accesses
@@ -1349,6 +1366,204 @@ __global__ __launch_bounds__(512) void gemm_bf16_kk256_kernel(const nsp_gemm_par
   }
 }
 
+// ---- KC x KC, 256 x 256 x 64 tiles, 8 waves, PHASE-INTERLEAVED main loop (round 4).
+// What the per-workgroup trace of the 128 x 128 kernel said (profiles/r03am): a k-tile costs a workgroup ~3.1 us for
+// 0.23 us of MFMA work, because it waits for one LDS-DMA round trip per k-tile; the first 256 x 256 kernel above has the
+// same one-tile-in-flight structure (vmcnt(0) + barrier per k-tile).  This kernel never drains the DMA queue inside a
+// tile:
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = four 32-row QUADRANTS (2 x 4 MFMA fragments each); a k-tile is four
+//     PHASES, phase q = {ds_read the A rows of quadrant q (+ the wave's 64 B rows in phase 0), issue ONE 16-KB load
+//     unit (2 LDS-DMA instructions per lane), s_barrier, 16 MFMAs, s_barrier};
+//   * the two waves of a SIMD (wave w and w + 4: row halves 0 / 1) run ONE BARRIER APART, so one of them is always in
+//     its MFMA segment (s_setprio 1) while the other issues its LDS reads and DMA requests;
+//   * load units of a k-tile: 0 / 1 = B rows 0-127 / 128-255, 2 = the A rows of quadrants 0-1 of both row halves,
+//     3 = those of quadrants 2-3.  The unit stream runs SIX units (1.5 k-tiles) ahead of the phase that is being
+//     multiplied and keeps running across the tile boundary (persistent workgroup, two 64-KB k-tile buffers).
+//     Six is the largest distance the two buffers allow: the later wave's reads of phase Q are only known to be
+//     complete behind the barrier that ends ITS MFMA segment of phase Q, so a region last read in phase Q may be
+//     re-armed from phase Q + 2 on; units 0 and 3 meet that bound exactly (GEMM section).
+//   * counted waits only: behind the issue of phase 4t+1 vmcnt(8) (unit 3 of k-tile t landed, four newer units in
+//     flight), behind phase 4t+3 vmcnt(6) (units 0-2 of k-tile t+1).  A wave's wait is followed by the barrier that
+//     closes its read segment, so every reader of the NEXT phase has a barrier between all eight waves' waits and its
+//     ds_read.
+//   * epilogue: both wave groups re-align (the early one waits one barrier), drain their own DMA queue (the next
+//     tile's first six units were requested during the last six phases and keep landing meanwhile) and run the
+//     standard fused epilogue through a private 4-KB staging slab per wave (XOR-swizzled, stage_idx<true>) -- the ring
+//     is never used for staging, both k-tile buffers stay armed.
+// Requires K % 128 == 0 (two k-tiles per loop iteration: buffer indices are compile-time), one problem, no split-K,
+// the fast epilogue's conditions, operand extents below 2^32 elements.  LDS 128 KB + 32 KB = all of the CU's 160 KB.
+// VAR (development A/B, NSP_GEMM_8P_VAR): bit 0 = no s_setprio around the MFMA segments, bit 1 = static priority 1 for the
+// second (later dispatched) wave half instead.
+template <int EPI, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
+                                                                int c_vec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 32 KB | B 32 KB) | 8 x 4 KB staging
+  constexpr int BUF = 65536, A_BYTES = 32768, STAGING = 131072;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS piece bases (M0) and row halves stay in SGPRs
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntiles = tiles_m * tiles_n;
+  const int nit = p.K >> 7;                    // loop iterations of two k-tiles
+  const int xq = blockIdx.x >> 3, xx = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  auto tile_of = [&](int step) { return per_xcd * (8 * step + xx) + xq; };   // gridDim.x % 8 == 0 (launcher)
+  const char* A = reinterpret_cast<const char*>(p.A);
+  const char* B = reinterpret_cast<const char*>(p.B);
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int fr = lane & 15, fg = lane >> 4;
+  // ---- DMA sources of the tile the unit stream is in.  Piece pc = wave * 2 + i of a unit = 8 rows x 128 B; lane
+  // (lrow, lpos) fetches the 16-B chunk lpos ^ lrow of its row (source-side swizzle: the DMA writes lane-linear)
+  const int lrow = lane >> 3, lpos = lane & 7;
+  const unsigned sw = (unsigned)((lpos ^ lrow) * 16);
+  unsigned aoff[2][2], boff[2][2];           // [unit 2 / 3 resp. 0 / 1][piece]: BYTE offsets from A / B (scalar base + 32-bit lane offset)
+  auto set_src = [&](int tile) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + lrow;                       // 0..127 inside the unit
+        const int arow = (r & 63) + ((r >> 6) << 7) + u * 64;          // quadrants 2u, 2u+1 of row half r >> 6
+        aoff[u][i] = (unsigned)min(tm * 256 + arow, p.M - 1) * (unsigned)(2 * p.a_rs) + sw;
+        boff[u][i] = (unsigned)min(tn * 256 + u * 128 + r, p.N - 1) * (unsigned)(2 * p.b_ns) + sw;
+      }
+  };
+  // unit j (0..3) of k-tile `kt` of the stream's tile into k-tile buffer `buf`
+  auto issue = [&](int j, int buf, int kt) {
+    unsigned char* base = ring + buf * BUF;
+    const unsigned ko = (unsigned)(kt * (2 * BK));     // added to the 32-bit lane offset: keeps the scalar-base + voffset form
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r0 = (wave * 2 + i) * 8;
+      if (j < 2) {
+        __builtin_amdgcn_global_load_lds((glb_void*)(B + (boff[j][i] + ko)),
+                                         (lds_void*)(base + A_BYTES + (j * 128 + r0) * 128), 16, 0, 0);
+      } else {
+        const int arow0 = (r0 & 63) + ((r0 >> 6) << 7) + (j - 2) * 64;
+        __builtin_amdgcn_global_load_lds((glb_void*)(A + (aoff[j - 2][i] + ko)), (lds_void*)(base + arow0 * 128), 16, 0, 0);
+      }
+    }
+  };
+  // ---- fragment addresses (bytes inside a k-tile buffer): row (.. + fr), 16-B chunk (4 s + fg) ^ (row & 7); the rows
+  // of one lane differ by multiples of 16, so (row & 7) = fr & 7 throughout, s = 1 is the s = 0 address ^ 64, and everything else is an immediate offset
+  const int chunk0 = (fg ^ (fr & 7)) << 4;
+  const int a_addr[2] = {(wr * 128 + fr) * 128 + chunk0, (wr * 128 + fr) * 128 + (chunk0 ^ 64)};   // [s]; + immediates
+  const int b_addr[2] = {A_BYTES + (wc * 64 + fr) * 128 + chunk0, A_BYTES + (wc * 64 + fr) * 128 + (chunk0 ^ 64)};
+  float* stage = reinterpret_cast<float*>(ring + STAGING) + wave * 1024;
+
+  int step = 0;
+  int tile = tile_of(0);
+  if (tile >= ntiles) return;
+  if ((VAR & 2) && wr == 1) __builtin_amdgcn_s_setprio(1);
+  set_src(tile);
+  // prologue: units 0..5 of the first tile (k-tile 0 -> buffer 0, units 0-1 of k-tile 1 -> buffer 1)
+#pragma unroll
+  for (int u = 0; u < 6; ++u) issue(u & 3, u >> 2, u >> 2);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // units 0-2: everything phase 0 reads
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bool first = true;
+  while (true) {
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int next_tile = tile_of(step + 1);
+    const bool has_next = next_tile < ntiles;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wr == 1) {                                     // the second row half runs one barrier behind the first
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+#pragma unroll 1   // (also keeps the unroller from PEELING iteration 0 -- a second copy of the eight phases whose register
+                    // allocation spilled the fragment addresses and reloaded them behind s_waitcnt vmcnt(0))
+    for (int it = 0; it < nit; ++it) {
+      const bool last = it == nit - 1;
+      bf16x8 bfr[2][4], afr[2][2];
+#pragma unroll
+      for (int ph = 0; ph < 8; ++ph) {
+        const int buf = ph >> 2, q = ph & 3;
+        const unsigned char* kb = ring + buf * BUF;
+        // ---- read segment: fragments of this phase, one load unit, the counted wait
+        if (q == 0) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+              bfr[s][ni] = *reinterpret_cast<const bf16x8*>(kb + b_addr[s] + ni * 2048);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            afr[s][mi] = *reinterpret_cast<const bf16x8*>(kb + a_addr[s] + (q * 32 + mi * 16) * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          // the stream is six units ahead: unit (ph + 6) & 3 of k-tile 2 it + (ph + 6) / 4 -- or, from phase 2 of the
+          // last iteration on, of the NEXT tile's k-tiles 0 / 1
+          const int j = (ph + 6) & 3, ahead = (ph + 6) >> 2, ibuf = ahead & 1;
+          if (!last || ph < 2) {
+            issue(j, ibuf, 2 * it + ahead);
+          } else if (has_next) {
+            if (ph == 2) set_src(next_tile);
+            issue(j, ibuf, ahead - 2);
+          }
+        }
+        if (ph == 1) {
+          if (first || it > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (ph == 5) {
+          if (!last || has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (ph == 3) {
+          if (!last || has_next) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else if (ph == 7) {
+          if (!last || has_next) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- multiply segment: quadrant q x this k-tile
+        if (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+              acc[q * 2 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][ni], afr[s][mi], acc[q * 2 + mi][ni], 0, 0, 0);
+        if (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (wr == 0) {                                     // re-align: both halves run their epilogues at the same time
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    // this wave's outstanding DMA (units 3-5 of the next tile) lands before the first store is issued: the counted
+    // waits of the next tile then never have a store among the operations they leave in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int mrow = tm * 256 + wr * 128, ncol = tn * 256 + wc * 64;
+    // everything the epilogue derives from the lane index is derived HERE, behind an opaque copy: otherwise the
+    // compiler hoists its address arithmetic out of the tile loop and the main loop spills (ISA audit, round 4)
+    int elane = lane;
+#ifndef NSP_HOST_EMULATION
+    asm volatile("" : "+v"(elane));
+#endif
+    gemm_epilogue_fast_dispatch<4, true, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol, elane, 0);
+    gemm_epilogue_fast_dispatch<4, true, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol, elane, 0);
+    if (!has_next) break;
+    ++step;
+    tile = next_tile;
+    first = false;
+  }
+}
+
 // ---- RC x RC (both operands contiguous along their OUTPUT index, reduction index strided: the
 // weight gradients dW = dY^T X) on the same LDS-DMA ring.  A stage holds the k-major images
 // [64 k][128 m] and [64 k][128 n] (256-B rows, unpadded: the DMA writes lane-linear); MFMA operands
@@ -1778,6 +1993,36 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       return NSP_OK;
     }
     const long long t256 = (long long)nsp_cdiv(p.M, 256) * nsp_cdiv(p.N, 256);
+    // 256 x 256 phase-interleaved persistent kernel (round 4): the default for one problem with the fast epilogue
+    // and enough 256-tiles (NSP_GEMM_8P=0 switches it off, NSP_GEMM_8P_MIN_TILES moves the threshold; both read on
+    // every call so that tests can flip them inside one process)
+    {
+      static bool attr8p = false;
+      if (!attr8p) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr8p = true;
+      }
+      const char* e8 = getenv("NSP_GEMM_8P");
+      const char* e8m = getenv("NSP_GEMM_8P_MIN_TILES");
+      const int on8 = e8 ? atoi(e8) : 1;
+      const long long min8 = e8m ? atoll(e8m) : 96;
+      if (on8 && p.epi_mode == NSP_EPI_NONE && fast_epi && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 &&
+          t256 >= min8 && (long long)p.M * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31)) {
+        const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
+        int g8 = (int)(t256 >= 256 ? 256 : (t256 + 7) / 8 * 8);
+        const char* e8g = getenv("NSP_GEMM_8P_GRID");   // tests: fewer workgroups, i.e. several tiles per workgroup on small problems
+        if (e8g && atoi(e8g) >= 8 && atoi(e8g) < g8) g8 = atoi(e8g) / 8 * 8;
+        const char* e8v = getenv("NSP_GEMM_8P_VAR");
+        const int var8 = e8v ? atoi(e8v) : 0;
+        if (var8 == 1) hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<0, 1>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
+        else if (var8 == 3) hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<0, 3>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
+        else hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<0, 0>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
+        NSP_LAUNCH_CHECK();
+        return NSP_OK;
+      }
+    }
     if (k256_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 4 && t256 >= k256_min && p.N >= 256) {
       const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
       hipLaunchKernelGGL(gemm_bf16_kk256_kernel, dim3(256), dim3(512), 131072, st, p, tm256, tn256, c_vec);

@@ -343,8 +343,18 @@ template <class P> static inline hipemu_bf16x4 hipemu_ds_read_tr16(P p) {
 // global_load_lds (16 B per lane): LDS destination = the wave-uniform base + 16 * lane.  The data is captured at issue
 // (kernel inputs do not change during a launch) and written to LDS when a s_waitcnt retires it (hipemu_waitcnt_vm):
 // a consumer that reads the tile without the wait (+ barrier) sees stale LDS, as it may on the hardware
+// HIPEMU_DMA_EAGER=1: the opposite extreme -- the data lands AT ISSUE, the earliest moment the hardware allows: a kernel
+// that re-arms an LDS region which another wave may still be reading (write-after-read) then reads the new tile early
+static inline bool hipemu_dma_eager() {
+  static const bool eager = getenv("HIPEMU_DMA_EAGER") && atoi(getenv("HIPEMU_DMA_EAGER")) != 0;
+  return eager;
+}
 template <class G, class L> static inline void hipemu_global_load_lds(G* g, L* lds, int size, int, int) {
   const int lane = hipemu::tid_flat & 63;
+  if (hipemu_dma_eager()) {
+    memcpy(reinterpret_cast<char*>(lds) + (size_t)size * lane, reinterpret_cast<const char*>(g), (size_t)size);
+    return;
+  }
   hipemu::Wave::Dma d;
   d.dst = reinterpret_cast<char*>(lds) + (size_t)size * lane;
   d.size = size;
@@ -353,6 +363,7 @@ template <class G, class L> static inline void hipemu_global_load_lds(G* g, L* l
 }
 #define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)              /* only ever applied to wave-uniform values */
 #define __builtin_amdgcn_s_setprio(p) ((void)0)        /* scheduling hint only */
 /* s_waitcnt as a builtin (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4) */
 #define __builtin_amdgcn_s_waitcnt(imm) hipemu_waitcnt_vm(((imm) & 15) | ((((imm) >> 14) & 3) << 4))

@@ -80,6 +80,13 @@ def test_weight_gradient_gemm_on_256_tiles(basic, rows, N, K, monkeypatch):
     basic.test_weight_gradient_gemm_on_256_tiles(rows, N, K, monkeypatch)
 
 
+@pytest.mark.parametrize('M,N,K,grid', [(1000, 384, 128, 0), (300, 4352, 256, 8), (300, 2304, 128, 8)])
+def test_phase_interleaved_256_tile_gemm(basic, M, N, K, grid, monkeypatch):
+    """(grid 8: 34 resp. 18 tiles on 8 workgroups -- the load-unit stream runs across tile boundaries, with two resp. one
+    loop iteration per tile; the emulator lands an LDS-DMA load only at the wait that retires it)"""
+    basic.test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch)
+
+
 @pytest.mark.parametrize('M,N,K', [(1000, 384, 128), (700, 2048, 64)])
 def test_persistent_gemm_with_deferred_epilogue(basic, M, N, K, monkeypatch):
     basic.test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch)

@@ -280,6 +280,52 @@ def test_weight_gradient_gemm_on_256_tiles(rows, N, K, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K,grid', [(1000, 384, 128, 0), (2051, 1000, 512, 8), (4096, 512, 2048, 0), (300, 4352, 256, 8), (300, 2304, 128, 8), (70000, 512, 384, 0)])
+def test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch):
+    """gemm_bf16_kk8p_kernel (256 x 256 tiles, 8 waves, load units six phases ahead with counted waits, persistent over
+    tiles) forced onto small problems: every fused epilogue against torch, ragged M / N, one / two / sixteen
+    loop iterations (K = 128 ... 2048), workgroups with 0, 1 and several tiles (70000 x 512: 548 tiles for 256
+    workgroups, the unit stream crossing tile boundaries), column-sum slabs, and the dropout mask of the 128 x 128 kernel."""
+    from neural_sp_amd import ops
+    monkeypatch.setenv('NSP_GEMM_8P', '1')
+    monkeypatch.setenv('NSP_GEMM_8P_MIN_TILES', '1')
+    if grid:
+        monkeypatch.setenv('NSP_GEMM_8P_GRID', str(grid))     # few workgroups: every one walks several tiles
+    torch.manual_seed(M + N)
+    dev = _dev()
+    a = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.5).bfloat16()
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    src = torch.randn(M, N, device=dev).bfloat16()
+    ref = a.float() @ w.float().t()
+    with ops.compute_mode('bf16'):
+        c = torch.empty(M, N, device=dev)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N)
+        assert _rel(c, ref) < 1e-5
+        c16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c16, N, bias=bias, act=2, pre_out=pre)
+        z = ref + bias
+        assert _rel(pre.float(), z) < 1e-2 and _rel(c16.float(), z * torch.sigmoid(z)) < 1e-2
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, bias=bias, res=res, alpha=0.5)
+        assert _rel(c, 0.5 * (ref + bias) + res) < 1e-5
+        slabs = torch.zeros(((M + 127) // 128 * 4, N), device=dev)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c16, N, dact_src=src, dact=2, colsum_slabs=slabs)
+        s = torch.sigmoid(src.float())
+        want = ref * (s * (1 + src.float() * (1 - s)))
+        assert _rel(c16.float(), want) < 1e-2
+        assert _rel(slabs.sum(0), want.sum(0)) < 1e-4      # (the slabs sum the fp32 values in front of the bf16 rounding)
+        # dropout: same mask as the 128 x 128 kernels (pure function of seed / element offset)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, dropout_p=0.3, seed=11, offset=0)
+        monkeypatch.setenv('NSP_GEMM_8P', '0')
+        c2 = torch.empty(M, N, device=dev)
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c2, N, dropout_p=0.3, seed=11, offset=0)
+        assert torch.equal(c == 0, c2 == 0) and _rel(c, c2) < 1e-6
+        assert 0.2 < (c == 0).float().mean().item() < 0.4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('M,N,K', [(1000, 384, 128), (2051, 1000, 512), (4096, 512, 2048), (700, 2048, 64)])
 def test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch):
     """gemm_bf16_kkp_kernel (persistent tiles, the epilogue of tile i sliced into the k-loop of tile i+1)
