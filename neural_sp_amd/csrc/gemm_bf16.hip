@@ -22,6 +22,10 @@
 //      4b..4b+3; lane i receives column i of the 4x16 block.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
+#ifndef NSP_GEMM_8P_AB
+#define NSP_GEMM_8P_AB 1   // development: also compile the staged-epilogue twin of every 8-phase kernel (NSP_GEMM_8P_VAR=4)
+#endif
 
 namespace {
 
@@ -1366,6 +1370,193 @@ __global__ __launch_bounds__(512) void gemm_bf16_kk256_kernel(const nsp_gemm_par
   }
 }
 
+// ---- DIRECT epilogue (round 4): no LDS.  The MFMA leaves lane (fr, fg) with C[row fr][4 consecutive columns] of every
+// 16 x 16 fragment; a store instruction of one fragment therefore covers 16 rows x 64 B (fp32) / 32 B (bf16).  The staged
+// epilogue above exists to turn that into full 256-B row segments -- at the price of a ds_write / ds_read round trip and a
+// serial chain per 16-row slab, which a kernel with ONE workgroup per CU (nothing else running during its epilogue)
+// pays in full: ~4 us per 256 x 256 tile even for a plain bf16 store.  Here every fragment is an independent chain
+// (bias -> act -> dropout -> side operand -> store); the four fragments of a row block are written back to back, so the
+// XCD's L2 sees the four 64-B pieces of a 256-B row segment within a few hundred cycles and merges them.
+// All memory operations are BUFFER instructions with the range check as the predicate (rows >= M, columns >= N get an
+// out-of-range offset: loads return 0, stores are dropped): no branches, so hipcc's counted waits survive.
+// Static specialisations only; requires N % 4 == 0 and M * ldc * 4 < 2^31 (32-bit byte offsets).
+typedef __attribute__((ext_vector_type(4))) unsigned int cu32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int cu32x2_t;
+template <class S>
+__device__ __forceinline__ void gemm_epilogue_direct(const nsp_gemm_params& p, f32x4 (&acc)[4][4], int mrow0, int ncol,
+                                                     int lane) {
+  constexpr bool has_dact = S::DACT != NSP_ACT_NONE, has_res = S::RES, has_side = has_dact || has_res;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int AUX_NT = 2;                      // gfx940+ cache policy: nt (see NSP_EPI_STORE above)
+  const int fr = lane & 15, fg = lane >> 4;
+  // Opaque copies of the scalars everything below is derived from: the persistent caller's tile loop encloses thirteen
+  // specialisations of this function, and without the pins hipcc hoists each one's loop-invariant values (buffer
+  // descriptors, thresholds, byte counts) in front of the MAIN loop, which then spills (ISA audit, round 4).
+  int M_ = p.M, ldc_ = (int)p.ldc;
+  float drop_p = p.dropout_p;
+#ifndef NSP_HOST_EMULATION
+  asm volatile("" : "+s"(M_), "+s"(ldc_), "+s"(drop_p));
+#endif
+  const long long celems = (long long)M_ * ldc_;
+  const unsigned c_bytes = (unsigned)(celems * (S::C16 ? 2 : 4));
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rpre =
+      __builtin_amdgcn_make_buffer_rsrc(S::PRE16 ? p.pre_out : p.C, 0, (unsigned)(celems * 2), 0x00020000);
+  const void* side_ptr = has_res ? reinterpret_cast<const void*>(p.res) : (has_dact ? p.dact_src : p.C);
+  const __amdgpu_buffer_rsrc_t rside = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(side_ptr), 0, (unsigned)(celems * (has_res ? 4 : 2)), 0x00020000);
+  const int n0 = ncol + fg * 4;
+  constexpr bool HAS_BIAS = !has_dact;     // data gradients carry no bias (the launcher checks): 16 registers less
+  float b4[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = min(n0 + ni * 16, p.N - 4);
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_BIAS && p.bias) b = *reinterpret_cast<const float4*>(p.bias + n);
+    b4[ni][0] = b.x; b4[ni][1] = b.y; b4[ni][2] = b.z; b4[ni][3] = b.w;
+  }
+  const uint32_t keep_thr = (uint32_t)(drop_p * 65536.f);
+  const float keep_inv = nsp_rcp(1.f - drop_p);
+  // element offset of fragment (mi, ni) = eoff0 + mi * 16 * ldc + ni * 16, or out of range
+  const unsigned ldc = (unsigned)ldc_;
+  auto elem_off = [&](int mi, int ni) -> unsigned {
+    const int m = mrow0 + mi * 16 + fr, n = n0 + ni * 16;
+    return (m < M_ && n < p.N) ? (unsigned)m * ldc + (unsigned)n : OOB;
+  };
+  // side operand of the CURRENT row block, one 16-B (fp32 residual) / 8-B (bf16 act' source) chunk per fragment; the
+  // chunk of fragment (mi + 1, ni) is requested into the same registers right after fragment (mi, ni) consumed its
+  // copy and BEFORE that fragment's store (in-order vmcnt: a wait for it then only covers stores a whole block old)
+  cu32x4_t side[4];
+  auto request = [&](int mi, int ni) {
+    const unsigned eo = elem_off(mi, ni);
+    if (has_res) {
+      side[ni] = __builtin_amdgcn_raw_buffer_load_b128(rside, eo == OOB ? OOB : eo * 4u, 0, AUX_NT);
+    } else {
+      const cu32x2_t h = __builtin_amdgcn_raw_buffer_load_b64(rside, eo == OOB ? OOB : eo * 2u, 0, AUX_NT);
+      side[ni][0] = h[0]; side[ni][1] = h[1];
+    }
+  };
+  if (has_side) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) request(0, ni);
+  }
+  constexpr bool SLABS = has_dact;     // column-sum slabs come with d(pre-activation) outputs only (the caller checks)
+  float cs[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[ni][e] = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const unsigned eo = elem_off(mi, ni);
+      const bool ok = eo != OOB;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = HAS_BIAS ? acc[mi][ni][e] + b4[ni][e] : acc[mi][ni][e];
+      const cu32x4_t sd = side[ni];
+      if (has_side && mi + 1 < 4) request(mi + 1, ni);
+      if (S::PRE16) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2_t, h), rpre, ok ? eo * 2u : OOB, 0, AUX_NT);
+      }
+      if (S::ACT != NSP_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], S::ACT);
+      }
+      if (has_dact) {
+        float d[4];
+        d[0] = __uint_as_float(sd[0] << 16); d[1] = __uint_as_float(sd[0] & 0xFFFF0000u);
+        d[2] = __uint_as_float(sd[1] << 16); d[3] = __uint_as_float(sd[1] & 0xFFFF0000u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], S::DACT);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      if (S::DROP) {
+        // (p.offset + element offset) is even (the dispatcher checks p.offset; n is a multiple of 4): two mixes per four
+        const unsigned long long base = (p.offset + (unsigned long long)(ok ? eo : 0u)) >> 1;
+        const uint32_t h0 = nsp_hash_u32(p.seed, base), h1 = nsp_hash_u32(p.seed, base + 1ull);
+        v[0] *= (h0 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
+        v[1] *= (h0 >> 16) < keep_thr ? 0.f : keep_inv;
+        v[2] *= (h1 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
+        v[3] *= (h1 >> 16) < keep_thr ? 0.f : keep_inv;
+      }
+      if (has_res) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(sd[e]);
+      }
+      if (S::C16) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2_t, h), rc, ok ? eo * 2u : OOB, 0, AUX_NT);
+      } else {
+        cu32x4_t q;
+        q[0] = __float_as_uint(v[0]); q[1] = __float_as_uint(v[1]); q[2] = __float_as_uint(v[2]); q[3] = __float_as_uint(v[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(q, rc, ok ? eo * 4u : OOB, 0, AUX_NT);
+      }
+      if (SLABS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[ni][e] += ok ? v[e] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: letting the scheduler interleave sixteen chains spills
+    }
+  }
+  if (SLABS && p.epi_f3) {
+    // column sums of the stored values over this wave's 64 rows: 4 mi in registers, 16 rows across the lanes of a
+    // 16-lane row group (xor 1, 2, 4, 8), one slab row per 64-row block
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = cs[ni][e];
+        x += __shfl_xor(x, 1, 64);
+        x += __shfl_xor(x, 2, 64);
+        x += __shfl_xor(x, 4, 64);
+        x += __shfl_xor(x, 8, 64);
+        cs[ni][e] = x;
+      }
+    if (fr == 0) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + ni * 16;
+        if (n < p.N)
+          *reinterpret_cast<float4*>(p.epi_f3 + (long long)(mrow0 >> 6) * p.N + n) =
+              make_float4(cs[ni][0], cs[ni][1], cs[ni][2], cs[ni][3]);
+      }
+    }
+  }
+}
+
+// calls f(EpiSpec<...>{}) for the specialisation that matches the call's epilogue (the same table as
+// gemm_epilogue_fast_dispatch) and returns true, or returns false
+template <class F>
+__host__ __device__ __forceinline__ bool epi_spec_visit(const nsp_gemm_params& p, F&& f) {
+  const bool c16 = p.c_dtype == NSP_DT_BF16;
+  const bool drop = p.dropout_p > 0.f;
+  const bool even = (p.offset & 1ull) == 0ull;
+  if (!(even || !drop)) return false;
+#define NSP_VISIT(...) do { f(EpiSpec<__VA_ARGS__>{}); return true; } while (0)
+  if (p.pre_out && p.pre_dtype == NSP_DT_BF16 && c16 && !p.res && !p.dact_src) {           // FFN first linear
+    if (p.act == NSP_ACT_SWISH) { if (drop) NSP_VISIT(NSP_ACT_SWISH, 0, true, true, false, true); NSP_VISIT(NSP_ACT_SWISH, 0, true, true, false, false); }
+    if (p.act == NSP_ACT_RELU) { if (drop) NSP_VISIT(NSP_ACT_RELU, 0, true, true, false, true); NSP_VISIT(NSP_ACT_RELU, 0, true, true, false, false); }
+  } else if (p.dact_src && p.dact_dtype == NSP_DT_BF16 && c16 && !p.res && !p.pre_out && p.act == NSP_ACT_NONE) {
+    if (p.dact == NSP_ACT_SWISH) { if (drop) NSP_VISIT(0, NSP_ACT_SWISH, true, false, false, true); NSP_VISIT(0, NSP_ACT_SWISH, true, false, false, false); }
+    if (p.dact == NSP_ACT_RELU) { if (drop) NSP_VISIT(0, NSP_ACT_RELU, true, false, false, true); NSP_VISIT(0, NSP_ACT_RELU, true, false, false, false); }
+    if (p.dact == NSP_ACT_TANH_OUT && !drop) NSP_VISIT(0, NSP_ACT_TANH_OUT, true, false, false, false);
+  } else if (p.res && !c16 && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE) {        // residual branches
+    if (drop) NSP_VISIT(0, 0, false, false, true, true);
+    NSP_VISIT(0, 0, false, false, true, false);
+  } else if (!p.res && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE && !drop) {      // plain (+ bias)
+    if (c16) NSP_VISIT(0, 0, true, false, false, false);
+    NSP_VISIT(0, 0, false, false, false, false);
+  }
+#undef NSP_VISIT
+  return false;
+}
+
 // ---- KC x KC, 256 x 256 x 64 tiles, 8 waves, PHASE-INTERLEAVED main loop (round 4).
 // What the per-workgroup trace of the 128 x 128 kernel said (profiles/r03am): a k-tile costs a workgroup ~3.1 us for
 // 0.23 us of MFMA work, because it waits for one LDS-DMA round trip per k-tile; the first 256 x 256 kernel above has the
@@ -1392,9 +1583,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_kk256_kernel(const nsp_gemm_par
 //     is never used for staging, both k-tile buffers stay armed.
 // Requires K % 128 == 0 (two k-tiles per loop iteration: buffer indices are compile-time), one problem, no split-K,
 // the fast epilogue's conditions, operand extents below 2^32 elements.  LDS 128 KB + 32 KB = all of the CU's 160 KB.
+// One kernel per epilogue specialisation S (EpiSpec<...>: the direct epilogue; EpiRuntime: everything else through the
+// staged run-time version): with all of them behind a run-time switch inside ONE persistent kernel, hipcc hoisted each
+// variant's tile-invariant values in front of the main loop and spilled ~800 registers (each variant alone: 226-232,
+// no scratch).  The launcher picks S with the table of epi_spec_visit.
 // VAR (development A/B, NSP_GEMM_8P_VAR): bit 0 = no s_setprio around the MFMA segments, bit 1 = static priority 1 for the
-// second (later dispatched) wave half instead.
-template <int EPI, int VAR = 0>
+// second (later dispatched) wave half instead, bit 2 = staged (LDS) epilogue for S instead of the direct one.
+template <class S, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
                                                                 int c_vec) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 32 KB | B 32 KB) | 8 x 4 KB staging
@@ -1555,8 +1750,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
 #ifndef NSP_HOST_EMULATION
     asm volatile("" : "+v"(elane));
 #endif
-    gemm_epilogue_fast_dispatch<4, true, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol, elane, 0);
-    gemm_epilogue_fast_dispatch<4, true, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol, elane, 0);
+    if constexpr (!S::kStatic || (VAR & 4)) {
+      gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol + (elane & 15) * 4, elane, 0);
+      gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol + (elane & 15) * 4, elane, 0);
+    } else {
+      gemm_epilogue_direct<S>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), mrow, ncol, elane);
+      gemm_epilogue_direct<S>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), mrow + 64, ncol, elane);
+    }
     if (!has_next) break;
     ++step;
     tile = next_tile;
@@ -1997,13 +2197,6 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     // and enough 256-tiles (NSP_GEMM_8P=0 switches it off, NSP_GEMM_8P_MIN_TILES moves the threshold; both read on
     // every call so that tests can flip them inside one process)
     {
-      static bool attr8p = false;
-      if (!attr8p) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        attr8p = true;
-      }
       const char* e8 = getenv("NSP_GEMM_8P");
       const char* e8m = getenv("NSP_GEMM_8P_MIN_TILES");
       const int on8 = e8 ? atoi(e8) : 1;
@@ -2016,9 +2209,27 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         if (e8g && atoi(e8g) >= 8 && atoi(e8g) < g8) g8 = atoi(e8g) / 8 * 8;
         const char* e8v = getenv("NSP_GEMM_8P_VAR");
         const int var8 = e8v ? atoi(e8v) : 0;
-        if (var8 == 1) hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<0, 1>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
-        else if (var8 == 3) hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<0, 3>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
-        else hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<0, 0>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
+        auto launch8 = [&](auto spec, auto var) {
+          using S8 = decltype(spec);
+          constexpr int V8 = decltype(var)::value;
+          static bool attr = false;     // (one flag per instantiation of this lambda's call operator)
+          if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<S8, V8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            attr = true;
+          }
+          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<S8, V8>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
+        };
+        // the direct epilogue's own conditions (32-bit byte offsets into C; column-sum slabs only with an act' source)
+        const bool direct_ok = (long long)p.M * p.ldc < (1ll << 29) && !(p.epi_f3 && !p.dact_src) && !(p.bias && p.dact_src);
+        bool done = false;
+        if (direct_ok) {
+#if NSP_GEMM_8P_AB
+          if (var8 == 4) done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 4>{}); });
+          else
+#endif
+          done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 0>{}); });
+        }
+        if (!done) launch8(EpiRuntime{}, std::integral_constant<int, 0>{});
         NSP_LAUNCH_CHECK();
         return NSP_OK;
       }

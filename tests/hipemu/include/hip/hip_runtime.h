@@ -317,6 +317,14 @@ static inline void hipemu_buf_store_b64(hipemu_u32x2 d, hipemu_rsrc r, unsigned 
     if (o + 4 <= r.num) memcpy(r.base + o, &w, 4);
   }
 }
+static inline void hipemu_buf_store_b128(hipemu_u32x4 d, hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  for (int i = 0; i < 4; ++i) {
+    const unsigned long long o = (unsigned long long)voff + soff + 4ull * i;
+    unsigned w = d[i];
+    if (o + 4 <= r.num) memcpy(r.base + o, &w, 4);
+  }
+}
+#define __builtin_amdgcn_raw_buffer_store_b128 hipemu_buf_store_b128
 #define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_buf_load_b128
 #define __builtin_amdgcn_raw_buffer_load_b64 hipemu_buf_load_b64

@@ -10,8 +10,8 @@ from neural_sp_amd import ops
 
 ops.set_compute_mode('bf16')
 dev = torch.device('cuda:0')
-ARMS = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '0'}),
-        ('8p-noprio', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '1'}), ('8p-static', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '3'})]
+ARMS = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p-direct', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '0'}),
+        ('8p-staged', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '4'})]
 if os.environ.get('ARMS'):
     ARMS = [a for a in ARMS if a[0] in os.environ['ARMS'].split(',')]
 
@@ -119,4 +119,4 @@ if __name__ == '__main__':
     if 'race' in what: race_screen(int(os.environ.get('RACE_REPS', '100')))
     if 'squares' in what: squares()
     if 'shapes' in what:
-        for M in (25600, 102400): run_shapes(M)
+        for M in (25600, 51200, 102400): run_shapes(M)
