@@ -1382,12 +1382,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_kk256_kernel(const nsp_gemm_par
 // Static specialisations only; requires N % 4 == 0 and M * ldc * 4 < 2^31 (32-bit byte offsets).
 typedef __attribute__((ext_vector_type(4))) unsigned int cu32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int cu32x2_t;
-template <class S>
+template <class S, int AUX_NT = 2>               // AUX_NT: gfx940+ cache policy of the stores / side loads (2 = nt, 0 = default)
 __device__ __forceinline__ void gemm_epilogue_direct(const nsp_gemm_params& p, f32x4 (&acc)[4][4], int mrow0, int ncol,
                                                      int lane) {
   constexpr bool has_dact = S::DACT != NSP_ACT_NONE, has_res = S::RES, has_side = has_dact || has_res;
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int AUX_NT = 2;                      // gfx940+ cache policy: nt (see NSP_EPI_STORE above)
   const int fr = lane & 15, fg = lane >> 4;
   // Opaque copies of the scalars everything below is derived from: the persistent caller's tile loop encloses thirteen
   // specialisations of this function, and without the pins hipcc hoists each one's loop-invariant values (buffer
@@ -1583,13 +1582,41 @@ __host__ __device__ __forceinline__ bool epi_spec_visit(const nsp_gemm_params& p
 //     is never used for staging, both k-tile buffers stay armed.
 // Requires K % 128 == 0 (two k-tiles per loop iteration: buffer indices are compile-time), one problem, no split-K,
 // the fast epilogue's conditions, operand extents below 2^32 elements.  LDS 128 KB + 32 KB = all of the CU's 160 KB.
+// ---- weight-gradient (RR) operand images of the 8-phase kernel: sub-images [64 k][64 columns], 128-B rows.  A transposed
+// read (ds_read_b64_tr_b16) of a 32-lane half touches 8 k-rows (k & 3, k bit 3) x 32 B; two 128-B rows share a 256-B bank
+// window, so the 32-B slot is (k & 1) * 4 + ((column slot) ^ (k bit 1 | k bit 3 << 1)): eight distinct slots, conflict-free.
+__device__ __forceinline__ int rr8_swz(int krow) { return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1; }
+// The transposed reads are issued from INLINE ASM.  Behind the builtin (__builtin_amdgcn_ds_read_tr16_b64) hipcc's wait
+// insertion assumes the read may alias every LDS-DMA load in flight and puts s_waitcnt vmcnt(0) in front of it -- the
+// ISA of the round-1..3 weight-gradient ring kernels shows exactly that wait ahead of their first transposed read, i.e.
+// their "2-stage rings" never had a load in flight across a read.  The compiler does not count an asm load (CDNA guide
+// 5.7 item 1), so the two halves of a fragment are written by two statements and every destination is named "+v" in the
+// wait statement in front of its first consumer (form (ii) there).
+struct RR8Frag { bf16x4 lo, hi; };
+__device__ __forceinline__ void rr8_read(RR8Frag& f, const unsigned char* addr) {
+#ifdef NSP_HOST_EMULATION
+  typedef bf16x4 lds_bf16x4;
+  f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(addr));
+  f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(addr + 4 * 128));
+#else
+  typedef __attribute__((address_space(3))) unsigned char lds_uchar;
+  const unsigned a = (unsigned)(uintptr_t)((lds_uchar*)addr);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(f.hi) : "v"(a) : "memory");
+#endif
+}
+__device__ __forceinline__ bf16x8 rr8_join(const RR8Frag& f) {
+  return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __attribute__((aligned(256))) unsigned int nsp_zero_line[64];   // 256 B of zeros (static storage)
+
 // One kernel per epilogue specialisation S (EpiSpec<...>: the direct epilogue; EpiRuntime: everything else through the
 // staged run-time version): with all of them behind a run-time switch inside ONE persistent kernel, hipcc hoisted each
 // variant's tile-invariant values in front of the main loop and spilled ~800 registers (each variant alone: 226-232,
 // no scratch).  The launcher picks S with the table of epi_spec_visit.
 // VAR (development A/B, NSP_GEMM_8P_VAR): bit 0 = no s_setprio around the MFMA segments, bit 1 = static priority 1 for the
 // second (later dispatched) wave half instead, bit 2 = staged (LDS) epilogue for S instead of the direct one.
-template <class S, int VAR = 0>
+template <class S, int VAR = 0, bool RR = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
                                                                 int c_vec) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 32 KB | B 32 KB) | 8 x 4 KB staging
@@ -1598,9 +1625,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS piece bases (M0) and row halves stay in SGPRs
   const int wr = wave >> 2, wc = wave & 3;
   const int ntiles = tiles_m * tiles_n;
-  const int nit = p.K >> 7;                    // loop iterations of two k-tiles
+  // KK: persistent over the tile list.  RR (weight gradients): ONE (tile, reduction split) per workgroup on the flat
+  // split-K grid of tile_coord; the split's k-tiles [ktbeg, ktbeg + 2 nit) -- an even count, k-rows beyond p.K read zeros
+  int nit = p.K >> 7;                          // loop iterations of two k-tiles
+  int ktbeg = 0, rr_tile = 0;
+  long long coff = 0;
+  if (RR) {
+    const TileCoord tc = tile_coord(p, ntiles);
+    rr_tile = tc.tile;
+    const int nkt_pad = ((p.K + 127) >> 7) << 1;
+    const int per = (((nkt_pad + p.splitk - 1) / p.splitk) + 1) & ~1;
+    ktbeg = min(tc.split * per, nkt_pad);
+    nit = (min(ktbeg + per, nkt_pad) - ktbeg) >> 1;
+    coff = p.c_ss ? (long long)tc.split * p.c_ss : 0;
+  }
   const int xq = blockIdx.x >> 3, xx = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-  auto tile_of = [&](int step) { return per_xcd * (8 * step + xx) + xq; };   // gridDim.x % 8 == 0 (launcher)
+  auto tile_of = [&](int step) {               // KK: gridDim.x % 8 == 0 (launcher)
+    if (RR) return step == 0 ? rr_tile : ntiles;
+    return per_xcd * (8 * step + xx) + xq;
+  };
   const char* A = reinterpret_cast<const char*>(p.A);
   const char* B = reinterpret_cast<const char*>(p.B);
   typedef __attribute__((address_space(3))) void lds_void;
@@ -1611,8 +1654,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   const int lrow = lane >> 3, lpos = lane & 7;
   const unsigned sw = (unsigned)((lpos ^ lrow) * 16);
   unsigned aoff[2][2], boff[2][2];           // [unit 2 / 3 resp. 0 / 1][piece]: BYTE offsets from A / B (scalar base + 32-bit lane offset)
+  // RR images: a load unit = two 8-KB sub-images [64 k][64 columns] (128-B rows; unit 2 / 3: quadrant pair 0-1 / 2-3 of
+  // row half 0 and 1; unit 0 / 1: the B columns of waves wc = 0, 1 / 2, 3), piece pc = wave * 2 + i = 8 k-rows of
+  // sub-image pc >> 3; the 16-B chunk index is XOR-ed with rr8_swz(k) on the source address and on the transposed read
   auto set_src = [&](int tile) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    if (RR) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int pc = wave * 2 + i, krow = (pc & 7) * 8 + lrow;
+          const int chunk = (lpos ^ rr8_swz(krow)) * 8;
+          // columns beyond M / N re-read the tile's first chunk: they only feed outputs that are never stored
+          int ma = tm * 256 + (pc >> 3) * 128 + u * 64 + chunk;
+          int nb = tn * 256 + (u * 2 + (pc >> 3)) * 64 + chunk;
+          if (ma >= p.M) ma = tm * 256;
+          if (nb >= p.N) nb = tn * 256;
+          aoff[u][i] = (unsigned)krow * (unsigned)(2 * p.a_cs) + (unsigned)(2 * ma);
+          boff[u][i] = (unsigned)krow * (unsigned)(2 * p.b_ks) + (unsigned)(2 * nb);
+        }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -1623,9 +1686,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
         boff[u][i] = (unsigned)min(tn * 256 + u * 128 + r, p.N - 1) * (unsigned)(2 * p.b_ns) + sw;
       }
   };
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(A), 0, RR ? (unsigned)((long long)p.K * p.a_cs * 2) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(B), 0, RR ? (unsigned)((long long)p.K * p.b_ks * 2) : 0u, 0x00020000);
   // unit j (0..3) of k-tile `kt` of the stream's tile into k-tile buffer `buf`
   auto issue = [&](int j, int buf, int kt) {
     unsigned char* base = ring + buf * BUF;
+    if (RR) {
+      // BUFFER LDS-DMA: the descriptors end at the last k-row, so the k-rows of a ragged (or padded) last k-tile are
+      // out of range and land as ZEROS -- no tail logic; the k-tile offset rides in the scalar offset field
+      const int kabs = ktbeg + kt;                      // k-rows kabs * 64 .. + 63
+      const int ska = kabs * (2 * BK) * (int)p.a_cs, skb = kabs * (2 * BK) * (int)p.b_ks;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pc = wave * 2 + i;
+        const int sub = j < 2 ? 4 + j * 2 + (pc >> 3) : (j - 2) * 2 + (pc >> 3);   // A sub-images 0..3, B sub-images 4..7
+        unsigned char* dst = base + sub * 8192 + (pc & 7) * 1024;
+        if (j < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void*)dst, 16, (int)boff[j][i], skb, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)dst, 16, (int)aoff[j - 2][i], ska, 0, 0);
+      }
+      return;
+    }
     const unsigned ko = (unsigned)(kt * (2 * BK));     // added to the 32-bit lane offset: keeps the scalar-base + voffset form
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1644,6 +1726,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   const int chunk0 = (fg ^ (fr & 7)) << 4;
   const int a_addr[2] = {(wr * 128 + fr) * 128 + chunk0, (wr * 128 + fr) * 128 + (chunk0 ^ 64)};   // [s]; + immediates
   const int b_addr[2] = {A_BYTES + (wc * 64 + fr) * 128 + chunk0, A_BYTES + (wc * 64 + fr) * 128 + (chunk0 ^ 64)};
+  // RR: lane (a = fr >> 2, b = fr & 3, g = fg) of a transposed read addresses k-row 32 s + 8 g + a (and + 4), columns
+  // cbase + 4 b .. + 3 of its sub-image; rr8_swz of that row does not depend on s
+  const int rr_k = fg * 8 + (fr >> 2);
+  const int rr_base = rr_k * 128 + ((fr & 1) << 3);
+  const int rr_c = ((fr >> 1) & 1) ^ rr8_swz(rr_k);           // chunk index of columns cbase = 0
   float* stage = reinterpret_cast<float*>(ring + STAGING) + wave * 1024;
 
   int step = 0;
@@ -1652,9 +1739,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   if ((VAR & 2) && wr == 1) __builtin_amdgcn_s_setprio(1);
   set_src(tile);
   // prologue: units 0..5 of the first tile (k-tile 0 -> buffer 0, units 0-1 of k-tile 1 -> buffer 1)
+  if (!RR || nit > 0) {                                // (RR: a split without k-tiles only writes its zero slab)
 #pragma unroll
-  for (int u = 0; u < 6; ++u) issue(u & 3, u >> 2, u >> 2);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // units 0-2: everything phase 0 reads
+    for (int u = 0; u < 6; ++u) issue(u & 3, u >> 2, u >> 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // units 0-2: everything phase 0 reads
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   bool first = true;
@@ -1676,25 +1765,41 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     for (int it = 0; it < nit; ++it) {
       const bool last = it == nit - 1;
       bf16x8 bfr[2][4], afr[2][2];
+      RR8Frag rb[2][4], ra[2][2];      // RR: the asm-loaded halves of the same fragments
 #pragma unroll
       for (int ph = 0; ph < 8; ++ph) {
         const int buf = ph >> 2, q = ph & 3;
         const unsigned char* kb = ring + buf * BUF;
         // ---- read segment: fragments of this phase, one load unit, the counted wait
-        if (q == 0) {
+        if (RR) {
+          if (q == 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni)
+                rr8_read(rb[s][ni], kb + (4 + wc) * 8192 + s * 4096 + rr_base + ((rr_c ^ (ni * 2)) << 4));
+          }
 #pragma unroll
           for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-              bfr[s][ni] = *reinterpret_cast<const bf16x8*>(kb + b_addr[s] + ni * 2048);
+            for (int mi = 0; mi < 2; ++mi)
+              rr8_read(ra[s][mi], kb + ((q >> 1) * 2 + wr) * 8192 + s * 4096 + rr_base + ((rr_c ^ ((q & 1) * 4 + mi * 2)) << 4));
+        } else {
+          if (q == 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni)
+                bfr[s][ni] = *reinterpret_cast<const bf16x8*>(kb + b_addr[s] + ni * 2048);
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+              afr[s][mi] = *reinterpret_cast<const bf16x8*>(kb + a_addr[s] + (q * 32 + mi * 16) * 128);
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            afr[s][mi] = *reinterpret_cast<const bf16x8*>(kb + a_addr[s] + (q * 32 + mi * 16) * 128);
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if (!(VAR & 32)) {      // (ablation bit 5: no load units at all -- wrong results, timing only)
           // the stream is six units ahead: unit (ph + 6) & 3 of k-tile 2 it + (ph + 6) / 4 -- or, from phase 2 of the
           // last iteration on, of the NEXT tile's k-tiles 0 / 1
           const int j = (ph + 6) & 3, ahead = (ph + 6) >> 2, ibuf = ahead & 1;
@@ -1705,7 +1810,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
             issue(j, ibuf, ahead - 2);
           }
         }
-        if (ph == 1) {
+        if (VAR & (16 | 32)) {  // (ablation bit 4: no counted waits -- wrong results, timing only)
+        } else if (ph == 1) {
           if (first || it > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else if (ph == 5) {
           if (!last || has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -1721,6 +1827,32 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         // ---- multiply segment: quadrant q x this k-tile
+        if (RR) {
+#ifndef NSP_HOST_EMULATION
+          // the asm reads of this phase have landed; every destination is named so that no consumer moves above the wait
+          if (q == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(rb[0][0].lo), "+v"(rb[0][0].hi), "+v"(rb[0][1].lo), "+v"(rb[0][1].hi), "+v"(rb[0][2].lo), "+v"(rb[0][2].hi),
+                           "+v"(rb[0][3].lo), "+v"(rb[0][3].hi), "+v"(rb[1][0].lo), "+v"(rb[1][0].hi), "+v"(rb[1][1].lo), "+v"(rb[1][1].hi));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(rb[1][2].lo), "+v"(rb[1][2].hi), "+v"(rb[1][3].lo), "+v"(rb[1][3].hi));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(ra[0][0].lo), "+v"(ra[0][0].hi), "+v"(ra[0][1].lo), "+v"(ra[0][1].hi), "+v"(ra[1][0].lo), "+v"(ra[1][0].hi),
+                         "+v"(ra[1][1].lo), "+v"(ra[1][1].hi));
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          if (q == 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni) bfr[s][ni] = rr8_join(rb[s][ni]);
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) afr[s][mi] = rr8_join(ra[s][mi]);
+        }
         if (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -1751,11 +1883,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     asm volatile("" : "+v"(elane));
 #endif
     if constexpr (!S::kStatic || (VAR & 4)) {
-      gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol + (elane & 15) * 4, elane, 0);
-      gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol + (elane & 15) * 4, elane, 0);
+      gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol + (elane & 15) * 4, elane, coff);
+      gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol + (elane & 15) * 4, elane, coff);
     } else {
-      gemm_epilogue_direct<S>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), mrow, ncol, elane);
-      gemm_epilogue_direct<S>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), mrow + 64, ncol, elane);
+      gemm_epilogue_direct<S, (VAR & 8) ? 0 : 2>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), mrow, ncol, elane);
+      gemm_epilogue_direct<S, (VAR & 8) ? 0 : 2>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), mrow + 64, ncol, elane);
     }
     if (!has_next) break;
     ++step;
@@ -1966,7 +2098,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_rr_glds_kernel(const ns
 // workgroup per CU, and an XCD's 32 workgroups are whole splits: each operand panel crosses the fabric once.
 // Ragged reduction length (K % 64 != 0: the compacted RNN-T lattice): rows >= K of the LAST k-tile are read
 // from row K - 1 (finite) for A and from a zero line for B, so their products vanish.
-__device__ __attribute__((aligned(256))) unsigned int nsp_zero_line[64];   // 256 B of zeros (static storage)
 
 __global__ __launch_bounds__(512) void gemm_bf16_rr256_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
                                                               int c_vec) {
@@ -2121,6 +2252,14 @@ inline bool rr256_shape_ok(long long M, long long N, long long K) {
 }
 inline bool rr256_enabled() { return true; }
 
+// 8-phase weight-gradient kernel (gemm_bf16_kk8p_kernel<.., RR = true>): NSP_GEMM_RR8P = 0 switches it off (read on every call)
+inline bool rr8p_shape_ok(long long M, long long N, long long K, long long lda, long long ldb) {
+  const char* e = getenv("NSP_GEMM_RR8P");
+  if (e && atoi(e) == 0) return false;
+  return M % 8 == 0 && N % 8 == 0 && M > 128 && N > 128 && K >= 4 * BK && (K + 128) * lda < (1ll << 31) &&
+         (K + 128) * ldb < (1ll << 31);
+}
+
 }  // namespace
 
 // called from nsp_gemm (gemm.hip) when both operands are bf16
@@ -2225,7 +2364,16 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         if (direct_ok) {
 #if NSP_GEMM_8P_AB
           if (var8 == 4) done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 4>{}); });
-          else
+          else if (var8 == 8) done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 8>{}); });
+          else if ((var8 == 20 || var8 == 36) && !p.res && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE && p.dropout_p == 0.f) {
+            // main-loop ablations (timing only, results are wrong), plain epilogues only
+            const bool c16 = p.c_dtype == NSP_DT_BF16;
+            if (var8 == 20 && c16) launch8(EpiSpec<0, 0, true, false, false, false>{}, std::integral_constant<int, 20>{});
+            else if (var8 == 20) launch8(EpiSpec<0, 0, false, false, false, false>{}, std::integral_constant<int, 20>{});
+            else if (c16) launch8(EpiSpec<0, 0, true, false, false, false>{}, std::integral_constant<int, 36>{});
+            else launch8(EpiSpec<0, 0, false, false, false, false>{}, std::integral_constant<int, 36>{});
+            done = true;
+          } else
 #endif
           done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 0>{}); });
         }
@@ -2256,6 +2404,21 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel<0>, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
     else   // odd widths / unaligned outputs / atomic split-K on a large grid: the generic epilogue lives in the ring kernels
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
+  }
+  else if (!a_kc && !b_kc && p.batch1 * p.batch2 == 1 && fast_epi && (p.splitk == 1 || p.c_ss) && p.epi_mode == NSP_EPI_NONE &&
+           rr8p_shape_ok(p.M, p.N, p.K, lda, ldb)) {
+    const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
+    const dim3 g(tm256 * tn256 * p.splitk);
+    const bool plain = !p.bias && !p.res && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE && p.dropout_p == 0.f &&
+                       p.c_dtype == NSP_DT_F32 && !p.epi_f3;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<EpiSpec<0, 0, false, false, false, false>, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<EpiRuntime, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      attr = true;
+    }
+    if (plain) hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<EpiSpec<0, 0, false, false, false, false>, 4, true>), g, dim3(512), 163840, st, p, tm256, tn256, c_vec);
+    else hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<EpiRuntime, 0, true>), g, dim3(512), 163840, st, p, tm256, tn256, c_vec);
   }
   else if (!a_kc && !b_kc && p.batch1 * p.batch2 == 1 && rr256_enabled() && rr256_shape_ok(p.M, p.N, p.K)) {
     static bool attr = false;
@@ -2295,6 +2458,16 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
 // reduction splits of a weight gradient dW[N, K] = dY[rows, N]^T X[rows, K] in bf16 mode, or 0 when the caller's
 // own rule applies (the 128 x 128 kernels).  256 x 256 tiles x splits ~ 256 workgroups = one per CU.
 extern "C" int nsp_wgrad_splitk(long long N, long long K, long long rows) {
+  if (rr8p_shape_ok(N, K, rows, N, K)) {
+    // 8-phase kernel: 256 x 256 tiles x splits ~ one workgroup per CU, an EVEN number of k-tiles per split (>= 4)
+    const long long tiles = (long long)nsp_cdiv((int)N, 256) * nsp_cdiv((int)K, 256);
+    const long long nkt_pad = ((rows + 127) >> 7) << 1;
+    long long sk = 256 / tiles;
+    if (sk > nkt_pad / 4) sk = nkt_pad / 4;
+    if (sk < 1) sk = 1;
+    const long long per = (((nkt_pad + sk - 1) / sk) + 1) & ~1ll;
+    return (int)((nkt_pad + per - 1) / per);      // no empty splits
+  }
   if (!rr256_enabled() || !rr256_shape_ok(N, K, rows)) return 0;
   const long long tiles = (long long)nsp_cdiv((int)N, 256) * nsp_cdiv((int)K, 256);
   const long long nkt = (rows + BK - 1) / BK;

@@ -370,6 +370,22 @@ template <class G, class L> static inline void hipemu_global_load_lds(G* g, L* l
   hipemu::wave->dma[lane].push_back(d);
 }
 #define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
+// buffer_load_dwordx4 ... lds (raw buffer, 16 B per lane): every dword is range-checked, out-of-range dwords land as 0
+template <class L> static inline void hipemu_raw_buffer_load_lds(hipemu_rsrc r, L* lds, int size, int voff, int soff, int off, int) {
+  const int lane = hipemu::tid_flat & 63;
+  hipemu::Wave::Dma d;
+  d.dst = reinterpret_cast<char*>(lds) + (size_t)size * lane;
+  d.size = size;
+  for (int i = 0; i < size / 4; ++i) {
+    unsigned w = 0;
+    const unsigned long long o = (unsigned long long)(unsigned)voff + (unsigned)soff + (unsigned)off + 4ull * i;
+    if (o + 4 <= r.num) memcpy(&w, r.base + o, 4);
+    memcpy(d.data + 4 * i, &w, 4);
+  }
+  if (hipemu_dma_eager()) { memcpy(d.dst, d.data, (size_t)size); return; }
+  hipemu::wave->dma[lane].push_back(d);
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds hipemu_raw_buffer_load_lds
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)              /* only ever applied to wave-uniform values */
 #define __builtin_amdgcn_s_setprio(p) ((void)0)        /* scheduling hint only */

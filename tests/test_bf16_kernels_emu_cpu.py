@@ -80,6 +80,11 @@ def test_weight_gradient_gemm_on_256_tiles(basic, rows, N, K, monkeypatch):
     basic.test_weight_gradient_gemm_on_256_tiles(rows, N, K, monkeypatch)
 
 
+@pytest.mark.parametrize('rows,N,K', [(1291, 1000, 264), (333, 136, 1280), (260, 256, 256)])
+def test_weight_gradient_gemm_on_the_phase_interleaved_kernel(basic, rows, N, K, monkeypatch):
+    basic.test_weight_gradient_gemm_on_the_phase_interleaved_kernel(rows, N, K, monkeypatch)
+
+
 @pytest.mark.parametrize('M,N,K,grid', [(1000, 384, 128, 0), (300, 4352, 256, 8), (300, 2304, 128, 8)])
 def test_phase_interleaved_256_tile_gemm(basic, M, N, K, grid, monkeypatch):
     """(grid 8: 34 resp. 18 tiles on 8 workgroups -- the load-unit stream runs across tile boundaries, with two resp. one

@@ -236,7 +236,8 @@ def test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch, shapes=((
         dy = torch.randn(rows, N, device=dev).bfloat16()
         x = torch.randn(rows, K, device=dev).bfloat16()
         ref = dy.float().t() @ x.float()
-        monkeypatch.setenv('NSP_GEMM_RR256', '0')     # (the 256 x 256 kernel has its own test below)
+        monkeypatch.setenv('NSP_GEMM_RR256', '0')     # (the 256 x 256 kernels have their own tests below)
+        monkeypatch.setenv('NSP_GEMM_RR8P', '0')
         with ops.compute_mode('bf16'):
             monkeypatch.setenv('NSP_GEMM_RR_RING', '0')
             base = ops.linear_wgrad(dy, x)
@@ -260,6 +261,7 @@ def test_weight_gradient_gemm_on_256_tiles(rows, N, K, monkeypatch):
     dy = torch.randn(rows, N, device=dev).bfloat16()
     x = torch.randn(rows, K, device=dev).bfloat16()
     ref = dy.float().t() @ x.float()
+    monkeypatch.setenv('NSP_GEMM_RR8P', '0')      # (the 8-phase kernel, which takes these shapes by default, has its own test)
     monkeypatch.setenv('NSP_GEMM_RR256', '1')     # (default: reductions of >= 2^19 rows only)
     assert _lib.lib().nsp_wgrad_splitk(N, K, rows) > 0
     with ops.compute_mode('bf16'):
@@ -277,6 +279,38 @@ def test_weight_gradient_gemm_on_256_tiles(rows, N, K, monkeypatch):
             part = torch.full((sk, N, K), float('nan'), device=dev)
             ops.gemm_raw(N, K, rows, dy, 1, N, x, K, 1, part, K, splitk=sk, c_ss=N * K)
             assert ((part.sum(0) - ref).abs().max() / scale).item() < 1e-4, sk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,N,K', [(2048, 640, 512), (1291, 1000, 264), (4096, 512, 2048), (333, 136, 1280), (260, 256, 256), (20000, 2048, 512)])
+def test_weight_gradient_gemm_on_the_phase_interleaved_kernel(rows, N, K, monkeypatch):
+    """gemm_bf16_kk8p_kernel<.., RR = true> (the default for weight gradients with both output extents > 128): k-major
+    sub-images [64 k][64 columns] filled by BUFFER LDS-DMA (k-rows beyond the reduction are out of range and land as zeros:
+    1291, 333, 260 rows; an odd number of k-tiles is padded to an even one the same way), transposed reads from inline
+    asm, split count from nsp_wgrad_splitk, explicit split counts incl. splits without k-tiles, ragged output edges."""
+    from neural_sp_amd import ops, _lib
+    torch.manual_seed(rows)
+    dev = _dev()
+    dy = torch.randn(rows, N, device=dev).bfloat16()
+    x = torch.randn(rows, K, device=dev).bfloat16()
+    ref = dy.float().t() @ x.float()
+    monkeypatch.setenv('NSP_GEMM_RR8P', '1')
+    sk = _lib.lib().nsp_wgrad_splitk(N, K, rows)
+    assert sk > 0
+    with ops.compute_mode('bf16'):
+        dw = ops.linear_wgrad(dy, x)
+        monkeypatch.setenv('NSP_GEMM_RR8P', '0')
+        monkeypatch.setenv('NSP_GEMM_RR256', '0')
+        base = ops.linear_wgrad(dy, x)
+    scale = ref.abs().max()
+    assert ((base - ref).abs().max() / scale).item() < 1e-4
+    assert ((dw - ref).abs().max() / scale).item() < 1e-4
+    with ops.compute_mode('bf16'):
+        monkeypatch.setenv('NSP_GEMM_RR8P', '1')
+        for sk in (1, 3, 8):
+            part = torch.full((sk, N, K), float('nan'), device=dev)
+            ops.gemm_raw(N, K, rows, dy, 1, N, x, K, 1, part, K, splitk=sk, c_ss=N * K, alpha=0.5)
+            assert ((2 * part.sum(0) - ref).abs().max() / scale).item() < 1e-4, sk
 
 
 @pytest.mark.gpu

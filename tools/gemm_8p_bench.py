@@ -11,7 +11,7 @@ from neural_sp_amd import ops
 ops.set_compute_mode('bf16')
 dev = torch.device('cuda:0')
 ARMS = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p-direct', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '0'}),
-        ('8p-staged', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '4'})]
+        ('8p-staged', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '4'}), ('8p-direct-l2', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '8'})]
 if os.environ.get('ARMS'):
     ARMS = [a for a in ARMS if a[0] in os.environ['ARMS'].split(',')]
 
@@ -87,6 +87,25 @@ def squares():
         print('%d^3: ' % n + ' | '.join(row))
 
 
+def ablate():
+    print('\n=== main-loop ablations (plain epilogues; results of the ablated arms are wrong): us (TFLOP/s) ===')
+    arms = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '4'}),
+            ('8p no waits', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '20'}), ('8p no loads', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '36'})]
+    print('%-36s ' % '' + ' '.join('%18s' % a for a, _ in arms))
+    for (M, N, K, odt) in ((8192, 8192, 8192, torch.bfloat16), (4096, 4096, 4096, torch.bfloat16), (102400, 1536, 512, torch.bfloat16),
+                           (102400, 512, 2048, torch.float32), (102400, 512, 512, torch.float32), (16384, 2048, 512, torch.bfloat16)):
+        x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+        out = torch.empty(M, N, device=dev, dtype=odt)
+        fn = lambda: ops._gemm_raw_untimed(M, N, K, x, K, 1, w, 1, K, out, N)
+        best = {n: 1e30 for n, _ in arms}
+        for r in range(3):
+            for n, env in arms:
+                setarm(env); fn(); fn()
+                best[n] = min(best[n], timeit(fn))
+        fl = 2.0 * M * N * K
+        print('%-36s ' % ('%d x %d x %d -> %s' % (M, N, K, 'bf16' if odt == torch.bfloat16 else 'fp32')) + ' '.join('%9.1f (%6.0f)' % (best[n], fl / best[n] / 1e6) for n, _ in arms))
+
+
 def race_screen(reps=200):
     """the same product again and again beside a result computed once with the 128 x 128 kernel: a too-early LDS read or a
     buffer re-armed too early shows as rare wrong tiles (they come and go with memory load -- hence the repetitions and
@@ -118,5 +137,6 @@ if __name__ == '__main__':
     what = sys.argv[1:] or ['race', 'shapes', 'squares']
     if 'race' in what: race_screen(int(os.environ.get('RACE_REPS', '100')))
     if 'squares' in what: squares()
+    if 'ablate' in what: ablate()
     if 'shapes' in what:
         for M in (25600, 51200, 102400): run_shapes(M)
