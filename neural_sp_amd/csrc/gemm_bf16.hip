@@ -24,7 +24,7 @@
 #include <cstdlib>
 #include <type_traits>
 #ifndef NSP_GEMM_8P_AB
-#define NSP_GEMM_8P_AB 1   // development: also compile the staged-epilogue twin of every 8-phase kernel (NSP_GEMM_8P_VAR=4)
+#define NSP_GEMM_8P_AB 0   // development (-DNSP_GEMM_8P_AB=1): also compile the direct-epilogue twins (NSP_GEMM_8P_VAR=0 / 8) and the main-loop ablations (20 / 36)
 #endif
 
 namespace {
@@ -1686,18 +1686,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
         boff[u][i] = (unsigned)min(tn * 256 + u * 128 + r, p.N - 1) * (unsigned)(2 * p.b_ns) + sw;
       }
   };
+  // (RR) descriptors rebased to the split's first k-row, so that 32-bit offsets only have to span ONE split (the RNN-T
+  // output layer reduces over 3.6 M rows x 2 KB); they end at the last k-row of the problem (clipped to 4 GB - 1: the
+  // clip can only bite in a split that does not reach the end anyway)
+  const long long rows_left = RR ? (long long)p.K - (long long)ktbeg * BK : 0;
+  const long long ext_a = rows_left > 0 ? rows_left * p.a_cs * 2 : 0, ext_b = rows_left > 0 ? rows_left * p.b_ks * 2 : 0;
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(A), 0, RR ? (unsigned)((long long)p.K * p.a_cs * 2) : 0u, 0x00020000);
+      const_cast<char*>(A) + (RR ? (long long)ktbeg * BK * p.a_cs * 2 : 0), 0, (unsigned)min(ext_a, 0xFFFFFFFFll), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(B), 0, RR ? (unsigned)((long long)p.K * p.b_ks * 2) : 0u, 0x00020000);
+      const_cast<char*>(B) + (RR ? (long long)ktbeg * BK * p.b_ks * 2 : 0), 0, (unsigned)min(ext_b, 0xFFFFFFFFll), 0x00020000);
   // unit j (0..3) of k-tile `kt` of the stream's tile into k-tile buffer `buf`
   auto issue = [&](int j, int buf, int kt) {
     unsigned char* base = ring + buf * BUF;
     if (RR) {
       // BUFFER LDS-DMA: the descriptors end at the last k-row, so the k-rows of a ragged (or padded) last k-tile are
       // out of range and land as ZEROS -- no tail logic; the k-tile offset rides in the scalar offset field
-      const int kabs = ktbeg + kt;                      // k-rows kabs * 64 .. + 63
-      const int ska = kabs * (2 * BK) * (int)p.a_cs, skb = kabs * (2 * BK) * (int)p.b_ks;
+      const int ska = kt * (2 * BK) * (int)p.a_cs, skb = kt * (2 * BK) * (int)p.b_ks;   // relative to the split's first k-row
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int pc = wave * 2 + i;
@@ -2253,11 +2257,13 @@ inline bool rr256_shape_ok(long long M, long long N, long long K) {
 inline bool rr256_enabled() { return true; }
 
 // 8-phase weight-gradient kernel (gemm_bf16_kk8p_kernel<.., RR = true>): NSP_GEMM_RR8P = 0 switches it off (read on every call)
-inline bool rr8p_shape_ok(long long M, long long N, long long K, long long lda, long long ldb) {
+inline bool rr8p_shape_ok(long long M, long long N, long long K, long long lda, long long ldb, int splitk) {
   const char* e = getenv("NSP_GEMM_RR8P");
   if (e && atoi(e) == 0) return false;
-  return M % 8 == 0 && N % 8 == 0 && M > 128 && N > 128 && K >= 4 * BK && (K + 128) * lda < (1ll << 31) &&
-         (K + 128) * ldb < (1ll << 31);
+  // 32-bit byte offsets inside ONE reduction split (+ the lane's 64 k-rows)
+  const long long per_rows = ((K + 127) / 128 * 2 + splitk - 1) / splitk * 64 + 256;
+  return M % 8 == 0 && N % 8 == 0 && M > 128 && N > 128 && K >= 4 * BK && per_rows * lda * 2 < (1ll << 31) &&
+         per_rows * ldb * 2 < (1ll << 31);
 }
 
 }  // namespace
@@ -2340,14 +2346,23 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       const char* e8m = getenv("NSP_GEMM_8P_MIN_TILES");
       const int on8 = e8 ? atoi(e8) : 1;
       const long long min8 = e8m ? atoll(e8m) : 96;
-      if (on8 && p.epi_mode == NSP_EPI_NONE && fast_epi && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 &&
+      // Where it wins (interleaved A/B at the step's shapes, profiles/r04c_gemm_8p_bench.log): every long reduction
+      // (K >= 1024: x1.12-1.24 at 102400 rows, x1.15-1.22 at 25600), and K = 512 only with a light epilogue on a grid
+      // that fills its last round of 256 workgroups (stacked QKV x1.07, the FFN data gradient x1.10 at 102400 rows).
+      // With K = 512 the exposed epilogue of ONE workgroup per CU costs what the faster main loop gains; the FFN
+      // first linear (two bf16 images, Swish, dropout: VALU-bound epilogue) and the thin N <= 1024 outputs stay on the
+      // 128 x 128 kernel, whose four workgroups per CU overlap their epilogues.  NSP_GEMM_8P = 2 forces it everywhere.
+      const long long rounds8 = (t256 + 255) / 256;
+      const bool fills = t256 * 10 >= rounds8 * 256 * 9;
+      const bool want8 = on8 >= 2 || p.K >= 1024 || (fills && !p.pre_out && p.N >= 1536);
+      if (on8 && want8 && p.epi_mode == NSP_EPI_NONE && fast_epi && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 &&
           t256 >= min8 && (long long)p.M * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31)) {
         const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
         int g8 = (int)(t256 >= 256 ? 256 : (t256 + 7) / 8 * 8);
         const char* e8g = getenv("NSP_GEMM_8P_GRID");   // tests: fewer workgroups, i.e. several tiles per workgroup on small problems
         if (e8g && atoi(e8g) >= 8 && atoi(e8g) < g8) g8 = atoi(e8g) / 8 * 8;
         const char* e8v = getenv("NSP_GEMM_8P_VAR");
-        const int var8 = e8v ? atoi(e8v) : 0;
+        const int var8 = e8v ? atoi(e8v) : 4;   // default: the staged epilogue (the direct one measured 0.4-0.9x, see gemm_epilogue_direct)
         auto launch8 = [&](auto spec, auto var) {
           using S8 = decltype(spec);
           constexpr int V8 = decltype(var)::value;
@@ -2361,22 +2376,22 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         // the direct epilogue's own conditions (32-bit byte offsets into C; column-sum slabs only with an act' source)
         const bool direct_ok = (long long)p.M * p.ldc < (1ll << 29) && !(p.epi_f3 && !p.dact_src) && !(p.bias && p.dact_src);
         bool done = false;
-        if (direct_ok) {
 #if NSP_GEMM_8P_AB
-          if (var8 == 4) done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 4>{}); });
-          else if (var8 == 8) done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 8>{}); });
-          else if ((var8 == 20 || var8 == 36) && !p.res && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE && p.dropout_p == 0.f) {
-            // main-loop ablations (timing only, results are wrong), plain epilogues only
-            const bool c16 = p.c_dtype == NSP_DT_BF16;
-            if (var8 == 20 && c16) launch8(EpiSpec<0, 0, true, false, false, false>{}, std::integral_constant<int, 20>{});
-            else if (var8 == 20) launch8(EpiSpec<0, 0, false, false, false, false>{}, std::integral_constant<int, 20>{});
-            else if (c16) launch8(EpiSpec<0, 0, true, false, false, false>{}, std::integral_constant<int, 36>{});
-            else launch8(EpiSpec<0, 0, false, false, false, false>{}, std::integral_constant<int, 36>{});
-            done = true;
-          } else
-#endif
-          done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 0>{}); });
+        if (direct_ok && var8 == 0) done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 0>{}); });
+        else if (direct_ok && var8 == 8) done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 8>{}); });
+        else if ((var8 == 20 || var8 == 36) && !p.res && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE && p.dropout_p == 0.f) {
+          // main-loop ablations (timing only, results are wrong), plain epilogues only
+          const bool c16 = p.c_dtype == NSP_DT_BF16;
+          if (var8 == 20 && c16) launch8(EpiSpec<0, 0, true, false, false, false>{}, std::integral_constant<int, 20>{});
+          else if (var8 == 20) launch8(EpiSpec<0, 0, false, false, false, false>{}, std::integral_constant<int, 20>{});
+          else if (c16) launch8(EpiSpec<0, 0, true, false, false, false>{}, std::integral_constant<int, 36>{});
+          else launch8(EpiSpec<0, 0, false, false, false, false>{}, std::integral_constant<int, 36>{});
+          done = true;
         }
+#else
+        (void)direct_ok; (void)var8;
+#endif
+        if (!done) done = epi_spec_visit(p, [&](auto spec) { launch8(spec, std::integral_constant<int, 4>{}); });
         if (!done) launch8(EpiRuntime{}, std::integral_constant<int, 0>{});
         NSP_LAUNCH_CHECK();
         return NSP_OK;
@@ -2406,7 +2421,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
   }
   else if (!a_kc && !b_kc && p.batch1 * p.batch2 == 1 && fast_epi && (p.splitk == 1 || p.c_ss) && p.epi_mode == NSP_EPI_NONE &&
-           rr8p_shape_ok(p.M, p.N, p.K, lda, ldb)) {
+           rr8p_shape_ok(p.M, p.N, p.K, lda, ldb, p.splitk)) {
     const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
     const dim3 g(tm256 * tn256 * p.splitk);
     const bool plain = !p.bias && !p.res && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE && p.dropout_p == 0.f &&
@@ -2458,7 +2473,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
 // reduction splits of a weight gradient dW[N, K] = dY[rows, N]^T X[rows, K] in bf16 mode, or 0 when the caller's
 // own rule applies (the 128 x 128 kernels).  256 x 256 tiles x splits ~ 256 workgroups = one per CU.
 extern "C" int nsp_wgrad_splitk(long long N, long long K, long long rows) {
-  if (rr8p_shape_ok(N, K, rows, N, K)) {
+  {
     // 8-phase kernel: 256 x 256 tiles x splits ~ one workgroup per CU, an EVEN number of k-tiles per split (>= 4)
     const long long tiles = (long long)nsp_cdiv((int)N, 256) * nsp_cdiv((int)K, 256);
     const long long nkt_pad = ((rows + 127) >> 7) << 1;
@@ -2466,7 +2481,8 @@ extern "C" int nsp_wgrad_splitk(long long N, long long K, long long rows) {
     if (sk > nkt_pad / 4) sk = nkt_pad / 4;
     if (sk < 1) sk = 1;
     const long long per = (((nkt_pad + sk - 1) / sk) + 1) & ~1ll;
-    return (int)((nkt_pad + per - 1) / per);      // no empty splits
+    const int plan = (int)((nkt_pad + per - 1) / per);      // no empty splits
+    if (rr8p_shape_ok(N, K, rows, N, K, plan)) return plan;
   }
   if (!rr256_enabled() || !rr256_shape_ok(N, K, rows)) return 0;
   const long long tiles = (long long)nsp_cdiv((int)N, 256) * nsp_cdiv((int)K, 256);

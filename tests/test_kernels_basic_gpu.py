@@ -321,7 +321,7 @@ def test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch):
     loop iterations (K = 128 ... 2048), workgroups with 0, 1 and several tiles (70000 x 512: 548 tiles for 256
     workgroups, the unit stream crossing tile boundaries), column-sum slabs, and the dropout mask of the 128 x 128 kernel."""
     from neural_sp_amd import ops
-    monkeypatch.setenv('NSP_GEMM_8P', '1')
+    monkeypatch.setenv('NSP_GEMM_8P', '2')                    # (2 = also where the launcher's rule prefers the 128 x 128 kernels)
     monkeypatch.setenv('NSP_GEMM_8P_MIN_TILES', '1')
     if grid:
         monkeypatch.setenv('NSP_GEMM_8P_GRID', str(grid))     # few workgroups: every one walks several tiles

@@ -10,8 +10,9 @@ from neural_sp_amd import ops
 
 ops.set_compute_mode('bf16')
 dev = torch.device('cuda:0')
-ARMS = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p-direct', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '0'}),
-        ('8p-staged', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '4'}), ('8p-direct-l2', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '8'})]
+ARMS = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p (rule)', {'NSP_GEMM_8P': '1'}), ('8p forced', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '4'})]
+if os.environ.get('NSP_8P_AB_BUILD'):      # a -DNSP_GEMM_8P_AB=1 build: the direct-epilogue twins
+    ARMS += [('8p-direct', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '0'}), ('8p-direct-l2', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '8'})]
 if os.environ.get('ARMS'):
     ARMS = [a for a in ARMS if a[0] in os.environ['ARMS'].split(',')]
 
@@ -89,8 +90,8 @@ def squares():
 
 def ablate():
     print('\n=== main-loop ablations (plain epilogues; results of the ablated arms are wrong): us (TFLOP/s) ===')
-    arms = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '4'}),
-            ('8p no waits', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '20'}), ('8p no loads', {'NSP_GEMM_8P': '1', 'NSP_GEMM_8P_VAR': '36'})]
+    arms = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '4'}),
+            ('8p no waits', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '20'}), ('8p no loads', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '36'})]
     print('%-36s ' % '' + ' '.join('%18s' % a for a, _ in arms))
     for (M, N, K, odt) in ((8192, 8192, 8192, torch.bfloat16), (4096, 4096, 4096, torch.bfloat16), (102400, 1536, 512, torch.bfloat16),
                            (102400, 512, 2048, torch.float32), (102400, 512, 512, torch.float32), (16384, 2048, 512, torch.bfloat16)):
@@ -118,7 +119,7 @@ def race_screen(reps=200):
         ops._gemm_raw_untimed(M, N, K, x, K, 1, w, 1, K, ref, N)
         bad = 0
         for nm, env in ARMS[1:]:
-            setarm(dict(env, NSP_GEMM_8P_MIN_TILES='1'))
+            setarm(dict(env, NSP_GEMM_8P_MIN_TILES='1', NSP_GEMM_8P='2'))
             for r in range(reps):
                 out.fill_(float('nan'))
                 ops._gemm_raw_untimed(M, N, K, x, K, 1, w, 1, K, out, N)
