@@ -21,6 +21,7 @@
 //      16-lane group, lane 4a+b supplies the address of matrix row a, columns
 //      4b..4b+3; lane i receives column i of the 4x16 block.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #ifndef NSP_GEMM_8P_AB
@@ -2271,6 +2272,13 @@ inline bool rr8p_shape_ok(long long M, long long N, long long K, long long lda, 
 // called from nsp_gemm (gemm.hip) when both operands are bf16
 int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   const bool a_kc = p.a_cs == 1, b_kc = p.b_ks == 1;
+  {
+    static int dbg = -1;       // NSP_GEMM_DEBUG=1: one line per launch on stderr (which shapes reach which kernel family)
+    if (dbg < 0) { const char* e = getenv("NSP_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg) fprintf(stderr, "[nsp_gemm_bf16] M %d N %d K %d a_kc %d b_kc %d splitk %d batch %dx%d epi %d c16 %d pre %d dact %d res %d drop %g\n", p.M, p.N, p.K,
+                     (int)a_kc, (int)b_kc, p.splitk, p.batch1, p.batch2, p.epi_mode, (int)(p.c_dtype == NSP_DT_BF16), (int)(p.pre_out != nullptr),
+                     p.dact_src ? p.dact : 0, (int)(p.res != nullptr), (double)p.dropout_p);
+  }
   if (!a_kc && p.a_rs != 1) return NSP_EINVAL;
   if (!b_kc && p.b_ns != 1) return NSP_EINVAL;
   const long long lda = a_kc ? p.a_rs : p.a_cs, ldb = b_kc ? p.b_ns : p.b_ks;
@@ -2478,8 +2486,8 @@ extern "C" int nsp_wgrad_splitk(long long N, long long K, long long rows) {
     const long long tiles = (long long)nsp_cdiv((int)N, 256) * nsp_cdiv((int)K, 256);
     const long long nkt_pad = ((rows + 127) >> 7) << 1;
     long long sk = 256 / tiles;
-    if (sk > nkt_pad / 4) sk = nkt_pad / 4;
-    if (sk < 1) sk = 1;
+    if (sk > nkt_pad / 12) sk = nkt_pad / 12;   // >= 12 k-tiles per split: the pipeline's fill and the fp32 slab (1 MB per
+    if (sk < 1) sk = 1;                         // 256 x 256 tile and split, written and reduced again) want amortising
     const long long per = (((nkt_pad + sk - 1) / sk) + 1) & ~1ll;
     const int plan = (int)((nkt_pad + per - 1) / per);      // no empty splits
     if (rr8p_shape_ok(N, K, rows, N, K, plan)) return plan;
