@@ -286,11 +286,11 @@ extern "C" int nsp_mono_alpha_bwd(const float* d_alpha, const float* p_choose, c
   if (rows <= 0 || klen <= 0) return NSP_OK;
   if (!d_alpha || !p_choose || !cprod || !aw_prev || !d_e || !d_aw_prev || stableemit >= 1.f) return NSP_EINVAL;
   if (klen > 8192) return NSP_EUNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)mono_alpha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8192 * 4);
-    attr = true;
-  }
+  // the opt-in is per DEVICE and can fail (a device with less LDS than 3 x 4 B per key): set it for the bytes this
+  // launch needs, on whatever device is current, and report instead of failing at launch with a generic error
+  if (3 * klen * sizeof(float) > 65536 &&
+      hipFuncSetAttribute((const void*)mono_alpha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * klen * sizeof(float))) != hipSuccess)
+    return NSP_EUNSUPPORTED;
   hipLaunchKernelGGL(mono_alpha_bwd_kernel, dim3(rows), dim3(64), 3 * klen * sizeof(float), (hipStream_t)stream, d_alpha,
                      p_choose, cprod, aw_prev, d_e, d_aw_prev, klen, eps, no_denom, stableemit);
   NSP_LAUNCH_CHECK();
@@ -302,6 +302,9 @@ extern "C" int nsp_chunk_beta_fwd(const float* u, const float* alpha, float* bet
   if (rows <= 0 || klen <= 0) return NSP_OK;
   if (!u || !alpha || !beta || w == 0 || w < -1) return NSP_EINVAL;
   if (w > 64 || klen > 8192) return NSP_EUNSUPPORTED;
+  if (2 * klen * sizeof(float) > 65536 &&
+      hipFuncSetAttribute((const void*)chunk_beta_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * klen * sizeof(float))) != hipSuccess)
+    return NSP_EUNSUPPORTED;
   hipLaunchKernelGGL(chunk_beta_fwd_kernel, dim3(rows), dim3(64), 2 * klen * sizeof(float), (hipStream_t)stream, u, alpha,
                      beta, klen, w, sf);
   NSP_LAUNCH_CHECK();
@@ -313,11 +316,9 @@ extern "C" int nsp_chunk_beta_bwd(const float* d_beta, const float* u, const flo
   if (rows <= 0 || klen <= 0) return NSP_OK;
   if (!d_beta || !u || !alpha || !d_u || !d_alpha || w == 0 || w < -1) return NSP_EINVAL;
   if (w > 64 || klen > 8192) return NSP_EUNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)chunk_beta_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 8192 * 4);
-    attr = true;
-  }
+  if (5 * klen * sizeof(float) > 65536 &&
+      hipFuncSetAttribute((const void*)chunk_beta_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(5 * klen * sizeof(float))) != hipSuccess)
+    return NSP_EUNSUPPORTED;
   hipLaunchKernelGGL(chunk_beta_bwd_kernel, dim3(rows), dim3(64), 5 * klen * sizeof(float), (hipStream_t)stream, d_beta, u,
                      alpha, d_u, d_alpha, klen, w, sf);
   NSP_LAUNCH_CHECK();

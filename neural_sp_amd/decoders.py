@@ -262,6 +262,10 @@ class RNNTransducer(DecoderBase):
         first use; None where the corresponding overlap is disabled / not applicable."""
         if not torch.cuda.is_available() or not next(self.parameters()).is_cuda:
             return None, None
+        if getattr(self, '_nsp_single_stream', False):
+            # stock DistributedDataParallel (no multi-stream communication hook): the whole step stays on the
+            # current stream, see Speech2Text._ddp_guard
+            return None, None
         dev = self.device
         side = ctc = None
         if self.rnnt_weight > 0 and os.environ.get('NSP_PREDNET_STREAM', '1') != '0':
@@ -297,6 +301,8 @@ class RNNTransducer(DecoderBase):
         the backward of these nodes on the same side stream (see ops.replay_graph_first for how
         that backward is made to start before the encoder's, not after it)."""
         if self.rnnt_weight <= 0 or not torch.cuda.is_available() or os.environ.get('NSP_PREDNET_STREAM', '1') == '0':
+            return
+        if getattr(self, '_nsp_single_stream', False):
             return
         dev = self.device
         self.ensure_streams()

@@ -204,8 +204,6 @@ class MoChA(nn.Module):
         if self.chunk_energy is not None:
             # soft_chunkwise_attention (mocha_train.py:13-58)
             u = self.chunk_energy(key, query, mask, cache)
-            if not ops.chunk_beta_supported(self.w):
-                raise NotImplementedError('MoChA chunk sizes above 64 frames (nsp_chunk_beta_fwd sums the window directly)')
             beta = ops.chunk_beta(u, alpha, self.w, self.sharpening_factor)     # clamped exp, window sums, beta: one kernel
             beta = self.dropout_attn(beta)
         aw = alpha if self.w == 1 else beta                                      # [B,1,1,T]

@@ -145,8 +145,6 @@ class MMA(nn.Module):
             u = u.unsqueeze(1)                                                       # [B,1,(H_ma*)H_ca,L,T]
             if self.H_ma > 1 and not self.share_ca:
                 u = u.view(bs, self.H_ma, self.H_ca, qlen, klen)
-            if not ops.chunk_beta_supported(self.w):
-                raise NotImplementedError('MMA chunk sizes above 64 frames (nsp_chunk_beta_fwd sums the window directly)')
             full = (bs, self.H_ma, self.H_ca, qlen, klen)
             beta = ops.chunk_beta(u.expand(full), a.expand(full), self.w, self.sharpening_factor)
             beta = self.dropout_attn(beta.reshape(bs, -1, qlen, klen))               # [B,H_ma*H_ca,L,T]

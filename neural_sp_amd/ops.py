@@ -185,7 +185,7 @@ def to_bf16(x2d, pad_to=8):
 import weakref  # noqa: E402
 
 _SHADOWS = {}          # (id(owner), attr) -> record
-_SHADOW_TABLE = {'key': None, 'table': None, 'n': 0, 'tiles': 0}
+_SHADOW_TABLE = {}       # device -> {'key', 'table', 'n', 'tiles'}: the device-side table of the last refresh
 _WEIGHT_EPOCH = [0]
 
 
@@ -200,64 +200,105 @@ def _wkey(w):
 
 
 
-def _shadow_register(owner, attr, dst, parts, make_entry):
-    """parts: [(src_param, dst_row0, dst_col0, rows, cols, transpose)] with src viewed as [N, K] row-major;
-    make_entry(): the tuple the getter caches on `owner.attr` for the CURRENT parameter versions."""
+def _shadow_register(owner, attr, dst, parts, key_params, single=True, extra=()):
+    """parts: [(src_param, dst_row0, dst_col0, rows, cols, transpose)] with src viewed as [N, K] row-major.
+    The getter caches `(key, dst) + extra` on `owner.attr`, key = _wkey(key_params[0]) (single) or the tuple of the
+    key_params' _wkey.  The registry holds WEAK references only -- to the owner, the source parameters AND the shadow
+    (which lives on as long as the owner's attribute does): a model that is deleted takes its records with it
+    (round-3 advisor finding: the old closures captured parameters and shadows strongly, so every model ever built in
+    the process stayed alive and was re-cast on every step)."""
     try:
-        rec = {'owner': weakref.ref(owner), 'attr': attr, 'dst': dst, 'make': make_entry,
+        rec = {'owner': weakref.ref(owner), 'attr': attr, 'dst': weakref.ref(dst), 'single': bool(single), 'extra': tuple(extra),
+               'keyp': [weakref.ref(kp) for kp in key_params],
                'parts': [(weakref.ref(sp), int(r0), int(c0), int(rows), int(cols), bool(tr)) for sp, r0, c0, rows, cols, tr in parts]}
     except TypeError:
         return
     _SHADOWS[(id(owner), attr)] = rec
-    _SHADOW_TABLE['key'] = None
+    _SHADOW_TABLE.clear()
+
+
+def _shadow_entry(rec):
+    """the tuple the getter would cache now, or None when anything it refers to is gone"""
+    dst = rec['dst']()
+    ps = [r() for r in rec['keyp']]
+    if dst is None or any(q is None for q in ps):
+        return None
+    key = _wkey(ps[0]) if rec['single'] else tuple(_wkey(q) for q in ps)
+    return (key, dst) + rec['extra']
+
+
+def optimizer_stepped():
+    """Start a new weight epoch: every copy derived from a parameter (bf16 casts, transposes, stacked / padded images)
+    counts as stale from now on.  Speech2Text calls refresh_weight_shadows(force=True) in every training forward, which
+    does the same; code that drives ops.linear / ops.LSTMStackFn directly with a FUSED optimizer (which does not move
+    Parameter._version) calls this after optimizer.step() -- or lets `track_optimizer(optimizer)` do it."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def track_optimizer(optimizer):
+    """register a step post-hook on `optimizer` that starts a new weight epoch after every step; returns the handle"""
+    return optimizer.register_step_post_hook(lambda *a, **k: optimizer_stepped())
 
 
 def refresh_weight_shadows(force=False):
     """Bring every registered bf16 shadow whose source parameters have moved on (optimizer step, load_state_dict, weight
-    noise) up to date with ONE launch on the current stream.  Called at the top of a training / evaluation step;
-    the per-weight getters then find their caches fresh.  Shadows not yet registered are built at first use.
+    noise) up to date with ONE launch per device on the current stream.  Called at the top of a training / evaluation
+    step; the per-weight getters then find their caches fresh.  Shadows not yet registered are built at first use.
     force=True (training steps): start a new weight epoch first -- every derived copy counts as stale whatever the
     parameters' version counters say (see _wkey)."""
     if force:
         _WEIGHT_EPOCH[0] += 1
     if not _SHADOWS or not bf16_mode():
         return
-    stale, dead = [], []
+    stale, dead = {}, []
     for k, rec in _SHADOWS.items():
-        owner = rec['owner']()
-        if owner is None or any(sp() is None for sp, *_ in rec['parts']):
+        owner, dst = rec['owner'](), rec['dst']()
+        srcs = [sp() for sp, *_ in rec['parts']]
+        if owner is None or dst is None or any(w is None for w in srcs):
             dead.append(k)
             continue
         ent = getattr(owner, rec['attr'], None)
-        if ent is None or ent[1] is not rec['dst']:
+        if ent is None or ent[1] is not dst:
             dead.append(k)                      # invalidated or rebuilt elsewhere: the getter re-registers
             continue
-        if ent[0] != rec['make']()[0]:
-            stale.append(rec)
+        # the kernel reads raw fp32 rows: a parameter that changed dtype / layout / device since it was registered
+        # (model.half(), .to(other device), a non-contiguous .data) goes back to its getter, which handles those
+        if any(w.dtype != torch.float32 or not w.is_contiguous() or w.device != dst.device for w in srcs):
+            dead.append(k)
+            try:
+                delattr(owner, rec['attr'])
+            except Exception:
+                pass
+            continue
+        now = _shadow_entry(rec)
+        if now is None:
+            dead.append(k)
+        elif ent[0] != now[0]:
+            stale.setdefault(dst.device, []).append((rec, dst, srcs))
     for k in dead:
         del _SHADOWS[k]
-    if not stale:
-        return
-    key = tuple((id(rec), rec['dst'].data_ptr()) + tuple(sp().data_ptr() for sp, *_ in rec['parts']) for rec in stale)
-    if _SHADOW_TABLE['key'] != key:
-        rows_, tiles = [], 0
-        for rec in stale:
-            dst = rec['dst']
-            for sp, r0, c0, rows, cols, tr in rec['parts']:
-                w = sp()
-                K = w[0].numel()
-                rows_.append([w.data_ptr(), dst.data_ptr() + 2 * (r0 * dst.stride(0) + c0), rows, cols, K, dst.stride(0),
-                              1 if tr else 0, tiles])
-                tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
-        dev = stale[0]['dst'].device
-        _SHADOW_TABLE.update(key=key, table=h2d(torch.tensor(rows_, dtype=torch.int64), dev), n=len(rows_), tiles=tiles)
-    _check(_lib.lib().nsp_shadow_refresh(_p(_SHADOW_TABLE['table']), _SHADOW_TABLE['n'], _SHADOW_TABLE['tiles'], _stream()),
-           'nsp_shadow_refresh')
-    for rec in stale:
-        try:
-            setattr(rec['owner'](), rec['attr'], rec['make']())
-        except Exception:
-            pass
+    for dev, recs in stale.items():
+        key = tuple((id(rec), dst.data_ptr()) + tuple(w.data_ptr() for w in srcs) for rec, dst, srcs in recs)
+        tab = _SHADOW_TABLE.get(dev)
+        if tab is None or tab['key'] != key:
+            rows_, tiles = [], 0
+            for rec, dst, srcs in recs:
+                for (sp, r0, c0, rows, cols, tr), w in zip(rec['parts'], srcs):
+                    K = w[0].numel()
+                    rows_.append([w.data_ptr(), dst.data_ptr() + 2 * (r0 * dst.stride(0) + c0), rows, cols, K, dst.stride(0),
+                                  1 if tr else 0, tiles])
+                    tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+            tab = _SHADOW_TABLE[dev] = dict(key=key, table=h2d(torch.tensor(rows_, dtype=torch.int64), dev), n=len(rows_), tiles=tiles)
+        if dev.type == 'cuda' and dev != torch.device('cuda', torch.cuda.current_device()):
+            with torch.cuda.device(dev):
+                _check(_lib.lib().nsp_shadow_refresh(_p(tab['table']), tab['n'], tab['tiles'], _stream()), 'nsp_shadow_refresh')
+        else:
+            _check(_lib.lib().nsp_shadow_refresh(_p(tab['table']), tab['n'], tab['tiles'], _stream()), 'nsp_shadow_refresh')
+        for rec, dst, srcs in recs:
+            try:
+                setattr(rec['owner'](), rec['attr'], _shadow_entry(rec))
+            except Exception:
+                pass
 
 
 def weight_bf16(w):
@@ -270,7 +311,7 @@ def weight_bf16(w):
     wb = to_bf16(w.detach().reshape(w.shape[0], -1))
     try:
         w._nsp_bf16 = (_wkey(w), wb)
-        _shadow_register(w, '_nsp_bf16', wb, [(w, 0, 0, w.shape[0], w[0].numel(), False)], lambda w=w, wb=wb: (_wkey(w), wb))
+        _shadow_register(w, '_nsp_bf16', wb, [(w, 0, 0, w.shape[0], w[0].numel(), False)], [w])
     except Exception:
         pass
     return wb
@@ -842,7 +883,7 @@ def invalidate_weight_shadows(module):
                 except AttributeError:
                     pass
             _SHADOWS.pop((id(p), name), None)
-    _SHADOW_TABLE['key'] = None
+    _SHADOW_TABLE.clear()
 
 
 # --------------------------------------------------------------------------
@@ -1525,7 +1566,7 @@ def _rows_padded_bf16(w, mult):
     out[:N] = wb
     try:
         w._nsp_rowpad16 = (_wkey(w), out)
-        _shadow_register(w, '_nsp_rowpad16', out, [(w, 0, 0, N, w[0].numel(), False)], lambda w=w, out=out: (_wkey(w), out))
+        _shadow_register(w, '_nsp_rowpad16', out, [(w, 0, 0, N, w[0].numel(), False)], [w])
     except Exception:
         pass
     return out
@@ -1819,11 +1860,37 @@ class ChunkBetaFn(torch.autograd.Function):
 
 
 def chunk_beta(u, alpha, w, sf=1.0):
+    if not chunk_beta_supported(w, u.shape[-1]):
+        return _chunk_beta_tensor_ops(u, alpha, w, sf)
     return ChunkBetaFn.apply(u, alpha, w, sf)
 
 
-def chunk_beta_supported(w):
-    return w == -1 or 1 < w <= 64
+def chunk_beta_supported(w, klen=0):
+    """what the scan kernels of csrc/mocha.hip take: chunk sizes up to 64 frames (or MILk, w = -1), rows up to 8192 keys"""
+    return (w == -1 or 1 < w <= 64) and klen <= 8192
+
+
+def _window_sums(x2d, back, fwd):
+    """sum over [j - back, j + fwd] of every row of x2d (zeros outside): a ones-filter correlation"""
+    import torch.nn.functional as F
+    ones = x2d.new_ones(1, 1, back + fwd + 1)
+    return F.conv1d(F.pad(x2d, [back, fwd]).unsqueeze(1), ones).squeeze(1)
+
+
+def _chunk_beta_tensor_ops(u, alpha, w, sf):
+    """Fallback for chunk sizes / row lengths the scan kernels do not take (any w, any klen): the same chunkwise soft-max
+    (mocha_train.py:36-57: shift by the row maximum, exp clamped at 1e-5, window sums of the denominators and of
+    alpha / denominator) as differentiable tensor ops.  No recipe of the reference reaches it (chunk sizes 4..16)."""
+    klen = u.shape[-1]
+    u2, a2 = u.reshape(-1, klen).float(), alpha.reshape(-1, klen).float()
+    ex = torch.clamp(torch.exp(u2 - u2.max(dim=-1, keepdim=True)[0]), min=1e-5)
+    if w == -1:
+        den = torch.cumsum(ex, dim=-1)
+        beta = ex * _window_sums(a2 * sf / den, 0, klen - 1)
+    else:
+        den = _window_sums(ex, w - 1, 0)
+        beta = ex * _window_sums(a2 * sf / den, 0, w - 1)
+    return beta.view(u.shape)
 
 
 class AddEnergyFn(torch.autograd.Function):
@@ -2075,7 +2142,7 @@ def _weight_t_shadow(w, bf16):
     try:
         setattr(w, name, (_wkey(w), wt))
         if bf16:
-            _shadow_register(w, name, wt, [(w, 0, 0, w[0].numel(), w.shape[0], True)], lambda w=w, wt=wt: (_wkey(w), wt))
+            _shadow_register(w, name, wt, [(w, 0, 0, w[0].numel(), w.shape[0], True)], [w])
     except Exception:
         pass
     return wt
@@ -2219,7 +2286,7 @@ def _cat_cached(owner, name, parts, build, layout=None):
     try:
         setattr(owner, name, (key, t))
         if layout is not None and t.dtype == torch.bfloat16:
-            _shadow_register(owner, name, t, layout(t), lambda parts=tuple(parts), t=t: (tuple(_wkey(p) for p in parts), t))
+            _shadow_register(owner, name, t, layout(t), list(parts), single=False)
     except Exception:
         pass
     return t
@@ -2642,8 +2709,7 @@ def _stacked_weight_bf16(ws):
         for w in ws:
             parts.append((w, r0, 0, w.shape[0], w[0].numel(), False))
             r0 += w.shape[0]
-        _shadow_register(ws[0], '_nsp_stack16', wb, parts,
-                         lambda ws=tuple(ws), wb=wb: (tuple(_wkey(w) for w in ws), wb, len(ws)))
+        _shadow_register(ws[0], '_nsp_stack16', wb, parts, list(ws), single=False, extra=(len(ws),))
     except Exception:
         pass
     return wb
@@ -2662,8 +2728,7 @@ def _stacked_weight_t_bf16(ws):
         for w in ws:
             parts.append((w, 0, c0, w[0].numel(), w.shape[0], True))
             c0 += w.shape[0]
-        _shadow_register(ws[0], '_nsp_stackt16', wt, parts,
-                         lambda ws=tuple(ws), wt=wt: (tuple(_wkey(w) for w in ws), wt, len(ws)))
+        _shadow_register(ws[0], '_nsp_stackt16', wt, parts, list(ws), single=False, extra=(len(ws),))
     except Exception:
         pass
     return wt

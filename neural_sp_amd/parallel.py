@@ -182,6 +182,7 @@ def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
                  for m in model.modules())
     kw = dict(broadcast_buffers=has_bn, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
     if local_rank is None:
+        model._nsp_ddp_hooked = True      # (CPU module: no streams to order)
         return DDP(model, **kw)
     pin_grad_streams(model)
     ddp = DDP(model, device_ids=[local_rank], **kw)
@@ -190,7 +191,42 @@ def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
     pstreams = param_streams(model) if os.environ.get('NSP_DDP_WAIT_ALL_STREAMS', '0') != '1' else None
     ddp.register_comm_hook(None, make_comm_hook(step_streams(model), compress, pstreams, ddp.comm_stats,
                                                 torch.cuda.current_stream(torch.device('cuda', local_rank))))
+    model._nsp_ddp_hooked = True          # Speech2Text._ddp_guard: the multi-stream step is safe under this wrapper
     return ddp
+
+
+def make_ddp_class():
+    """The class `neural_sp_amd.install()` puts where train.py finds `DistributedDataParallel` (train.py:20,263):
+    torch's DDP, constructed exactly as the caller asks, plus -- when the wrapped module is this package's
+    Speech2Text on a HIP device -- what `wrap_ddp` adds: gradient accumulators pinned to their streams BEFORE the
+    reducer is built, and the multi-stream communication hook after.  Anything else is plain torch DDP."""
+    from torch.nn.parallel import DistributedDataParallel as TorchDDP
+    if getattr(TorchDDP, '_nsp_patched', False):
+        return TorchDDP
+
+    class DistributedDataParallel(TorchDDP):
+        _nsp_patched = True
+
+        def __init__(self, module, device_ids=None, *args, **kwargs):
+            from .speech2text import Speech2Text
+            ours = isinstance(module, Speech2Text) and device_ids and next(module.parameters()).is_cuda
+            if ours:
+                pin_grad_streams(module)
+                has_bn = any(type(m).__name__.startswith('BatchNorm') for m in module.modules())
+                kwargs.setdefault('broadcast_buffers', has_bn)
+                kwargs.setdefault('bucket_cap_mb', 48)
+                kwargs.setdefault('gradient_as_bucket_view', True)
+            super().__init__(module, device_ids, *args, **kwargs)
+            if ours:
+                dev = device_ids[0]
+                dev = dev if isinstance(dev, torch.device) else torch.device('cuda', int(dev))
+                self.comm_stats = CommStats()
+                pstreams = param_streams(module) if os.environ.get('NSP_DDP_WAIT_ALL_STREAMS', '0') != '1' else None
+                self.register_comm_hook(None, make_comm_hook(step_streams(module), os.environ.get('NSP_DDP_COMPRESS') or None,
+                                                             pstreams, self.comm_stats, torch.cuda.current_stream(dev)))
+                module._nsp_ddp_hooked = True
+    DistributedDataParallel.__name__ = 'DistributedDataParallel'
+    return DistributedDataParallel
 
 
 @contextlib.contextmanager

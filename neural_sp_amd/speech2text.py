@@ -324,7 +324,8 @@ class Speech2Text(nn.Module):
         Returns (nbest_hyps_id `[B][1][L]`, aws None).  Beam search / LM fusion / streaming /
         ensembles are inference-side and raise NotImplementedError."""
         self.eval()
-        ops.refresh_weight_shadows(force=True)
+        ops.refresh_weight_shadows(force=not getattr(self, '_nsp_eval_epoch_started', False))   # (once per evaluation phase, see _forward)
+        self._nsp_eval_epoch_started = True
         base = task.split('.')[0]
         if base not in ('ys', 'ys_sub1', 'ys_sub2'):
             raise ValueError(task)
@@ -365,11 +366,42 @@ class Speech2Text(nn.Module):
             loss, observation = self._forward(batch, task)
         return loss, observation
 
+    def _ddp_guard(self):
+        """train.py:263 wraps the model in stock `DistributedDataParallel(model, device_ids=...)`.  Its reducer orders
+        a bucket's all-reduce only after the stream of the gradient hook that completes the bucket; this step produces
+        gradients on up to three HIP streams (main, prediction network, CTC branch), so with the stock wrapper a
+        collective could read a bucket before another stream has written its part -- silently wrong gradients.
+        Unless the model went through `parallel.wrap_ddp` (or the DDP class `neural_sp_amd.install()` puts in its
+        place), which registers the multi-stream communication hook, a training forward inside an initialised process
+        group of more than one rank therefore keeps the WHOLE step on the current stream (correct under any wrapper,
+        a few per cent slower) and says so once."""
+        import torch.distributed as dist
+        unsafe = (not getattr(self, '_nsp_ddp_hooked', False) and dist.is_available() and dist.is_initialized()
+                  and dist.get_world_size() > 1)
+        for name in ('dec_fwd', 'dec_fwd_sub1', 'dec_fwd_sub2'):
+            dec = getattr(self, name, None)
+            if dec is not None and hasattr(dec, 'ensure_streams'):
+                dec._nsp_single_stream = unsafe
+        if unsafe and not getattr(Speech2Text, '_warned_stock_ddp', False):
+            Speech2Text._warned_stock_ddp = True
+            logger.warning('neural_sp_amd: process group of %d ranks without the multi-stream DDP hook -- the step runs on '
+                           'ONE stream (correct with stock DistributedDataParallel).  Call neural_sp_amd.install() before '
+                           'train.py imports DistributedDataParallel, or wrap with neural_sp_amd.parallel.wrap_ddp, to '
+                           'overlap the prediction network and the CTC branch again.', dist.get_world_size())
+        return unsafe
+
     def _forward(self, batch, task):
+        if torch.is_grad_enabled():
+            self._ddp_guard()
         # every bf16 weight shadow that the last optimizer step made stale: one launch (before the side stream's
         # step-start event, so that the prediction network reads the refreshed images)
         # (forced in evaluation too: the last optimizer step of a fused optimizer leaves no trace in the version counters)
-        ops.refresh_weight_shadows(force=True)
+        # (in evaluation the epoch is forced on the FIRST batch after a training forward only -- the last optimizer step of a
+        # fused optimizer leaves no trace in the version counters -- not once per batch, which rebuilt every unregistered
+        # cache for each evaluation batch)
+        training = torch.is_grad_enabled() and self.training
+        ops.refresh_weight_shadows(force=training or not getattr(self, '_nsp_eval_epoch_started', False))
+        self._nsp_eval_epoch_started = not training
         if isinstance(getattr(self, 'dec_fwd', None), RNNT) and task in ('all', 'ys'):
             # the prediction network overlaps with the encoder on a side stream; it is enqueued
             # right after the encoder's front-end so that neither stream starts the step idle
@@ -473,7 +505,8 @@ class Speech2Text(nn.Module):
     def ctc_forced_align(self, xs, ys, task='ys'):
         """speech2text.py:470-492: CTC forced alignment -> trigger points `[B,L+1]` (np.int32)."""
         self.eval()
-        ops.refresh_weight_shadows(force=True)
+        ops.refresh_weight_shadows(force=not getattr(self, '_nsp_eval_epoch_started', False))   # (once per evaluation phase, see _forward)
+        self._nsp_eval_epoch_started = True
         with torch.no_grad():
             eout_dict = self.encode(xs, 'ys')
             ctc = self.dec_fwd.ctc

@@ -42,7 +42,7 @@ def model_args(small=False):
                                dec_bottleneck_dim=32)
 
 
-def run(rank, world, port, out_path, compress, device='cuda'):
+def run(rank, world, port, out_path, compress, device='cuda', mode='wrap'):
     """device='cpu': the same two-rank run on the host-emulated kernels (tests/test_ddp_gloo_cpu.py) -- CPU tensors, gloo
     all-reduce through the CPU branch of the comm hook, no streams"""
     if device == 'cpu':
@@ -50,11 +50,14 @@ def run(rank, world, port, out_path, compress, device='cuda'):
         torch.set_num_threads(2)
         from tests.cpu_ops_shim import host_logic_on_cpu
         with host_logic_on_cpu(real_kernels=True, real_conv=False, mode='bf16'):
-            return _run(rank, world, port, out_path, compress, device)
-    return _run(rank, world, port, out_path, compress, device)
+            return _run(rank, world, port, out_path, compress, device, mode)
+    return _run(rank, world, port, out_path, compress, device, mode)
 
 
-def _run(rank, world, port, out_path, compress, device):
+def _run(rank, world, port, out_path, compress, device, mode='wrap'):
+    """mode: 'wrap' = parallel.wrap_ddp; 'stock' = train.py:263 as written, `DistributedDataParallel(model, device_ids)`
+    of an unpatched torch (the model's own guard must keep the step on one stream); 'install' = the same line after
+    `neural_sp_amd.install()` (the patched class adds the multi-stream hook)."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
@@ -85,7 +88,17 @@ def _run(rank, world, port, out_path, compress, device):
         result['single'] = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
         result['single_loss'] = loss.item()
         model.zero_grad(set_to_none=True)
-    if on_gpu:
+    if on_gpu and mode == 'stock':
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        assert not getattr(DDP, '_nsp_patched', False)
+        ddp = DDP(model, device_ids=[0], bucket_cap_mb=1)                       # train.py:263 (small buckets: several at XS size)
+    elif on_gpu and mode == 'install':
+        import neural_sp_amd
+        assert 'torch.nn.parallel.DistributedDataParallel' in neural_sp_amd.install()
+        from torch.nn.parallel import DistributedDataParallel as DDP            # what train.py:20 now imports
+        ddp = DDP(model, device_ids=[0], bucket_cap_mb=1)
+        assert model._nsp_ddp_hooked and len(model._nsp_grad_accumulators) > 0
+    elif on_gpu:
         ddp = parallel.wrap_ddp(model, 0, bucket_cap_mb=1, compress=compress)   # 1 MB: several buckets even at XS size
         assert len(model._nsp_grad_accumulators) > 0
     else:
@@ -101,6 +114,9 @@ def _run(rank, world, port, out_path, compress, device):
         losses.append(loss.item())
     sync()
     ops.lstm_check()
+    if on_gpu:
+        single_stream = bool(getattr(model.dec_fwd, '_nsp_single_stream', False))
+        assert single_stream == (mode == 'stock'), (mode, single_stream)       # only the stock wrapper falls back to one stream
     grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
     # every rank must hold the same averaged gradient
     flat = torch.cat([g.flatten() for g in grads.values()])

@@ -19,14 +19,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('compress', [None, 'bf16'])
-def test_two_rank_ddp_gradients_equal_single_process(compress):
+@pytest.mark.parametrize('compress,mode', [(None, 'wrap'), ('bf16', 'wrap'), (None, 'stock'), (None, 'install')])
+def test_two_rank_ddp_gradients_equal_single_process(compress, mode):
+    """mode 'stock': the reference's own line (train.py:263), `DistributedDataParallel(model, device_ids=[0])` of an
+    unpatched torch around the transducer model -- Speech2Text's guard keeps the step on one stream, so the reducer's
+    single-stream ordering is enough; 'install': the same line after `neural_sp_amd.install()` (multi-stream hook)."""
     import torch.multiprocessing as mp
     from tests import ddp_hip_worker
     world = 2
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, 'res.pt')
-        mp.spawn(ddp_hip_worker.run, args=(world, _free_port(), out, compress), nprocs=world, join=True)
+        mp.spawn(ddp_hip_worker.run, args=(world, _free_port(), out, compress, 'cuda', mode), nprocs=world, join=True)
         res = torch.load(out, weights_only=False)
     assert all(res['same']), 'ranks disagree on the reduced gradient'
     assert set(res['ddp']) == set(res['single'])

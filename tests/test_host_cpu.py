@@ -247,3 +247,35 @@ def test_bench_cpu_baseline_leg_runs_with_dropout_as_configured():
         torch.set_num_threads(threads)
     assert out['kind'] == 'port' and out['unit'] == 'frames/s' and out['value'] > 0 and out['cores'] == 4
     assert 'full training step' in out['sample'] or 'probe' in out['sample']
+
+
+def test_install_substitutes_ddp_and_is_idempotent(monkeypatch):
+    """neural_sp_amd.install(): what train.py:20 imports afterwards is a torch-DDP subclass that adds the multi-stream
+    hook for this package's Speech2Text; a second call changes nothing."""
+    import torch.nn.parallel as tnp
+    import neural_sp_amd
+    stock = tnp.DistributedDataParallel
+    monkeypatch.setattr(tnp, 'DistributedDataParallel', stock)                 # restored after the test
+    monkeypatch.setattr(tnp.distributed, 'DistributedDataParallel', stock)
+    assert not getattr(stock, '_nsp_patched', False)
+    done = neural_sp_amd.install()
+    assert 'torch.nn.parallel.DistributedDataParallel' in done
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    assert DDP is not stock and issubclass(DDP, stock) and DDP._nsp_patched and DDP.__name__ == 'DistributedDataParallel'
+    assert neural_sp_amd.install() == []
+
+
+def test_training_forward_without_the_ddp_hook_goes_single_stream(monkeypatch):
+    """Speech2Text._ddp_guard: inside a process group of more than one rank, a model that did not go through wrap_ddp /
+    the installed DDP class keeps its step on one stream (decoders' ensure_streams() -> (None, None))."""
+    import torch.distributed as dist
+    from neural_sp_amd.configs import conformer_rnnt_args
+    from neural_sp_amd.speech2text import Speech2Text
+    model = Speech2Text(conformer_rnnt_args('XS', n_layers=2, vocab=40))
+    assert model._ddp_guard() is False and not model.dec_fwd._nsp_single_stream
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a: 2)
+    assert model._ddp_guard() is True and model.dec_fwd._nsp_single_stream
+    assert model.dec_fwd.ensure_streams() == (None, None)
+    model._nsp_ddp_hooked = True                                               # what wrap_ddp / the installed class set
+    assert model._ddp_guard() is False and not model.dec_fwd._nsp_single_stream

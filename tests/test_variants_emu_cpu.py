@@ -59,3 +59,40 @@ def test_weight_copies_follow_updates_that_do_not_bump_the_version_counter():
     from tests.cpu_ops_shim import host_logic_on_cpu
     with host_logic_on_cpu(real_kernels=True, real_conv=False, mode='bf16'):
         vc.check_weights_changed_without_version_bump('emu')
+
+
+def test_weight_shadow_registry_holds_no_strong_references():
+    import torch
+    """ADVICE r3 (medium): the registry of bf16 weight shadows kept every parameter and shadow of every model ever built
+    alive (its refresh closures captured them).  Now it holds weak references only: deleting the owner empties it at the
+    next refresh, and a parameter whose dtype changed under the registry goes back to its getter."""
+    import gc
+    import weakref
+    from neural_sp_amd import ops
+    from tests.hipemu.shim import emulated_kernels
+    with emulated_kernels(), ops.compute_mode('bf16'):
+        ops.refresh_weight_shadows(force=True)
+        n0 = len(ops._SHADOWS)
+        w = torch.nn.Parameter(torch.randn(24, 16))
+        w2 = torch.nn.Parameter(torch.randn(8, 16))
+        wb = ops.weight_bf16(w)
+        ops.weight_bf16(w2)
+        assert len(ops._SHADOWS) == n0 + 2
+        with torch.no_grad():
+            w.mul_(2.0)                                   # version moves: the one-launch refresh rewrites the shadow in place
+        ops.refresh_weight_shadows()
+        assert ops.weight_bf16(w) is wb and torch.equal(wb[:, :16].float(), w.detach().bfloat16().float())
+        with torch.no_grad():
+            w.mul_(0.5)
+        ops.optimizer_stepped()                            # what a fused optimizer's step hook does (track_optimizer)
+        ops.refresh_weight_shadows()
+        assert torch.equal(ops.weight_bf16(w)[:, :16].float(), w.detach().bfloat16().float())
+        wr, wbr = weakref.ref(w), weakref.ref(wb)
+        del w, wb
+        gc.collect()
+        assert wr() is None and wbr() is None, 'the registry kept the parameter / its shadow alive'
+        ops.refresh_weight_shadows(force=True)
+        assert len(ops._SHADOWS) == n0 + 1
+        w2.data = w2.data.double()                         # dtype changed under the registry: record dropped, cache cleared
+        ops.refresh_weight_shadows(force=True)
+        assert len(ops._SHADOWS) == n0 and not hasattr(w2, '_nsp_bf16')
