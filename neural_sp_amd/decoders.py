@@ -224,7 +224,8 @@ class RNNTransducer(DecoderBase):
                 # The two loss branches are independent and each contains a long latency-bound
                 # lattice kernel on B workgroups (CTC alpha/beta ~0.4 ms, RNN-T ~0.5 ms): the CTC
                 # branch runs on its own stream beside the transducer branch, forward and backward.
-                ctc_stream = self.ensure_streams()[1]
+                ctc_stream = self.ensure_streams()[1]        # (None in single-stream mode: stock DDP, Speech2Text._ddp_guard)
+            if ctc_stream is not None:
                 cur = torch.cuda.current_stream(eouts.device)
                 ctc_stream.wait_stream(cur)
                 with torch.cuda.stream(ctc_stream):

@@ -57,6 +57,16 @@ def step_streams(model):
     return out
 
 
+def mark_hooked(model):
+    """the model is (about to be) under a wrapper with the multi-stream communication hook: Speech2Text._ddp_guard keeps
+    the multi-stream step, and a single-stream fallback chosen by an earlier un-wrapped forward is lifted"""
+    model._nsp_ddp_hooked = True
+    for name in ('dec_fwd', 'dec_fwd_sub1', 'dec_fwd_sub2'):
+        dec = getattr(model, name, None)
+        if dec is not None and hasattr(dec, 'ensure_streams'):
+            dec._nsp_single_stream = False
+
+
 def pin_grad_streams(model):
     """Create (and keep alive on the model) the AccumulateGrad nodes of the parameters whose
     gradients are produced on a side stream, with that stream current.  Must run before DDP is
@@ -181,9 +191,9 @@ def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
     has_bn = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) or type(m).__name__.startswith('BatchNorm')
                  for m in model.modules())
     kw = dict(broadcast_buffers=has_bn, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+    mark_hooked(model)
     if local_rank is None:
-        model._nsp_ddp_hooked = True      # (CPU module: no streams to order)
-        return DDP(model, **kw)
+        return DDP(model, **kw)           # (CPU module: no streams to order)
     pin_grad_streams(model)
     ddp = DDP(model, device_ids=[local_rank], **kw)
     compress = compress if compress is not None else (os.environ.get('NSP_DDP_COMPRESS') or None)
@@ -191,7 +201,6 @@ def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
     pstreams = param_streams(model) if os.environ.get('NSP_DDP_WAIT_ALL_STREAMS', '0') != '1' else None
     ddp.register_comm_hook(None, make_comm_hook(step_streams(model), compress, pstreams, ddp.comm_stats,
                                                 torch.cuda.current_stream(torch.device('cuda', local_rank))))
-    model._nsp_ddp_hooked = True          # Speech2Text._ddp_guard: the multi-stream step is safe under this wrapper
     return ddp
 
 
@@ -211,6 +220,7 @@ def make_ddp_class():
             from .speech2text import Speech2Text
             ours = isinstance(module, Speech2Text) and device_ids and next(module.parameters()).is_cuda
             if ours:
+                mark_hooked(module)
                 pin_grad_streams(module)
                 has_bn = any(type(m).__name__.startswith('BatchNorm') for m in module.modules())
                 kwargs.setdefault('broadcast_buffers', has_bn)
@@ -224,7 +234,6 @@ def make_ddp_class():
                 pstreams = param_streams(module) if os.environ.get('NSP_DDP_WAIT_ALL_STREAMS', '0') != '1' else None
                 self.register_comm_hook(None, make_comm_hook(step_streams(module), os.environ.get('NSP_DDP_COMPRESS') or None,
                                                              pstreams, self.comm_stats, torch.cuda.current_stream(dev)))
-                module._nsp_ddp_hooked = True
     DistributedDataParallel.__name__ = 'DistributedDataParallel'
     return DistributedDataParallel
 
