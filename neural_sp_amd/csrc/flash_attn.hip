@@ -43,6 +43,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
+// 16-B LDS read the compiler does not see (see the dK/dV kernel); T = f32x4 or u32x4
+template <class T>
+__device__ __forceinline__ void fa_lds_read4(T& dst, const void* p) {
+#ifdef NSP_HOST_EMULATION
+  dst = *reinterpret_cast<const T*>(p);
+#else
+  typedef __attribute__((address_space(3))) unsigned char lds_uchar;
+  const unsigned a = (unsigned)(uintptr_t)((lds_uchar*)const_cast<void*>(p));
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(a) : "memory");
+#endif
+}
+
 __device__ __forceinline__ bool fa_visible(const nsp_attn_mask_params& p, int klen, int i, int j) {
   bool ok = j < klen;
   if (p.causal) ok = ok && (j <= i + p.lookahead);
@@ -516,26 +528,31 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
   const __bf16* dobase = dO + h * DK;
   // per-tile staging registers: Q / dO tiles, one float4 of the position table, and (threads 0..63) the
   // statistics of query q0 + tid
-  struct Stat { float c0, mx, inv, dd; unsigned hash; };
+  // RAW loaded values only: every use of them (scaling, selects) happens in *_store at the END of the iteration, so the
+  // loads -- issued BEFORE the next tile's DMA -- are not waited for until then
+  struct Stat { float mx, inv, dd, farv; unsigned hash; int qi; };
+  // STRAIGHT-LINE loads (round 4, ISA audit): with the loads inside conditional expressions (`qi < T ? LSE[..] : 0`,
+  // `c < rp ? src[c] * sl2 : 0`) hipcc put every one of them into its own branch with an s_waitcnt vmcnt(0) behind it --
+  // up to eight SERIALISED global round trips at the top of every query-tile iteration of this kernel.  All addresses
+  // are clamped to valid ones and everything is requested back to back.
+  const bool has_far = QP && p.clamp > 0;
   auto stat_load = [&](int q0) {
     Stat s_;
-    s_.c0 = 0.f; s_.mx = 0.f; s_.inv = 0.f; s_.dd = 0.f; s_.hash = 0u;
+    s_.mx = 0.f; s_.inv = 0.f; s_.dd = 0.f; s_.farv = 0.f; s_.hash = 0u; s_.qi = q0 + (int)threadIdx.x;
     if (threadIdx.x < 64) {
-      const int qi = q0 + threadIdx.x;
-      const int qc = min(qi, T - 1);
+      const int qc = min(s_.qi, T - 1);
       const long long ri = ((long long)b * p.H + h) * T + qc;
-      s_.mx = LSE[ri];
-      s_.inv = qi < T ? LSE[nrow + ri] : 0.f;           // rows beyond T contribute nothing
-      s_.dd = Drow[ri];
-      const float far = (QP && p.clamp > 0) ? QP[((brow0 + qc) * p.H + h) * rp + p.clamp] * sl2 : 0.f;
-      s_.c0 = far - s_.mx;
-      s_.hash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
+      const float* farp = has_far ? QP + ((brow0 + qc) * p.H + h) * rp + p.clamp : LSE + ri;   // (any readable word)
+      s_.mx = LSE[ri]; s_.inv = LSE[nrow + ri]; s_.dd = Drow[ri]; s_.farv = *farp;
+      s_.hash = drop ? fa_rowhash(p, b, h, T, s_.qi) : 0u;
     }
     return s_;
   };
   auto stat_store = [&](int buf, const Stat& s_) {
     if (threadIdx.x < 64) {
-      st_c0[buf][threadIdx.x] = s_.c0; st_max[buf][threadIdx.x] = s_.mx; st_inv[buf][threadIdx.x] = s_.inv;
+      st_c0[buf][threadIdx.x] = (has_far ? s_.farv * sl2 : 0.f) - s_.mx;
+      st_max[buf][threadIdx.x] = s_.mx;
+      st_inv[buf][threadIdx.x] = s_.qi < T ? s_.inv : 0.f;      // rows beyond T contribute nothing
       st_d[buf][threadIdx.x] = s_.dd; st_hash[buf][threadIdx.x] = s_.hash;
     }
   };
@@ -545,15 +562,19 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
       const int ql = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
       const int q = min(q0 + ql, T - 1);
       const float* src = QP + ((brow0 + q) * p.H + h) * rp;
-      v.x = c4 + 0 < rp ? src[c4 + 0] * sl2 : 0.f;
-      v.y = c4 + 1 < rp ? src[c4 + 1] * sl2 : 0.f;
-      v.z = c4 + 2 < rp ? src[c4 + 2] * sl2 : 0.f;
-      v.w = c4 + 3 < rp ? src[c4 + 3] * sl2 : 0.f;
+      v.x = src[min(c4 + 0, rp - 1)]; v.y = src[min(c4 + 1, rp - 1)];
+      v.z = src[min(c4 + 2, rp - 1)]; v.w = src[min(c4 + 3, rp - 1)];
     }
     return v;
   };
-  auto qp_store = [&](int buf, const float4& v) {
-    *reinterpret_cast<float4*>(&QPs[buf][threadIdx.x >> 2][(threadIdx.x & 3) * 4]) = v;
+  auto qp_store = [&](int buf, const float4& a) {
+    const int c4 = (threadIdx.x & 3) * 4;
+    float4 v;
+    v.x = c4 + 0 < rp ? a.x * sl2 : 0.f;
+    v.y = c4 + 1 < rp ? a.y * sl2 : 0.f;
+    v.z = c4 + 2 < rp ? a.z * sl2 : 0.f;
+    v.w = c4 + 3 < rp ? a.w * sl2 : 0.f;
+    *reinterpret_cast<float4*>(&QPs[buf][threadIdx.x >> 2][c4]) = v;
   };
   float4 qpr = qp_load(0);
   Stat str = stat_load(0);
@@ -598,17 +619,23 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
     bf16x8 Pt[2], dSt[2];     // X operands: rows = keys, k = [block 2s: queries 4g..4g+3 | block 2s+1: same]
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
-      const float4 c0v = *reinterpret_cast<const float4*>(&st_c0[cur][qb * 16 + 4 * g]);
-      const float4 mxv = *reinterpret_cast<const float4*>(&st_max[cur][qb * 16 + 4 * g]);
-      const float4 inv = *reinterpret_cast<const float4*>(&st_inv[cur][qb * 16 + 4 * g]);
-      const float4 ddv = *reinterpret_cast<const float4*>(&st_d[cur][qb * 16 + 4 * g]);
-      const float c0a[4] = {c0v.x, c0v.y, c0v.z, c0v.w}, mxa[4] = {mxv.x, mxv.y, mxv.z, mxv.w};
-      const float ina[4] = {inv.x, inv.y, inv.z, inv.w}, dda[4] = {ddv.x, ddv.y, ddv.z, ddv.w};
-      unsigned ha[4] = {0u, 0u, 0u, 0u};
-      if (drop) {
-        const uint4 hv = *reinterpret_cast<const uint4*>(&st_hash[cur][qb * 16 + 4 * g]);
-        ha[0] = hv.x; ha[1] = hv.y; ha[2] = hv.z; ha[3] = hv.w;
-      }
+      // The statistics rows are read through INLINE ASM: in front of a compiler-visible read of these arrays hipcc
+      // put an s_waitcnt vmcnt(0) (ISA audit, round 4) -- i.e. the next query tile's Q / dO DMA, issued a few dozen
+      // instructions earlier, was drained right here, before the soft-max arithmetic it is supposed to hide behind.
+      // (The compiler does not count asm loads: the destinations are named in the wait statement, CDNA guide 5.7.)
+      f32x4 c0v, mxv, inv, ddv;
+      u32x4 hv = {0u, 0u, 0u, 0u};
+      fa_lds_read4(c0v, &st_c0[cur][qb * 16 + 4 * g]);
+      fa_lds_read4(mxv, &st_max[cur][qb * 16 + 4 * g]);
+      fa_lds_read4(inv, &st_inv[cur][qb * 16 + 4 * g]);
+      fa_lds_read4(ddv, &st_d[cur][qb * 16 + 4 * g]);
+      if (drop) fa_lds_read4(hv, &st_hash[cur][qb * 16 + 4 * g]);
+#ifndef NSP_HOST_EMULATION
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0v), "+v"(mxv), "+v"(inv), "+v"(ddv), "+v"(hv));
+#endif
+      const float c0a[4] = {c0v[0], c0v[1], c0v[2], c0v[3]}, mxa[4] = {mxv[0], mxv[1], mxv[2], mxv[3]};
+      const float ina[4] = {inv[0], inv[1], inv[2], inv[3]}, dda[4] = {ddv[0], ddv[1], ddv[2], ddv[3]};
+      const unsigned ha[4] = {hv[0], hv[1], hv[2], hv[3]};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ql = qb * 16 + 4 * g + e;
