@@ -124,6 +124,10 @@ def cpu_baseline(args, margs, cores):
         timed.append(run(batch))
     dt = sorted(timed)[len(timed) // 2]
     return {'value': round(frames / dt, 2), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            # the reference itself cannot travel to the GPU box; calibration of the port against it in the build container
+            'port_over_reference': 1.16,
+            'port_over_reference_source': 'profiles/r03_cpu_reference_vs_port.txt (tools/ref_vs_port_cpu.py: reference 501 vs port 580 '
+                                          'frames/s on the same 8 cores, same step) -- the reference is ~14 % SLOWER than this value',
             'sample': '%d utterance(s) of the bench workload (%d frames): full training step (fwd + CTC/RNN-T loss + '
                       'bwd + clip + Adam) of the same Conformer-%s model through oracle/model_ref.py in fp32 on %d '
                       'torch threads; 1 warm-up + %d timed steps, median %.2f s (all: %s)'
@@ -163,17 +167,20 @@ def main():
         sys.exit(_spawn_ranks(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if a.gpus != world:
-        print('bench.py: --gpus %d but the launcher started %d rank(s); using the launcher\'s world size'
-              % (a.gpus, world), file=sys.stderr)
+        sys.exit('bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to print a line whose '
+                 'n_gpus would not be what ran' % (a.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1
     assert torch.cuda.is_available(), 'bench.py measures the HIP path; no GPU is visible'
     if a.same_device:
         local_rank = 0
-        # ranks sharing one device cannot guarantee co-residency of each other's grid-barrier kernels
-        # (two half-resident persistent grids wait on each other until the barrier times out)
-        os.environ['NSP_LSTM_PERSISTENT'] = '0'
+        # ranks sharing one device cannot guarantee co-residency of each other's grid-barrier kernels (two half-resident
+        # persistent grids wait on each other until the barrier times out): rank 0 keeps the persistent LSTM -- so that
+        # the grid-barrier kernel runs beside the other rank's kernels and under the communication hook -- the others
+        # take per-stage launches, which always terminate
+        if rank != 0:
+            os.environ['NSP_LSTM_PERSISTENT'] = '0'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if distributed:
@@ -183,6 +190,7 @@ def main():
             dist.init_process_group(backend='nccl', device_id=dev)
         else:
             dist.init_process_group(backend=a.dist_backend)
+        assert dist.get_world_size() == world == a.gpus, (dist.get_world_size(), world, a.gpus)
 
     from neural_sp_amd import ops
     from neural_sp_amd.configs import conformer_rnnt_args, synthetic_batch
@@ -403,11 +411,12 @@ def main():
         peak_tf = 2500.0 if a.mode == 'bf16' else 157.3
         roof = None
         if kev is not None and kev['launches'] > 0:
-            ach = kev['flops'] / (kev['ms'] * 1e-3) / 1e12
+            ach = kev.get('algo_flops', kev['flops']) / (kev['ms'] * 1e-3) / 1e12
             side = kev['side']
-            roof = {'kernel': 'bf16 MFMA GEMM class of libnsp_hip.so on the main stream: gemm_bf16_kk_glds_kernel<0|1|2> '
-                              '(activations x weights, data gradients; RNN-T joint logits / dlogits), gemm_bf16_rr_ring_kernel<2> / '
-                              'gemm_bf16_kernel<false,false> (weight gradients), gemm_bf16_kk_ring_kernel<NS,MI> (small grids); '
+            roof = {'kernel': 'bf16 MFMA GEMM class of libnsp_hip.so on the main stream: gemm_bf16_kk8p_kernel<S, ., RR> (phase-'
+                              'interleaved 256 x 256 tiles: long reductions, stacked QKV, every weight gradient), gemm_bf16_kk_glds_kernel<0|1|2> '
+                              '(K = 512 activations x weights, data gradients; RNN-T joint logits / dlogits), '
+                              'gemm_bf16_kernel<.,.> / gemm_bf16_kk_ring_kernel<NS,MI> (small grids); '
                               '%d launches = every main-stream GEMM of every %d-th timed step, rank 0.  The %d side-stream '
                               'launches of those steps (CTC head, prediction-network projections: %.1f %% of the GEMM flops) run '
                               'beside main-stream kernels, so their event pairs (%.2f ms) measure co-scheduling and are kept out'
@@ -415,10 +424,36 @@ def main():
                                  100.0 * side['flops'] / max(1.0, side['flops'] + kev['flops']), side['ms']),
                     'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                     'frac': round(ach / peak_tf, 4), 'traffic': None, 'traffic_measured_in_run': False,
-                    'flop_per_launch': round(kev['flops'] / kev['launches'], 1),
+                    # `achieved` / `frac` count ALGORITHMIC flops: 2 M N K of every GEMM the path defines; the
+                    # recomputed logits of the RNN-T joint backward count zero and the vocabulary padding (1000 -> 1024
+                    # columns) is not work.  What the kernels execute is kept beside it.
+                    'flops_basis': 'algorithmic',
+                    'executed': {'achieved': round(kev['flops'] / (kev['ms'] * 1e-3) / 1e12, 2),
+                                 'frac': round(kev['flops'] / (kev['ms'] * 1e-3) / 1e12 / peak_tf, 4),
+                                 'flop_per_launch': round(kev['flops'] / kev['launches'], 1)},
+                    'flop_per_launch': round(kev.get('algo_flops', kev['flops']) / kev['launches'], 1),
                     'avg_launch_us': round(kev['ms'] * 1e3 / kev['launches'], 2),
                     'achieved_all_streams': round((kev['flops'] + side['flops']) / ((kev['ms'] + side['ms']) * 1e-3) / 1e12, 2),
                     'gemm_share_of_step': round(kev['ms'] / (dt * 1e3 * len(range(0, a.steps, a.event_stride)) / a.steps), 3)}
+            # the other kernel classes of the step, timed the same way (HIP events around every launch of the sampled
+            # steps): MFMA classes against the dense bf16 peak, streaming classes against the node's measured copy rate
+            steps_sampled = max(1, len(range(0, a.steps, a.event_stride)))
+            cls = []
+            for cname, c in sorted(kev.get('classes', {}).items(), key=lambda kv: -kv[1]['ms']):
+                if c['launches'] == 0 or c['ms'] <= 0:
+                    continue
+                ent = {'class': cname, 'launches_per_step': round(c['launches'] / steps_sampled, 1),
+                       'ms_per_step': round(c['ms'] / steps_sampled, 3)}
+                if c['unit'] == 'flop':
+                    tf = c['work'] / (c['ms'] * 1e-3) / 1e12
+                    ent.update(bound='mfma', achieved=round(tf, 1), unit='TFLOP/s', peak=peak_tf, frac=round(tf / peak_tf, 4))
+                else:
+                    tb = c['work'] / (c['ms'] * 1e-3) / 1e12
+                    ent.update(bound='hbm', achieved=round(tb, 2), unit='TB/s', peak=8.0, frac=round(tb / 8.0, 4))
+                if cname.endswith('@side'):
+                    ent['note'] = 'side stream: the event pairs include co-scheduling with main-stream kernels'
+                cls.append(ent)
+            roof['classes'] = cls
             # HBM bytes per GEMM launch cannot be counted from inside the process: it is the committed result of
             # the rocprofv3 PMC passes over this same command and workload (profiles/pmc_gemm_traffic.json:
             # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction, with the git revision and the
@@ -429,10 +464,14 @@ def main():
             if default_wl and tjd0:
                 tjd = tjd0
                 roof['traffic'] = round(tjd['hbm_bytes_per_launch'])
+                if tjd.get('algorithmic_bytes_per_launch'):
+                    roof['traffic_algorithmic'] = round(tjd['algorithmic_bytes_per_launch'])
+                    roof['traffic_over_algorithmic'] = round(tjd['hbm_bytes_per_launch'] / tjd['algorithmic_bytes_per_launch'], 3)
                 roof['traffic_source'] = 'profiles/pmc_gemm_traffic.json (rocprofv3 PMC passes at %s, bytes per launch; NOT measured in this run)' % tjd.get('revision', 'unknown revision')
         out = {
+            'encoder_mfu': None,     # (the north-star figure leads the line; filled below)
             'metric': 'speech-frames/sec/node (Conformer-L + CTC+RNN-T, 80-d fbank)',
-            'value': round(frames / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps,
+            'value': round(frames / dt, 1), 'unit': 'frames/s', 'n_gpus': world, 'ranks_seen': (dist.get_world_size() if distributed else 1), 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if a.mode == 'bf16' else 'f32',
             'data': 'synthetic',

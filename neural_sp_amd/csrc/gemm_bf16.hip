@@ -2275,9 +2275,20 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   {
     static int dbg = -1;       // NSP_GEMM_DEBUG=1: one line per launch on stderr (which shapes reach which kernel family)
     if (dbg < 0) { const char* e = getenv("NSP_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if (dbg) fprintf(stderr, "[nsp_gemm_bf16] M %d N %d K %d a_kc %d b_kc %d splitk %d batch %dx%d epi %d c16 %d pre %d dact %d res %d drop %g\n", p.M, p.N, p.K,
-                     (int)a_kc, (int)b_kc, p.splitk, p.batch1, p.batch2, p.epi_mode, (int)(p.c_dtype == NSP_DT_BF16), (int)(p.pre_out != nullptr),
-                     p.dact_src ? p.dact : 0, (int)(p.res != nullptr), (double)p.dropout_p);
+    if (dbg) {
+      // algorithmic HBM bytes of the launch: both operands once, every output image once, every side operand once
+      const long long nb = (long long)p.batch1 * p.batch2, mn = (long long)p.M * p.N;
+      const long long csz_ = p.c_dtype == NSP_DT_BF16 ? 2 : 4;
+      long long bytes = nb * (2ll * p.M * p.K + 2ll * p.N * p.K);
+      if (p.epi_mode == NSP_EPI_RNNT_LSE) bytes += (long long)p.M * (p.N / 64) * 8 + 8ll * p.M;
+      else bytes += nb * mn * csz_ * (p.c_ss ? p.splitk : 1);
+      if (p.pre_out) bytes += mn * (p.pre_dtype == NSP_DT_BF16 ? 2 : 4);
+      if (p.dact_src) bytes += mn * (p.dact_dtype == NSP_DT_BF16 ? 2 : 4);
+      if (p.res) bytes += mn * 4;
+      fprintf(stderr, "[nsp_gemm_bf16] M %d N %d K %d a_kc %d b_kc %d splitk %d batch %dx%d epi %d c16 %d pre %d dact %d res %d drop %g algbytes %lld\n", p.M, p.N, p.K,
+              (int)a_kc, (int)b_kc, p.splitk, p.batch1, p.batch2, p.epi_mode, (int)(p.c_dtype == NSP_DT_BF16), (int)(p.pre_out != nullptr),
+              p.dact_src ? p.dact : 0, (int)(p.res != nullptr), (double)p.dropout_p, bytes);
+    }
   }
   if (!a_kc && p.a_rs != 1) return NSP_EINVAL;
   if (!b_kc && p.b_ns != 1) return NSP_EINVAL;

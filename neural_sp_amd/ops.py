@@ -622,9 +622,11 @@ def layernorm_fwd_raw(x2d, gamma, beta, eps, act=0, want_pre=False, want16=False
     mean = torch.empty((rows,), device=x2d.device, dtype=torch.float32)
     rstd = torch.empty((rows,), device=x2d.device, dtype=torch.float32)
     y_pre = torch.empty_like(x2d) if (act != 0 and want_pre) else None
-    _check(_lib.lib().nsp_layernorm_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
-                                        (rows), (d), (eps),
-                                        (act), _p(y_pre), _p(y16), _stream()), 'nsp_layernorm_fwd')
+    nbytes = rows * d * (4 + (4 if want32 else 0) + (2 if want16 else 0) + (4 if y_pre is not None else 0))
+    with _kev_class('layernorm_fwd', nbytes, 'byte'):
+        _check(_lib.lib().nsp_layernorm_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
+                                            (rows), (d), (eps),
+                                            (act), _p(y_pre), _p(y16), _stream()), 'nsp_layernorm_fwd')
     return y, mean, rstd, y_pre, y16
 
 
@@ -632,11 +634,13 @@ def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0, dres=None):
     rows, d = x2d.shape
     dx = torch.empty_like(x2d)
     dgb = zeros_small((2, d), x2d.device)
-    _check(_lib.lib().nsp_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(y_pre), _p(dres),
-                                        _p(dx), (dgb.data_ptr()),
-                                        (dgb.data_ptr() + 4 * d),
-                                        (rows), (d), (act),
-                                        _stream()), 'nsp_layernorm_bwd')
+    nbytes = rows * d * (12 + (4 if y_pre is not None else 0) + (4 if dres is not None else 0))     # dy, x, dx (+ pre-activation, residual gradient)
+    with _kev_class('layernorm_bwd', nbytes, 'byte'):
+        _check(_lib.lib().nsp_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(y_pre), _p(dres),
+                                            _p(dx), (dgb.data_ptr()),
+                                            (dgb.data_ptr() + 4 * d),
+                                            (rows), (d), (act),
+                                            _stream()), 'nsp_layernorm_bwd')
     return dx, dgb[0], dgb[1]
 
 
@@ -1258,7 +1262,8 @@ class Conv3x3ReLUFn(torch.autograd.Function):
         x_in = x
         x = _c(x)
         w_cl = weight.permute(0, 2, 3, 1).contiguous()  # [Co,3,3,Ci]
-        y = _conv3x3_fwd(x, w_cl, bias, True, out16=_maps16())
+        with _kev_class('conv_frontend_fwd', x.numel() * x.element_size() + x.numel() // x.shape[-1] * w_cl.shape[0] * (2 if _maps16() else 4), 'byte'):
+            y = _conv3x3_fwd(x, w_cl, bias, True, out16=_maps16())
         if x.shape[-1] != 1 and y.dtype == torch.bfloat16 and x.dtype != torch.bfloat16:
             x = x.to(torch.bfloat16)
         ctx.save_for_backward(x, w_cl, y)
@@ -2064,12 +2069,15 @@ _KEV = {'on': False, 'events': [], 'flops': 0.0, 'side_events': [], 'side_flops'
 _gemm_raw_untimed = gemm_raw
 
 
-def _kev_record(e0, e1, flops):
+def _kev_record(e0, e1, flops, algo=None):
     # launches on a side stream (CTC head, prediction-network projections) are kept apart: they run
     # beside main-stream kernels, so their event pairs measure co-scheduling, not the kernel
+    # `algo`: the ALGORITHMIC flops of the launch where they differ from the executed 2 M N K (the
+    # recomputed logits of the RNN-T joint backward count zero, the vocabulary padding 1000 -> 1024 is not work)
     if torch.cuda.current_stream() == torch.cuda.default_stream():
         _KEV['events'].append((e0, e1))
         _KEV['flops'] += flops
+        _KEV['algo_flops'] = _KEV.get('algo_flops', 0.0) + (flops if algo is None else algo)
     else:
         _KEV['side_events'].append((e0, e1))
         _KEV['side_flops'] += flops
@@ -2091,7 +2099,9 @@ gemm_raw = _gemm_raw_timed
 
 
 def rnnt_joint_gemm_timed(fn, M, Vp, J, *args):
-    """Call nsp_rnnt_joint_gemm and, when bench.py's per-launch events are on, record it like any other GEMM."""
+    """Call nsp_rnnt_joint_gemm and, when bench.py's per-launch events are on, record it like any other GEMM.
+    args[0] = 1 (forward logits: algorithmic work 2 M V J) or 2 (backward: the logits are RECOMPUTED -- executed,
+    not algorithmic), args[5] = V."""
     if not _KEV['on']:
         return fn(*args)
     e0 = torch.cuda.Event(enable_timing=True)
@@ -2099,13 +2109,39 @@ def rnnt_joint_gemm_timed(fn, M, Vp, J, *args):
     e0.record()
     rc = fn(*args)
     e1.record()
-    _kev_record(e0, e1, 2.0 * M * Vp * J)
+    _kev_record(e0, e1, 2.0 * M * Vp * J, algo=(2.0 * M * args[5] * J if args[0] == 1 else 0.0))
     return rc
+
+
+import contextlib as _contextlib  # noqa: E402
+
+
+@_contextlib.contextmanager
+def _kev_class(name, work, unit):
+    """bench.py's `roofline.classes`: HIP events around one launch (group) of a NON-GEMM kernel class on sampled steps,
+    with its algorithmic work (`unit` = 'flop' or 'byte').  Side-stream launches are recorded under `<name>@side`:
+    their event pairs measure co-scheduling with main-stream kernels."""
+    if not _KEV['on']:
+        yield
+        return
+    if torch.cuda.current_stream() != torch.cuda.default_stream():
+        name = name + '@side'
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    try:
+        yield
+    finally:
+        e1.record()
+        c = _KEV.setdefault('classes', {}).setdefault(name, {'events': [], 'work': 0.0, 'unit': unit})
+        c['events'].append((e0, e1))
+        c['work'] += float(work)
 
 
 def kernel_events_start():
     _KEV['on'], _KEV['events'], _KEV['flops'] = True, [], 0.0
     _KEV['side_events'], _KEV['side_flops'] = [], 0.0
+    _KEV['algo_flops'], _KEV['classes'] = 0.0, {}
 
 
 def kernel_events_enable(on):
@@ -2121,9 +2157,11 @@ def kernel_events_stop():
     torch.cuda.synchronize()
     ms = sum(e0.elapsed_time(e1) for e0, e1 in _KEV['events'])
     sms = sum(e0.elapsed_time(e1) for e0, e1 in _KEV['side_events'])
-    out = {'launches': len(_KEV['events']), 'ms': ms, 'flops': _KEV['flops'],
-           'side': {'launches': len(_KEV['side_events']), 'ms': sms, 'flops': _KEV['side_flops']}}
-    _KEV['events'], _KEV['side_events'] = [], []
+    out = {'launches': len(_KEV['events']), 'ms': ms, 'flops': _KEV['flops'], 'algo_flops': _KEV.get('algo_flops', 0.0),
+           'side': {'launches': len(_KEV['side_events']), 'ms': sms, 'flops': _KEV['side_flops']},
+           'classes': {n: {'launches': len(c['events']), 'ms': sum(a.elapsed_time(b) for a, b in c['events']),
+                           'work': c['work'], 'unit': c['unit']} for n, c in _KEV.get('classes', {}).items()}}
+    _KEV['events'], _KEV['side_events'], _KEV['classes'] = [], [], {}
     return out
 
 
@@ -2331,6 +2369,13 @@ def _lstm_xchg(P, cols, dev):
 
 
 def _lstm_stack_launch(which, P, dev):
+    # (roofline.classes: recurrent + inter-layer products of the stack, 2 flops per MAC; backward = data + weight-side products)
+    work = 2.0 * P.B * P.L * 4 * P.H * P.H * (2 * P.nl - 1) * (1 if which == 'fwd' else 2)
+    with _kev_class('lstm_' + which, work, 'flop'):
+        return _lstm_stack_launch_impl(which, P, dev)
+
+
+def _lstm_stack_launch_impl(which, P, dev):
     """Persistent single-launch recurrence when the shape qualifies (H % 256 == 0, H <= 1024;
     NSP_LSTM_PERSISTENT=0 disables) AND the device can hold the whole grid (the C side checks
     occupancy x CU count and answers NSP_EUNSUPPORTED otherwise), else one launch per wavefront
@@ -2898,8 +2943,9 @@ def flash_attn_fwd_raw(qkv16, d, QP, mp, want_o32=True):
     O = torch.empty((M, d), device=qkv16.device, dtype=torch.bfloat16)
     O32 = torch.empty((M, d), device=qkv16.device, dtype=torch.float32) if want_o32 else None
     LSE = torch.empty((2, mp.B, mp.H, mp.Tq), device=qkv16.device, dtype=torch.float32)  # max, 1/sum
-    _check(_lib.lib().nsp_flash_attn_fwd(_p(qkv16), d, _p(QP), _p(O), _p(O32), _p(LSE), ctypes.byref(mp), _stream()),
-           'nsp_flash_attn_fwd')
+    with _kev_class('flash_fwd', 4.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop'):
+        _check(_lib.lib().nsp_flash_attn_fwd(_p(qkv16), d, _p(QP), _p(O), _p(O32), _p(LSE), ctypes.byref(mp), _stream()),
+               'nsp_flash_attn_fwd')
     return O, O32, LSE
 
 
@@ -2910,6 +2956,7 @@ def flash_attn_bwd_raw(qkv16, d, QP, dO16, O32, LSE, mp, dqkv16):
     dq32 = torch.empty((M, d), device=dev, dtype=torch.float32)
     dQP = torch.empty_like(QP) if QP is not None else None
     D = torch.empty((mp.B, mp.H, mp.Tq), device=dev, dtype=torch.float32)
-    _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O32), _p(LSE), _p(D), _p(dqkv16),
-                                         _p(dq32), _p(dQP), ctypes.byref(mp), _stream()), 'nsp_flash_attn_bwd')
+    with _kev_class('flash_bwd', 10.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop'):
+        _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O32), _p(LSE), _p(D), _p(dqkv16),
+                                             _p(dq32), _p(dQP), ctypes.byref(mp), _stream()), 'nsp_flash_attn_bwd')
     return dq32, dQP

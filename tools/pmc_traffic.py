@@ -53,7 +53,16 @@ if __name__ == '__main__':
         n = sum(r[2] for r in g)
         rd = sum(r[3] * r[2] for r in g) / n
         wr = sum(r[4] * r[2] for r in g) / n
-        json.dump({'kernel_class': 'bf16 GEMM class (all gemm_bf16_* kernels of libnsp_hip.so, incl. the RNN-T joint GEMMs)',
+        alg = None
+        if len(sys.argv) > 6:
+            # NSP_GEMM_DEBUG=1 dump of the SAME command: one line per bf16 GEMM launch with its algorithmic HBM bytes
+            vals = [int(l.rsplit('algbytes', 1)[1]) for l in open(sys.argv[6]) if 'algbytes' in l]
+            alg = {'launches': len(vals), 'bytes_per_launch': sum(vals) / max(1, len(vals))}
+        json.dump({'algorithmic_bytes_per_launch': alg['bytes_per_launch'] if alg else None,
+                   'algorithmic_launches': alg['launches'] if alg else None,
+                   'algorithmic_definition': 'both operands once + every output image (split-K slabs included) + every side operand once, '
+                                             'summed over all bf16 GEMM launches of the traced steps (NSP_GEMM_DEBUG=1 pass of the same command) / launches',
+                   'kernel_class': 'bf16 GEMM class (all gemm_bf16_* kernels of libnsp_hip.so, incl. the RNN-T joint GEMMs)',
                    'workload': 'bench.py default (Conformer-L, per-GPU batch %d, bf16), 2 steps in the trace' % BATCH,
                    'per_gpu_batch': BATCH,
                    'launches': n, 'hbm_bytes_per_launch': rd + wr, 'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
