@@ -123,6 +123,10 @@ int nsp_wgrad_splitk(long long N, long long K, long long rows);
 int nsp_shadow_refresh(const long long* table, int n_entries, int total_tiles, void* stream);
 /* out[i] = sum_s part[s*n + i] (i < n): the deterministic reduction of split-K slabs */
 int nsp_splitk_reduce(const float* part, float* out, int splits, long long n, void* stream);
+/* TEST HOOK (tests/test_kernels_conv_loss_gpu.py): n_wg workgroups of 1024 threads that do nothing but hold their CU for
+ * `cycles` shader cycles -- what a resident collective (an RCCL channel set) or any long kernel of another stream does to
+ * the grid-barrier LSTM: it has to become resident beside them, later but correctly. */
+int nsp_debug_occupy(int n_wg, long long cycles, void* stream);
 
 int nsp_gemm(const nsp_gemm_params* p, void* stream);
 /* same call with the struct fields as positional arguments (cheaper to marshal from ctypes) */

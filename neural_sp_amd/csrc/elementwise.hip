@@ -561,3 +561,20 @@ extern "C" int nsp_shadow_refresh(const long long* table, int n_entries, int tot
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
+
+
+// ---- test hook: workgroups that only occupy compute units (see include/nsp_hip.h)
+namespace {
+__global__ __launch_bounds__(1024) void occupy_kernel(long long cycles) {
+  __shared__ unsigned char hold[65536];      // + 64 KB of LDS per workgroup: at most two of them share a CU
+  const long long t0 = (long long)__builtin_readcyclecounter();
+  while ((long long)__builtin_readcyclecounter() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+  if (cycles < 0) hold[threadIdx.x] = 1;     // (keeps the array)
+}
+}  // namespace
+extern "C" int nsp_debug_occupy(int n_wg, long long cycles, void* stream) {
+  if (n_wg <= 0) return NSP_OK;
+  hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(1024), 0, (hipStream_t)stream, cycles);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}

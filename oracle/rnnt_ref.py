@@ -15,7 +15,7 @@ asserts only shape and loss >= 0.  This file restates the published algorithm
 with the call-site semantics: blank = 0, labels padded with blank
 (rnn_transducer.py:233), per-utterance -log P reduced by the mean over the batch.
 It is pinned by (a) exhaustive path enumeration on tiny lattices and (b) autograd
-vs finite differences (tests/test_oracle_rnnt.py).
+vs finite differences (tests/test_oracle_cpu.py (test_rnnt_*)).
 """
 import itertools
 
