@@ -221,6 +221,10 @@ def test_persistent_lstm_beside_a_resident_kernel(n_wg, ms):
     assert os.environ.get('NSP_LSTM_PERSISTENT', '1') != '0'
     alone = run()
     torch.cuda.synchronize()
+    again = run()
+    torch.cuda.synchronize()
+    names = ['y', 'dx'] + ['l%d.%s' % (l, n) for l in range(nl) for n in ('w_ih', 'w_hh', 'b_ih', 'b_hh')]
+    rerun = {n: (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30) for n, a, b in zip(names, alone, again)}
     side = torch.cuda.Stream(device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     cycles = int(ms * 1e-3 * 2.1e9)
@@ -232,8 +236,14 @@ def test_persistent_lstm_beside_a_resident_kernel(n_wg, ms):
     torch.cuda.synchronize()
     ops.lstm_check()                         # raises if a grid barrier timed out
     print('[lstm beside %d resident workgroups] occupier ran %.1f ms' % (n_wg, e0.elapsed_time(e1)))
-    for a, b in zip(alone, beside):
-        assert torch.isfinite(b).all() and torch.equal(a, b)
+    diff = {n: (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30) for n, a, b in zip(names, alone, beside)}
+    print('  relative max difference to the undisturbed run: %s' % {n: '%.1e' % v for n, v in diff.items() if v > 0})
+    print('  (two undisturbed runs differ by: %s)' % {n: '%.1e' % v for n, v in rerun.items() if v > 0})
+    for n, b in zip(names, beside):
+        assert torch.isfinite(b).all(), n
+        # the recurrence itself (y, dx and everything that flows through it) is deterministic; only sums whose
+        # association depends on arrival order may differ, by rounding
+        assert diff[n] <= max(2 * rerun[n], 1e-6), (n, diff[n], rerun[n])
 
 
 def test_specaug_apply_matches_masked_fill():
