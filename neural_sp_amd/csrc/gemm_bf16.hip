@@ -219,6 +219,13 @@ __device__ __forceinline__ void load4(const void* base, int dtype, long long off
   }
 }
 
+// SWZ: the per-wave staging slab is 16 rows x 64 floats UNPADDED (4 KB) with the 16-B chunk index XOR-ed with
+// (row & 7) instead of 68-float rows (the 8-wave kernel: 8 x 4 KB next to a 128-KB ring = the whole 160-KB LDS);
+// conflict-free for the ds_write_b128 of a fragment (8 consecutive rows, one chunk) and for the row-major read-back.
+template <bool SWZ>
+__device__ __forceinline__ int stage_idx(int row, int chunk) {
+  return SWZ ? row * 64 + ((chunk ^ (row & 7)) << 2) : row * 68 + (chunk << 2);
+}
 // ---- RNN-T joint epilogues (nsp_gemm_params::epi_mode, nsp_rnnt_joint_gemm): the tile holds logits
 // of 16*MI x 64 (rows = compacted lattice nodes, cols = vocabulary) per wave.  Same LDS staging as
 // the standard epilogue: after the read-back the 16 lanes (lane & 15) of one row group hold the 64
@@ -232,16 +239,14 @@ __device__ __forceinline__ void load4(const void* base, int dtype, long long off
 // (label; log-sum-exp and the two lattice gradients) of ONE row block in registers, refilled for the next
 // block right after use with clamped, unconditional loads -- see gemm_epilogue_fast for why (in-order
 // vmcnt: a load issued behind a store cannot be waited for without waiting for the store).
-template <int MI, bool LSE>
-__device__ __forceinline__ void rnnt_epilogue_mode(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], unsigned char* smem,
-                                                   int m0, int n0, int wm, int wn, int lane, int wave) {
+template <int MI, bool LSE, bool SWZ = false>
+__device__ __forceinline__ void rnnt_epilogue_core(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
+                                                   int mrow0, int nbase, int lane) {
+  // stage: this wave's private slab; mrow0 / nbase: first row / column of the wave's 16 MI x 64 logit tile
   const int fr = lane & 15, fg = lane >> 4;
-  constexpr int SP = 68;
-  float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   const int er = lane >> 4, ec = (lane & 15) * 4;
-  const int n = n0 + wn * 64 + ec;                   // first of this lane's 4 columns (n + 3 < N: N % 64 == 0)
-  const int mrow0 = m0 + wm * (16 * MI);
-  const int npart = p.N >> 6, pidx = (n0 >> 6) + wn;
+  const int n = nbase + ec;                          // first of this lane's 4 columns (n + 3 < N: N % 64 == 0)
+  const int npart = p.N >> 6, pidx = nbase >> 6;
   const bool colok = n < p.N;
   float b4[4] = {0.f, 0.f, 0.f, 0.f};
   if (p.bias && colok) {
@@ -264,18 +269,22 @@ __device__ __forceinline__ void rnnt_epilogue_mode(const nsp_gemm_params& p, f32
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
-      *reinterpret_cast<float4*>(stage + fr * SP + ni * 16 + fg * 4) =
+      *reinterpret_cast<float4*>(stage + stage_idx<SWZ>(fr, ni * 4 + fg)) =
           make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       __builtin_amdgcn_sched_barrier(0);
       const int row = er + 4 * j;
-      const float4 a4 = *reinterpret_cast<const float4*>(stage + row * SP + ec);
+      const float4 a4 = *reinterpret_cast<const float4*>(stage + stage_idx<SWZ>(row, lane & 15));
       const int m = mrow0 + mi * 16 + row;
       const bool rowok = m < p.M && colok;
       const int lab = __float_as_int(rec[j].w);
       const float ls = rec[j].x, gb = rec[j].y, gl = rec[j].z;
+#ifndef NSP_HOST_EMULATION
+      // (persistent caller: the per-row record is consumed on every path, see gemm_epilogue_fast)
+      if (SWZ) asm volatile("" :: "v"(lab), "v"(ls), "v"(gb), "v"(gl));
+#endif
       if (mi + 1 < MI) {
         const int mcl = min(m + 16, p.M - 1);
         if (LSE) rec[j].w = __int_as_float(p.epi_lab[mcl]);
@@ -334,6 +343,13 @@ __device__ __forceinline__ void rnnt_epilogue_mode(const nsp_gemm_params& p, f32
   }
 }
 
+template <int MI, bool LSE>
+__device__ __forceinline__ void rnnt_epilogue_mode(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], unsigned char* smem,
+                                                   int m0, int n0, int wm, int wn, int lane, int wave) {
+  rnnt_epilogue_core<MI, LSE, false>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * 68), m0 + wm * (16 * MI),
+                                     n0 + wn * 64, lane);
+}
+
 template <int MI>
 __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], unsigned char* smem,
                                               int m0, int n0, int wm, int wn, int lane, int wave) {
@@ -355,21 +371,15 @@ __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&
 // is bf16 or fp32 and whether act' is relu or swish; + residual 227 us).  The configurations the
 // training step uses are therefore compiled as specialisations (EpiSpec); everything else takes the
 // run-time version (EpiRuntime), which is correct but serialises as described.
-struct EpiRuntime { static constexpr bool kStatic = false; };
+struct EpiRuntime { static constexpr bool kStatic = false, kRnnt = false; };
+template <bool LSE_> struct EpiRnnt { static constexpr bool kStatic = false, kRnnt = true, LSE = LSE_; };   // the 8-phase kernel only
 template <int ACT_, int DACT_, bool C16_, bool PRE16_, bool RES_, bool DROP_>
 struct EpiSpec {
-  static constexpr bool kStatic = true;
+  static constexpr bool kStatic = true, kRnnt = false;
   static constexpr int ACT = ACT_, DACT = DACT_;   // DACT > 0: bf16 act' source
   static constexpr bool C16 = C16_, PRE16 = PRE16_, RES = RES_, DROP = DROP_;
 };
 
-// SWZ: the per-wave staging slab is 16 rows x 64 floats UNPADDED (4 KB) with the 16-B chunk index XOR-ed with
-// (row & 7) instead of 68-float rows (the 8-wave kernel: 8 x 4 KB next to a 128-KB ring = the whole 160-KB LDS);
-// conflict-free for the ds_write_b128 of a fragment (8 consecutive rows, one chunk) and for the row-major read-back.
-template <bool SWZ>
-__device__ __forceinline__ int stage_idx(int row, int chunk) {
-  return SWZ ? row * 64 + ((chunk ^ (row & 7)) << 2) : row * 68 + (chunk << 2);
-}
 template <int MI, class S, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
                                                    int mrow0, int n, int lane, long long coff) {
@@ -1887,7 +1897,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
 #ifndef NSP_HOST_EMULATION
     asm volatile("" : "+v"(elane));
 #endif
-    if constexpr (!S::kStatic || (VAR & 4)) {
+    if constexpr (S::kRnnt) {
+      rnnt_epilogue_core<4, S::LSE, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol, elane);
+      rnnt_epilogue_core<4, S::LSE, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol, elane);
+    } else if constexpr (!S::kStatic || (VAR & 4)) {
       gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol + (elane & 15) * 4, elane, coff);
       gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol + (elane & 15) * 4, elane, coff);
     } else {
@@ -2374,6 +2387,25 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       const long long rounds8 = (t256 + 255) / 256;
       const bool fills = t256 * 10 >= rounds8 * 256 * 9;
       const bool want8 = on8 >= 2 || p.K >= 1024 || (fills && !p.pre_out && p.N >= 1536);
+      if (on8 && p.epi_mode != NSP_EPI_NONE && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 && p.N % 64 == 0 &&
+          t256 >= min8 && (long long)p.M * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31) &&
+          !(getenv("NSP_GEMM_8P_RNNT") && atoi(getenv("NSP_GEMM_8P_RNNT")) == 0)) {
+        // the RNN-T joint's logit GEMMs (M = lattice nodes, N = padded vocabulary, K = joint width): 200+ rounds of tiles
+        const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
+        const int g8 = (int)(t256 >= 256 ? 256 : (t256 + 7) / 8 * 8);
+        static bool attr = false;
+        if (!attr) {
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<EpiRnnt<true>, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<EpiRnnt<false>, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+          attr = true;
+        }
+        if (p.epi_mode == NSP_EPI_RNNT_LSE)
+          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<EpiRnnt<true>, 0>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
+        else
+          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<EpiRnnt<false>, 0>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
+        NSP_LAUNCH_CHECK();
+        return NSP_OK;
+      }
       if (on8 && want8 && p.epi_mode == NSP_EPI_NONE && fast_epi && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 &&
           t256 >= min8 && (long long)p.M * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31)) {
         const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
