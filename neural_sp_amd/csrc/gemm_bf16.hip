@@ -1651,9 +1651,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     coff = p.c_ss ? (long long)tc.split * p.c_ss : 0;
   }
   const int xq = blockIdx.x >> 3, xx = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-  auto tile_of = [&](int step) {               // KK: gridDim.x % 8 == 0 (launcher)
-    if (RR) return step == 0 ? rr_tile : ntiles;
-    return per_xcd * (8 * step + xx) + xq;
+  // Tile order (KK).  Narrow outputs (< 16 tile columns: every GEMM of the training step): the 32 workgroups of an XCD
+  // take 32 CONSECUTIVE tiles of the n-fastest list -- a few A panels x all their column tiles, so every A panel crosses
+  // the fabric once and the whole weight matrix stays in the XCD's L2.  Wide outputs (N >= 4096: the 8192^3 square the
+  // roofline quotes beside the library GEMM): 32 consecutive tiles are ONE A panel against 32 different B panels, and
+  // every B panel is fetched again for every row of tiles -- measured 5.2 TB/s of fabric traffic, the kernel's limit
+  // there.  The XCD then takes a 4 x 8 SUPER-TILE (4 A panels + 8 B panels for 32 tiles: 12 panel loads instead of 33).
+  const bool wide = !RR && tiles_n >= 16 && per_xcd == 32;
+  const int sn_cnt = (tiles_n + 7) >> 3, s_cnt = ((tiles_m + 3) >> 2) * sn_cnt;
+  auto tile_of = [&](int step) {               // KK: gridDim.x % 8 == 0 (launcher); returns ntiles when the list is exhausted
+    if constexpr (RR) return step == 0 ? rr_tile : ntiles;
+    if (!wide) return min(per_xcd * (8 * step + xx) + xq, ntiles);
+    const int sidx = 8 * step + xx;
+    if (sidx >= s_cnt) return ntiles;
+    const int sm = sidx / sn_cnt, sn = sidx - sm * sn_cnt;
+    const int tm_ = sm * 4 + (xq >> 3), tn_ = sn * 8 + (xq & 7);
+    return (tm_ < tiles_m && tn_ < tiles_n) ? tm_ * tiles_n + tn_ : -1;     // -1: a hole of a ragged super-tile, skipped
+  };
+  auto next_step = [&](int from) {             // first step >= from whose tile exists (or the end of the list)
+    int st_ = from;
+    if constexpr (!RR) {
+      while (tile_of(st_) < 0) ++st_;
+    }
+    return st_;
   };
   const char* A = reinterpret_cast<const char*>(p.A);
   const char* B = reinterpret_cast<const char*>(p.B);
@@ -1748,8 +1768,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   const int rr_c = ((fr >> 1) & 1) ^ rr8_swz(rr_k);           // chunk index of columns cbase = 0
   float* stage = reinterpret_cast<float*>(ring + STAGING) + wave * 1024;
 
-  int step = 0;
-  int tile = tile_of(0);
+  int step = next_step(0);
+  int tile = tile_of(step);
   if (tile >= ntiles) return;
   if ((VAR & 2) && wr == 1) __builtin_amdgcn_s_setprio(1);
   set_src(tile);
@@ -1764,7 +1784,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   bool first = true;
   while (true) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int next_tile = tile_of(step + 1);
+    const int step_n = next_step(step + 1);
+    const int next_tile = tile_of(step_n);
     const bool has_next = next_tile < ntiles;
     f32x4 acc[8][4];
 #pragma unroll
@@ -1908,7 +1929,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
       gemm_epilogue_direct<S, (VAR & 8) ? 0 : 2>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), mrow + 64, ncol, elane);
     }
     if (!has_next) break;
-    ++step;
+    step = step_n;
     tile = next_tile;
     first = false;
   }
@@ -2389,8 +2410,11 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       const bool want8 = on8 >= 2 || p.K >= 1024 || (fills && !p.pre_out && p.N >= 1536);
       if (on8 && p.epi_mode != NSP_EPI_NONE && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 && p.N % 64 == 0 &&
           t256 >= min8 && (long long)p.M * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31) &&
-          !(getenv("NSP_GEMM_8P_RNNT") && atoi(getenv("NSP_GEMM_8P_RNNT")) == 0)) {
-        // the RNN-T joint's logit GEMMs (M = lattice nodes, N = padded vocabulary, K = joint width): 200+ rounds of tiles
+          getenv("NSP_GEMM_8P_RNNT") && atoi(getenv("NSP_GEMM_8P_RNNT")) != 0) {
+        // the RNN-T joint's logit GEMMs (M = lattice nodes, N = padded vocabulary, K = joint width): 200+ rounds of tiles.
+        // OPT-IN (NSP_GEMM_8P_RNNT=1): measured inside the step (4 alternating runs, profiles/r04q_rnnt_8p_ab.log) the
+        // forward logit GEMM is 0.95 ms SLOWER here than on the 128 x 128 kernel (loss forward 8.4 -> 9.4 ms) and the
+        // backward one equal -- K = 512 and an epilogue of ~12 VALU per logit: one workgroup per CU cannot hide it.
         const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
         const int g8 = (int)(t256 >= 256 ? 256 : (t256 + 7) / 8 * 8);
         static bool attr = false;

@@ -314,7 +314,8 @@ def test_weight_gradient_gemm_on_the_phase_interleaved_kernel(rows, N, K, monkey
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('M,N,K,grid', [(1000, 384, 128, 0), (2051, 1000, 512, 8), (4096, 512, 2048, 0), (300, 4352, 256, 8), (300, 2304, 128, 8), (70000, 512, 384, 0)])
+@pytest.mark.parametrize('M,N,K,grid', [(1000, 384, 128, 0), (2051, 1000, 512, 8), (4096, 512, 2048, 0), (300, 4352, 256, 8), (300, 2304, 128, 8), (70000, 512, 384, 0),
+                                        (4300, 4600, 256, 0)])     # 17 x 18 tiles: the 4 x 8 super-tile order of wide outputs, ragged super-tiles
 def test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch):
     """gemm_bf16_kk8p_kernel (256 x 256 tiles, 8 waves, load units six phases ahead with counted waits, persistent over
     tiles) forced onto small problems: every fused epilogue against torch, ragged M / N, one / two / sixteen

@@ -334,6 +334,7 @@ def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, monkeypatc
     # J % 128 == 0: the logit GEMMs (LSE / DLOGITS epilogues) take the phase-interleaved 256 x 256 kernel, here also on
     # grids far below its usual threshold (one to a few tiles per workgroup, ragged M and N edges)
     monkeypatch.setenv('NSP_GEMM_8P_MIN_TILES', '1')
+    monkeypatch.setenv('NSP_GEMM_8P_RNNT', '1')       # (opt-in: measured slower than the 128 x 128 kernel inside the step)
     torch.manual_seed(B * 1000 + T)
     e = (torch.randn(B, T, J, device=_dev()) * 0.7).requires_grad_()
     gq = (torch.randn(B, U + 1, J, device=_dev()) * 0.7).requires_grad_()
