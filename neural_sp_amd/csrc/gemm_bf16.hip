@@ -1688,6 +1688,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   // RR images: a load unit = two 8-KB sub-images [64 k][64 columns] (128-B rows; unit 2 / 3: quadrant pair 0-1 / 2-3 of
   // row half 0 and 1; unit 0 / 1: the B columns of waves wc = 0, 1 / 2, 3), piece pc = wave * 2 + i = 8 k-rows of
   // sub-image pc >> 3; the 16-B chunk index is XOR-ed with rr8_swz(k) on the source address and on the transposed read
+  const char* Atile = A;                     // (KK) first row of the A panel of the tile the unit stream is in
   auto set_src = [&](int tile) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     if (RR) {
@@ -1713,9 +1714,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
       for (int i = 0; i < 2; ++i) {
         const int r = (wave * 2 + i) * 8 + lrow;                       // 0..127 inside the unit
         const int arow = (r & 63) + ((r >> 6) << 7) + u * 64;          // quadrants 2u, 2u+1 of row half r >> 6
-        aoff[u][i] = (unsigned)min(tm * 256 + arow, p.M - 1) * (unsigned)(2 * p.a_rs) + sw;
+        aoff[u][i] = (unsigned)min(arow, p.M - 1 - tm * 256) * (unsigned)(2 * p.a_rs) + sw;    // relative to the tile's first row
         boff[u][i] = (unsigned)min(tn * 256 + u * 128 + r, p.N - 1) * (unsigned)(2 * p.b_ns) + sw;
       }
+    // the scalar base moves with the tile: the 32-bit lane offsets then span 256 rows, whatever M is (the RNN-T joint's
+    // data gradient reads a 3.6 M x 1024 bf16 operand: 7.4 GB)
+    Atile = A + (long long)tm * 256 * p.a_rs * 2;
   };
   // (RR) descriptors rebased to the split's first k-row, so that 32-bit offsets only have to span ONE split (the RNN-T
   // output layer reduces over 3.6 M rows x 2 KB); they end at the last k-row of the problem (clipped to 4 GB - 1: the
@@ -1752,7 +1756,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
                                          (lds_void*)(base + A_BYTES + (j * 128 + r0) * 128), 16, 0, 0);
       } else {
         const int arow0 = (r0 & 63) + ((r0 >> 6) << 7) + (j - 2) * 64;
-        __builtin_amdgcn_global_load_lds((glb_void*)(A + (aoff[j - 2][i] + ko)), (lds_void*)(base + arow0 * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(Atile + (aoff[j - 2][i] + ko)), (lds_void*)(base + arow0 * 128), 16, 0, 0);
       }
     }
   };
@@ -1934,6 +1938,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     first = false;
   }
 }
+
+// (Round 4, measured and REMOVED -- commit "GEMM: 256 x 128 x 32 tiles on four waves" in the history, numbers in
+// profiles/r04s_gemm_2w_256x128_two_workgroups_negative.log: the 8-phase kernel's wave tile (128 x 64) on 4 waves with a
+// three-stage ring of 24-KB k-tiles, 72 KB, so that TWO workgroups share a CU and one can run its epilogue while the
+// other multiplies.  Correct (race screen clean), but 0.85-1.0x the 128 x 128 kernel at every shape of the step, 0.74x
+// the 8-phase kernel at K = 2048: two stages ahead of a 0.45-us k-step is 0.9 us of prefetch against a ~2-us DMA round
+// trip -- with 2 x 48 KB in flight per CU at 1.5x the 8-phase kernel's bytes per flop it is latency-bound at ~0.8
+// PFLOP/s before any epilogue overlap can matter.)
 
 // ---- RC x RC (both operands contiguous along their OUTPUT index, reduction index strided: the
 // weight gradients dW = dY^T X) on the same LDS-DMA ring.  A stage holds the k-major images
@@ -2409,7 +2421,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       const bool fills = t256 * 10 >= rounds8 * 256 * 9;
       const bool want8 = on8 >= 2 || p.K >= 1024 || (fills && !p.pre_out && p.N >= 1536);
       if (on8 && p.epi_mode != NSP_EPI_NONE && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 && p.N % 64 == 0 &&
-          t256 >= min8 && (long long)p.M * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31) &&
+          t256 >= min8 && 256ll * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31) &&
           getenv("NSP_GEMM_8P_RNNT") && atoi(getenv("NSP_GEMM_8P_RNNT")) != 0) {
         // the RNN-T joint's logit GEMMs (M = lattice nodes, N = padded vocabulary, K = joint width): 200+ rounds of tiles.
         // OPT-IN (NSP_GEMM_8P_RNNT=1): measured inside the step (4 alternating runs, profiles/r04q_rnnt_8p_ab.log) the
@@ -2431,7 +2443,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         return NSP_OK;
       }
       if (on8 && want8 && p.epi_mode == NSP_EPI_NONE && fast_epi && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 &&
-          t256 >= min8 && (long long)p.M * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31)) {
+          t256 >= min8 && 256ll * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31)) {
         const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
         int g8 = (int)(t256 >= 256 ? 256 : (t256 + 7) / 8 * 8);
         const char* e8g = getenv("NSP_GEMM_8P_GRID");   // tests: fewer workgroups, i.e. several tiles per workgroup on small problems
