@@ -1939,7 +1939,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   }
 }
 
-// (Round 4, measured and REMOVED -- commit "GEMM: 256 x 128 x 32 tiles on four waves" in the history, numbers in
+// (Round 4, measured and REMOVED -- kernel text kept in profiles/r04s_gemm_kk2w_kernel_source.hip.txt, numbers in
 // profiles/r04s_gemm_2w_256x128_two_workgroups_negative.log: the 8-phase kernel's wave tile (128 x 64) on 4 waves with a
 // three-stage ring of 24-KB k-tiles, 72 KB, so that TWO workgroups share a CU and one can run its epilogue while the
 // other multiplies.  Correct (race screen clean), but 0.85-1.0x the 128 x 128 kernel at every shape of the step, 0.74x

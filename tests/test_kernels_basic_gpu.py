@@ -361,6 +361,32 @@ def test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_phase_interleaved_gemm_with_an_operand_beyond_4_gb(monkeypatch):
+    """The RNN-T joint's data gradient reads a [3.6 M, 1024] bf16 operand (7.4 GB): the 8-phase kernel addresses A with a
+    scalar base per tile + 32-bit lane offsets.  2.2 M x 1024 (4.5 GB) x a [512, 1024] weight with the tanh' epilogue,
+    checked on the row blocks at both ends and either side of the 4-GB line."""
+    from neural_sp_amd import ops
+    monkeypatch.setenv('NSP_GEMM_8P', '1')
+    dev = _dev()
+    M, N, K = 2200003, 512, 1024
+    torch.manual_seed(5)
+    a = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+    for r0 in range(0, M, 262144):
+        a[r0:r0 + 262144] = (torch.randn(min(262144, M - r0), K, device=dev) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    h = torch.tanh(torch.randn(M, N, device=dev)).bfloat16()
+    out = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)
+    with ops.compute_mode('bf16'):
+        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, out, N, dact_src=h, dact=6)
+    line = (1 << 32) // (2 * K)                      # first row whose byte offset needs a 33rd bit
+    for r0 in (0, line - 300, line + 5, M - 700):
+        rows = slice(r0, r0 + 700)
+        want = (a[rows].float() @ w.float().t()) * (1 - h[rows].float() ** 2)
+        assert _rel(out[rows].float(), want) < 1e-2, r0
+    assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('M,N,K', [(1000, 384, 128), (2051, 1000, 512), (4096, 512, 2048), (700, 2048, 64)])
 def test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch):
     """gemm_bf16_kkp_kernel (persistent tiles, the epilogue of tile i sliced into the k-loop of tile i+1)
