@@ -506,6 +506,16 @@ int nsp_rnnt_joint_gemm(int epi_mode, const void* h16, const void* w16, const fl
                         float* rec /* DLOGITS: workspace [M,4] fp32, 16-B aligned; LSE: NULL */, void* stream);
 int nsp_rnnt_lse_merge(const float* part, int npart, float* lse, float* raw_b_to_lpb, float* raw_l_to_lpl,
                        const int* lab, long long M, void* stream);
+/* The same two passes, NODE-STATIONARY (J = 128 / 256 / 512; anything else: NSP_EUNSUPPORTED -> use nsp_rnnt_joint_gemm):
+ * one workgroup owns 256 lattice nodes for the WHOLE padded vocabulary, so nothing per 64-column block exists.
+ *   NSP_EPI_RNNT_LSE    : lse [M], f1 [M] = logit(blank) - lse, f2 [M] = logit(lab[m]) - lse (-inf where lab[m] < 0) are
+ *                         WRITTEN (what nsp_rnnt_joint_gemm + nsp_rnnt_lse_merge leave behind); dbslabs / d16 unused.
+ *   NSP_EPI_RNNT_DLOGITS: lse, f1 = g_blank, f2 = g_label [M] are READ (scaled by scale * scale_dev[0]); d16 bf16 [M, Vp]
+ *                         receives the gradient image; dbslabs (optional) fp32 [ceil(M / 256), Vp] its column sums per
+ *                         workgroup, every entry written (rnn_transducer.py:239-242,262-276). */
+int nsp_rnnt_joint_rows(int epi_mode, const void* h16, const void* w16, const float* bias, long long M, int V, int Vp,
+                        int J, int blank, const int* lab, float* lse, float* f1, float* f2, float* dbslabs, void* d16,
+                        float scale, const float* scale_dev, void* stream);
 int nsp_rnnt_lattice_compact(const float* lp_blank, const float* lp_label, const int* elens, const int* ylens,
                              const long long* roff, float* alpha, float* beta, float* nll, float* g_blank,
                              float* g_label, int B, int U1max, void* stream);

@@ -1651,6 +1651,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     coff = p.c_ss ? (long long)tc.split * p.c_ss : 0;
   }
   const int xq = blockIdx.x >> 3, xx = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  if constexpr (!RR) {
+    // STAGGER (c_vec >> 8, NSP_GEMM_8P_STAGGER): the 32 workgroups of an XCD start in four groups ~3.9 us x the factor
+    // apart.  All 256 persistent workgroups otherwise start together and do identical work: main loops and epilogues
+    // of the whole chip coincide, the epilogues' stores arrive at HBM in bursts (measured below).
+    const int sg = c_vec >> 8;
+    if (sg > 0) {
+      const int grp = xq & 3;
+      for (int i = 0; i < grp * sg; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   // Tile order (KK).  Narrow outputs (< 16 tile columns: every GEMM of the training step): the 32 workgroups of an XCD
   // take 32 CONSECUTIVE tiles of the n-fastest list -- a few A panels x all their column tiles, so every A panel crosses
   // the fabric once and the whole weight matrix stays in the XCD's L2.  Wide outputs (N >= 4096: the 8192^3 square the
@@ -2450,6 +2460,8 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         if (e8g && atoi(e8g) >= 8 && atoi(e8g) < g8) g8 = atoi(e8g) / 8 * 8;
         const char* e8v = getenv("NSP_GEMM_8P_VAR");
         const int var8 = e8v ? atoi(e8v) : 4;   // default: the staged epilogue (the direct one measured 0.4-0.9x, see gemm_epilogue_direct)
+        const char* e8s = getenv("NSP_GEMM_8P_STAGGER");
+        const int stagger8 = e8s ? atoi(e8s) & 15 : 0;
         auto launch8 = [&](auto spec, auto var) {
           using S8 = decltype(spec);
           constexpr int V8 = decltype(var)::value;
@@ -2458,7 +2470,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<S8, V8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             attr = true;
           }
-          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<S8, V8>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
+          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<S8, V8>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, (c_vec & 255) | (stagger8 << 8));
         };
         // the direct epilogue's own conditions (32-bit byte offsets into C; column-sum slabs only with an act' source)
         const bool direct_ok = (long long)p.M * p.ldc < (1ll << 29) && !(p.epi_f3 && !p.dact_src) && !(p.bias && p.dact_src);

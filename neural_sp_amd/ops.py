@@ -1651,16 +1651,25 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         w16 = _rows_padded_bf16(w_out, 64)                                   # [Vp, J]
         bias = _vec_padded(b_out, Vp, dev)
         npart = Vp // 64
-        part = torch.empty((max(M, 1), npart, 2), device=dev, dtype=torch.float32)
         aux = torch.empty((7, max(M, 1)), device=dev, dtype=torch.float32)   # lse, lpb, lpl, alpha, beta, gb, gl
         nll = torch.empty((B,), device=dev, dtype=torch.float32)
-        _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_gemm, M, Vp, J,
-                                     1, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(part),
-                                     _p(aux[1]), _p(aux[2]), None, None, 1.0, None, None, _stream()),
-               'nsp_rnnt_joint_gemm(lse)')
-        _check(L.nsp_rnnt_lse_merge(_p(part), npart, _p(aux[0]), _p(aux[1]), _p(aux[2]), _p(lab), M, _stream()),
-               'nsp_rnnt_lse_merge')
-        del part
+        rows = _rnnt_rows_kernel(J)
+        if rows:
+            # node-stationary kernel: a workgroup sweeps the whole vocabulary for its 256 nodes -- lse and the two
+            # log-probabilities come out directly (no per-block partials, no merge pass)
+            _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_rows, M, Vp, J,
+                                         1, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
+                                         _p(aux[1]), _p(aux[2]), None, None, 1.0, None, _stream()),
+                   'nsp_rnnt_joint_rows(lse)')
+        else:
+            part = torch.empty((max(M, 1), npart, 2), device=dev, dtype=torch.float32)
+            _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_gemm, M, Vp, J,
+                                         1, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(part),
+                                         _p(aux[1]), _p(aux[2]), None, None, 1.0, None, None, _stream()),
+                   'nsp_rnnt_joint_gemm(lse)')
+            _check(L.nsp_rnnt_lse_merge(_p(part), npart, _p(aux[0]), _p(aux[1]), _p(aux[2]), _p(lab), M, _stream()),
+                   'nsp_rnnt_lse_merge')
+            del part
         _check(L.nsp_rnnt_lattice_compact(_p(aux[1]), _p(aux[2]), _p(elens), _p(ylens), _p(roff), _p(aux[3]),
                                           _p(aux[4]), _p(nll), _p(aux[5]), _p(aux[6]), B, U1, _stream()),
                'nsp_rnnt_lattice_compact')
@@ -1679,13 +1688,20 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         dl = _f32c(dloss).reshape(-1)                    # upstream gradient stays on the device
         w16 = _rows_padded_bf16(w_out, 64)
         d16 = torch.empty((max(M, 1), Vp), device=dev, dtype=torch.bfloat16)
-        nslab = (M + 127) // 128 * 2
-        dbpart = torch.zeros((max(nslab, 1), Vp), device=dev, dtype=torch.float32) if ctx.has_bias else None
-        rec = torch.empty((max(M, 1), 4), device=dev, dtype=torch.float32)   # per-node records of the DLOGITS epilogue
-        _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_gemm, M, Vp, J,
-                                     2, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
-                                     _p(aux[5]), _p(aux[6]), _p(dbpart), _p(d16), 1.0 / B, _p(dl), _p(rec), _stream()),
-               'nsp_rnnt_joint_gemm(dlogits)')
+        if _rnnt_rows_kernel(J):
+            dbpart = torch.empty(((M + 255) // 256, Vp), device=dev, dtype=torch.float32) if ctx.has_bias else None
+            _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_rows, M, Vp, J,
+                                         2, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
+                                         _p(aux[5]), _p(aux[6]), _p(dbpart), _p(d16), 1.0 / B, _p(dl), _stream()),
+                   'nsp_rnnt_joint_rows(dlogits)')
+        else:
+            nslab = (M + 127) // 128 * 2
+            dbpart = torch.zeros((max(nslab, 1), Vp), device=dev, dtype=torch.float32) if ctx.has_bias else None
+            rec = torch.empty((max(M, 1), 4), device=dev, dtype=torch.float32)   # per-node records of the DLOGITS epilogue
+            _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_gemm, M, Vp, J,
+                                         2, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
+                                         _p(aux[5]), _p(aux[6]), _p(dbpart), _p(d16), 1.0 / B, _p(dl), _p(rec), _stream()),
+                   'nsp_rnnt_joint_gemm(dlogits)')
         db = colsum(dbpart)[:V] if ctx.has_bias else None
         # dW = dlogits^T h  (split over the M rows, deterministic slab reduction)
         sk = _wgrad_splitk(V, J, M, True)
@@ -1706,6 +1722,12 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         dg = torch.empty((B, U1, J), device=dev, dtype=torch.float32)
         _check(L.nsp_splitk_reduce(_p(slabs), _p(dg), nsl, B * U1 * J, _stream()), 'nsp_splitk_reduce')
         return de, dg, dw.view(w_out.shape), db, None, None, None, None, None, None
+
+
+def _rnnt_rows_kernel(J):
+    """the node-stationary joint kernel (csrc/rnnt_fused.hip, nsp_rnnt_joint_rows) takes joint widths whose operand
+    fragments fit a wave's registers; NSP_RNNT_ROWS=0 keeps the tiled GEMM epilogues (read on every call: A/B, tests)"""
+    return J in (128, 256, 512) and os.environ.get('NSP_RNNT_ROWS', '1') != '0'
 
 
 def rnnt_joint_fused_supported(J, U1, M):

@@ -174,7 +174,7 @@ static inline void hipemu_waitcnt_vm(int n) {     // s_waitcnt vmcnt(n): all but
   std::vector<hipemu::Wave::Dma>& q = hipemu::wave->dma[hipemu::tid_flat & 63];
   const int retire = (int)q.size() - n;
   if (retire <= 0) return;
-  for (int i = 0; i < retire; ++i) memcpy(q[i].dst, q[i].data, (size_t)q[i].size);
+  for (int i = 0; i < retire; ++i) if (q[i].size) memcpy(q[i].dst, q[i].data, (size_t)q[i].size);
   q.erase(q.begin(), q.begin() + retire);
 }
 static inline void hipemu_raw_barrier() {         // s_barrier alone: no memory wait
@@ -231,7 +231,12 @@ static inline hipemu_swap_pair hipemu_permlane_swap(unsigned a, unsigned b, int 
 static inline hipemu_swap_pair __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) { return hipemu_permlane_swap(a, b, 16); }
 static inline hipemu_swap_pair __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) { return hipemu_permlane_swap(a, b, 32); }
 // DPP quad_perm (dpp_ctrl < 0x100: lane l reads lane (l & ~3) | ((ctrl >> 2 (l & 3)) & 3)); all rows / banks enabled
-static inline int hipemu_src_quad(int lane, int ctrl) { return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3); }
+// + row_mirror (0x140: lane l reads lane 15 - l of its 16-lane row) and row_half_mirror (0x141: 7 - l within 8 lanes)
+static inline int hipemu_src_quad(int lane, int ctrl) {
+  if (ctrl == 0x140) return (lane & ~15) | (15 - (lane & 15));
+  if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));
+  return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+}
 static inline int __builtin_amdgcn_update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
   return hipemu_shfl(src, hipemu_src_quad, ctrl);
 }
@@ -310,7 +315,16 @@ template <int N, class V> static inline V hipemu_buf_load(hipemu_rsrc r, unsigne
 }
 static inline hipemu_u32x4 hipemu_buf_load_b128(hipemu_rsrc r, unsigned v, unsigned s, int) { return hipemu_buf_load<4, hipemu_u32x4>(r, v, s); }
 static inline hipemu_u32x2 hipemu_buf_load_b64(hipemu_rsrc r, unsigned v, unsigned s, int) { return hipemu_buf_load<2, hipemu_u32x2>(r, v, s); }
+// a buffer store occupies a slot of the lane's in-order vmcnt queue like any other vector-memory operation: kernels
+// that leave stores in flight behind an LDS-DMA load (s_waitcnt vmcnt(n > 0), rnnt_joint_rows_kernel) count them
+static inline void hipemu_vm_marker() {
+  hipemu::Wave::Dma d;
+  d.dst = nullptr;
+  d.size = 0;
+  hipemu::wave->dma[hipemu::tid_flat & 63].push_back(d);
+}
 static inline void hipemu_buf_store_b64(hipemu_u32x2 d, hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  hipemu_vm_marker();
   for (int i = 0; i < 2; ++i) {
     const unsigned long long o = (unsigned long long)voff + soff + 4ull * i;
     unsigned w = d[i];
@@ -318,6 +332,7 @@ static inline void hipemu_buf_store_b64(hipemu_u32x2 d, hipemu_rsrc r, unsigned 
   }
 }
 static inline void hipemu_buf_store_b128(hipemu_u32x4 d, hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  hipemu_vm_marker();
   for (int i = 0; i < 4; ++i) {
     const unsigned long long o = (unsigned long long)voff + soff + 4ull * i;
     unsigned w = d[i];

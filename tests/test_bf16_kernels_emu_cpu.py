@@ -123,7 +123,14 @@ def test_rnnt_joint_loss_bf16_fused_backward(convloss, U, J, V):
 
 @pytest.mark.parametrize('B,T,U,J,V', [(3, 21, 6, 32, 29), (4, 37, 40, 64, 43), (2, 9, 0, 64, 130), (3, 30, 9, 128, 130)])
 def test_rnnt_joint_loss_fused_compact(convloss, B, T, U, J, V, monkeypatch):
-    convloss.test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, monkeypatch)
+    convloss.test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, '0', monkeypatch)
+
+
+@pytest.mark.parametrize('B,T,U,J,V', [(3, 30, 9, 128, 130), (3, 21, 6, 256, 29)])
+def test_rnnt_joint_loss_node_stationary_kernel(convloss, B, T, U, J, V, monkeypatch):
+    """nsp_rnnt_joint_rows on the emulator: 3 resp. 1 vocabulary slices (the two-slice ring wraps; V = 29: a slice that
+    is mostly padding, lanes without a single valid column), 256-node workgroups with ragged ends"""
+    convloss.test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, '1', monkeypatch)
 
 
 def test_lstm_vs_torch_bf16(convloss):

@@ -321,7 +321,8 @@ def test_lstm_stack_persistent_matches_wavefront(nl, p_drop, B, L, H, monkeypatc
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,T,U,J,V', [(3, 21, 6, 32, 29), (4, 37, 40, 64, 43), (3, 50, 70, 96, 1000),
                                        (5, 120, 33, 512, 1000), (2, 9, 0, 64, 130), (3, 30, 9, 128, 130), (5, 100, 33, 256, 1000)])
-def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, monkeypatch):
+@pytest.mark.parametrize('rows', ['1', '0'])
+def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, rows, monkeypatch):
     """The fused / compacted RNN-T joint (csrc/rnnt_fused.hip + the NSP_EPI_RNNT_* GEMM epilogues):
     loss and all four gradients against the fp64 lattice oracle on the materialised joint, ragged
     lengths incl. an empty label sequence and T_b = 1, V % 64 != 0.  Memory: no fp32 [.,V] tensor exists;
@@ -335,6 +336,11 @@ def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, monkeypatc
     # grids far below its usual threshold (one to a few tiles per workgroup, ragged M and N edges)
     monkeypatch.setenv('NSP_GEMM_8P_MIN_TILES', '1')
     monkeypatch.setenv('NSP_GEMM_8P_RNNT', '1')       # (opt-in: measured slower than the 128 x 128 kernel inside the step)
+    # rows = '1': J = 128 / 256 / 512 take the node-stationary kernel (nsp_rnnt_joint_rows: whole vocabulary per workgroup,
+    # no partials / merge / packed records); '0' keeps every width on the tiled GEMM epilogues
+    monkeypatch.setenv('NSP_RNNT_ROWS', rows)
+    if rows == '1' and J not in (128, 256, 512):
+        pytest.skip('joint width outside the node-stationary kernel: same path as rows = 0')
     torch.manual_seed(B * 1000 + T)
     e = (torch.randn(B, T, J, device=_dev()) * 0.7).requires_grad_()
     gq = (torch.randn(B, U + 1, J, device=_dev()) * 0.7).requires_grad_()
