@@ -227,6 +227,44 @@ __device__ __forceinline__ bf16x8 frag_tr_dma(const unsigned char* tile, int cba
   return o;
 }
 
+// The same transposed fragment as two INLINE-ASM reads (round 4).  __builtin_amdgcn_ds_read_tr16_b64 is modelled as
+// reading memory an LDS-DMA in flight may write, so hipcc puts an s_waitcnt vmcnt(0) in front of the first one: in the
+// forward and dQ kernels that drained the NEXT tile's K / V DMA in the middle of the current tile (before P V resp.
+// dS K) instead of at the tile's end.  The compiler does not count an asm load: the destinations are named in the
+// s_waitcnt statement that follows the batch (CDNA guide 5.7).
+struct FaTr { bf16x4 lo, hi; };
+__device__ __forceinline__ void fa_tr_issue(FaTr& f, const unsigned char* tile, int cbase, int k0, int k1, int r) {
+  const int a = r >> 2, b = r & 3;
+  const int ch = (cbase >> 3) + (b >> 1), sub = (b & 1) * 8;
+  const int r0 = k0 + a, r1 = k1 + a;
+  const unsigned char* p0 = tile + r0 * KD + ((ch ^ (r0 & 7)) << 4) + sub;
+  const unsigned char* p1 = tile + r1 * KD + ((ch ^ (r1 & 7)) << 4) + sub;
+#ifdef NSP_HOST_EMULATION
+  f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+  f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
+#else
+  typedef __attribute__((address_space(3))) unsigned char lds_uchar;
+  const unsigned a0 = (unsigned)(uintptr_t)((lds_uchar*)const_cast<unsigned char*>(p0));
+  const unsigned a1 = (unsigned)(uintptr_t)((lds_uchar*)const_cast<unsigned char*>(p1));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1) : "memory");
+#endif
+}
+__device__ __forceinline__ bf16x8 fa_tr_join(const FaTr& f) {
+  return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// (all eight fragments of a 64 x 64 tile: issue, then wait for the first / second four)
+__device__ __forceinline__ void fa_tr_wait(FaTr (&t)[8], int half) {
+#ifndef NSP_HOST_EMULATION
+  if (half == 0)
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(t[0].lo), "+v"(t[0].hi), "+v"(t[1].lo), "+v"(t[1].hi), "+v"(t[2].lo), "+v"(t[2].hi), "+v"(t[3].lo), "+v"(t[3].hi));
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[4].lo), "+v"(t[4].hi), "+v"(t[5].lo), "+v"(t[5].hi), "+v"(t[6].lo), "+v"(t[6].hi), "+v"(t[7].lo), "+v"(t[7].hi));
+#else
+  (void)t; (void)half;
+#endif
+}
+
 // forward: one workgroup per (128-query tile, head, utterance); 4 waves x 32 queries (two 16-query
 // fragments share every K / V fragment read); K / V tiles double-buffered in LDS with the next tile's
 // global loads in flight during the current tile's arithmetic -> ONE barrier per key tile.
@@ -395,16 +433,22 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
       }
     }
     // O^T[dd][query] += V^T P^T : X = V^T fragment (rows dd), Y = P fragment (rows queries)
+    {
+      FaTr vt[8];                                     // [ddf * 2 + s]
 #pragma unroll
-    for (int ddf = 0; ddf < 4; ++ddf)
+      for (int i = 0; i < 8; ++i) fa_tr_issue(vt[i], Vc, (i >> 1) * 16, 32 * (i & 1) + 4 * g, 32 * (i & 1) + 16 + 4 * g, r);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 vT = frag_tr_dma(Vc, ddf * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r);
+      for (int hf = 0; hf < 2; ++hf) {
+        fa_tr_wait(vt, hf);
 #pragma unroll
-        for (int f = 0; f < NQ; ++f) {
-          o_acc[f][ddf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pf[f][s], o_acc[f][ddf], 0, 0, 0);
+        for (int i = hf * 4; i < hf * 4 + 4; ++i) {
+          const bf16x8 vT = fa_tr_join(vt[i]);
+#pragma unroll
+          for (int f = 0; f < NQ; ++f)
+            o_acc[f][i >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, Pf[f][i & 1], o_acc[f][i >> 1], 0, 0, 0);
         }
       }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 have landed ...
     __syncthreads();                                     // ... everybody's have; tile kt's buffers are free
   }
@@ -825,12 +869,18 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
         }
       }
     // dQ^T[dk'][query] += K^T dS^T : X = K^T fragment (rows dk', k = keys), Y = dS fragment
+    {
+      FaTr kt_[8];                                    // [df * 2 + s]
 #pragma unroll
-    for (int df = 0; df < 4; ++df)
+      for (int i = 0; i < 8; ++i) fa_tr_issue(kt_[i], Kc, (i >> 1) * 16, 32 * (i & 1) + 4 * g, 32 * (i & 1) + 16 + 4 * g, r);
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        dq_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            frag_tr_dma(Kc, df * 16, 32 * s + 4 * g, 32 * s + 16 + 4 * g, r), dSf[s], dq_acc[df], 0, 0, 0);
+      for (int hf = 0; hf < 2; ++hf) {
+        fa_tr_wait(kt_, hf);
+#pragma unroll
+        for (int i = hf * 4; i < hf * 4 + 4; ++i)
+          dq_acc[i >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_tr_join(kt_[i]), dSf[i & 1], dq_acc[i >> 1], 0, 0, 0);
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }

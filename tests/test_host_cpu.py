@@ -257,6 +257,11 @@ def test_install_substitutes_ddp_and_is_idempotent(monkeypatch):
     stock = tnp.DistributedDataParallel
     monkeypatch.setattr(tnp, 'DistributedDataParallel', stock)                 # restored after the test
     monkeypatch.setattr(tnp.distributed, 'DistributedDataParallel', stock)
+    try:        # (an earlier test of this process may have imported the reference: its class name is restored as well)
+        import neural_sp.models.seq2seq.speech2text as ref_mod
+        monkeypatch.setattr(ref_mod, 'Speech2Text', ref_mod.Speech2Text)
+    except ImportError:
+        pass
     assert not getattr(stock, '_nsp_patched', False)
     done = neural_sp_amd.install()
     assert 'torch.nn.parallel.DistributedDataParallel' in done
