@@ -414,8 +414,9 @@ def main():
             ach = kev.get('algo_flops', kev['flops']) / (kev['ms'] * 1e-3) / 1e12
             side = kev['side']
             roof = {'kernel': 'bf16 MFMA GEMM class of libnsp_hip.so on the main stream: gemm_bf16_kk8p_kernel<S, ., RR> (phase-'
-                              'interleaved 256 x 256 tiles: long reductions, stacked QKV, every weight gradient), gemm_bf16_kk_glds_kernel<0|1|2> '
-                              '(K = 512 activations x weights, data gradients; RNN-T joint logits / dlogits), '
+                              'interleaved 256 x 256 tiles: long reductions, stacked QKV, every weight gradient), gemm_bf16_kk_glds_kernel<0> '
+                              '(K = 512 activations x weights, data gradients), rnnt_joint_rows_kernel<16, LSE|DLOGITS> (the RNN-T joint\'s '
+                              'two logit passes, node-stationary), '
                               'gemm_bf16_kernel<.,.> / gemm_bf16_kk_ring_kernel<NS,MI> (small grids); '
                               '%d launches = every main-stream GEMM of every %d-th timed step, rank 0.  The %d side-stream '
                               'launches of those steps (CTC head, prediction-network projections: %.1f %% of the GEMM flops) run '

@@ -779,6 +779,17 @@ extern "C" int nsp_rnnt_joint_rows(int epi_mode, const void* h16, const void* w1
                        blank, lab, lse, f1, f2, dbslabs, reinterpret_cast<__bf16*>(d16), scale, scale_dev, dbg);       \
   } while (0)
   const bool l = epi_mode == NSP_EPI_RNNT_LSE;
+  {
+    static int gdbg = -1;      // NSP_GEMM_DEBUG=1: the launch in the GEMM launcher's line format (tools/pmc_traffic.py reads algbytes)
+    if (gdbg < 0) { const char* e = getenv("NSP_GEMM_DEBUG"); gdbg = e ? atoi(e) : 0; }
+    if (gdbg) {
+      // algorithmic HBM bytes: h and W_out once; LSE: label in, three floats out per node; DLOGITS: label + three floats in
+      // per node, the bf16 image and the bias-gradient slab rows out
+      long long bytes = 2ll * M * J + 2ll * Vp * J + 16ll * M;
+      if (!l) bytes += 2ll * M * Vp + (dbslabs ? 4ll * ((M + 255) / 256) * Vp : 0);
+      fprintf(stderr, "[nsp_gemm_bf16] M %lld N %d K %d node-stationary joint kernel epi %d algbytes %lld\n", M, Vp, J, epi_mode, bytes);
+    }
+  }
   const char* edbg = getenv("NSP_RNNT_ROWS_DEBUG");
   const int dbg = edbg ? atoi(edbg) : 0;
   if (J == 512) { if (l) NSP_JR(16, true); else NSP_JR(16, false); }

@@ -49,7 +49,7 @@ if __name__ == '__main__':
     if len(sys.argv) > 3:
         import json
         BATCH = int(sys.argv[5]) if len(sys.argv) > 5 else 128
-        g = [r for r in rows if r[1].startswith('gemm_bf16')]
+        g = [r for r in rows if r[1].startswith('gemm_bf16') or 'rnnt_joint_rows_kernel' in r[1]]   # (the joint's logit passes: node-stationary kernel)
         n = sum(r[2] for r in g)
         rd = sum(r[3] * r[2] for r in g) / n
         wr = sum(r[4] * r[2] for r in g) / n
@@ -62,7 +62,7 @@ if __name__ == '__main__':
                    'algorithmic_launches': alg['launches'] if alg else None,
                    'algorithmic_definition': 'both operands once + every output image (split-K slabs included) + every side operand once, '
                                              'summed over all bf16 GEMM launches of the traced steps (NSP_GEMM_DEBUG=1 pass of the same command) / launches',
-                   'kernel_class': 'bf16 GEMM class (all gemm_bf16_* kernels of libnsp_hip.so, incl. the RNN-T joint GEMMs)',
+                   'kernel_class': 'bf16 GEMM class (all gemm_bf16_* kernels of libnsp_hip.so + rnnt_joint_rows_kernel, the RNN-T joint logit passes)',
                    'workload': 'bench.py default (Conformer-L, per-GPU batch %d, bf16), 2 steps in the trace' % BATCH,
                    'per_gpu_batch': BATCH,
                    'launches': n, 'hbm_bytes_per_launch': rd + wr, 'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
