@@ -34,6 +34,7 @@
 // 256 MFMA flops -- the ablation's "everything removed but fragment reads, max, rescale and conversions" build
 // still takes 42 % of the forward.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -403,26 +404,34 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
       const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // m_run = -inf on the first tile -> 0
       const float c0 = addc - m_new;
       float rs = 0.f;
-      float kp[4][4];
-      if (drop) fa_keep(kp, rowhash[f], kt * 64, g, thr16, inv_keep);
+      // compiled once per (uniform tile?, dropout?) and chosen once per fragment: with the two wave-uniform flags tested
+      // per score hipcc evaluated BOTH exponentials of `uni ? exp2(fma) : exp2(ev - m)` and selected (ISA audit, round 4)
+      auto probs = [&](auto uni_, auto drop_) {
+        constexpr bool UNI = decltype(uni_)::value, DROP = decltype(drop_)::value;
+        float kp[4][4];
+        if (DROP) fa_keep(kp, rowhash[f], kt * 64, g, thr16, inv_keep);
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
+        for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int e2 = 0; e2 < 4; e2 += 2) {
-          f32x2 pr;
+          for (int e2 = 0; e2 < 4; e2 += 2) {
+            f32x2 pr;
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int e = e2 + q;
-            float v = uni ? __builtin_amdgcn_exp2f(fmaf(s_acc[f][kf][e], sl2, c0))
-                          : __builtin_amdgcn_exp2f(ev[kf][e] - m_new);
-            rs += v;
-            if (drop) v *= kp[kf][e];
-            pr[q] = v;
+            for (int q = 0; q < 2; ++q) {
+              const int e = e2 + q;
+              float v;
+              if constexpr (UNI) v = __builtin_amdgcn_exp2f(fmaf(s_acc[f][kf][e], sl2, c0));
+              else v = __builtin_amdgcn_exp2f(ev[kf][e] - m_new);
+              rs += v;
+              if constexpr (DROP) v *= kp[kf][e];
+              pr[q] = v;
+            }
+            const bf16x2 hi = __builtin_convertvector(pr, bf16x2);
+            Pf[f][kf >> 1][(kf & 1) * 4 + e2] = hi[0];
+            Pf[f][kf >> 1][(kf & 1) * 4 + e2 + 1] = hi[1];
           }
-          const bf16x2 hi = __builtin_convertvector(pr, bf16x2);
-          Pf[f][kf >> 1][(kf & 1) * 4 + e2] = hi[0];
-          Pf[f][kf >> 1][(kf & 1) * 4 + e2 + 1] = hi[1];
-        }
+      };
+      if (uni) { if (drop) probs(std::true_type{}, std::true_type{}); else probs(std::true_type{}, std::false_type{}); }
+      else { if (drop) probs(std::false_type{}, std::true_type{}); else probs(std::false_type{}, std::false_type{}); }
       // l_run is this LANE's partial row sum (its 16 keys per tile); alpha is common to the four lanes of a
       // query, so the partials are combined once, after the last tile
       l_run[f] = l_run[f] * alpha + rs;
@@ -661,65 +670,81 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
     const FaTile tl = fa_tile(p, QP != nullptr, q0, k0, T, klen);
     const bool uni = tl.plain && (QP == nullptr || tl.far);
     bf16x8 Pt[2], dSt[2];     // X operands: rows = keys, k = [block 2s: queries 4g..4g+3 | block 2s+1: same]
+    // The tile class (uniform / near the diagonal / masked) and dropout are wave-uniform but known only at run time:
+    // tested per element inside the unrolled loops they became three scalar branches around EVERY score (ISA audit,
+    // round 4: ~50 branches per tile, basic blocks of a dozen instructions, no scheduling across scores).  The element
+    // loop is compiled once per class (KIND 0 uniform, 1 near, 2 general; DROP) and the class is chosen once per tile.
+    auto tile_scores = [&](auto kind_, auto drop_) {
+      constexpr int KIND = decltype(kind_)::value;
+      constexpr bool DROP = decltype(drop_)::value;
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-      // The statistics rows are read through INLINE ASM: in front of a compiler-visible read of these arrays hipcc
-      // put an s_waitcnt vmcnt(0) (ISA audit, round 4) -- i.e. the next query tile's Q / dO DMA, issued a few dozen
-      // instructions earlier, was drained right here, before the soft-max arithmetic it is supposed to hide behind.
-      // (The compiler does not count asm loads: the destinations are named in the wait statement, CDNA guide 5.7.)
-      f32x4 c0v, mxv, inv, ddv;
-      u32x4 hv = {0u, 0u, 0u, 0u};
-      fa_lds_read4(c0v, &st_c0[cur][qb * 16 + 4 * g]);
-      fa_lds_read4(mxv, &st_max[cur][qb * 16 + 4 * g]);
-      fa_lds_read4(inv, &st_inv[cur][qb * 16 + 4 * g]);
-      fa_lds_read4(ddv, &st_d[cur][qb * 16 + 4 * g]);
-      if (drop) fa_lds_read4(hv, &st_hash[cur][qb * 16 + 4 * g]);
+      for (int qb = 0; qb < 4; ++qb) {
+        // The statistics rows are read through INLINE ASM: in front of a compiler-visible read of these arrays hipcc
+        // put an s_waitcnt vmcnt(0) (ISA audit, round 4) -- i.e. the next query tile's Q / dO DMA, issued a few dozen
+        // instructions earlier, was drained right here, before the soft-max arithmetic it is supposed to hide behind.
+        // (The compiler does not count asm loads: the destinations are named in the wait statement, CDNA guide 5.7.)
+        f32x4 c0v, mxv, inv, ddv;
+        u32x4 hv = {0u, 0u, 0u, 0u};
+        fa_lds_read4(c0v, &st_c0[cur][qb * 16 + 4 * g]);
+        fa_lds_read4(mxv, &st_max[cur][qb * 16 + 4 * g]);
+        fa_lds_read4(inv, &st_inv[cur][qb * 16 + 4 * g]);
+        fa_lds_read4(ddv, &st_d[cur][qb * 16 + 4 * g]);
+        if (DROP) fa_lds_read4(hv, &st_hash[cur][qb * 16 + 4 * g]);
 #ifndef NSP_HOST_EMULATION
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0v), "+v"(mxv), "+v"(inv), "+v"(ddv), "+v"(hv));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0v), "+v"(mxv), "+v"(inv), "+v"(ddv), "+v"(hv));
 #endif
-      const float c0a[4] = {c0v[0], c0v[1], c0v[2], c0v[3]}, mxa[4] = {mxv[0], mxv[1], mxv[2], mxv[3]};
-      const float ina[4] = {inv[0], inv[1], inv[2], inv[3]}, dda[4] = {ddv[0], ddv[1], ddv[2], ddv[3]};
-      const unsigned ha[4] = {hv[0], hv[1], hv[2], hv[3]};
+        const float c0a[4] = {c0v[0], c0v[1], c0v[2], c0v[3]}, mxa[4] = {mxv[0], mxv[1], mxv[2], mxv[3]};
+        const float ina[4] = {inv[0], inv[1], inv[2], inv[3]}, dda[4] = {ddv[0], ddv[1], ddv[2], ddv[3]};
+        const unsigned ha[4] = {hv[0], hv[1], hv[2], hv[3]};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int ql = qb * 16 + 4 * g + e;
-        float ex;
-        bool vis = true;
-        if (uni) {
-          ex = __builtin_amdgcn_exp2f(fmaf(s_acc[qb][e], sl2, c0a[e]));
-        } else if (tl.plain) {          // near the diagonal, no mask predicate (fa_logits_near)
-          const int dlt = q0 + ql - key;
-          const int rel = min(dlt < 0 ? -dlt : dlt, p.clamp);
-          ex = __builtin_amdgcn_exp2f(fmaf(s_acc[qb][e], sl2, QPs[cur][ql][rel]) - mxa[e]);
-        } else {
-          const int qi = q0 + ql;
-          float v = s_acc[qb][e] * sl2;
-          if (QP) {
-            int rel = qi > key ? qi - key : key - qi;
-            if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
-            v += QPs[cur][ql][rel];
+        for (int e = 0; e < 4; ++e) {
+          const int ql = qb * 16 + 4 * g + e;
+          float ex;
+          bool vis = true;
+          if constexpr (KIND == 0) {
+            ex = __builtin_amdgcn_exp2f(fmaf(s_acc[qb][e], sl2, c0a[e]));
+          } else if constexpr (KIND == 1) {          // near the diagonal, no mask predicate (fa_logits_near)
+            const int dlt = q0 + ql - key;
+            const int rel = min(dlt < 0 ? -dlt : dlt, p.clamp);
+            ex = __builtin_amdgcn_exp2f(fmaf(s_acc[qb][e], sl2, QPs[cur][ql][rel]) - mxa[e]);
+          } else {
+            const int qi = q0 + ql;
+            float v = s_acc[qb][e] * sl2;
+            if (QP) {
+              int rel = qi > key ? qi - key : key - qi;
+              if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+              v += QPs[cur][ql][rel];
+            }
+            vis = tl.plain || fa_visible(p, klen, qi, key);
+            if (!vis) v = -FLT_MAX;
+            ex = __builtin_amdgcn_exp2f(v - mxa[e]);
+            if (key >= T) ex = 0.f;                          // tile padding: not in the softmax
           }
-          vis = tl.plain || fa_visible(p, klen, qi, key);
-          if (!vis) v = -FLT_MAX;
-          ex = __builtin_amdgcn_exp2f(v - mxa[e]);
-          if (key >= T) ex = 0.f;                          // tile padding: not in the softmax
+          float keep = 1.f;
+          if constexpr (DROP) {
+            unsigned y = ha[e] + pair_mix;
+            y ^= y << 13; y ^= y >> 17; y ^= y << 5;
+            y = __umul24(y >> 8, 0x85EBCBu) ^ y;
+            keep = ((y >> half_shift) & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
+          }
+          // pdr = the value forward fed into P V, bit for bit (integer row max: see the forward kernel); the first
+          // term pairs it with dP so that sum_j of it equals D_i = dO_i . O_i, the second uses the fp32
+          // probability that sums to one with the saved 1 / l
+          const float pdr = (float)(__bf16)(ex * keep);
+          float ds = ina[e] * p.scale * fmaf(pdr, dp_acc[qb][e], -ex * dda[e]);
+          if (KIND == 2 && !vis) ds = 0.f;
+          Pt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)(pdr * ina[e]);
+          dSt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)ds;
         }
-        float keep = 1.f;
-        if (drop) {
-          unsigned y = ha[e] + pair_mix;
-          y ^= y << 13; y ^= y >> 17; y ^= y << 5;
-          y = __umul24(y >> 8, 0x85EBCBu) ^ y;
-          keep = ((y >> half_shift) & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
-        }
-        // pdr = the value forward fed into P V, bit for bit (integer row max: see the forward kernel); the first
-        // term pairs it with dP so that sum_j of it equals D_i = dO_i . O_i, the second uses the fp32
-        // probability that sums to one with the saved 1 / l
-        const float pdr = (float)(__bf16)(ex * keep);
-        float ds = ina[e] * p.scale * fmaf(pdr, dp_acc[qb][e], -ex * dda[e]);
-        if (!vis) ds = 0.f;
-        Pt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)(pdr * ina[e]);
-        dSt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)ds;
       }
+    };
+    {
+      typedef std::integral_constant<int, 0> K0;
+      typedef std::integral_constant<int, 1> K1;
+      typedef std::integral_constant<int, 2> K2;
+      if (uni) { if (drop) tile_scores(K0{}, std::true_type{}); else tile_scores(K0{}, std::false_type{}); }
+      else if (tl.plain) { if (drop) tile_scores(K1{}, std::true_type{}); else tile_scores(K1{}, std::false_type{}); }
+      else { if (drop) tile_scores(K2{}, std::true_type{}); else tile_scores(K2{}, std::false_type{}); }
     }
     // dV[key][dd] += sum_q Pd[q][key] dO[q][dd] ; dK[key][dk'] += sum_q dS[q][key] Q[q][dk']
 #pragma unroll
@@ -838,36 +863,55 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     const bool uni = tl.plain && (qrow == nullptr || tl.far);   // see the forward kernel
     const float c0 = ((uni && qrow) ? qrow[p.clamp] : 0.f) - rmax;
     const float rs_ = rinv * p.scale;
-    float ev[4][4], kp[4][4];
-    unsigned vis = 0xFFFFu;
-    if (!uni) {
-      if (tl.plain) fa_logits_near(s_acc, ev, qrow, sl2, qi, kt * 64, g, p.clamp);
-      else vis = fa_logits(s_acc, ev, p, qrow, sl2, qi, kt * 64, g, klen, tl);
-    }
-    if (drop) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
+    // the element loop is compiled per tile class (KIND 0 uniform: no mask, relative term constant; 1 near the diagonal;
+    // 2 masked) x dropout and chosen once per tile -- see flash_bwd_dkv_kernel (per-score tests of the wave-uniform
+    // flags evaluated both exponentials and put branches around every score)
+    auto tile_scores = [&](auto kind_, auto drop_) {
+      constexpr int KIND = decltype(kind_)::value;
+      constexpr bool DROP = decltype(drop_)::value;
+      float ev[4][4], kp[4][4];
+      unsigned vis = 0xFFFFu;
+      if constexpr (KIND == 1) fa_logits_near(s_acc, ev, qrow, sl2, qi, kt * 64, g, p.clamp);
+      if constexpr (KIND == 2) vis = fa_logits(s_acc, ev, p, qrow, sl2, qi, kt * 64, g, klen, tl);
+      if constexpr (DROP) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+      for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = kt * 64 + kf * 16 + 4 * g + e;
-        float ex = uni ? __builtin_amdgcn_exp2f(fmaf(s_acc[kf][e], sl2, c0)) : __builtin_amdgcn_exp2f(ev[kf][e] - rmax);
-        if (!tl.plain && key >= T) ex = 0.f;
-        const float keep = drop ? kp[kf][e] : 1.f;
-        const float pdr = (float)(__bf16)(ex * keep);       // forward's P V operand, bit for bit (see flash_bwd_dkv_kernel)
-        float ds = rs_ * fmaf(pdr, dp_acc[kf][e], -ex * dsum);
-        if (!tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
-        dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
-        if (QP) {
-          if (tl.far) {
-            far += ds;
-          } else if (ds != 0.f) {
-            int rel = qi > key ? qi - key : key - qi;
-            if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
-            if (p.clamp > 0 && rel == p.clamp) far += ds;
-            else atomicAdd(&dQPs[ql][rel], ds);  // LDS, near-diagonal elements only
+        for (int e = 0; e < 4; ++e) {
+          const int key = kt * 64 + kf * 16 + 4 * g + e;
+          float ex;
+          if constexpr (KIND == 0) ex = __builtin_amdgcn_exp2f(fmaf(s_acc[kf][e], sl2, c0));
+          else ex = __builtin_amdgcn_exp2f(ev[kf][e] - rmax);
+          if (KIND == 2 && !tl.plain && key >= T) ex = 0.f;
+          const float keep = DROP ? kp[kf][e] : 1.f;
+          const float pdr = (float)(__bf16)(ex * keep);       // forward's P V operand, bit for bit (see flash_bwd_dkv_kernel)
+          float ds = rs_ * fmaf(pdr, dp_acc[kf][e], -ex * dsum);
+          if (KIND == 2 && !tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
+          dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
+          if constexpr (KIND == 0) {
+            far += ds;                         // (only read when there is a relative term: a uniform tile is a far one then)
+          } else {
+            if (QP) {
+              if (tl.far) {
+                far += ds;
+              } else if (ds != 0.f) {
+                int rel = qi > key ? qi - key : key - qi;
+                if (p.clamp > 0 && rel > p.clamp) rel = p.clamp;
+                if (p.clamp > 0 && rel == p.clamp) far += ds;
+                else atomicAdd(&dQPs[ql][rel], ds);  // LDS, near-diagonal elements only
+              }
+            }
           }
         }
-      }
+    };
+    {
+      typedef std::integral_constant<int, 0> K0;
+      typedef std::integral_constant<int, 1> K1;
+      typedef std::integral_constant<int, 2> K2;
+      if (uni) { if (drop) tile_scores(K0{}, std::true_type{}); else tile_scores(K0{}, std::false_type{}); }
+      else if (tl.plain) { if (drop) tile_scores(K1{}, std::true_type{}); else tile_scores(K1{}, std::false_type{}); }
+      else { if (drop) tile_scores(K2{}, std::true_type{}); else tile_scores(K2{}, std::false_type{}); }
+    }
     // dQ^T[dk'][query] += K^T dS^T : X = K^T fragment (rows dk', k = keys), Y = dS fragment
     {
       FaTr kt_[8];                                    // [df * 2 + s]
