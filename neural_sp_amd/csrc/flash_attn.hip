@@ -489,25 +489,6 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
   }
 }
 
-// D[b,h,i] = sum_dd dO[i,dd] * O[i,dd]   (one wave per (b,i,h) row of 64); O is the forward's
-// fp32 output (see the hi/lo note there), dO the bf16 image the dP MFMAs consume
-__global__ __launch_bounds__(256) void flash_dot_kernel(const __bf16* __restrict__ dO,
-                                                        const float* __restrict__ O, float* __restrict__ D,
-                                                        int B, int T, int H, int d) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long n = (long long)B * T * H;
-  for (long long row = (long long)blockIdx.x * 4 + w; row < n; row += (long long)gridDim.x * 4) {
-    const int hh = (int)(row % H);
-    const long long bt = row / H;
-    const float v = (float)dO[bt * d + hh * DK + lane] * O[bt * d + hh * DK + lane];
-    const float s = wave_reduce_sum(v);
-    if (lane == 0) {
-      const long long b = bt / T, i = bt % T;
-      D[(b * H + hh) * T + i] = s;
-    }
-  }
-}
-
 // ---- backward, part 1: dK / dV.  One workgroup per 64-key tile, looping over 64-query tiles.
 // Wave w owns keys k0 + 16 w .. + 15 for the WHOLE pipeline: it computes S and dP as
 // S[query][key] = mfma(X = Q fragment, Y = K fragment), so a lane holds ONE key (lane & 15) and four
@@ -784,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
 // atomics from the key-parallel kernel: 88 M atomics per call at T = 800 made it 4x slower).
 __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
-    const float* __restrict__ LSE, const float* __restrict__ Drow, float* __restrict__ dq32,
+    const float* __restrict__ O32, const float* __restrict__ LSE, float* __restrict__ Drow, float* __restrict__ dq32,
     float* __restrict__ dQP, const nsp_attn_mask_params p) {
   __shared__ __attribute__((aligned(16))) unsigned char KV[4 * 64 * KD + 2 * 64 * 17 * 4];   // one LDS object (see the forward kernel)
   unsigned char (*Ks)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV);
@@ -823,7 +804,25 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
   const long long ri = ((long long)b * p.H + h) * T + qc;
   const float rmax = LSE[ri];
   const float rinv = qi < T ? LSE[nrow + ri] : 0.f;
-  const float dsum = Drow[ri];
+  // D_i = dO_i . O_i of this lane's query, formed HERE from the dO fragment the lane holds anyway and the matching 16
+  // values of the forward's fp32 output (round 4: was a separate pass over dO and O, flash_dot_kernel, 1.0 ms per step
+  // and 12 launches), and handed to the dK/dV kernel -- which runs after this one -- through Drow
+  float dsum;
+  {
+    const float* op = O32 + (brow0 + qc) * d + h * DK;
+    float t = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float4 o0 = *reinterpret_cast<const float4*>(op + s2 * 32 + g * 8);
+      const float4 o1 = *reinterpret_cast<const float4*>(op + s2 * 32 + g * 8 + 4);
+      t = fmaf((float)dOf[s2][0], o0.x, t); t = fmaf((float)dOf[s2][1], o0.y, t);
+      t = fmaf((float)dOf[s2][2], o0.z, t); t = fmaf((float)dOf[s2][3], o0.w, t);
+      t = fmaf((float)dOf[s2][4], o1.x, t); t = fmaf((float)dOf[s2][5], o1.y, t);
+      t = fmaf((float)dOf[s2][6], o1.z, t); t = fmaf((float)dOf[s2][7], o1.w, t);
+    }
+    dsum = fa_xsum4(t);
+    if (g == 0 && qi < T) Drow[ri] = dsum;
+  }
   const bool drop = p.dropout_p > 0.f;
   const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
@@ -987,16 +986,12 @@ extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const
   if (QP && !dQP) return NSP_EINVAL;
   if (p.r_pitch < p.R) p.r_pitch = p.R;
   hipStream_t st = (hipStream_t)stream;
-  long long n = (long long)p.B * p.Tq * p.H;
-  int g1 = nsp_cdiv(n, 4);
-  if (g1 > 8192) g1 = 8192;
-  hipLaunchKernelGGL(flash_dot_kernel, dim3(g1), dim3(256), 0, st, reinterpret_cast<const __bf16*>(dO),
-                     O32, D, p.B, p.Tq, p.H, d);
   dim3 grid(((p.Tq + 63) / 64) * p.H, p.B);
+  // the dQ kernel first: it forms D = dO . O for its queries and leaves it in D for the dK/dV kernel
+  hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
+                     reinterpret_cast<const __bf16*>(dO), O32, LSE, D, dq32, dQP, p);
   hipLaunchKernelGGL(flash_bwd_dkv_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
                      QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
-  hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
-                     reinterpret_cast<const __bf16*>(dO), LSE, D, dq32, dQP, p);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
