@@ -1653,7 +1653,7 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         npart = Vp // 64
         aux = torch.empty((7, max(M, 1)), device=dev, dtype=torch.float32)   # lse, lpb, lpl, alpha, beta, gb, gl
         nll = torch.empty((B,), device=dev, dtype=torch.float32)
-        rows = _rnnt_rows_kernel(J)
+        rows = _rnnt_rows_kernel(J, Vp)
         if rows:
             # node-stationary kernel: a workgroup sweeps the whole vocabulary for its 256 nodes -- lse and the two
             # log-probabilities come out directly (no per-block partials, no merge pass)
@@ -1688,7 +1688,7 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         dl = _f32c(dloss).reshape(-1)                    # upstream gradient stays on the device
         w16 = _rows_padded_bf16(w_out, 64)
         d16 = torch.empty((max(M, 1), Vp), device=dev, dtype=torch.bfloat16)
-        if _rnnt_rows_kernel(J):
+        if _rnnt_rows_kernel(J, Vp):
             dbpart = torch.empty(((M + 255) // 256, Vp), device=dev, dtype=torch.float32) if ctx.has_bias else None
             _check(rnnt_joint_gemm_timed(L.nsp_rnnt_joint_rows, M, Vp, J,
                                          2, _p(h16), _p(w16), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux[0]),
@@ -1724,10 +1724,12 @@ class RNNTJointLossFusedFn(torch.autograd.Function):
         return de, dg, dw.view(w_out.shape), db, None, None, None, None, None, None
 
 
-def _rnnt_rows_kernel(J):
+def _rnnt_rows_kernel(J, Vp):
     """the node-stationary joint kernel (csrc/rnnt_fused.hip, nsp_rnnt_joint_rows) takes joint widths whose operand
-    fragments fit a wave's registers; NSP_RNNT_ROWS=0 keeps the tiled GEMM epilogues (read on every call: A/B, tests)"""
-    return J in (128, 256, 512) and os.environ.get('NSP_RNNT_ROWS', '1') != '0'
+    fragments fit a wave's registers and vocabularies whose bias fits the LDS left beside the two-slice ring (J = 512:
+    3072 words); NSP_RNNT_ROWS=0 keeps the tiled GEMM epilogues (read on every call: A/B, tests)"""
+    return (J in (128, 256, 512) and 2 * 64 * J * 2 + 8 * 2048 + 2 * 8 * 64 * 4 + Vp * 4 <= 163840
+            and os.environ.get('NSP_RNNT_ROWS', '1') != '0')
 
 
 def rnnt_joint_fused_supported(J, U1, M):

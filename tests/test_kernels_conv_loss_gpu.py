@@ -319,8 +319,69 @@ def test_lstm_stack_persistent_matches_wavefront(nl, p_drop, B, L, H, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,J,V,blank', [(1, 128, 70, 69), (300, 256, 1000, 0), (70001, 512, 257, 5), (513, 512, 64, 63)])
+def test_rnnt_joint_rows_matches_tiled_gemm_path(M, J, V, blank):
+    """nsp_rnnt_joint_rows (node-stationary: 256 nodes x whole vocabulary per workgroup) against nsp_rnnt_joint_gemm
+    (+ nsp_rnnt_lse_merge), the path it replaces, on the same operands: one node, a ragged last workgroup, a blank
+    index that is not 0 (last column of the vocabulary; of a vocabulary that fills its last 64-column slice exactly),
+    vocabulary padding inside the last slice (V = 257: 63 padded columns), labels -1 (no label) mixed in.  Forward:
+    log-sum-exp and both log-probabilities; backward: the bf16 gradient image and the bias-gradient sums."""
+    from neural_sp_amd import ops, _lib
+    from neural_sp_amd.ops import _p, _stream
+    L = _lib.lib()
+    dev = _dev()
+    Vp = (V + 63) // 64 * 64
+    torch.manual_seed(M + V)
+    h = torch.tanh(torch.randn(M, J, device=dev)).bfloat16()
+    w = torch.zeros(Vp, J, device=dev, dtype=torch.bfloat16)
+    w[:V] = (torch.randn(V, J, device=dev) * (2.0 / J ** 0.5)).bfloat16()
+    bias = torch.zeros(Vp, device=dev)
+    bias[:V] = torch.randn(V, device=dev)
+    lab = torch.randint(-1, V, (M,), device=dev, dtype=torch.int32)
+    aux_r = torch.full((3, M), float('nan'), device=dev)
+    aux_g = torch.full((3, M), float('nan'), device=dev)
+    part = torch.empty(M, Vp // 64, 2, device=dev)
+    with ops.compute_mode('bf16'):
+        assert L.nsp_rnnt_joint_rows(1, _p(h), _p(w), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux_r[0]), _p(aux_r[1]),
+                                     _p(aux_r[2]), None, None, 1.0, None, _stream()) == 0
+        assert L.nsp_rnnt_joint_gemm(1, _p(h), _p(w), _p(bias), M, V, Vp, J, blank, _p(lab), _p(part), _p(aux_g[1]),
+                                     _p(aux_g[2]), None, None, 1.0, None, None, _stream()) == 0
+        assert L.nsp_rnnt_lse_merge(_p(part), Vp // 64, _p(aux_g[0]), _p(aux_g[1]), _p(aux_g[2]), _p(lab), M, _stream()) == 0
+        # against torch as well: fp32 logits of the bf16 operands
+        logits = h.float() @ w[:V].float().t() + bias[:V]
+        lse = torch.logsumexp(logits, -1)
+        assert (aux_r[0] - lse).abs().max().item() < 2e-4
+        assert (aux_r[1] - (logits[:, blank] - lse)).abs().max().item() < 2e-4
+        has = lab >= 0
+        pick = logits.gather(1, lab.clamp(min=0).long()[:, None])[:, 0] - lse
+        assert (aux_r[2][has] - pick[has]).abs().max().item() < 2e-4 if has.any() else True
+        assert torch.isinf(aux_r[2][~has]).all() and (aux_r[2][~has] < 0).all()
+        assert (aux_r[0] - aux_g[0]).abs().max().item() < 1e-5 and (aux_r[1] - aux_g[1]).abs().max().item() < 1e-5
+        gb = torch.rand(M, device=dev) * 0.01
+        gl = torch.rand(M, device=dev) * 0.01 * has
+        d_r = torch.full((M, Vp), float('nan'), device=dev, dtype=torch.bfloat16)
+        d_g = torch.full((M, Vp), float('nan'), device=dev, dtype=torch.bfloat16)
+        db_r = torch.full(((M + 255) // 256, Vp), float('nan'), device=dev)
+        db_g = torch.zeros((M + 127) // 128 * 2, Vp, device=dev)
+        rec = torch.empty(M, 4, device=dev)
+        sd = torch.tensor([2.0], device=dev)
+        assert L.nsp_rnnt_joint_rows(2, _p(h), _p(w), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux_g[0]), _p(gb), _p(gl),
+                                     _p(db_r), _p(d_r), 0.25, _p(sd), _stream()) == 0
+        assert L.nsp_rnnt_joint_gemm(2, _p(h), _p(w), _p(bias), M, V, Vp, J, blank, _p(lab), _p(aux_g[0]), _p(gb), _p(gl),
+                                     _p(db_g), _p(d_g), 0.25, _p(sd), _p(rec), _stream()) == 0
+    want = -(0.5 * (gb + gl))[:, None] * torch.exp(logits - aux_g[0][:, None])
+    want[:, blank] += 0.5 * gb
+    want[has, lab[has].long()] += 0.5 * gl[has]
+    assert torch.isfinite(d_r.float()).all() and (d_r[:, V:] == 0).all()
+    assert (d_r[:, :V].float() - want).abs().max().item() < 1e-2 * want.abs().max().item() + 1e-6
+    assert (d_r.float() - d_g.float()).abs().max().item() <= 1e-2 * want.abs().max().item()
+    assert _rel(db_r.sum(0)[:V], want.sum(0)) < 2e-3 and _rel(db_r.sum(0), db_g.sum(0)) < 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,T,U,J,V', [(3, 21, 6, 32, 29), (4, 37, 40, 64, 43), (3, 50, 70, 96, 1000),
-                                       (5, 120, 33, 512, 1000), (2, 9, 0, 64, 130), (3, 30, 9, 128, 130), (5, 100, 33, 256, 1000)])
+                                       (5, 120, 33, 512, 1000), (2, 9, 0, 64, 130), (3, 30, 9, 128, 130), (5, 100, 33, 256, 1000),
+                                       (2, 12, 4, 128, 38000)])     # (a vocabulary whose bias does not fit beside the node-stationary kernel's ring: tiled path)
 @pytest.mark.parametrize('rows', ['1', '0'])
 def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, rows, monkeypatch):
     """The fused / compacted RNN-T joint (csrc/rnnt_fused.hip + the NSP_EPI_RNNT_* GEMM epilogues):
@@ -339,8 +400,8 @@ def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, rows, monk
     # rows = '1': J = 128 / 256 / 512 take the node-stationary kernel (nsp_rnnt_joint_rows: whole vocabulary per workgroup,
     # no partials / merge / packed records); '0' keeps every width on the tiled GEMM epilogues
     monkeypatch.setenv('NSP_RNNT_ROWS', rows)
-    if rows == '1' and J not in (128, 256, 512):
-        pytest.skip('joint width outside the node-stationary kernel: same path as rows = 0')
+    if rows == '1' and (J not in (128, 256, 512) or V > 3000):
+        pytest.skip('outside the node-stationary kernel: same path as rows = 0')
     torch.manual_seed(B * 1000 + T)
     e = (torch.randn(B, T, J, device=_dev()) * 0.7).requires_grad_()
     gq = (torch.randn(B, U + 1, J, device=_dev()) * 0.7).requires_grad_()
