@@ -217,6 +217,12 @@ int nsp_grad_prep(const float* dy, const void* pre, int pre_bf16, void* out, int
 int nsp_glu_fwd(const float* x, float* y, long long rows, int C, void* stream);
 int nsp_glu_bwd(const float* x, const float* dy, float* dx, long long rows, int C,
                 void* stream);
+/* GLU on the bf16 image the pointwise conv's GEMM epilogue writes (throughput mode; conformer_convolution.py:107-112):
+ * forward y fp32 [rows, C] from x16 bf16 [rows, 2C]; backward dx16 bf16 [rows, 2C] (the operand of the gradient GEMMs) and
+ * its column sums as slabs [nsp_grad_prep_slabs(rows), 2C] fp32, every row written (bias gradient).  C % 8 == 0;
+ * backward: C / 4 a divisor of 256. */
+int nsp_glu_fwd_b16(const void* x16, float* y, long long rows, int C, void* stream);
+int nsp_glu_bwd_b16(const void* x16, const float* dy, void* dx16, float* colsum_slabs, int rows, int C, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Attention score softmax with relative-position term and in-kernel masks. *

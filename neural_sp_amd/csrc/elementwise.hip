@@ -274,6 +274,73 @@ __global__ void glu_bwd_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
+// ---- GLU on a bf16 image (throughput mode, round 4).  The pointwise conv that feeds the GLU writes its [rows, 2C]
+// output as bf16 from the GEMM epilogue; forward reads that image (2 KB per frame instead of 4 KB of fp32) and the
+// SAME image is what backward keeps.  Backward writes d x directly as the bf16 operand of the two gradient GEMMs and
+// accumulates its column sums (the pointwise conv's bias gradient) on the way -- one slab row per block, as
+// grad_prep_colsum_kernel -- where the fp32 path ran glu_bwd (fp32 in / out) and then grad_prep_colsum over its result:
+// 16 KB -> 6 KB per frame at C = 512.
+__global__ void glu_fwd_b16_kernel(const __bf16* __restrict__ x, float* __restrict__ y, long long rows, int C) {
+  const int C8 = C >> 3;
+  const long long total = rows * C8;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / C8;
+    const int c = (int)(i % C8);
+    const bf16x8 a = reinterpret_cast<const bf16x8*>(x + r * 2 * C)[c];
+    const bf16x8 b = reinterpret_cast<const bf16x8*>(x + r * 2 * C + C)[c];
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)a[e] * nsp_sigmoid((float)b[e]);
+    float4* yp = reinterpret_cast<float4*>(y + r * C) + 2 * c;
+    yp[0] = make_float4(o[0], o[1], o[2], o[3]);
+    yp[1] = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
+// block = a band of rows; thread (row lane rl, column group tc of 4 channels) -- C / 4 <= 256 column groups
+__global__ __launch_bounds__(256) void glu_bwd_b16_colsum_kernel(
+    const __bf16* __restrict__ x, const float* __restrict__ dy, __bf16* __restrict__ dx, int rows, int C,
+    int rows_per_block, float* __restrict__ colsum) {
+  __shared__ float red[256][8];
+  const int C4 = C >> 2;
+  const int rl = threadIdx.x / C4, nrl = 256 / C4;
+  const int tc = threadIdx.x % C4;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < nrl) {
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      const long long rb = (long long)r * 2 * C;
+      const bf16x4 a = reinterpret_cast<const bf16x4*>(x + rb)[tc];
+      const bf16x4 b = reinterpret_cast<const bf16x4*>(x + rb + C)[tc];
+      const float4 g4 = reinterpret_cast<const float4*>(dy + (long long)r * C)[tc];
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+      bf16x4 da, db;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sg = nsp_sigmoid((float)b[e]);
+        const float va = g[e] * sg, vb = g[e] * (float)a[e] * sg * (1.f - sg);
+        da[e] = (__bf16)va; db[e] = (__bf16)vb;
+        acc[e] += va; acc[4 + e] += vb;
+      }
+      reinterpret_cast<bf16x4*>(dx + rb)[tc] = da;
+      reinterpret_cast<bf16x4*>(dx + rb + C)[tc] = db;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  if (rl == 0) {
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nrl; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum[e] += red[j * C4 + tc][e];
+    float* cs = colsum + (long long)blockIdx.x * 2 * C;
+    *reinterpret_cast<float4*>(cs + tc * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    *reinterpret_cast<float4*>(cs + C + tc * 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
+  }
+}
+
 // y[i] = alpha*x[i] + z[i % period]  (sinusoidal table broadcast over the batch,
 // positional_embedding.py:85-88)
 __global__ void scale_add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ z,
@@ -453,6 +520,27 @@ extern "C" int nsp_grad_prep_slabs(int rows) {
   int rpb = nsp_cdiv(rows, 1024);
   if (rpb < 8) rpb = 8;
   return nsp_cdiv(rows, rpb);
+}
+
+extern "C" int nsp_glu_fwd_b16(const void* x16, float* y, long long rows, int C, void* stream) {
+  if (rows <= 0) return NSP_OK;
+  if (C % 8 || (reinterpret_cast<uintptr_t>(x16) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return NSP_EUNSUPPORTED;
+  hipLaunchKernelGGL(glu_fwd_b16_kernel, dim3(ew_grid(rows * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     reinterpret_cast<const __bf16*>(x16), y, rows, C);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+extern "C" int nsp_glu_bwd_b16(const void* x16, const float* dy, void* dx16, float* colsum_slabs, int rows, int C,
+                               void* stream) {
+  if (rows <= 0) return NSP_OK;
+  if (C % 4 || C / 4 > 256 || 256 % (C / 4) || !colsum_slabs) return NSP_EUNSUPPORTED;
+  int rpb = nsp_cdiv(rows, 1024);
+  if (rpb < 8) rpb = 8;
+  hipLaunchKernelGGL(glu_bwd_b16_colsum_kernel, dim3(nsp_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const __bf16*>(x16), dy, reinterpret_cast<__bf16*>(dx16), rows, C, rpb, colsum_slabs);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
 }
 
 extern "C" int nsp_glu_fwd(const float* x, float* y, long long rows, int C, void* stream) {

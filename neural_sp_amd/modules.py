@@ -344,8 +344,7 @@ class ConformerConvBlock(nn.Module):
 
     def forward(self, xs, residual=None, out_dropout=0.0):
         C = xs.shape[-1]
-        h = ops.linear(xs, self.pointwise_conv1.weight, self.pointwise_conv1.bias)  # [2C,C,1] == [2C,C]
-        h = ops.glu(h)
+        h = ops.linear_glu(xs, self.pointwise_conv1.weight, self.pointwise_conv1.bias)  # [2C,C,1] == [2C,C]
         h = ops.depthwise_conv1d(h, self.depthwise_conv.weight, self.depthwise_conv.bias, self.causal)
         if isinstance(self.norm, nn.LayerNorm):
             h = ops.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act='swish')

@@ -94,6 +94,11 @@ def test_phase_interleaved_256_tile_gemm(basic, M, N, K, grid, monkeypatch):
     basic.test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch)
 
 
+@pytest.mark.parametrize('M,C', [(300, 64), (37, 256)])
+def test_linear_glu_on_the_bf16_image(basic, M, C, monkeypatch):
+    basic.test_linear_glu_on_the_bf16_image(M, C, monkeypatch)
+
+
 @pytest.mark.parametrize('M,N,K', [(1000, 384, 128), (700, 2048, 64)])
 def test_persistent_gemm_with_deferred_epilogue(basic, M, N, K, monkeypatch):
     basic.test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch)

@@ -361,6 +361,39 @@ def test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,C', [(1000, 64), (2051, 512), (37, 256)])
+def test_linear_glu_on_the_bf16_image(M, C, monkeypatch):
+    """ops.linear_glu in bf16 mode (LinearGLUFn: the pointwise conv's [M, 2C] output only ever exists as the bf16 image
+    the GEMM epilogue writes; backward's GLU kernel emits the bf16 gradient operand + bias-gradient slabs) against torch
+    on the bf16-rounded operands, and against the unfused linear + glu pair (NSP_LINEAR_GLU=0)."""
+    from neural_sp_amd import ops
+    torch.manual_seed(M + C)
+    dev = _dev()
+    x = (torch.randn(M, C, device=dev) * 0.7).requires_grad_()
+    w = torch.nn.Parameter(torch.randn(2 * C, C, 1, device=dev) / C ** 0.5)        # Conv1d(kernel 1) layout
+    b = torch.nn.Parameter(torch.randn(2 * C, device=dev) * 0.3)
+    dy = torch.randn(M, C, device=dev)
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('NSP_LINEAR_GLU', mode)
+        with ops.compute_mode('bf16'):
+            y = ops.linear_glu(x, w, b)
+            assert y.grad_fn.__class__.__name__.startswith('LinearGLUFn' if mode == '1' else 'GLUFn')
+            outs[mode] = (y.detach(),) + torch.autograd.grad(y, (x, w, b), dy)
+    xr = x.detach().bfloat16().float().requires_grad_()
+    wr = w.detach().bfloat16().float().requires_grad_()
+    br = b.detach().clone().requires_grad_()
+    h = xr @ wr[:, :, 0].t() + br
+    yr = h[:, :C] * torch.sigmoid(h[:, C:])
+    ref = (yr.detach(),) + torch.autograd.grad(yr, (xr, wr, br), dy)
+    for a, r, name in zip(outs['1'], ref, ('y', 'dx', 'dw', 'db')):
+        assert a.shape == r.shape, name
+        assert _rel(a, r) < 2e-2, name
+    for a, u, name in zip(outs['1'], outs['0'], ('y', 'dx', 'dw', 'db')):
+        assert _rel(a, u) < 2e-2, name
+
+
+@pytest.mark.gpu
 def test_phase_interleaved_gemm_with_an_operand_beyond_4_gb(monkeypatch):
     """The RNN-T joint's data gradient reads a [3.6 M, 1024] bf16 operand (7.4 GB): the 8-phase kernel addresses A with a
     scalar base per tile + 32-bit lane offsets.  2.2 M x 1024 (4.5 GB) x a [512, 1024] weight with the tanh' epilogue,
