@@ -167,6 +167,12 @@ int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                       const float* mean, const float* rstd, const float* y_pre,
                       const float* dres, float* dx, float* dgamma, float* dbeta,
                       int rows, int d, int act, void* stream);
+/* the same with the pre-activation RECOMPUTED as xhat * gamma + beta from the operands the pass reads anyway: forward
+ * then needs to store neither y_pre nor (when only a GEMM consumes the bf16 image) the fp32 output
+ * (conformer_convolution.py:119-124 in throughput mode) */
+int nsp_layernorm_bwd_recompute(const float* dy, const float* x, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, const float* dres, float* dx,
+                                float* dgamma, float* dbeta, int rows, int d, int act, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Elementwise helpers (vectorised, grid-stride).                           *

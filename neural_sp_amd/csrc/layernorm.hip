@@ -75,18 +75,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ y_pre,
     const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int rows, int d, int act) {
+    float* __restrict__ dbeta, int rows, int d, int act, const float* __restrict__ beta_re) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][4][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int d4 = d >> 2;
   const float inv_d = 1.f / (float)d;
-  float4 dg[VPL], db[VPL], gm[VPL];
+  float4 dg[VPL], db[VPL], gm[VPL], bt[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     int c = lane + i * 64;
     gm[i] = c < d4 ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // beta_re: the pre-activation y_pre = xhat gamma + beta is RECOMPUTED from what this kernel reads anyway
+    // (nsp_layernorm_bwd_recompute: forward then stores neither the fp32 output nor the pre-activation)
+    bt[i] = (beta_re && c < d4) ? reinterpret_cast<const float4*>(beta_re)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // software pipeline over the wave's rows: the loads of row r+1 are in flight while row r is
   // reduced and stored (a wave's rows were strictly serial before: load -> 2 wave reductions ->
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     nrs = rstd[r];
     const float4* xr = reinterpret_cast<const float4*>(x + r * d);
     const float4* gr = reinterpret_cast<const float4*>(dy + r * d);
-    const float4* pr = (act != NSP_ACT_NONE) ? reinterpret_cast<const float4*>(y_pre + r * d) : nullptr;
+    const float4* pr = (act != NSP_ACT_NONE && y_pre) ? reinterpret_cast<const float4*>(y_pre + r * d) : nullptr;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + i * 64;
@@ -127,12 +130,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       if (c < d4) {
         float4 xv = xv_[i];
         float4 gv = gv_[i];
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         if (act != NSP_ACT_NONE) {
-          float4 p = pv_[i];
+          float4 p;
+          if (y_pre) p = pv_[i];
+          else p = make_float4(fmaf(xh[i].x, gm[i].x, bt[i].x), fmaf(xh[i].y, gm[i].y, bt[i].y),
+                               fmaf(xh[i].z, gm[i].z, bt[i].z), fmaf(xh[i].w, gm[i].w, bt[i].w));
           gv.x *= nsp_dact(p.x, act); gv.y *= nsp_dact(p.y, act);
           gv.z *= nsp_dact(p.z, act); gv.w *= nsp_dact(p.w, act);
         }
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         db[i].x += gv.x; db[i].y += gv.y; db[i].z += gv.z; db[i].w += gv.w;
         dg[i].x += gv.x * xh[i].x; dg[i].y += gv.y * xh[i].y;
         dg[i].z += gv.z * xh[i].z; dg[i].w += gv.w * xh[i].w;
@@ -204,19 +210,36 @@ extern "C" int nsp_layernorm_fwd(const float* x, const float* gamma, const float
   return NSP_OK;
 }
 
+static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         const float* y_pre, const float* beta_re, const float* dres, float* dx, float* dgamma,
+                         float* dbeta, int rows, int d, int act, void* stream);
+
 extern "C" int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, const float* y_pre,
                                  const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
                                  int d, int act, void* stream) {
-  if (d % 4 || d > 2048 || rows <= 0) return NSP_EUNSUPPORTED;
   if (act != NSP_ACT_NONE && !y_pre) return NSP_EINVAL;
+  return ln_bwd_launch(dy, x, gamma, mean, rstd, y_pre, nullptr, dres, dx, dgamma, dbeta, rows, d, act, stream);
+}
+
+extern "C" int nsp_layernorm_bwd_recompute(const float* dy, const float* x, const float* gamma, const float* beta,
+                                           const float* mean, const float* rstd, const float* dres, float* dx,
+                                           float* dgamma, float* dbeta, int rows, int d, int act, void* stream) {
+  if (!beta) return NSP_EINVAL;
+  return ln_bwd_launch(dy, x, gamma, mean, rstd, nullptr, beta, dres, dx, dgamma, dbeta, rows, d, act, stream);
+}
+
+static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         const float* y_pre, const float* beta_re, const float* dres, float* dx, float* dgamma,
+                         float* dbeta, int rows, int d, int act, void* stream) {
+  if (d % 4 || d > 2048 || rows <= 0) return NSP_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   int grid = nsp_cdiv(rows, 4 * 8);  // >= 8 rows per wave to amortise the column atomics
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
   const size_t shmem = sizeof(float) * 8 * d;
   const int vpl = nsp_cdiv(d, 256);
-#define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), shmem, st, dy, x, gamma, mean, rstd, y_pre, dres, dx, dgamma, dbeta, rows, d, act)
+#define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), shmem, st, dy, x, gamma, mean, rstd, y_pre, dres, dx, dgamma, dbeta, rows, d, act, beta_re)
   if (vpl <= 1) LN_BWD(1);
   else if (vpl <= 2) LN_BWD(2);
   else if (vpl <= 4) LN_BWD(4);

@@ -347,7 +347,7 @@ class ConformerConvBlock(nn.Module):
         h = ops.linear_glu(xs, self.pointwise_conv1.weight, self.pointwise_conv1.bias)  # [2C,C,1] == [2C,C]
         h = ops.depthwise_conv1d(h, self.depthwise_conv.weight, self.depthwise_conv.bias, self.causal)
         if isinstance(self.norm, nn.LayerNorm):
-            h = ops.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act='swish')
+            h = ops.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act='swish', gemm_only=True)
         elif isinstance(self.norm, nn.BatchNorm1d):
             # "time-independent normalization" on the [B*T, C, 1] view (:119-122): one row per frame
             h = ops.batch_norm_act(h, self.norm, self.training, act='swish')

@@ -630,43 +630,55 @@ def layernorm_fwd_raw(x2d, gamma, beta, eps, act=0, want_pre=False, want16=False
     return y, mean, rstd, y_pre, y16
 
 
-def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0, dres=None):
+def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0, dres=None, beta_recompute=None):
+    """beta_recompute (with y_pre None): the activation's pre-image is recomputed inside the kernel as xhat gamma + beta"""
     rows, d = x2d.shape
     dx = torch.empty_like(x2d)
     dgb = zeros_small((2, d), x2d.device)
     nbytes = rows * d * (12 + (4 if y_pre is not None else 0) + (4 if dres is not None else 0))     # dy, x, dx (+ pre-activation, residual gradient)
     with _kev_class('layernorm_bwd', nbytes, 'byte'):
-        _check(_lib.lib().nsp_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(y_pre), _p(dres),
-                                            _p(dx), (dgb.data_ptr()),
-                                            (dgb.data_ptr() + 4 * d),
-                                            (rows), (d), (act),
-                                            _stream()), 'nsp_layernorm_bwd')
+        if beta_recompute is not None and y_pre is None and act != 0:
+            _check(_lib.lib().nsp_layernorm_bwd_recompute(_p(dy2d), _p(x2d), _p(gamma), _p(beta_recompute), _p(mean), _p(rstd),
+                                                          _p(dres), _p(dx), (dgb.data_ptr()), (dgb.data_ptr() + 4 * d),
+                                                          (rows), (d), (act), _stream()), 'nsp_layernorm_bwd_recompute')
+        else:
+            _check(_lib.lib().nsp_layernorm_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(y_pre), _p(dres),
+                                                _p(dx), (dgb.data_ptr()),
+                                                (dgb.data_ptr() + 4 * d),
+                                                (rows), (d), (act),
+                                                _stream()), 'nsp_layernorm_bwd')
     return dx, dgb[0], dgb[1]
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, act):
+    def forward(ctx, x, gamma, beta, eps, act, gemm_only=False):
         x2d = _f32c(x).reshape(-1, x.shape[-1])
         want16 = bf16_mode() and x2d.shape[1] % 8 == 0
-        y, mean, rstd, y_pre, y16 = layernorm_fwd_raw(x2d, gamma, beta, eps, act, want_pre=True, want16=want16)
-        ctx.save_for_backward(x2d, gamma, mean, rstd, y_pre)
+        # gemm_only (the caller's promise: the result is read by a GEMM and nothing else -- the Conformer conv module's
+        # LayerNorm + Swish in front of its second pointwise conv): in throughput mode only the bf16 image is written,
+        # 2 of the kernel's 14 bytes per element; the fp32 output is a stride-0 NaN (see LayerNormSplitFn) and the
+        # activation's pre-image is recomputed in backward from xhat, gamma, beta instead of stored
+        lean = bool(gemm_only) and want16 and act != 0 and os.environ.get('NSP_LN_SKIP32', '1') != '0'
+        y, mean, rstd, y_pre, y16 = layernorm_fwd_raw(x2d, gamma, beta, eps, act, want_pre=not lean, want16=want16,
+                                                      want32=not lean)
+        ctx.save_for_backward(x2d, gamma, mean, rstd, y_pre, beta if lean else None)
         ctx.act = act
-        out = y.view(x.shape)
+        out = _nan_scalar(x.device).expand(x.shape).view(x.shape) if lean else y.view(x.shape)
         if y16 is not None:
             out._nsp16 = y16  # bf16 shadow [rows, d] for the consuming GEMM (saves its cast pass)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x2d, gamma, mean, rstd, y_pre = ctx.saved_tensors
+        x2d, gamma, mean, rstd, y_pre, beta_re = ctx.saved_tensors
         dy2d = _f32c(dy).reshape(x2d.shape)
-        dx, dg, db = layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, ctx.act)
-        return dx.view(dy.shape), dg, db, None, None
+        dx, dg, db = layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, ctx.act, beta_recompute=beta_re)
+        return dx.view(dy.shape), dg, db, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-12, act='none'):
-    return LayerNormFn.apply(x, gamma, beta, eps, ACT[act] if not isinstance(act, int) else act)
+def layer_norm(x, gamma, beta, eps=1e-12, act='none', gemm_only=False):
+    return LayerNormFn.apply(x, gamma, beta, eps, ACT[act] if not isinstance(act, int) else act, gemm_only)
 
 
 class LayerNormSplitFn(torch.autograd.Function):
@@ -2919,8 +2931,18 @@ class SelfAttnFn(torch.autograd.Function):
         if pos_in is not None:
             R = pos_in.shape[0]
             Rp = _r8(R)
-            pe16 = torch.zeros((Rp, d), device=dev, dtype=torch.bfloat16)  # rows >= R stay zero
-            pe16[:R] = to_bf16(_f32c(pos_in))
+            # the zero-padded bf16 image of the position table is shared by every layer that receives this table
+            # object in this forward (12 blocks x {fill, cast, copy} per step otherwise)
+            ent = getattr(pos_in, '_nsp_pe16', None)
+            if ent is not None and ent[0] == (pos_in._version, Rp) and ent[1].device == dev:
+                pe16 = ent[1]
+            else:
+                pe16 = torch.zeros((Rp, d), device=dev, dtype=torch.bfloat16)  # rows >= R stay zero
+                pe16[:R] = to_bf16(_f32c(pos_in))
+                try:
+                    pos_in._nsp_pe16 = ((pos_in._version, Rp), pe16)
+                except Exception:
+                    pass
             pos16 = torch.empty((Rp, d), device=dev, dtype=torch.bfloat16)
             gemm_raw(Rp, d, d, pe16, d, 1, weight_bf16(w_pos), 1, d, pos16, d)
             QP = torch.empty((B, T, H, Rp), device=dev, dtype=torch.float32)

@@ -49,7 +49,7 @@ def _ffn(x, w1, b1, w2, b2, act, p_h=0.0, res=None, alpha=1.0, p_o=0.0):
     return _linear(_linear(x, w1, b1, act), w2, b2, res=res, alpha=alpha)
 
 
-def _layer_norm(x, gamma, beta, eps=1e-12, act='none'):
+def _layer_norm(x, gamma, beta, eps=1e-12, act='none', gemm_only=False):
     return _act(F.layer_norm(x, (x.shape[-1],), gamma, beta, eps), act)
 
 

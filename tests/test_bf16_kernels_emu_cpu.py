@@ -94,6 +94,11 @@ def test_phase_interleaved_256_tile_gemm(basic, M, N, K, grid, monkeypatch):
     basic.test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch)
 
 
+@pytest.mark.parametrize('rows,d', [(70, 256)])
+def test_layer_norm_swish_for_a_gemm_only_consumer(basic, rows, d):
+    basic.test_layer_norm_swish_for_a_gemm_only_consumer(rows, d)
+
+
 @pytest.mark.parametrize('M,C', [(300, 64), (37, 256)])
 def test_linear_glu_on_the_bf16_image(basic, M, C, monkeypatch):
     basic.test_linear_glu_on_the_bf16_image(M, C, monkeypatch)

@@ -361,6 +361,36 @@ def test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('rows,d', [(333, 512), (70, 256)])
+def test_layer_norm_swish_for_a_gemm_only_consumer(rows, d):
+    """ops.layer_norm(act='swish', gemm_only=True) in bf16 mode: forward writes only the bf16 image (the fp32-typed result
+    is a NaN placeholder that a linear layer never reads), backward recomputes the Swish pre-image from xhat, gamma,
+    beta (nsp_layernorm_bwd_recompute) -- against torch through the consuming linear layer."""
+    from neural_sp_amd import ops
+    torch.manual_seed(rows)
+    dev = _dev()
+    x = (torch.randn(rows, d, device=dev) * 2 + 0.3).requires_grad_()
+    g = torch.nn.Parameter(torch.rand(d, device=dev) + 0.5)
+    b = torch.nn.Parameter(torch.randn(d, device=dev) * 0.2)
+    w = torch.nn.Parameter(torch.randn(64, d, device=dev) / d ** 0.5)
+    dy = torch.randn(rows, 64, device=dev)
+    with ops.compute_mode('bf16'):
+        h = ops.layer_norm(x, g, b, 1e-12, act='swish', gemm_only=True)
+        assert torch.isnan(h).all() and h._nsp16.dtype == torch.bfloat16
+        y = ops.linear(h, w)
+        got = (y.detach(), h._nsp16.float()) + torch.autograd.grad(y, (x, g, b), dy)
+    xr = x.detach().clone().requires_grad_()
+    gr = g.detach().clone().requires_grad_()
+    br = b.detach().clone().requires_grad_()
+    z = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-12)
+    hr = z * torch.sigmoid(z)
+    yr = hr @ w.detach().t()
+    ref = (yr.detach(), hr.detach()) + torch.autograd.grad(yr, (xr, gr, br), dy)
+    for a, r, name in zip(got, ref, ('y', 'h16', 'dx', 'dgamma', 'dbeta')):
+        assert _rel(a, r) < 2e-2, name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('M,C', [(1000, 64), (2051, 512), (37, 256)])
 def test_linear_glu_on_the_bf16_image(M, C, monkeypatch):
     """ops.linear_glu in bf16 mode (LinearGLUFn: the pointwise conv's [M, 2C] output only ever exists as the bf16 image
