@@ -170,6 +170,13 @@ int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
 /* the same with the pre-activation RECOMPUTED as xhat * gamma + beta from the operands the pass reads anyway: forward
  * then needs to store neither y_pre nor (when only a GEMM consumes the bf16 image) the fp32 output
  * (conformer_convolution.py:119-124 in throughput mode) */
+/* act = none, plus the "prepared" image of dx for the backward of the Linear whose output x is: g16 bf16 [rows, d] =
+ * g_alpha * dx * dropout_keep(g_seed, g_offset + element index, g_p) (the mask that Linear's epilogue applied in
+ * forward) and its column sums ACCUMULATED into gsum [d] (fp32, zeroed by the caller).  d % 8 == 0. */
+int nsp_layernorm_bwd_prep(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                           const float* dres, float* dx, float* dgamma, float* dbeta, void* g16, float* gsum,
+                           float g_alpha, float g_p, unsigned long long g_seed, unsigned long long g_offset,
+                           int rows, int d, void* stream);
 int nsp_layernorm_bwd_recompute(const float* dy, const float* x, const float* gamma, const float* beta,
                                 const float* mean, const float* rstd, const float* dres, float* dx,
                                 float* dgamma, float* dbeta, int rows, int d, int act, void* stream);

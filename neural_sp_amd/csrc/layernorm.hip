@@ -70,19 +70,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-template <int VPL>
+// PREP (round 4): dx is the gradient of the residual stream at the point between two sub-blocks, and the sub-block in
+// front of it needs exactly one thing from it for its last linear layer's backward: g = alpha * dx * dropout_mask as the
+// bf16 operand of the gradient GEMMs, plus its column sums (bias gradient).  That was a separate pass over dx
+// (grad_prep_colsum: 4 B read + 2 B written per element, 52 launches per step); here it is two more bytes written while
+// dx is still in registers.
+template <int VPL, bool PREP = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ y_pre,
     const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int rows, int d, int act, const float* __restrict__ beta_re) {
+    float* __restrict__ dbeta, int rows, int d, int act, const float* __restrict__ beta_re,
+    __bf16* __restrict__ g16 = nullptr, float* __restrict__ gsum = nullptr, float g_alpha = 1.f, float g_p = 0.f,
+    unsigned long long g_seed = 0ull, unsigned long long g_offset = 0ull) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][4][d]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int d4 = d >> 2;
   const float inv_d = 1.f / (float)d;
-  float4 dg[VPL], db[VPL], gm[VPL], bt[VPL];
+  float4 dg[VPL], db[VPL], gm[VPL], bt[VPL], gs[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
+    gs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     int c = lane + i * 64;
@@ -161,6 +169,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
                                rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
         if (dres) { o.x += rv_[i].x; o.y += rv_[i].y; o.z += rv_[i].z; o.w += rv_[i].w; }
         dxr[c] = o;
+        if constexpr (PREP) {
+          float kp[4];
+          nsp_keep_scale4(g_seed, g_offset + (unsigned long long)(row * d + 4ll * c), g_p, kp);   // (p = 0: keeps everything, scale 1)
+          const float q0 = o.x * g_alpha * kp[0], q1 = o.y * g_alpha * kp[1], q2 = o.z * g_alpha * kp[2], q3 = o.w * g_alpha * kp[3];
+          bf16x4 h;
+          h[0] = (__bf16)q0; h[1] = (__bf16)q1; h[2] = (__bf16)q2; h[3] = (__bf16)q3;
+          reinterpret_cast<bf16x4*>(g16 + row * d)[c] = h;
+          gs[i].x += q0; gs[i].y += q1; gs[i].z += q2; gs[i].w += q3;
+        }
       }
     }
   }
@@ -185,6 +202,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     }
     unsafeAtomicAdd(dgamma + c, a);
     unsafeAtomicAdd(dbeta + c, b);
+  }
+  if constexpr (PREP) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      int c = lane + i * 64;
+      if (c < d4) shg[w * d4 + c] = gs[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+      float a = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) a += sh[ww * d + c];
+      unsafeAtomicAdd(gsum + c, a);
+    }
   }
 }
 
@@ -212,7 +244,9 @@ extern "C" int nsp_layernorm_fwd(const float* x, const float* gamma, const float
 
 static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                          const float* y_pre, const float* beta_re, const float* dres, float* dx, float* dgamma,
-                         float* dbeta, int rows, int d, int act, void* stream);
+                         float* dbeta, int rows, int d, int act, void* stream, void* g16 = nullptr, float* gsum = nullptr,
+                         float g_alpha = 1.f, float g_p = 0.f, unsigned long long g_seed = 0ull,
+                         unsigned long long g_offset = 0ull);
 
 extern "C" int nsp_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, const float* y_pre,
@@ -229,9 +263,20 @@ extern "C" int nsp_layernorm_bwd_recompute(const float* dy, const float* x, cons
   return ln_bwd_launch(dy, x, gamma, mean, rstd, nullptr, beta, dres, dx, dgamma, dbeta, rows, d, act, stream);
 }
 
+extern "C" int nsp_layernorm_bwd_prep(const float* dy, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                                      void* g16, float* gsum, float g_alpha, float g_p, unsigned long long g_seed,
+                                      unsigned long long g_offset, int rows, int d, void* stream) {
+  if (!g16 || !gsum || d % 8 || (reinterpret_cast<uintptr_t>(g16) & 7)) return NSP_EINVAL;
+  if (g_p < 0.f || g_p >= 1.f) return NSP_EINVAL;
+  return ln_bwd_launch(dy, x, gamma, mean, rstd, nullptr, nullptr, dres, dx, dgamma, dbeta, rows, d, NSP_ACT_NONE, stream,
+                       g16, gsum, g_alpha, g_p, g_seed, g_offset);
+}
+
 static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                          const float* y_pre, const float* beta_re, const float* dres, float* dx, float* dgamma,
-                         float* dbeta, int rows, int d, int act, void* stream) {
+                         float* dbeta, int rows, int d, int act, void* stream, void* g16, float* gsum, float g_alpha,
+                         float g_p, unsigned long long g_seed, unsigned long long g_offset) {
   if (d % 4 || d > 2048 || rows <= 0) return NSP_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   int grid = nsp_cdiv(rows, 4 * 8);  // >= 8 rows per wave to amortise the column atomics
@@ -240,11 +285,18 @@ static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, co
   const size_t shmem = sizeof(float) * 8 * d;
   const int vpl = nsp_cdiv(d, 256);
 #define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), shmem, st, dy, x, gamma, mean, rstd, y_pre, dres, dx, dgamma, dbeta, rows, d, act, beta_re)
-  if (vpl <= 1) LN_BWD(1);
+#define LN_BWDP(V) hipLaunchKernelGGL((ln_bwd_kernel<V, true>), dim3(grid), dim3(256), shmem, st, dy, x, gamma, mean, rstd, y_pre, dres, dx, dgamma, dbeta, rows, d, act, beta_re, reinterpret_cast<__bf16*>(g16), gsum, g_alpha, g_p, g_seed, g_offset)
+  if (g16) {
+    if (vpl <= 1) LN_BWDP(1);
+    else if (vpl <= 2) LN_BWDP(2);
+    else if (vpl <= 4) LN_BWDP(4);
+    else LN_BWDP(8);
+  } else if (vpl <= 1) LN_BWD(1);
   else if (vpl <= 2) LN_BWD(2);
   else if (vpl <= 4) LN_BWD(4);
   else LN_BWD(8);
 #undef LN_BWD
+#undef LN_BWDP
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

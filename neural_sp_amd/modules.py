@@ -208,11 +208,12 @@ class RelativeMultiheadAttentionMechanism(nn.Module):
             w_pos = self.w_pos if self.xl_like else self.w_value
             cfg = mask.cfg() if mask is not None else {}
             cfg.update(H=H, clamp=self.clamp_len, dropout=self.dropout_attn_p, training=self.training)
-            return ops.SelfAttnFn.apply(key, self.w_query.weight, self.w_key.weight, self.w_value.weight,
-                                        self.w_query.bias, self.w_key.bias, self.w_value.bias,
-                                        self.w_out.weight, self.w_out.bias, pe[:R], w_pos.weight,
-                                        mask.klens if mask is not None else None, cfg, residual,
-                                        out_dropout if self.training else 0.0)
+            cv, aw = ops.SelfAttnFn.apply(key, self.w_query.weight, self.w_key.weight, self.w_value.weight,
+                                          self.w_query.bias, self.w_key.bias, self.w_value.bias,
+                                          self.w_out.weight, self.w_out.bias, pe[:R], w_pos.weight,
+                                          mask.klens if mask is not None else None, cfg, residual,
+                                          out_dropout if self.training else 0.0)
+            return ops.tag_prep(cv), aw
         k = ops.linear(key, self.w_key.weight, self.w_key.bias).view(bs, klen, H, dk)
         v = ops.linear(key, self.w_value.weight, self.w_value.bias).view(bs, klen, H, dk)
         q = ops.linear(key, self.w_query.weight, self.w_query.bias).view(bs, qlen, H, dk)
@@ -282,7 +283,7 @@ class MultiheadAttentionMechanism(nn.Module):
                                           self.w_out.weight, self.w_out.bias, None, None,
                                           mask.klens if mask is not None else None, cfg, residual,
                                           out_dropout if self.training else 0.0)
-            return cv, aw, {}
+            return ops.tag_prep(cv), aw, {}
         k = ops.linear(key, self.w_key.weight, self.w_key.bias).view(bs, klen, H, dk)
         v = ops.linear(value, self.w_value.weight, self.w_value.bias).view(bs, klen, H, dk)
         q = ops.linear(query, self.w_query.weight, self.w_query.bias).view(bs, qlen, H, dk)

@@ -95,6 +95,48 @@ def zeros_small(shape, device, dtype=torch.float32):
     return ent[0][off:off + n * (4 if dtype == torch.float32 else 2)].view(dtype).view(shape)
 
 
+# ---- residual-gradient hand-over (round 4).  In a pre-norm block  y = res + dropout(alpha * Linear(h)),  z = LN(y), ...  the
+# gradient of y is produced by the LayerNorm backward kernel of the NEXT sub-block, and the first thing the Linear's
+# backward does with it is a pass that scales it, re-applies the dropout mask and rounds it to the bf16 operand of its
+# gradient GEMMs (grad_prep_colsum: 52 launches, 2.6 ms per step).  The Linear's forward therefore OFFERS what that pass
+# needs (alpha, p, seed, offset) on its output tensor; a LayerNorm whose input carries an offer makes its backward
+# kernel write the prepared image as well (nsp_layernorm_bwd_prep) and leaves it here under the offer's token; the
+# Linear's backward takes it if the gradient it receives is that very tensor (same storage: nothing was accumulated
+# into it on the way) and falls back to grad_prep otherwise.
+_PREP = {}             # token -> (data_ptr of dx, g16 [rows, N] bf16, gsum [N] fp32)
+_PREP_TOKEN = [0]
+_LAST_PREP = [None]
+_PREP_STATS = {'made': 0, 'taken': 0}     # (tests: how many hand-overs the LayerNorm kernels made / the Linears took)
+
+
+def _prep_offer(ok, alpha, p, seed, offset, N):
+    if not (ok and bf16_mode() and N % 8 == 0 and os.environ.get('NSP_LN_PREP', '1') != '0'):
+        _LAST_PREP[0] = None
+        return None
+    _PREP_TOKEN[0] += 1
+    _LAST_PREP[0] = (_PREP_TOKEN[0], float(alpha), float(p), int(seed), int(offset), int(N))
+    return _PREP_TOKEN[0]
+
+
+def tag_prep(y):
+    """put the offer of the Function that has just produced y on y (call right after .apply)"""
+    lp, _LAST_PREP[0] = _LAST_PREP[0], None
+    if lp is not None and torch.is_tensor(y) and y.shape[-1] == lp[5]:
+        try:
+            y._nsp_prep = lp
+        except Exception:
+            pass
+    return y
+
+
+def _prep_take(token, dy2d):
+    ent = _PREP.pop(token, None) if token is not None else None
+    if ent is not None and ent[0] == dy2d.data_ptr() and tuple(ent[1].shape) == tuple(dy2d.shape):
+        _PREP_STATS['taken'] += 1
+        return ent[1], ent[2]
+    return None
+
+
 def h2d(x, device, dtype=None):
     """Host data (numpy array / list / CPU tensor) -> device tensor through a PINNED staging block,
     asynchronously on the current stream.  A pageable-memory copy blocks the host until everything
@@ -233,6 +275,7 @@ def optimizer_stepped():
     does the same; code that drives ops.linear / ops.LSTMStackFn directly with a FUSED optimizer (which does not move
     Parameter._version) calls this after optimizer.step() -- or lets `track_optimizer(optimizer)` do it."""
     _WEIGHT_EPOCH[0] += 1
+    _PREP.clear()
 
 
 def track_optimizer(optimizer):
@@ -248,6 +291,7 @@ def refresh_weight_shadows(force=False):
     parameters' version counters say (see _wkey)."""
     if force:
         _WEIGHT_EPOCH[0] += 1
+        _PREP.clear()        # (hand-overs nobody took: a backward that was never run)
     if not _SHADOWS or not bf16_mode():
         return
     stale, dead = {}, []
@@ -488,6 +532,7 @@ class LinearFn(torch.autograd.Function):
         y = linear_fwd(xa, weight, bias, act, res2d, alpha, pre_out=pre,
                        dropout_p=dropout_p, seed=seed, offset=offset)
         ctx.save_for_backward(xa, weight, pre)
+        ctx.prep_token = _prep_offer(res is not None and use16 and act == 0, alpha, dropout_p, seed, offset, N)
         ctx.act, ctx.alpha = act, alpha
         ctx.mode = get_compute_mode()      # backward runs in the mode of its forward (nested compute_mode blocks)
         ctx.drop = (dropout_p, seed, offset)
@@ -506,11 +551,16 @@ class LinearFn(torch.autograd.Function):
         # roundup8(N) columns and the padded rows / entries of dW / db are dropped below
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         with compute_mode(ctx.mode):
-            g = grad_prep(dy2d, pre, ctx.act, ctx.alpha, p, seed, offset, xa.dtype == torch.bfloat16, want_colsum=want_db)
+            got = _prep_take(getattr(ctx, 'prep_token', None), dy2d)
             dx = dw = db = None
-            if want_db:
-                g, db = g
-                db = db[:N]
+            if got is not None:          # the LayerNorm backward that produced dy has prepared it already
+                g, db = got
+                db = db[:N] if want_db else None
+            else:
+                g = grad_prep(dy2d, pre, ctx.act, ctx.alpha, p, seed, offset, xa.dtype == torch.bfloat16, want_colsum=want_db)
+                if want_db:
+                    g, db = g
+                    db = db[:N]
             if ctx.needs_input_grad[0]:
                 dx = linear_dgrad(g, weight)[:, :ctx.xshape[-1]].reshape(ctx.xshape)
             if ctx.needs_input_grad[1]:
@@ -519,8 +569,8 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None, act='none', res=None, alpha=1.0, dropout_p=0.0):
-    return LinearFn.apply(x, weight, bias, ACT[act] if not isinstance(act, int) else act, res,
-                          float(alpha), float(dropout_p))
+    return tag_prep(LinearFn.apply(x, weight, bias, ACT[act] if not isinstance(act, int) else act, res,
+                                   float(alpha), float(dropout_p)))
 
 
 def dropout_raw(x, p, seed, offset, alpha=1.0):
@@ -630,14 +680,26 @@ def layernorm_fwd_raw(x2d, gamma, beta, eps, act=0, want_pre=False, want16=False
     return y, mean, rstd, y_pre, y16
 
 
-def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0, dres=None, beta_recompute=None):
-    """beta_recompute (with y_pre None): the activation's pre-image is recomputed inside the kernel as xhat gamma + beta"""
+def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0, dres=None, beta_recompute=None, prep=None):
+    """beta_recompute (with y_pre None): the activation's pre-image is recomputed inside the kernel as xhat gamma + beta.
+    prep = an offer (token, alpha, p, seed, offset, N) carried by the LayerNorm's input (see _PREP): the kernel also
+    writes the prepared bf16 image of dx and its column sums, left in _PREP under the token."""
     rows, d = x2d.shape
     dx = torch.empty_like(x2d)
     dgb = zeros_small((2, d), x2d.device)
-    nbytes = rows * d * (12 + (4 if y_pre is not None else 0) + (4 if dres is not None else 0))     # dy, x, dx (+ pre-activation, residual gradient)
+    use_prep = prep is not None and act == 0 and prep[5] == d and d % 8 == 0 and bf16_mode()
+    nbytes = rows * d * (12 + (4 if y_pre is not None else 0) + (4 if dres is not None else 0) + (2 if use_prep else 0))     # dy, x, dx (+ pre-activation, residual gradient, prepared image)
     with _kev_class('layernorm_bwd', nbytes, 'byte'):
-        if beta_recompute is not None and y_pre is None and act != 0:
+        if use_prep:
+            g16 = torch.empty((rows, d), device=x2d.device, dtype=torch.bfloat16)
+            gsum = zeros_small((d,), x2d.device)
+            _check(_lib.lib().nsp_layernorm_bwd_prep(_p(dy2d), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+                                                     (dgb.data_ptr()), (dgb.data_ptr() + 4 * d), _p(g16), _p(gsum),
+                                                     prep[1], prep[2], prep[3], prep[4], (rows), (d), _stream()),
+                   'nsp_layernorm_bwd_prep')
+            _PREP[prep[0]] = (dx.data_ptr(), g16, gsum)
+            _PREP_STATS['made'] += 1
+        elif beta_recompute is not None and y_pre is None and act != 0:
             _check(_lib.lib().nsp_layernorm_bwd_recompute(_p(dy2d), _p(x2d), _p(gamma), _p(beta_recompute), _p(mean), _p(rstd),
                                                           _p(dres), _p(dx), (dgb.data_ptr()), (dgb.data_ptr() + 4 * d),
                                                           (rows), (d), (act), _stream()), 'nsp_layernorm_bwd_recompute')
@@ -664,6 +726,7 @@ class LayerNormFn(torch.autograd.Function):
                                                       want32=not lean)
         ctx.save_for_backward(x2d, gamma, mean, rstd, y_pre, beta if lean else None)
         ctx.act = act
+        ctx.prep = getattr(x, '_nsp_prep', None) if act == 0 else None
         out = _nan_scalar(x.device).expand(x.shape).view(x.shape) if lean else y.view(x.shape)
         if y16 is not None:
             out._nsp16 = y16  # bf16 shadow [rows, d] for the consuming GEMM (saves its cast pass)
@@ -673,7 +736,7 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2d, gamma, mean, rstd, y_pre, beta_re = ctx.saved_tensors
         dy2d = _f32c(dy).reshape(x2d.shape)
-        dx, dg, db = layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, ctx.act, beta_recompute=beta_re)
+        dx, dg, db = layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, ctx.act, beta_recompute=beta_re, prep=ctx.prep)
         return dx.view(dy.shape), dg, db, None, None, None
 
 
@@ -698,6 +761,7 @@ class LayerNormSplitFn(torch.autograd.Function):
         skip32 = want16 and os.environ.get('NSP_LN_SKIP32', '1') != '0'
         y, mean, rstd, _, y16 = layernorm_fwd_raw(x2d, gamma, beta, eps, 0, want_pre=False, want16=want16, want32=not skip32)
         ctx.save_for_backward(x2d, gamma, mean, rstd)
+        ctx.prep = getattr(x, '_nsp_prep', None)
         if skip32:
             out = _nan_scalar(x.device).expand(x.shape)
             out = out.view(x.shape)
@@ -714,7 +778,7 @@ class LayerNormSplitFn(torch.autograd.Function):
             return dres, None, None, None
         dy2d = _f32c(dy).reshape(x2d.shape)
         r2d = _f32c(dres).reshape(x2d.shape) if dres is not None else None
-        dx, dg, db = layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, None, 0, dres=r2d)
+        dx, dg, db = layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, None, 0, dres=r2d, prep=ctx.prep)
         return dx.view(dy.shape), dg, db, None
 
 
@@ -2809,6 +2873,7 @@ class FFNFn(torch.autograd.Function):
         res2d = _f32c(res).reshape(-1, N) if res is not None else None
         y = linear_fwd(h, w2, b2, 0, res2d, alpha, dropout_p=p_o, seed=s2[0], offset=s2[1])
         ctx.save_for_backward(xa, w1, w2, pre, h)
+        ctx.prep_token = _prep_offer(res is not None and use16, alpha, p_o, s2[0], s2[1], N)
         ctx.cfg = (act, p_h, s1, alpha, p_o, s2, res is not None, x.shape, use16)
         return y.view(*x.shape[:-1], N)
 
@@ -2820,7 +2885,11 @@ class FFNFn(torch.autograd.Function):
         dy2d = _f32c(dy).reshape(-1, N)
         # both bias gradients ride in the kernels that produce their operands: db2 inside grad_prep,
         # db1 as column-sum slabs of the data-gradient GEMM's epilogue (no pass over g2 / d(pre))
-        g2, db2 = grad_prep(dy2d, None, 0, alpha, p_o, s2[0], s2[1], use16, want_colsum=True)
+        got = _prep_take(getattr(ctx, 'prep_token', None), dy2d)
+        if got is not None:
+            g2, db2 = got
+        else:
+            g2, db2 = grad_prep(dy2d, None, 0, alpha, p_o, s2[0], s2[1], use16, want_colsum=True)
         dw2 = linear_wgrad(g2, h).view(w2.shape)
         # d(pre) = (g2 W2) * dropout_h mask * act'(pre): all in the data-gradient epilogue
         M, dff = pre.shape
@@ -2847,8 +2916,8 @@ class FFNFn(torch.autograd.Function):
 
 
 def ffn(x, w1, b1, w2, b2, act, p_h=0.0, res=None, alpha=1.0, p_o=0.0):
-    return FFNFn.apply(x, w1, b1, w2, b2, ACT[act] if not isinstance(act, int) else act,
-                       float(p_h), res, float(alpha), float(p_o))
+    return tag_prep(FFNFn.apply(x, w1, b1, w2, b2, ACT[act] if not isinstance(act, int) else act,
+                                float(p_h), res, float(alpha), float(p_o)))
 
 
 # --------------------------------------------------------------------------
@@ -2978,6 +3047,7 @@ class SelfAttnFn(torch.autograd.Function):
         ctx.save_for_backward(x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens, QP, LSE, cv32)
         ctx.cfg = (B, T, d, H, dk, R, Rp, Tkp, clamp, scale, mask_args, p_o, s_o, res is not None,
                    bq is not None, bo is not None)
+        ctx.prep_token = _prep_offer(res is not None, 1.0, p_o, s_o[0], s_o[1], d)
         if aw is None:
             aw = cv16.new_zeros(1)  # the fused path has no probability tensor to hand out
         ctx.mark_non_differentiable(aw)
@@ -2993,10 +3063,16 @@ class SelfAttnFn(torch.autograd.Function):
         dev = dy.device
         M, d3 = B * T, 3 * d
         dy2d = _f32c(dy).reshape(M, d)
-        g = grad_prep(dy2d, None, 0, 1.0, p_o, s_o[0], s_o[1], True, want_colsum=has_o_bias)
+        got = _prep_take(getattr(ctx, 'prep_token', None), dy2d)
         dbo = None
-        if has_o_bias:
-            g, dbo = g
+        if got is not None:
+            g, dbo = got
+            if not has_o_bias:
+                dbo = None
+        else:
+            g = grad_prep(dy2d, None, 0, 1.0, p_o, s_o[0], s_o[1], True, want_colsum=has_o_bias)
+            if has_o_bias:
+                g, dbo = g
         dwo = linear_wgrad(g, cv16).view(wo.shape)
         dO = linear_dgrad(g, wo, out_bf16=True)                                   # [M, d] bf16
         dqkv = torch.empty((M, d3), device=dev, dtype=torch.bfloat16)

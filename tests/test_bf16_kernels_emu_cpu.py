@@ -94,6 +94,10 @@ def test_phase_interleaved_256_tile_gemm(basic, M, N, K, grid, monkeypatch):
     basic.test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch)
 
 
+def test_residual_gradient_prepared_by_the_layer_norm_backward(basic, monkeypatch):
+    basic.test_residual_gradient_prepared_by_the_layer_norm_backward(monkeypatch)
+
+
 @pytest.mark.parametrize('rows,d', [(70, 256)])
 def test_layer_norm_swish_for_a_gemm_only_consumer(basic, rows, d):
     basic.test_layer_norm_swish_for_a_gemm_only_consumer(rows, d)

@@ -361,6 +361,55 @@ def test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_residual_gradient_prepared_by_the_layer_norm_backward(monkeypatch):
+    """The pre-norm chain  y1 = x + drop(0.5 FFN(LN(x)));  y2 = y1 + drop(Linear(LN(y1)));  out = LN(y2)  in bf16 mode: the
+    LayerNorm backward kernels of the second and third norm hand the prepared bf16 gradient image (scale, dropout mask,
+    bias-gradient sums) to the FFN's / Linear's backward (ops._PREP; nsp_layernorm_bwd_prep).  Same gradients as with the
+    hand-over switched off (the image is bit-identical: same arithmetic on the same dx), both hand-overs made and taken,
+    and a gradient that is ACCUMULATED on the way (a second consumer of y1) falls back to grad_prep."""
+    from neural_sp_amd import ops
+    dev = _dev()
+    d, dff, rows = 256, 512, 300
+    torch.manual_seed(3)
+    P = lambda *sh: torch.nn.Parameter(torch.randn(*sh, device=dev) / sh[-1] ** 0.5)
+    w1, b1, w2, b2, wl, bl = P(dff, d), P(dff), P(d, dff), P(d), P(d, d), P(d)
+    g1, be1, g2, be2, g3, be3 = [torch.nn.Parameter(torch.rand(d, device=dev) + 0.5) for _ in range(6)]
+    x0 = torch.randn(2, rows // 2, d, device=dev)
+    dout = torch.randn(2, rows // 2, d, device=dev)
+
+    def run(extra_consumer):
+        ops._DROPOUT_STATE['counter'] = 0          # the same dropout streams in every run
+        x = x0.clone().requires_grad_()
+        with ops.compute_mode('bf16'):
+            ops.optimizer_stepped()
+            z1, r1 = ops.layer_norm_split(x, g1, be1)
+            y1 = ops.ffn(z1, w1, b1, w2, b2, 'swish', p_h=0.1, res=r1, alpha=0.5, p_o=0.1)
+            z2, r2 = ops.layer_norm_split(y1, g2, be2)
+            y2 = ops.linear(z2, wl, bl, res=r2, dropout_p=0.1)
+            out = ops.layer_norm(y2, g3, be3)
+            loss = (out * dout).sum()
+            if extra_consumer:
+                loss = loss + y1.sum() * 1e-3
+            return torch.autograd.grad(loss, (x, w1, b1, w2, b2, wl, bl, g1, g2, g3))
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('NSP_LN_PREP', mode)
+        torch.manual_seed(11)
+        ops._PREP_STATS.update(made=0, taken=0)
+        outs[mode] = run(False)
+        if mode == '1':
+            assert ops._PREP_STATS == {'made': 2, 'taken': 2}, ops._PREP_STATS
+        else:
+            assert ops._PREP_STATS == {'made': 0, 'taken': 0}
+    for a, b in zip(outs['1'], outs['0']):
+        assert _rel(a, b) < 1e-5
+    monkeypatch.setenv('NSP_LN_PREP', '1')
+    ops._PREP_STATS.update(made=0, taken=0)
+    run(True)
+    assert ops._PREP_STATS['made'] == 2 and ops._PREP_STATS['taken'] == 1, ops._PREP_STATS      # y1's gradient was accumulated: grad_prep
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('rows,d', [(333, 512), (70, 256)])
 def test_layer_norm_swish_for_a_gemm_only_consumer(rows, d):
     """ops.layer_norm(act='swish', gemm_only=True) in bf16 mode: forward writes only the bf16 image (the fp32-typed result
