@@ -149,7 +149,7 @@ def test_rnnt_joint_loss_node_stationary_kernel(convloss, B, T, U, J, V, monkeyp
     convloss.test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, '1', monkeypatch)
 
 
-@pytest.mark.parametrize('M,J,V,blank', [(1, 128, 70, 69), (300, 256, 130, 0)])
+@pytest.mark.parametrize('M,J,V,blank', [(1, 128, 70, 69), (300, 256, 130, 0), (40, 512, 70, 3)])
 def test_rnnt_joint_rows_matches_tiled_gemm_path(convloss, M, J, V, blank):
     convloss.test_rnnt_joint_rows_matches_tiled_gemm_path(M, J, V, blank)
 
