@@ -86,13 +86,13 @@ def build():
     return LIB
 
 
-if __name__ == '__main__':
-    print(build())
-
-
 def asan_runtime():
     """path of the shared ASan runtime of the host clang (to LD_PRELOAD into python)"""
     out = subprocess.run([_cxx(), '-print-file-name=libclang_rt.asan-x86_64.so'], stdout=subprocess.PIPE).stdout.decode().strip()
+    if not os.path.isabs(out) or not os.path.exists(out):      # (clang prints the bare name when it does not find the file)
+        import glob
+        hits = sorted(glob.glob('/opt/rocm*/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so'))
+        out = hits[-1] if hits else out
     return out
 
 
