@@ -501,7 +501,14 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
 // query tile and 36 KB of LDS).  The wave's K / V fragments are 16 registers; Q / dO tiles and the
 // per-query statistics (row max, 1/sum, D, dropout row hash, far-diagonal position score) of the NEXT
 // query tile are fetched while the current one is processed: one barrier per query tile.
-__global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
+// H2 (the default; NSP_FLASH_DKV_HALVES=0 selects the one-pass form): the 64-query tile is processed as two halves of
+// 32 queries (S / dP / P / dS of one half live at a time) under __launch_bounds__(256, 3), i.e. 168 VGPRs (24 B of
+// scratch) and a third wave per SIMD for a kernel that at 255 VGPRs waits more than it issues.  Same
+// arithmetic in the same order per accumulator: dK / dV are BIT-identical to the one-pass form (checked on the
+// emulator for uniform / near / masked tiles with and without dropout).  Measured (profiles/r04zn_...): backward
+// T = 800 845 -> 816 us, T = 400 302 -> 280 us at B = 64.
+template <bool H2>
+__global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, __bf16* __restrict__ dqkv,
     const nsp_attn_mask_params p) {
@@ -636,21 +643,24 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
       tile_dma(Qs[cur ^ 1], qbase, ld3, brow0, q0 + 64, T, wave, lane);
       tile_dma(dOs[cur ^ 1], dobase, d, brow0, q0 + 64, T, wave, lane);
     }
-    // S[query][key], dP[query][key] for the 4 query blocks: lane = key r, queries qb*16 + 4g + e
-    f32x4 s_acc[4], dp_acc[4];
+    const FaTile tl = fa_tile(p, QP != nullptr, q0, k0, T, klen);
+    const bool uni = tl.plain && (QP == nullptr || tl.far);
+    constexpr int NQB = H2 ? 2 : 4;          // query blocks (of 16) processed together
+    auto half_tile = [&](const int hq) {
+    const int qb0 = hq * NQB;
+    // S[query][key], dP[query][key] for NQB query blocks: lane = key r, queries (qb0 + qb)*16 + 4g + e
+    f32x4 s_acc[NQB], dp_acc[NQB];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
       s_acc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
       dp_acc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        s_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc_dma(Qs[cur], qb * 16, s2, r, g), Kf[s2], s_acc[qb], 0, 0, 0);
-        dp_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc_dma(dOs[cur], qb * 16, s2, r, g), Vf[s2], dp_acc[qb], 0, 0, 0);
+        s_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc_dma(Qs[cur], (qb0 + qb) * 16, s2, r, g), Kf[s2], s_acc[qb], 0, 0, 0);
+        dp_acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc_dma(dOs[cur], (qb0 + qb) * 16, s2, r, g), Vf[s2], dp_acc[qb], 0, 0, 0);
       }
     }
-    const FaTile tl = fa_tile(p, QP != nullptr, q0, k0, T, klen);
-    const bool uni = tl.plain && (QP == nullptr || tl.far);
-    bf16x8 Pt[2], dSt[2];     // X operands: rows = keys, k = [block 2s: queries 4g..4g+3 | block 2s+1: same]
+    bf16x8 Pt[NQB / 2], dSt[NQB / 2];     // X operands: rows = keys, k = [block 2s: queries 4g..4g+3 | block 2s+1: same]
     // The tile class (uniform / near the diagonal / masked) and dropout are wave-uniform but known only at run time:
     // tested per element inside the unrolled loops they became three scalar branches around EVERY score (ISA audit,
     // round 4: ~50 branches per tile, basic blocks of a dozen instructions, no scheduling across scores).  The element
@@ -659,18 +669,19 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
       constexpr int KIND = decltype(kind_)::value;
       constexpr bool DROP = decltype(drop_)::value;
 #pragma unroll
-      for (int qb = 0; qb < 4; ++qb) {
+      for (int qb = 0; qb < NQB; ++qb) {
+        const int qq = qb0 + qb;             // query block inside the 64-query tile
         // The statistics rows are read through INLINE ASM: in front of a compiler-visible read of these arrays hipcc
         // put an s_waitcnt vmcnt(0) (ISA audit, round 4) -- i.e. the next query tile's Q / dO DMA, issued a few dozen
         // instructions earlier, was drained right here, before the soft-max arithmetic it is supposed to hide behind.
         // (The compiler does not count asm loads: the destinations are named in the wait statement, CDNA guide 5.7.)
         f32x4 c0v, mxv, inv, ddv;
         u32x4 hv = {0u, 0u, 0u, 0u};
-        fa_lds_read4(c0v, &st_c0[cur][qb * 16 + 4 * g]);
-        fa_lds_read4(mxv, &st_max[cur][qb * 16 + 4 * g]);
-        fa_lds_read4(inv, &st_inv[cur][qb * 16 + 4 * g]);
-        fa_lds_read4(ddv, &st_d[cur][qb * 16 + 4 * g]);
-        if (DROP) fa_lds_read4(hv, &st_hash[cur][qb * 16 + 4 * g]);
+        fa_lds_read4(c0v, &st_c0[cur][qq * 16 + 4 * g]);
+        fa_lds_read4(mxv, &st_max[cur][qq * 16 + 4 * g]);
+        fa_lds_read4(inv, &st_inv[cur][qq * 16 + 4 * g]);
+        fa_lds_read4(ddv, &st_d[cur][qq * 16 + 4 * g]);
+        if (DROP) fa_lds_read4(hv, &st_hash[cur][qq * 16 + 4 * g]);
 #ifndef NSP_HOST_EMULATION
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0v), "+v"(mxv), "+v"(inv), "+v"(ddv), "+v"(hv));
 #endif
@@ -679,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
         const unsigned ha[4] = {hv[0], hv[1], hv[2], hv[3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int ql = qb * 16 + 4 * g + e;
+          const int ql = qq * 16 + 4 * g + e;
           float ex;
           bool vis = true;
           if constexpr (KIND == 0) {
@@ -729,14 +740,23 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(
     }
     // dV[key][dd] += sum_q Pd[q][key] dO[q][dd] ; dK[key][dk'] += sum_q dS[q][key] Q[q][dk']
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int sl = 0; sl < NQB / 2; ++sl) {
+      const int s2 = hq * (NQB / 2) + sl;      // 32-query k-step inside the tile
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const bf16x8 doT = frag_tr_dma(dOs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
         const bf16x8 qT = frag_tr_dma(Qs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
-        dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pt[s2], doT, dv_acc[df], 0, 0, 0);
-        dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dSt[s2], qT, dk_acc[df], 0, 0, 0);
+        dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pt[sl], doT, dv_acc[df], 0, 0, 0);
+        dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dSt[sl], qT, dk_acc[df], 0, 0, 0);
       }
+    }
+    };
+    if constexpr (H2) {
+#pragma unroll 1
+      for (int hq = 0; hq < 2; ++hq) half_tile(hq);
+    } else {
+      half_tile(0);
+    }
     if (qt + 1 < nqt) {
       qp_store(cur ^ 1, qpr);
       stat_store(cur ^ 1, str);
@@ -990,8 +1010,13 @@ extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const
   // the dQ kernel first: it forms D = dO . O for its queries and leaves it in D for the dK/dV kernel
   hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
                      reinterpret_cast<const __bf16*>(dO), O32, LSE, D, dq32, dQP, p);
-  hipLaunchKernelGGL(flash_bwd_dkv_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
-                     QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
+  const char* eh = getenv("NSP_FLASH_DKV_HALVES");
+  if (!eh || atoi(eh) != 0)
+    hipLaunchKernelGGL(flash_bwd_dkv_kernel<true>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
+                       QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
+  else
+    hipLaunchKernelGGL(flash_bwd_dkv_kernel<false>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
+                       QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -118,6 +118,14 @@ def test_flash_attention_matches_reference(flash, T, with_pos, causal, nc):
     flash.test_flash_attention_matches_reference(T, with_pos, causal, nc)
 
 
+def test_flash_backward_one_pass_variant(flash, monkeypatch):
+    """flash_bwd_dkv_kernel<false> (NSP_FLASH_DKV_HALVES=0: the whole 64-query tile at once, 255 VGPRs -- the form before
+    the two-halves default, kept as the A/B arm)"""
+    monkeypatch.setenv('NSP_FLASH_DKV_HALVES', '0')
+    flash.test_flash_attention_matches_reference(130, True, False, 0)
+    flash.test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward()
+
+
 def test_flash_attention_dropout_mask(flash):
     flash.test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward()
 
