@@ -284,3 +284,43 @@ def test_training_forward_without_the_ddp_hook_goes_single_stream(monkeypatch):
     assert model.dec_fwd.ensure_streams() == (None, None)
     model._nsp_ddp_hooked = True                                               # what wrap_ddp / the installed class set
     assert model._ddp_guard() is False and not model.dec_fwd._nsp_single_stream
+
+
+def test_kernel_event_classes_bookkeeping(monkeypatch):
+    """ops._kev_class (bench.py's roofline.classes): off -> one shared no-op context; on -> an event pair and the work
+    of every use under the class name, '<name>@side' when the current stream is not the default one (events and streams
+    mocked: the bookkeeping is host logic)."""
+    from neural_sp_amd import ops
+
+    class Ev(object):
+        n = 0
+
+        def __init__(self, enable_timing=False):
+            assert enable_timing
+            self.recorded = False
+
+        def record(self):
+            Ev.n += 1
+            self.recorded = True
+    cur = ['main']
+    monkeypatch.setattr(torch.cuda, 'Event', Ev)
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a: cur[0])
+    monkeypatch.setattr(torch.cuda, 'default_stream', lambda *a: 'main')
+    monkeypatch.setitem(ops._KEV, 'on', False)
+    a, b = ops._kev_class('ln', 10.0, 'byte'), ops._kev_class('flash', 3.0, 'flop')
+    assert a is b
+    with a:
+        pass
+    assert Ev.n == 0
+    monkeypatch.setitem(ops._KEV, 'on', True)
+    monkeypatch.setitem(ops._KEV, 'classes', {})
+    for w in (10.0, 5.0):
+        with ops._kev_class('ln', w, 'byte'):
+            pass
+    cur[0] = 'side'
+    with ops._kev_class('ln', 1.0, 'byte'):
+        pass
+    cl = ops._KEV['classes']
+    assert set(cl) == {'ln', 'ln@side'} and cl['ln']['work'] == 15.0 and cl['ln']['unit'] == 'byte'
+    assert len(cl['ln']['events']) == 2 and len(cl['ln@side']['events']) == 1 and Ev.n == 6
+    assert all(e0.recorded and e1.recorded for e0, e1 in cl['ln']['events'])
