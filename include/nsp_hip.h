@@ -127,6 +127,12 @@ int nsp_splitk_reduce(const float* part, float* out, int splits, long long n, vo
  * `cycles` shader cycles -- what a resident collective (an RCCL channel set) or any long kernel of another stream does to
  * the grid-barrier LSTM: it has to become resident beside them, later but correctly. */
 int nsp_debug_occupy(int n_wg, long long cycles, void* stream);
+/* TEST HOOK (tests/test_hostile_neighbour_gpu.py): n_wg short-lived workgroups of 256 threads that fill lds_bytes (<= 64 KB,
+ * multiple of 4) of LDS `rounds` times and ~96 VGPRs + ~96 AGPRs per lane with `pattern`, then exit.  Run on another stream
+ * (or by another process) beside the step, they are what a second rank on the same device, an RCCL kernel or any other
+ * tenant is to the step's kernels: every LDS byte and register a kernel reads before writing then holds `pattern` (e.g. a
+ * NaN) instead of what the previous kernel of the same stream left there, and LDS / issue slots are contended. */
+int nsp_debug_scribble(int n_wg, int lds_bytes, unsigned int pattern, int rounds, void* stream);
 
 int nsp_gemm(const nsp_gemm_params* p, void* stream);
 /* same call with the struct fields as positional arguments (cheaper to marshal from ctypes) */

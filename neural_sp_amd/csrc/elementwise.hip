@@ -666,3 +666,34 @@ extern "C" int nsp_debug_occupy(int n_wg, long long cycles, void* stream) {
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
+
+// ---- test hook: a hostile neighbour (see include/nsp_hip.h).  Short-lived workgroups that overwrite their LDS allocation,
+// ~96 VGPRs and ~96 AGPRs with `pattern` and exit: whatever kernel gets the CU slot next finds that pattern in every LDS
+// byte / register it reads before writing.  `rounds` LDS sweeps per workgroup also load the CU's LDS pipe.
+namespace {
+__global__ __launch_bounds__(256) void scribble_kernel(unsigned int pattern, int lds_dwords, int rounds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char scr[];
+  unsigned int* w = reinterpret_cast<unsigned int*>(scr);
+  for (int r = 0; r < rounds; ++r) {
+    for (int i = threadIdx.x; i < lds_dwords; i += 256) w[i] = pattern + (r == rounds ? 1u : 0u);
+    __syncthreads();
+  }
+#ifndef NSP_HOST_EMULATION
+  unsigned int v[96], a[96];
+#pragma unroll
+  for (int i = 0; i < 96; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(pattern));
+#pragma unroll
+  for (int i = 0; i < 96; ++i) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a[i]) : "v"(pattern));
+#pragma unroll
+  for (int i = 0; i < 96; ++i) asm volatile("" :: "v"(v[i]), "a"(a[i]));
+#endif
+}
+}  // namespace
+extern "C" int nsp_debug_scribble(int n_wg, int lds_bytes, unsigned int pattern, int rounds, void* stream) {
+  if (n_wg <= 0) return NSP_OK;
+  if (lds_bytes < 0 || lds_bytes > 65536 || (lds_bytes & 3)) return NSP_EINVAL;
+  hipLaunchKernelGGL(scribble_kernel, dim3(n_wg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, pattern,
+                     lds_bytes / 4, rounds);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
