@@ -183,6 +183,19 @@ def test_rnnt_joint_loss():
         assert _rel(a.cpu().double(), r) < 2e-4
 
 
+@pytest.mark.parametrize('path', ['padded', 'compact'])
+def test_rnnt_lattice_kernels_reproduce_the_published_warp_transducer_answers(path):
+    """device twin of tests/test_kernels_emu_cpu.py: nsp_rnnt_logsoftmax_gather / nsp_rnnt_lattice / nsp_rnnt_grad_logits and
+    nsp_rnnt_lattice_compact through the C ABI against warp-transducer's published known answers (third-party pin of a17)"""
+    from neural_sp_amd import _lib
+    from tests import rnnt_known_answers as K
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for ka in K.CASES:
+        nll, g = (K.through_padded_kernels if path == 'padded' else K.through_compact_lattice)(L, ka, lambda t: t.to(_dev()), st)
+        K.check(ka, nll, g)
+
+
 @pytest.mark.parametrize('U,J,V', [(6, 32, 32), (40, 64, 40), (70, 96, 1000)])
 def test_rnnt_joint_loss_bf16_fused_backward(U, J, V):
     """bf16 mode: tanh' applied in the data-gradient GEMM epilogue (bf16 dz image) and the single

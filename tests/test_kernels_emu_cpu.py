@@ -214,6 +214,18 @@ def test_rnnt_lattice_kernels_against_the_fp64_oracle():
     assert _lib.prototypes()['nsp_rnnt_lattice'][1][-1] is not None
 
 
+@pytest.mark.parametrize('path', ['padded', 'compact'])
+def test_rnnt_lattice_kernels_reproduce_the_published_warp_transducer_answers(path):
+    """the RNN-T lattice kernels (csrc/rnnt.hip padded grid; csrc/rnnt_fused.hip compact layout) on the host emulator against
+    the known-answer cases of warp-transducer's unit tests (tests/rnnt_known_answers.py), directly -- not via the oracle"""
+    from tests import rnnt_known_answers as K
+    from tests.hipemu.shim import emulated_kernels
+    with emulated_kernels() as L:
+        for ka in K.CASES:
+            nll, g = (K.through_padded_kernels if path == 'padded' else K.through_compact_lattice)(L, ka)
+            K.check(ka, nll, g)
+
+
 def _lstm_case(seed=7, B=3, n=6, I=16, H=32):
     torch.manual_seed(seed)
     ref = torch.nn.LSTM(I, H, 1, batch_first=True)

@@ -109,3 +109,16 @@ def test_reference_live_matches_fixture():
     batch.update(xlens=[len(x) for x in batch['xs']], ys_sub1=[], ys_sub2=[], trigger_points=None)
     loss, _ = model(batch, task='all')
     assert abs(loss.item() - fix['loss'].item()) < 1e-4 * abs(fix['loss'].item())
+
+
+@pytest.mark.parametrize('ka', __import__('tests.rnnt_known_answers', fromlist=['CASES']).CASES, ids=lambda k: k['name'].split(' (')[0].replace(' ', '_'))
+def test_rnnt_oracle_reproduces_the_published_warp_transducer_answers(ka):
+    """oracle/rnnt_ref.py (Graves 2012 restated) against the known-answer cases of HawkAaron/warp-transducer's own unit tests
+    -- the library behind the reference's CPU path (rnn_transducer.py:254-256): costs to 1e-6, the 30 published gradient
+    entries of `small_test` to 5e-7.  This pins the RNN-T row of the oracle to a third-party vector."""
+    from tests import rnnt_known_answers as K
+    acts, labels, elens, ylens = K.tensors(ka, torch.float64)
+    acts.requires_grad_(True)
+    nll = rnnt_loss_ref(torch.log_softmax(acts, -1), labels.long(), elens.long(), ylens.long(), blank=0)
+    (g,) = torch.autograd.grad(nll.sum(), [acts])
+    K.check(ka, nll, g, tol_cost=1e-6, tol_grad=5e-7)     # (the published gradients are float32 prints)
