@@ -283,6 +283,17 @@ class Speech2Text(nn.Module):
     def reset_session(self):
         pass
 
+    # evaluators/*.py read these after every decoded batch (speech2text.py:700-707): streaming statistics of a MoChA /
+    # triggered-attention decoder, the defaults for everything else
+    def streamable(self):
+        return getattr(self.dec_fwd, 'streamable', False)
+
+    def quantity_rate(self):
+        return getattr(self.dec_fwd, 'quantity_rate', 1.0)
+
+    def last_success_frame_ratio(self):
+        return getattr(self.dec_fwd, 'last_success_frame_ratio', 0)
+
     def plot_attention(self):
         """speech2text.py:494-503, called by train.py:484-487 every 10*print_step steps on rank 0.
         Drawing the attention maps needs the probabilities the fused kernels never materialise (and

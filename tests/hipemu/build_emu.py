@@ -59,6 +59,17 @@ def build():
     if cxx is None:
         raise RuntimeError('no host clang++ (ext_vector_type / __bf16 support is needed) for the HIP emulator')
     os.makedirs(OUT, exist_ok=True)
+    # one builder at a time (pytest-xdist workers all arrive here after a source change)
+    import fcntl
+    with open(os.path.join(OUT, 'build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(cxx)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(cxx):
     srcs = [os.path.join(CSRC, s) for s in EMULATED_SOURCES] + [os.path.join(HERE, 'emu_runtime.cpp')]
     deps = srcs + [os.path.join(HERE, 'include', 'hip', 'hip_runtime.h'), os.path.join(CSRC, 'common.h'),
                    os.path.join(ROOT, 'include', 'nsp_hip.h')]
