@@ -125,13 +125,28 @@ def cpu_baseline(args, margs, cores):
     dt = sorted(timed)[len(timed) // 2]
     return {'value': round(frames / dt, 2), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
             # the reference itself cannot travel to the GPU box; calibration of the port against it in the build container
-            'port_over_reference': 1.16,
-            'port_over_reference_source': 'profiles/r03_cpu_reference_vs_port.txt (tools/ref_vs_port_cpu.py: reference 501 vs port 580 '
-                                          'frames/s on the same 8 cores, same step) -- the reference is ~14 % SLOWER than this value',
+            # NOT measured in this run: a static calibration read from the committed profile (None if the file is missing)
+            'port_over_reference_static_calibration': _port_over_reference(),
             'sample': '%d utterance(s) of the bench workload (%d frames): full training step (fwd + CTC/RNN-T loss + '
                       'bwd + clip + Adam) of the same Conformer-%s model through oracle/model_ref.py in fp32 on %d '
                       'torch threads; 1 warm-up + %d timed steps, median %.2f s (all: %s)'
                       % (n, frames, args.size, threads, len(timed), dt, ', '.join('%.2f' % t for t in timed))}
+
+
+def _port_over_reference():
+    """{'ratio', 'source', 'measured'}: port / reference CPU speed as tools/ref_vs_port_cpu.py measured it in the build
+    container (the only place both exist), parsed from the committed profile -- a calibration of `cpu_baseline.kind =
+    'port'`, not a number of this run"""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_cpu_reference_vs_port.txt')
+    try:
+        text = open(path).read()
+        ref = float(re.search(r'^reference .*-> ([0-9.]+) frames/s', text, re.M).group(1))
+        port = float(re.search(r'^port .*-> ([0-9.]+) frames/s', text, re.M).group(1))
+    except Exception:
+        return None
+    return {'ratio': round(port / ref, 3), 'reference_frames_per_s': ref, 'port_frames_per_s': port,
+            'source': 'profiles/r03_cpu_reference_vs_port.txt', 'measured': 'round 3, build container, 8 cores; static'}
 
 
 def _free_port():

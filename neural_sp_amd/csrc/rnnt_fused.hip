@@ -768,11 +768,15 @@ extern "C" int nsp_rnnt_joint_rows(int epi_mode, const void* h16, const void* w1
   hipStream_t st = (hipStream_t)stream;
 #define NSP_JR(NKS, LSE_)                                                                                              \
   do {                                                                                                                 \
-    static bool attr = false;                                                                                          \
-    if (!attr) {                                                                                                       \
+    /* opt in to the whole 160 KB once per (kernel, device): `lds` depends on the vocabulary, so a later call with a   \
+       larger one (a second decoder, a sub-task head) must not find a smaller limit from the first call */            \
+    static unsigned long long optin_devs = 0;                                                                          \
+    int dev_ = 0;                                                                                                      \
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;           /* (unknown device: opt in on every call) */          \
+    if (dev_ < 0 || dev_ >= 64 || !((optin_devs >> dev_) & 1ull)) {                                                     \
       if (hipFuncSetAttribute((const void*)rnnt_joint_rows_kernel<NKS, LSE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds) != hipSuccess) return NSP_EUNSUPPORTED;                                        \
-      attr = true;                                                                                                     \
+                              163840) != hipSuccess) return NSP_EUNSUPPORTED;                                          \
+      if (dev_ >= 0 && dev_ < 64) optin_devs |= 1ull << dev_;                                                           \
     }                                                                                                                  \
     hipLaunchKernelGGL((rnnt_joint_rows_kernel<NKS, LSE_>), grid, dim3(512), lds, st,                                  \
                        reinterpret_cast<const __bf16*>(h16), reinterpret_cast<const __bf16*>(w16), bias, (int)M, V, Vp, \

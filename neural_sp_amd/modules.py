@@ -208,6 +208,14 @@ class RelativeMultiheadAttentionMechanism(nn.Module):
             w_pos = self.w_pos if self.xl_like else self.w_value
             cfg = mask.cfg() if mask is not None else {}
             cfg.update(H=H, clamp=self.clamp_len, dropout=self.dropout_attn_p, training=self.training)
+            cache = getattr(pos_embs, '_nsp_pe16', None)        # (one dict per forward, on the tensor every layer receives)
+            if cache is None:
+                cache = {}
+                try:
+                    pos_embs._nsp_pe16 = cache
+                except Exception:
+                    pass
+            cfg['pe16_cache'] = cache
             cv, aw = ops.SelfAttnFn.apply(key, self.w_query.weight, self.w_key.weight, self.w_value.weight,
                                           self.w_query.bias, self.w_key.bias, self.w_value.bias,
                                           self.w_out.weight, self.w_out.bias, pe[:R], w_pos.weight,

@@ -103,7 +103,7 @@ def zeros_small(shape, device, dtype=torch.float32):
 # kernel write the prepared image as well (nsp_layernorm_bwd_prep) and leaves it here under the offer's token; the
 # Linear's backward takes it if the gradient it receives is that very tensor (same storage: nothing was accumulated
 # into it on the way) and falls back to grad_prep otherwise.
-_PREP = {}             # token -> (data_ptr of dx, g16 [rows, N] bf16, gsum [N] fp32)
+_PREP = {}             # token -> (dx, its version counter, g16 [rows, N] bf16, gsum [N] fp32)
 _PREP_TOKEN = [0]
 _LAST_PREP = [None]
 _PREP_STATS = {'made': 0, 'taken': 0}     # (tests: how many hand-overs the LayerNorm kernels made / the Linears took)
@@ -130,10 +130,17 @@ def tag_prep(y):
 
 
 def _prep_take(token, dy2d):
+    """the prepared image filed under `token`, if the gradient that arrived IS the dx it was made from: same memory (the
+    entry keeps dx alive, so the address cannot have been recycled, and a tensor with a second owner is never accumulated
+    into in place by the engine) and unmodified since (version counter: an in-place `+=` of a second consumer's gradient
+    bumps it)"""
     ent = _PREP.pop(token, None) if token is not None else None
-    if ent is not None and ent[0] == dy2d.data_ptr() and tuple(ent[1].shape) == tuple(dy2d.shape):
+    if ent is None:
+        return None
+    dx, ver, g16, gsum = ent
+    if dx.data_ptr() == dy2d.data_ptr() and dx._version == ver and dy2d._version == ver and tuple(g16.shape) == tuple(dy2d.shape):
         _PREP_STATS['taken'] += 1
-        return ent[1], ent[2]
+        return g16, gsum
     return None
 
 
@@ -168,6 +175,11 @@ def h2d_packed(arrays, device):
 
 
 def _f32c(t):
+    if getattr(t, '_nsp_placeholder', False):
+        # LayerNorm*Fn in throughput mode hands autograd a stride-0 NaN where only the bf16 image `_nsp16` exists: a consumer
+        # that arrives here is about to read it as data (e.g. a GEMM whose width is not a multiple of 8 takes the fp32 path)
+        raise RuntimeError('neural_sp_amd: the fp32 image of this LayerNorm output was not written (bf16 image only); its '
+                           'consumer cannot use the bf16 image -- set NSP_LN_SKIP32=0 or make the width a multiple of 8')
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
@@ -697,7 +709,7 @@ def layernorm_bwd_raw(dy2d, x2d, gamma, mean, rstd, y_pre, act=0, dres=None, bet
                                                      (dgb.data_ptr()), (dgb.data_ptr() + 4 * d), _p(g16), _p(gsum),
                                                      prep[1], prep[2], prep[3], prep[4], (rows), (d), _stream()),
                    'nsp_layernorm_bwd_prep')
-            _PREP[prep[0]] = (dx.data_ptr(), g16, gsum)
+            _PREP[prep[0]] = (dx, dx._version, g16, gsum)
             _PREP_STATS['made'] += 1
         elif beta_recompute is not None and y_pre is None and act != 0:
             _check(_lib.lib().nsp_layernorm_bwd_recompute(_p(dy2d), _p(x2d), _p(gamma), _p(beta_recompute), _p(mean), _p(rstd),
@@ -728,6 +740,8 @@ class LayerNormFn(torch.autograd.Function):
         ctx.act = act
         ctx.prep = getattr(x, '_nsp_prep', None) if act == 0 else None
         out = _nan_scalar(x.device).expand(x.shape).view(x.shape) if lean else y.view(x.shape)
+        if lean:
+            out._nsp_placeholder = True
         if y16 is not None:
             out._nsp16 = y16  # bf16 shadow [rows, d] for the consuming GEMM (saves its cast pass)
         return out
@@ -765,6 +779,7 @@ class LayerNormSplitFn(torch.autograd.Function):
         if skip32:
             out = _nan_scalar(x.device).expand(x.shape)
             out = out.view(x.shape)
+            out._nsp_placeholder = True
         else:
             out = y.view(x.shape)
         if y16 is not None:
@@ -3021,18 +3036,17 @@ class SelfAttnFn(torch.autograd.Function):
         if pos_in is not None:
             R = pos_in.shape[0]
             Rp = _r8(R)
-            # the zero-padded bf16 image of the position table is shared by every layer that receives this table
-            # object in this forward (12 blocks x {fill, cast, copy} per step otherwise)
-            ent = getattr(pos_in, '_nsp_pe16', None)
-            if ent is not None and ent[0] == (pos_in._version, Rp) and ent[1].device == dev:
-                pe16 = ent[1]
-            else:
+            # the zero-padded bf16 image of the position table is shared by every layer of this forward: the cache is a dict
+            # owned by the position-embedding tensor the encoder made once for the step (modules.py hands it down in cfg;
+            # `pos_in` itself is a fresh slice object per layer, an attribute on it would never be found again)
+            cache = cfg.get('pe16_cache')
+            key = (pos_in.data_ptr(), pos_in._version, R, Rp, str(dev))
+            pe16 = cache.get(key) if cache is not None else None
+            if pe16 is None:
                 pe16 = torch.zeros((Rp, d), device=dev, dtype=torch.bfloat16)  # rows >= R stay zero
                 pe16[:R] = to_bf16(_f32c(pos_in))
-                try:
-                    pos_in._nsp_pe16 = ((pos_in._version, Rp), pe16)
-                except Exception:
-                    pass
+                if cache is not None:
+                    cache[key] = pe16
             pos16 = torch.empty((Rp, d), device=dev, dtype=torch.bfloat16)
             gemm_raw(Rp, d, d, pe16, d, 1, weight_bf16(w_pos), 1, d, pos16, d)
             QP = torch.empty((B, T, H, Rp), device=dev, dtype=torch.float32)

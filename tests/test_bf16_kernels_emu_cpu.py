@@ -94,6 +94,10 @@ def test_phase_interleaved_256_tile_gemm(basic, M, N, K, grid, monkeypatch):
     basic.test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch)
 
 
+def test_layernorm_bf16_only_output_refuses_an_fp32_consumer(basic):
+    basic.test_layernorm_bf16_only_output_refuses_an_fp32_consumer()
+
+
 def test_residual_gradient_prepared_by_the_layer_norm_backward(basic, monkeypatch):
     basic.test_residual_gradient_prepared_by_the_layer_norm_backward(monkeypatch)
 

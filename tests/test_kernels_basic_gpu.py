@@ -361,6 +361,29 @@ def test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_layernorm_bf16_only_output_refuses_an_fp32_consumer():
+    """Throughput mode: a pre-norm LayerNorm writes only the bf16 image of its output (`_nsp16`); the fp32-typed tensor autograd
+    sees is a stride-0 NaN.  A GEMM consumer takes the image; a consumer that would read the fp32 tensor as data (an FFN
+    whose inner width is not a multiple of 8 runs on the fp32 path) must RAISE, not train on NaN."""
+    from neural_sp_amd import ops
+    torch.manual_seed(2)
+    d = 64
+    x = torch.randn(3, 7, d, device=_dev(), requires_grad=True)
+    g, b = torch.ones(d, device=_dev(), requires_grad=True), torch.zeros(d, device=_dev(), requires_grad=True)
+    w = (torch.randn(128, d, device=_dev()) * 0.1).requires_grad_()
+    w1, b1 = (torch.randn(100, d, device=_dev()) * 0.1).requires_grad_(), torch.zeros(100, device=_dev(), requires_grad=True)
+    w2, b2 = (torch.randn(d, 100, device=_dev()) * 0.1).requires_grad_(), torch.zeros(d, device=_dev(), requires_grad=True)
+    with ops.compute_mode('bf16'):
+        xn, res = ops.layer_norm_split(x, g, b)
+        assert getattr(xn, '_nsp_placeholder', False) and xn._nsp16.dtype == torch.bfloat16
+        y = ops.linear(xn, w, None)                                 # reads the bf16 image
+        ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (d,), g, b, 1e-12), w)
+        assert torch.isfinite(y).all() and _rel(y, ref) < 2e-2
+        with pytest.raises(RuntimeError, match='fp32 image'):
+            ops.ffn(xn, w1, b1, w2, b2, 'relu')                     # inner width 100: fp32 path -> would read the placeholder
+
+
+@pytest.mark.gpu
 def test_residual_gradient_prepared_by_the_layer_norm_backward(monkeypatch):
     """The pre-norm chain  y1 = x + drop(0.5 FFN(LN(x)));  y2 = y1 + drop(Linear(LN(y1)));  out = LN(y2)  in bf16 mode: the
     LayerNorm backward kernels of the second and third norm hand the prepared bf16 gradient image (scale, dropout mask,
