@@ -176,20 +176,38 @@ def _ev():
     return e
 
 
+def rank_binding(gpus, same_device, env, n_devices):
+    """(world, rank, local_rank, device index) of this process from the launcher's environment (one rank per GPU of ONE
+    node: device = LOCAL_RANK), or SystemExit with the reason: a line is only printed for the job that was asked for.
+    Pure function of its arguments (tests/test_host_cpu.py drives it without a GPU)."""
+    world = int(env.get('WORLD_SIZE', '1'))
+    if gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to print a line whose '
+                         'n_gpus would not be what ran' % (gpus, world))
+    rank, local_rank = int(env.get('RANK', '0')), int(env.get('LOCAL_RANK', '0'))
+    if not (0 <= rank < world):
+        raise SystemExit('bench.py: RANK %d outside WORLD_SIZE %d' % (rank, world))
+    if world > 1 and 'LOCAL_RANK' not in env:
+        raise SystemExit('bench.py: WORLD_SIZE %d without LOCAL_RANK: launch with torch.distributed.run (one rank per GPU)' % world)
+    if same_device:
+        return world, rank, local_rank, 0
+    if local_rank != rank:
+        raise SystemExit('bench.py: LOCAL_RANK %d != RANK %d: this benchmark is one node, one rank per GPU' % (local_rank, rank))
+    if local_rank >= n_devices:
+        raise SystemExit('bench.py: LOCAL_RANK %d but only %d device(s) visible: --gpus %d needs %d GPUs on this node '
+                         '(two ranks on one device are a different measurement: --same-device)' % (local_rank, n_devices, gpus, gpus))
+    return world, rank, local_rank, local_rank
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(_spawn_ranks(a))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if a.gpus != world:
-        sys.exit('bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to print a line whose '
-                 'n_gpus would not be what ran' % (a.gpus, world))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
     assert torch.cuda.is_available(), 'bench.py measures the HIP path; no GPU is visible'
+    world, rank, local_rank, dev_index = rank_binding(a.gpus, a.same_device, os.environ, torch.cuda.device_count())
+    distributed = world > 1
     if a.same_device:
-        local_rank = 0
+        local_rank = dev_index
         # ranks sharing one device cannot guarantee co-residency of each other's grid-barrier kernels (two half-resident
         # persistent grids wait on each other until the barrier times out): rank 0 keeps the persistent LSTM -- so that
         # the grid-barrier kernel runs beside the other rank's kernels and under the communication hook -- the others

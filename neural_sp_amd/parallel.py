@@ -126,8 +126,35 @@ def param_streams(model):
     return out
 
 
-def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_stream=None):
-    """DDP communication hook: all-reduce(mean) of one bucket, launched from a gather stream.  The gather stream
+def _reduce_scatter_all_gather(buf, group, world, on_device):
+    """mean-reduce `buf` (already divided by world) as reduce-scatter + all-gather: every rank reduces
+    1/world of the bucket, then the reduced shards are gathered.  On 8 fully connected GPUs both halves are one-hop
+    exchanges over all 7 xGMI links at once, and the shard boundary is where a sharded optimizer step would sit.  The same
+    bytes per rank as a ring all-reduce; which of the two RCCL runs faster on a given node is a measurement this build has
+    not been able to make (no multi-GPU box).  Returns a future of `buf`."""
+    import torch.distributed as dist
+    n = buf.numel()
+    pad = (-n) % world
+    src = buf if pad == 0 else torch.cat([buf, buf.new_zeros(pad)])
+    shard = torch.empty((src.numel() // world,), device=buf.device, dtype=buf.dtype)
+    if on_device:
+        # same communicator, same (gather) stream: RCCL runs the two collectives in issue order
+        dist.reduce_scatter_tensor(shard, src, group=group, async_op=True)
+        fut = dist.all_gather_into_tensor(src, shard, group=group, async_op=True).get_future()
+    else:
+        dist.reduce_scatter_tensor(shard, src, group=group)          # (gloo runs work items on a thread pool: order by waiting)
+        fut = dist.all_gather_into_tensor(src, shard, group=group, async_op=True).get_future()
+
+    def done(f):
+        if pad:
+            buf.copy_(src[:n])
+        return buf
+    return fut.then(done)
+
+
+def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_stream=None, algorithm=None):
+    """DDP communication hook: all-reduce(mean) of one bucket, launched from a gather stream.  `algorithm`: 'all_reduce'
+    (default; NSP_DDP_ALGO) or 'rs_ag' = reduce-scatter + all-gather (_reduce_scatter_all_gather).  The gather stream
     waits for the hook's (main) stream and for the side streams that produced gradients OF THIS BUCKET
     (`pstreams` = param_streams(model)): a bucket of encoder parameters no longer waits for the prediction
     network's LSTM backward (8 ms per 64 utterances on its side stream), so the early buckets' collectives start
@@ -135,12 +162,17 @@ def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_strea
     `compress='bf16'` sends bf16; `stats` (CommStats) collects what bench.py prints."""
     import torch.distributed as dist
     gather = {}
+    algorithm = algorithm or os.environ.get('NSP_DDP_ALGO') or 'all_reduce'
+    if algorithm not in ('all_reduce', 'rs_ag'):
+        raise ValueError('NSP_DDP_ALGO / algorithm must be all_reduce or rs_ag, not %r' % (algorithm,))
 
     def hook(state, bucket):
         buf = bucket.buffer()
         group = state if state is not None else dist.group.WORLD
         world = dist.get_world_size(group)
         if not buf.is_cuda:
+            if algorithm == 'rs_ag':
+                return _reduce_scatter_all_gather(buf.div_(world), group, world, False)
             return dist.all_reduce(buf.div_(world), group=group, async_op=True).get_future().then(lambda f: f.value()[0])
         dev = buf.device
         g = gather.get(dev)
@@ -171,13 +203,18 @@ def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_strea
         with torch.cuda.stream(g):
             if compress == 'bf16':
                 send = buf.to(torch.bfloat16).div_(world)
-                fut = dist.all_reduce(send, group=group, async_op=True).get_future()
+                if algorithm == 'rs_ag':
+                    fut = _reduce_scatter_all_gather(send, group, world, True)
+                else:
+                    fut = dist.all_reduce(send, group=group, async_op=True).get_future().then(lambda f: f.value()[0])
 
                 def decompress(f):
-                    buf.copy_(f.value()[0])
+                    buf.copy_(f.value())
                     return buf
                 return fut.then(decompress)
             buf.div_(world)
+            if algorithm == 'rs_ag':
+                return _reduce_scatter_all_gather(buf, group, world, True)
             fut = dist.all_reduce(buf, group=group, async_op=True).get_future()
         return fut.then(lambda f: f.value()[0])
     return hook

@@ -235,6 +235,13 @@ class Speech2Text(nn.Module):
                                         getattr(self, 'vocab_' + sub), getattr(self, 'ctc_weight_' + sub),
                                         getattr(self, sub + '_weight'), None)
                 setattr(self, 'dec_fwd_' + sub, dec_sub)
+        # Constant tables (the XL position embedding's `inv_freq`, ...) are the same on every rank by construction: keep them
+        # out of stock DistributedDataParallel's per-forward buffer broadcast (train.py:263 leaves broadcast_buffers=True) --
+        # one collective, and one cross-rank synchronisation at the top of every step, saved.  BatchNorm statistics are
+        # state, not tables: they stay in.  (They remain in state_dict either way.)
+        self._ddp_params_and_buffers_to_ignore = [
+            n for n, _ in self.named_buffers()
+            if n.rsplit('.', 1)[-1] not in ('running_mean', 'running_var', 'num_batches_tracked')]
 
     # ---- bookkeeping members touched by neural_sp/bin/asr/train.py (speech2text.py:206-237, base.py)
     @property

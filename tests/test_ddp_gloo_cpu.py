@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, algorithm=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -29,6 +29,8 @@ def _worker(rank, world, port, q):
     torch.manual_seed(0)
     model = nn.Sequential(nn.Linear(8, 16), nn.Tanh(), nn.Linear(16, 1))
     ddp = parallel.wrap_ddp(model, None)
+    if algorithm is not None:      # the package's communication hook (CPU branch) with the chosen collective; 161 parameters: an
+        ddp.register_comm_hook(None, parallel.make_comm_hook([], algorithm=algorithm))      # odd bucket -> the padded path
     g = torch.Generator().manual_seed(1)
     X = torch.randn(12, 8, generator=g)
     Y = torch.randn(12, 1, generator=g)
@@ -44,12 +46,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_ddp_gloo_world2_matches_single_process():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('algorithm', [None, 'all_reduce', 'rs_ag'])
+def test_ddp_gloo_world2_matches_single_process(algorithm):
+    """algorithm None: torch DDP's own all-reduce; 'all_reduce' / 'rs_ag': parallel.make_comm_hook with an all-reduce or
+    with reduce-scatter + all-gather -- all three must give the single-process gradient"""
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, algorithm)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])

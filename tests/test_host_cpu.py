@@ -324,3 +324,50 @@ def test_kernel_event_classes_bookkeeping(monkeypatch):
     assert set(cl) == {'ln', 'ln@side'} and cl['ln']['work'] == 15.0 and cl['ln']['unit'] == 'byte'
     assert len(cl['ln']['events']) == 2 and len(cl['ln@side']['events']) == 1 and Ev.n == 6
     assert all(e0.recorded and e1.recorded for e0, e1 in cl['ln']['events'])
+
+
+def test_bench_rank_to_device_binding_and_refusals():
+    """bench.py --gpus N: device = LOCAL_RANK, and every way the launcher's environment can disagree with the job that was
+    asked for ends in SystemExit before anything is measured (the N > 1 path has never met real devices)"""
+    import importlib.util
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    env8 = lambda r: {'WORLD_SIZE': '8', 'RANK': str(r), 'LOCAL_RANK': str(r), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '1'}
+    for r in range(8):
+        assert bench.rank_binding(8, False, env8(r), 8) == (8, r, r, r)
+    assert bench.rank_binding(1, False, {}, 1) == (1, 0, 0, 0)
+    assert bench.rank_binding(2, True, {'WORLD_SIZE': '2', 'RANK': '1', 'LOCAL_RANK': '1'}, 1) == (2, 1, 1, 0)     # --same-device
+    for args in [(4, False, env8(0), 8),                                       # --gpus 4 under an 8-rank launcher
+                 (8, False, env8(5), 4),                                       # 8 ranks, 4 devices visible
+                 (1, False, {'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'}, 8),
+                 (2, False, {'WORLD_SIZE': '2', 'RANK': '1'}, 8),              # no LOCAL_RANK
+                 (2, False, {'WORLD_SIZE': '2', 'RANK': '1', 'LOCAL_RANK': '0'}, 8),     # two ranks -> one device without --same-device
+                 (2, False, {'WORLD_SIZE': '2', 'RANK': '2', 'LOCAL_RANK': '2'}, 8)]:
+        with pytest.raises(SystemExit):
+            bench.rank_binding(*args)
+
+
+def test_constant_buffers_are_not_broadcast_by_stock_ddp(tmp_path):
+    """train.py:263 `DDP(model)` with torch's defaults broadcasts every buffer from rank 0 before every forward; the
+    model's buffers that are constant tables (inv_freq) opt out through torch DDP's own `_ddp_params_and_buffers_to_ignore`,
+    BatchNorm statistics (conformer_normalization: batch_norm) stay in; state_dict is unchanged"""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from neural_sp_amd.configs import conformer_rnnt_args
+    from neural_sp_amd.speech2text import Speech2Text
+    model = Speech2Text(conformer_rnnt_args('XS', n_layers=2, vocab=40, conformer_normalization='batch_norm'))
+    names = [n for n, _ in model.named_buffers()]
+    assert any(n.endswith('inv_freq') for n in names) and any(n.endswith('running_mean') for n in names)
+    assert 'enc.pos_emb.inv_freq' in model.state_dict()
+    dist.init_process_group('gloo', init_method='file://' + str(tmp_path / 'store'), rank=0, world_size=1)
+    try:
+        ddp = DDP(model)
+        synced = set(id(b) for b in ddp.modules_buffers)
+        by_name = dict(model.named_buffers())
+        assert id(by_name['enc.pos_emb.inv_freq']) not in synced
+        assert all(id(b) in synced for n, b in by_name.items() if n.endswith('running_mean') or n.endswith('running_var'))
+    finally:
+        dist.destroy_process_group()
