@@ -247,16 +247,25 @@ class RNNTransducer(DecoderBase):
         observation['loss'] = loss.detach()
         return loss, observation
 
-    def _prediction_network(self, ys, dev):
-        """ys -> w_dec(recurrency(embed([eos]+y)))  `[B, L+1, J]` (rnn_transducer.py:229-236,273)."""
+    def _prediction_network(self, ys, dev, defer_tail=False):
+        """ys -> w_dec(recurrency(embed([eos]+y)))  `[B, L+1, J]` (rnn_transducer.py:229-236,273).
+        defer_tail: when the LSTM stack runs as one (persistent) launch, stop behind it and return ('deferred', y_top) --
+        the caller runs `_prediction_network_tail` after `ops.lstm_forward_resolve()`, so that a launch that timed out at
+        its grid barrier is re-run before anything has read its output (ops._LSTM_FWD_RESCUE)."""
         L = max(len(y) for y in ys) + 1
         ys_in_np = np.full((len(ys), L), self.pad, dtype=np.int64)
         for b, y in enumerate(ys):
             ys_in_np[b, 0] = self.eos
             ys_in_np[b, 1:len(y) + 1] = np.asarray(y, dtype=np.int64)
         ys_in = ops.h2d(ys_in_np, dev)
-        dout, _ = self.recurrency(self.embed_token_id(ys_in), None, need_state=False)
+        dout, st = self.recurrency(self.embed_token_id(ys_in), None, need_state=False, defer_tail=defer_tail)
+        if st == 'deferred':
+            return ('deferred', dout)
         return ops.linear(dout, self.w_dec.weight, None)
+
+    def _prediction_network_tail(self, out):
+        """the dropout behind the last LSTM layer and the output projection (rnn_transducer.py:303,273)"""
+        return ops.linear(ops.dropout(out, self.dropout.p, self.training), self.w_dec.weight, None)
 
     def ensure_streams(self):
         """(prediction-network side stream, CTC-branch stream) of the training step, created on
@@ -314,7 +323,7 @@ class RNNTransducer(DecoderBase):
         else:
             self._side_stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._side_stream):
-            dec_proj = self._prediction_network(ys, dev)
+            dec_proj = self._prediction_network(ys, dev, defer_tail=True)
             self._pred_done = torch.cuda.Event()
             self._pred_done.record(self._side_stream)
         self._pending_dec_proj = (dec_proj, id(ys))
@@ -328,6 +337,12 @@ class RNNTransducer(DecoderBase):
         if pending is not None and pending[1] == id(ys):
             dec_proj = pending[0]
             cur = torch.cuda.current_stream(dev)
+            if isinstance(dec_proj, tuple):           # ('deferred', LSTM output): check the launch, then the network's tail
+                ops.lstm_forward_resolve()
+                with torch.cuda.stream(self._side_stream):
+                    dec_proj = self._prediction_network_tail(dec_proj[1])
+                    self._pred_done = torch.cuda.Event()
+                    self._pred_done.record(self._side_stream)
             cur.wait_event(self._pred_done)
             dec_proj.record_stream(cur)
             if torch.is_grad_enabled() and dec_proj.requires_grad \
@@ -335,7 +350,10 @@ class RNNTransducer(DecoderBase):
                 dec_proj = ops.replay_graph_first(
                     dec_proj, self._side_stream if os.environ.get('NSP_REPLAY_SIDE', '1') != '0' else None)
         else:
-            dec_proj = self._prediction_network(ys, dev)                        # `[B,L+1,J]`
+            dec_proj = self._prediction_network(ys, dev, defer_tail=True)       # `[B,L+1,J]`
+            if isinstance(dec_proj, tuple):
+                ops.lstm_forward_resolve()
+                dec_proj = self._prediction_network_tail(dec_proj[1])
         enc_proj = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias)       # `[B,T,J]`
         loss, _ = ops.rnnt_joint_loss(enc_proj, dec_proj, self.output.weight, self.output.bias,
                                       lab, elens_dev, ylens_dev, self.blank,
@@ -415,10 +433,10 @@ class RNNTransducer(DecoderBase):
         # embedding lookup = row gather of a [V, emb] table (host-side indexing glue)
         return ops.dropout(self.embed(indices), self.dropout_emb.p, self.training)
 
-    def recurrency(self, ys_emb, dstate, need_state=True):
+    def recurrency(self, ys_emb, dstate, need_state=True, defer_tail=False):
         if dstate is None:
             dstate = self.zero_state(ys_emb.size(0)) if need_state else None
-        if (not need_state and self.proj is None and ys_emb.is_cuda
+        if (not need_state and self.proj is None and ops.on_kernel_device(ys_emb)
                 and os.environ.get('NSP_LSTM_STACK', '1') != '0'):
             layers = [(r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0) for r in self.rnn]
             if ops.lstm_stack_supported(layers, ys_emb):
@@ -426,6 +444,8 @@ class RNNTransducer(DecoderBase):
                 # layers is fused, the one after the last layer is the ordinary op
                 p = self.dropout.p if self.training else 0.0
                 out = ops.lstm_stack(ys_emb, layers, p)
+                if defer_tail:
+                    return out, 'deferred'
                 return ops.dropout(out, self.dropout.p, self.training), None
         new_hxs, new_cxs = [], []
         for lth in range(self.n_layers):

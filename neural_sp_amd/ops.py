@@ -54,6 +54,11 @@ def _p(t):
     return t.data_ptr()
 
 
+def on_kernel_device(t):
+    """is `t` where the kernels run?  (the HIP device; tests/hipemu points this at the host for the emulated library)"""
+    return t.is_cuda
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -2604,6 +2609,7 @@ def _lstm_stack_launch_impl(which, P, dev):
         fn = lib.nsp_lstm_stack_fwd_persistent if which == 'fwd' else lib.nsp_lstm_stack_bwd_persistent
         B, L, H, nl = P.B, P.L, P.H, P.nl
         fell_back = False
+        checks = []
         for b0 in range(0, B, 64):
             Q = P
             if B > 64:
@@ -2636,10 +2642,54 @@ def _lstm_stack_launch_impl(which, P, dev):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             _LSTM_DEAD_CHECKS.append((flag, ev, which))
+            checks.append((flag, ev))
         if not fell_back:
-            return
+            return checks
     fn = lib.nsp_lstm_stack_fwd if which == 'fwd' else lib.nsp_lstm_stack_bwd
     _check(fn(ctypes.byref(P), _stream()), 'nsp_lstm_stack_' + which)
+    return []
+
+
+# ---- in-step rescue of a FORWARD whose persistent launch timed out at its grid barrier (its workgroups never became
+# co-resident).  The forward registers what a re-run needs; the decoder calls lstm_forward_resolve() where the prediction
+# network's output joins the step, BEFORE anything has consumed it (decoders.RNNT defers the network's tail -- dropout and
+# the output projection -- to that point): the host waits for the launch's event (free in practice: the launch started a
+# whole encoder forward earlier), reads its `dead` word, and on a time-out re-runs the recurrence with one launch per stage
+# on the same stream into the same tensors, switches the process to per-stage launches and says so.  A BACKWARD time-out
+# still raises at the next poll (its results have been consumed by the weight-gradient GEMMs by the time it is known).
+_LSTM_FWD_RESCUE = []
+_LSTM_RESCUES = [0]          # (how many forwards have been re-run in this process: tests, logs)
+
+
+def lstm_forward_resolve():
+    """-> number of forward launches that had to be re-run"""
+    if not _LSTM_FWD_RESCUE:
+        return 0
+    pending = list(_LSTM_FWD_RESCUE)
+    del _LSTM_FWD_RESCUE[:]
+    n = 0
+    for P, keep, checks, stream in pending:
+        dead = False
+        for flag, ev in checks:
+            ev.synchronize()
+            dead = dead or int(flag[0]) != 0
+        if os.environ.get('NSP_LSTM_TEST_FAKE_TIMEOUT', '0') == '1':      # test hook: treat the next launch as timed out, once
+            os.environ['NSP_LSTM_TEST_FAKE_TIMEOUT'] = '0'
+            dead = True
+        if not dead:
+            continue
+        n += 1
+        _LSTM_RESCUES[0] += 1
+        mine = set(id(f) for f, _ in checks)
+        _LSTM_DEAD_CHECKS[:] = [c for c in _LSTM_DEAD_CHECKS if id(c[0]) not in mine]
+        os.environ['NSP_LSTM_PERSISTENT'] = '0'
+        import logging
+        logging.getLogger(__name__).warning(
+            'neural_sp_amd: a persistent LSTM forward timed out at its grid barrier (its %d workgroups did not become '
+            'co-resident); re-running the recurrence with one launch per stage and keeping per-stage launches for the rest '
+            'of this process (NSP_LSTM_PERSISTENT=0)', P.nl * (P.H // 16))
+        _check(_lib.lib().nsp_lstm_stack_fwd(ctypes.byref(P), stream), 'nsp_lstm_stack_fwd (rescue)')
+    return n
 
 
 def lstm_check():
@@ -2695,8 +2745,11 @@ class LSTMStackFn(torch.autograd.Function):
                 seeds.append(sd)
                 P.seed[l], P.offset[l] = sd
         xchg = _lstm_xchg(P, 2 * H, dev)
-        _lstm_stack_launch('fwd', P, dev)
+        checks = _lstm_stack_launch('fwd', P, dev)
         del xchg
+        if checks or os.environ.get('NSP_LSTM_TEST_FAKE_TIMEOUT', '0') == '1':
+            del _LSTM_FWD_RESCUE[:-3]          # (launches nobody resolved -- ops.lstm_stack driven directly -- do not pile up)
+            _LSTM_FWD_RESCUE.append((P, keep + [y_top] + hp16 + yd16 + c_all + gates, checks or [], _stream()))
         ctx.save_for_backward(xa, *ws, *hp16, *yd16, *c_all, *gates)
         ctx.cfg = (nl, B, L, I, H, float(p_drop), seeds)
         return y_top

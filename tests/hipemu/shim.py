@@ -32,14 +32,15 @@ def emu_lib():
 def emulated_kernels():
     from neural_sp_amd import _lib, ops
     import torch
-    saved = (_lib.lib, ops._p, ops._stream, ops.zeros_small, ops._require_device)
+    saved = (_lib.lib, ops._p, ops._stream, ops.zeros_small, ops._require_device, ops.on_kernel_device)
     lib = emu_lib()
     _lib.lib = lambda: lib
     ops._p = lambda t: None if t is None else t.data_ptr()
     ops._stream = lambda: 0
     ops.zeros_small = lambda shape, device, dtype=torch.float32: torch.zeros(shape, device=device, dtype=dtype)
     ops._require_device = lambda *tensors: None
+    ops.on_kernel_device = lambda t: True
     try:
         yield lib
     finally:
-        _lib.lib, ops._p, ops._stream, ops.zeros_small, ops._require_device = saved
+        _lib.lib, ops._p, ops._stream, ops.zeros_small, ops._require_device, ops.on_kernel_device = saved

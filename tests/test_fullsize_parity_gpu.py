@@ -246,6 +246,42 @@ def test_persistent_lstm_beside_a_resident_kernel(n_wg, ms):
         assert diff[n] <= max(2 * rerun[n], 1e-6), (n, diff[n], rerun[n])
 
 
+def test_prediction_network_forward_is_rerun_in_step_after_a_grid_barrier_timeout(monkeypatch):
+    """device twin of tests/test_e2e_emu_cpu.py: the XS transducer step (2 x 256 persistent LSTM stack on its side stream) with
+    the NEXT persistent forward declared timed out (NSP_LSTM_TEST_FAKE_TIMEOUT): the decoder re-runs the recurrence with one
+    launch per stage before the network's tail reads it -- same loss bit for bit (the two recurrences are bit-identical),
+    same gradients up to atomic-sum rounding, one rescue counted, per-stage launches from then on."""
+    from neural_sp_amd import ops
+    from neural_sp_amd.speech2text import Speech2Text
+    from tests import ddp_hip_worker as W
+    monkeypatch.setenv('NSP_LSTM_PERSISTENT', '1')
+    with ops.compute_mode('bf16'):
+        args = W.model_args(small=False)
+        torch.manual_seed(7)
+        model = Speech2Text(args).to(torch.device('cuda', 0))
+        batch = W.sub_batch(W.global_batch(args.vocab), [1, 3])
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            loss, _ = model(batch, task='all')
+            loss.backward()
+            torch.cuda.synchronize()
+            ops.lstm_check()
+            return loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        l0, g0 = step()
+        l0b, g0b = step()
+        before = ops._LSTM_RESCUES[0]
+        monkeypatch.setenv('NSP_LSTM_TEST_FAKE_TIMEOUT', '1')
+        l1, g1 = step()
+        assert ops._LSTM_RESCUES[0] == before + 1 and os.environ['NSP_LSTM_PERSISTENT'] == '0'
+        l2, g2 = step()                                    # per-stage launches from here on
+        assert l0 == l0b == l1 == l2, (l0, l0b, l1, l2)
+        for n in g0:
+            rerun = (g0b[n] - g0[n]).abs().max().item()
+            for g in (g1, g2):
+                assert (g[n] - g0[n]).abs().max().item() <= max(4 * rerun, 2e-6 * g0[n].abs().max().item()), n
+
+
 def test_specaug_apply_matches_masked_fill():
     """nsp_specaug_apply (spec_augment.py:112-140): one set of frequency / time bands zeroed for
     the whole batch, everything else untouched -- bit-exact against a torch masked fill."""
