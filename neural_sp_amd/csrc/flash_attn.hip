@@ -978,16 +978,12 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
   if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16 && p.R >= (p.clamp + 1 < p.Tk ? p.clamp + 1 : p.Tk)))
     return NSP_EUNSUPPORTED;
   if (p.r_pitch < p.R) p.r_pitch = p.R;
-  const char* e = getenv("NSP_FLASH_NQ");
-  const int nq = e ? atoi(e) : 1;   // 16 queries per wave measured faster than 32 (occupancy 3 vs 2; round 3: 228 vs 311 us at T = 800, B = 64)
-  // (forcing 4 waves per SIMD -- 128 VGPRs, 8 dwords spilled -- measured equal to the 137-VGPR / 3-wave build)
-  if (nq == 1) {
+  // 16 queries per wave (flash_fwd_kernel<1>): measured faster than 32 (occupancy 3 vs 2; round 3: 228 vs 311 us at T = 800,
+  // B = 64; the <2> instantiation and its switch were removed in round 5).  Forcing 4 waves per SIMD -- 128 VGPRs, 8 dwords
+  // spilled -- measured equal to the 137-VGPR / 3-wave build.
+  {
     dim3 grid(((p.Tq + 63) / 64) * p.H, p.B);
     hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE, p);
-  } else {
-    dim3 grid(((p.Tq + 127) / 128) * p.H, p.B);
-    hipLaunchKernelGGL(flash_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE, p);
   }
   NSP_LAUNCH_CHECK();
@@ -1010,13 +1006,10 @@ extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const
   // the dQ kernel first: it forms D = dO . O for its queries and leaves it in D for the dK/dV kernel
   hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
                      reinterpret_cast<const __bf16*>(dO), O32, LSE, D, dq32, dQP, p);
-  const char* eh = getenv("NSP_FLASH_DKV_HALVES");
-  if (!eh || atoi(eh) != 0)
-    hipLaunchKernelGGL(flash_bwd_dkv_kernel<true>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
-                       QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
-  else
-    hipLaunchKernelGGL(flash_bwd_dkv_kernel<false>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
-                       QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
+  // the 64-query tile as two halves of 32 (168 VGPRs, a third wave per SIMD; the whole-tile form -- 255 VGPRs -- and its
+  // switch were removed in round 5: bit-identical results, 3-7 % slower, profiles/r04zn_flash_dkv_two_halves_ab.log)
+  hipLaunchKernelGGL(flash_bwd_dkv_kernel<true>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
+                     QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

@@ -371,11 +371,10 @@ __device__ __forceinline__ void rnnt_epilogue(const nsp_gemm_params& p, f32x4 (&
 // is bf16 or fp32 and whether act' is relu or swish; + residual 227 us).  The configurations the
 // training step uses are therefore compiled as specialisations (EpiSpec); everything else takes the
 // run-time version (EpiRuntime), which is correct but serialises as described.
-struct EpiRuntime { static constexpr bool kStatic = false, kRnnt = false; };
-template <bool LSE_> struct EpiRnnt { static constexpr bool kStatic = false, kRnnt = true, LSE = LSE_; };   // the 8-phase kernel only
+struct EpiRuntime { static constexpr bool kStatic = false; };
 template <int ACT_, int DACT_, bool C16_, bool PRE16_, bool RES_, bool DROP_>
 struct EpiSpec {
-  static constexpr bool kStatic = true, kRnnt = false;
+  static constexpr bool kStatic = true;
   static constexpr int ACT = ACT_, DACT = DACT_;   // DACT > 0: bf16 act' source
   static constexpr bool C16 = C16_, PRE16 = PRE16_, RES = RES_, DROP = DROP_;
 };
@@ -976,411 +975,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
   gemm_epilogue<MI, true, (NS == 2 && MI == 4)>(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
-// ---- KC x KC, 128 x 128 x 64, PERSISTENT with a DEFERRED epilogue.
-// Measured on the kernels above (tools/gemm_epilogue_probe.py, M = 51200, N = 2048, fp32 out):
-// t(K) = 121 us + 0.183 us * K, i.e. the main loop alone runs at 1145 TFLOP/s but every launch pays
-// "all of C at ~3.5 TB/s" on top: workgroups start together, share the CU's matrix pipe evenly and so
-// reach their epilogues together -- the chip alternates between a compute phase with idle HBM and a
-// store phase with idle MFMA (the fused bias/activation/dropout epilogues add their VALU time to
-// that second phase: y = swish(x W^T + b) with K = 512 ran at 376 TFLOP/s).
-// Here a workgroup owns a list of tiles and the epilogue of tile i is executed in 8 slices INSIDE the
-// k-loop of tile i+1 (the finished accumulators stay in registers): stores, epilogue VALU and loads
-// (bias, residual, act' source) overlap with MFMA work, on every CU, all the time.
-//   * 4 waves (2 x 2), wave tile 64 x 64; 2-stage LDS-DMA ring (64 KB) running continuously across
-//     tile boundaries + 8 KB of staging (8 rows x 64 cols per wave, XOR-swizzled) = 72 KB -> two
-//     workgroups per CU, ~190 VGPRs;
-//   * slice c = (mi = c/2, rows 8*(c%2)..+7 of that fragment row): staged through LDS so that 16 lanes
-//     store 256 contiguous bytes of one output row (same reason as gemm_epilogue);
-//   * tile order: n-fastest, grid-stride -> the tiles in flight at any time are a contiguous range of
-//     the tile list (A panels shared through L2), remapped so that a range lands on one XCD.
-// Handles the standard epilogue (no split-K, single problem) and the two RNN-T joint epilogues.
-// MEASURED (round 2, tools/gemm_epilogue_probe.py / gemm_shapes_bench.py): correct, but 20-45 % SLOWER
-// than the classic kernels at every shape of the step (e.g. 51200 x 2048 x 512 fp32 out: 270 vs 211 us),
-// so it is opt-in (NSP_GEMM_PERSIST=1).  Why: (1) vmcnt on gfx9 retires loads and stores in issue order,
-// so the `s_waitcnt vmcnt(0)` that proves the next k-tile's LDS-DMA has landed also waits for the
-// previous slice's global stores to be acknowledged (1.6 us per slice measured); (2) two workgroups
-// per CU hide less DMA latency than the classic kernel's four; and the premise was wrong: starting the
-// classic kernel's workgroups 3-17 us apart (stagger experiment) changed nothing, i.e. its
-// t(K) = a + b K is not a lockstep artefact -- the main loop is bound by the L2 -> LDS fill rate of
-// 128 x 128 tiles (~26 B/clk/CU at 1.15 PFLOP/s) and the epilogue by the ~4.5 TB/s HBM write ceiling.
-struct EpiCarry { float csum[4]; };
-
-__device__ __forceinline__ void kkp_epi_vec(const nsp_gemm_params& p, int m, int n, float (&v)[4], int c_vec,
-                                            float sc, EpiCarry& cy, int lane) {
-  // one float4 (row m, cols n..n+3) of the finished tile; all 16 lanes of a row group are in here together
-  if (p.epi_mode == NSP_EPI_NONE) {
-    if (m >= p.M || n >= p.N) return;
-    const long long off = (long long)m * p.ldc + n;
-    const int nv = min(4, p.N - n);
-    const bool vec = c_vec && nv == 4;
-    if (p.bias) {
-      float b4[4] = {0.f, 0.f, 0.f, 0.f};
-      load4(p.bias, NSP_DT_F32, n, b4, nv, vec);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += b4[e];
-    }
-    if (p.pre_out) store4(p.pre_out, p.pre_dtype, off, v, nv, vec);
-    if (p.act != NSP_ACT_NONE) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], p.act);
-    }
-    if (p.dact_src) {
-      float d[4] = {0.f, 0.f, 0.f, 0.f};
-      load4(p.dact_src, p.dact_dtype, off, d, nv, vec);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], p.dact);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-    if (p.dropout_p > 0.f) {
-      float kp[4];
-      nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= kp[e];
-    }
-    if (p.res) {
-      float r4[4] = {0.f, 0.f, 0.f, 0.f};
-      load4(p.res, NSP_DT_F32, off, r4, nv, vec);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += r4[e];
-    }
-    store4(p.C, p.c_dtype, off, v, nv, vec);
-    return;
-  }
-  // RNN-T joint epilogues (N % 64 == 0; bias padded to N)
-  const bool rowok = m < p.M && n < p.N;
-  if (p.bias && n < p.N) {
-    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
-  if (p.epi_mode == NSP_EPI_RNNT_LSE) {
-    float mx = -FLT_MAX;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) if (n + e < p.epi_ncols) mx = fmaxf(mx, v[e]);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float sm = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) if (n + e < p.epi_ncols) sm += __expf(v[e] - mx);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
-    if (rowok) {
-      if ((lane & 15) == 0)
-        *reinterpret_cast<float2*>(p.epi_f0 + ((long long)m * (p.N >> 6) + (n >> 6)) * 2) = make_float2(mx, sm);
-      const int lab = p.epi_lab[m];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e == p.epi_blank) p.epi_f1[m] = v[e];
-        if (n + e == lab) p.epi_f2[m] = v[e];
-      }
-    }
-  } else {
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    if (rowok) {
-      const float ls = p.epi_f0[m];
-      const float gb = p.epi_f1[m] * sc, gl = p.epi_f2[m] * sc;
-      const int lab = p.epi_lab[m];
-      const float gs = gb + gl;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e < p.epi_ncols) {
-          float t = -gs * __expf(v[e] - ls);
-          if (n + e == p.epi_blank) t += gb;
-          if (n + e == lab) t += gl;
-          g[e] = t;
-        }
-      }
-      bf16x4 o;
-      o[0] = (__bf16)g[0]; o[1] = (__bf16)g[1]; o[2] = (__bf16)g[2]; o[3] = (__bf16)g[3];
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C) + (long long)m * p.ldc + n) = o;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cy.csum[e] += g[e];
-  }
-}
-
-// slice c (0..7, wave-uniform runtime value) of a finished wave tile: fragment row mi = c/2, rows
-// 8*(c%2) .. +7 of it.  The fragment row is picked with selects (48 v_cndmask), NOT by indexing the
-// register array (that would send the accumulators through scratch) and NOT by instantiating the
-// epilogue per slice (8 x 3 call sites of it made a 110k-line kernel that spilled).
-__device__ __forceinline__ void kkp_epi_slice(int c, const nsp_gemm_params& p, const f32x4 (&acc)[4][4], float* stage,
-                                              int mbase, int nbase, int lane, int c_vec, float sc, EpiCarry& cy) {
-  const int mi = c >> 1, half = c & 1;
-  const int fr = lane & 15, fg = lane >> 4;
-  f32x4 t[4];
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) t[ni] = acc[0][ni];
-#pragma unroll
-  for (int m2 = 1; m2 < 4; ++m2)
-    if (m2 == mi) {               // wave-uniform scalar branch; constant register indices inside
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) t[ni] = acc[m2][ni];
-    }
-  if ((fr >> 3) == half) {
-    const int row = fr & 7;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-      *reinterpret_cast<float4*>(stage + row * 64 + (((ni * 4 + fg) ^ row) << 2)) =
-          make_float4(t[ni][0], t[ni][1], t[ni][2], t[ni][3]);
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int c4 = lane & 15;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (lane >> 4) + 4 * j;
-    const float4 a4 = *reinterpret_cast<const float4*>(stage + row * 64 + ((c4 ^ row) << 2));
-    float v[4] = {a4.x, a4.y, a4.z, a4.w};
-    kkp_epi_vec(p, mbase + mi * 16 + half * 8 + row, nbase + c4 * 4, v, c_vec, sc, cy, lane);
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (c == 7 && p.epi_mode == NSP_EPI_RNNT_DLOGITS && p.epi_f3) {
-    // column sums of this wave's 64 rows x 64 cols -> one slab row per 64-row block
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      cy.csum[e] += __shfl_xor(cy.csum[e], 16, 64);
-      cy.csum[e] += __shfl_xor(cy.csum[e], 32, 64);
-    }
-    const int n = nbase + c4 * 4;
-    if (lane < 16 && n < p.N)
-      *reinterpret_cast<float4*>(p.epi_f3 + (long long)(mbase >> 6) * p.N + n) =
-          make_float4(cy.csum[0], cy.csum[1], cy.csum[2], cy.csum[3]);
-  }
-}
-
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kkp_kernel(const nsp_gemm_params p, int tiles_m,
-                                                                    int tiles_n, int c_vec) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 16 KB | B 16 KB) | staging 8 KB
-  constexpr int STAGE = 32768;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  float* stage = reinterpret_cast<float*>(ring + 2 * STAGE) + wave * 512;
-  const int ntiles = tiles_m * tiles_n;
-  const int nkt = p.K / BK;
-  const int G = gridDim.x;
-  // grid-stride over the XCD-remapped tile list: workgroup g takes tiles xcd_remap(g + i*G)
-  const __bf16* A = reinterpret_cast<const __bf16*>(p.A);
-  const __bf16* B = reinterpret_cast<const __bf16*>(p.B);
-  const int lrow = lane >> 3, lpos = lane & 7;
-  const int fr = lane & 15, fg = lane >> 4;
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  const __bf16* asrc[4];
-  const __bf16* bsrc[4];
-  auto tile_at = [&](int i) {
-    const long long lin = (long long)blockIdx.x + (long long)i * G;
-    return lin < ntiles ? xcd_remap((int)lin, ntiles) : ntiles;
-  };
-  auto set_src = [&](int tile) {
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave * 4 + i) * 8 + lrow;
-      const int sw = (lpos ^ (row & 7)) * 8;
-      asrc[i] = A + (long long)min(tm * BM + row, p.M - 1) * p.a_rs + sw;
-      bsrc[i] = B + (long long)min(tn * BN + row, p.N - 1) * p.b_ns + sw;
-    }
-  };
-  auto issue = [&](int st, int kt) {
-    unsigned char* sa = ring + st * STAGE;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + k0), (lds_void*)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + k0), (lds_void*)(sa + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
-    }
-  };
-  const float sc = p.epi_scale * (p.epi_scale_dev ? p.epi_scale_dev[0] : 1.f);
-  int it = 0;
-  int tile = tile_at(0);
-  if (tile >= ntiles) return;
-  set_src(tile);
-  issue(0, 0);
-  int seq = 0;
-  f32x4 prev[4][4];
-  int pm = 0, pn = 0;
-  bool have_prev = false;
-  EpiCarry cy;
-  while (tile < ntiles) {
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int next_tile = tile_at(it + 1);
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (have_prev) { cy.csum[0] = cy.csum[1] = cy.csum[2] = cy.csum[3] = 0.f; }
-    auto ktile = [&](int kt) {
-      const int st = seq & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 1 < nkt) {
-        issue(st ^ 1, kt + 1);
-      } else if (next_tile < ntiles) {
-        set_src(next_tile);
-        issue(st ^ 1, 0);
-      }
-      const unsigned char* smA = ring + st * STAGE;
-      const unsigned char* smB = smA + 16384;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 af[4], bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int ra = wm * 64 + i * 16 + fr, rb = wn * 64 + i * 16 + fr;
-          af[i] = *reinterpret_cast<const bf16x8*>(smA + ra * 128 + (((s2 * 4 + fg) ^ (ra & 7)) << 4));
-          bf[i] = *reinterpret_cast<const bf16x8*>(smB + rb * 128 + (((s2 * 4 + fg) ^ (rb & 7)) << 4));
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-      }
-      ++seq;
-    };
-    // k-tile kt < 8 carries slice kt of the PREVIOUS tile's epilogue behind its MFMAs
-    for (int kt = 0; kt < nkt; ++kt) {
-      ktile(kt);
-      if (have_prev && kt < 8) kkp_epi_slice(kt, p, prev, stage, pm, pn, lane, c_vec, sc, cy);
-    }
-    if (have_prev)
-      for (int c = nkt; c < 8; ++c) kkp_epi_slice(c, p, prev, stage, pm, pn, lane, c_vec, sc, cy);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) prev[i][j] = acc[i][j];
-    pm = tm * BM + wm * 64;
-    pn = tn * BN + wn * 64;
-    have_prev = true;
-    ++it;
-    tile = next_tile;
-  }
-  // the last tile of this workgroup: nothing left to hide it behind
-  cy.csum[0] = cy.csum[1] = cy.csum[2] = cy.csum[3] = 0.f;
-  for (int c = 0; c < 8; ++c) kkp_epi_slice(c, p, prev, stage, pm, pn, lane, c_vec, sc, cy);
-}
-
-// ---- KC x KC, 256 x 256 x 64 tile, 8 waves (2 x 4; wave tile 128 x 64 = 8 x 4 MFMA fragments, 128
-// accumulator registers), PERSISTENT over output tiles.  Why: the 128 x 128 kernels above read
-// (64 + 64) rows x 128 B of fragments per wave per k-tile for 32 MFMAs; here a wave reads
-// (128 + 64) rows for 64 MFMAs, and a k-tile moves 64 KB global -> LDS for 4x the flops -- per
-// flop: 0.75x the LDS fragment traffic, 0.5x the DMA / L2 traffic.  One workgroup per CU (128 KB
-// of LDS: two 64-KB stages {A 256 x 128 B | B 256 x 128 B}), two waves per SIMD covering each
-// other's LDS reads and waits.  With a single workgroup per CU nobody else hides a tile's
-// prologue (first DMA latency) or epilogue, so the workgroup walks a list of tiles and the DMA
-// ring runs CONTINUOUSLY across tile boundaries: the first k-tile of tile i+1 lands while tile
-// i's last k-tile is multiplied and its epilogue (staged through the just-consumed LDS stage) runs.
-// Tile order: workgroup w (XCD w % 8, dispatch is round-robin) takes, at step s, tile
-// 32 (8 s + w % 8) + w / 8 of the n-fastest tile list: the 32 workgroups of one XCD work on 32
-// consecutive tiles = a few A panels x all their N tiles at the same time (A read once per XCD L2).
-// Requires K % 64 == 0, batch == 1, splitk == 1.
-// MEASURED (round 2): 968 vs 846 TFLOP/s at 8192^3, equal at 4096^3, but 0.6-0.7x the classic kernels at
-// the step's K = 512 shapes (one workgroup per CU: nothing hides the 256 KB-per-tile epilogue), so it is
-// opt-in (NSP_GEMM_256=1); the next step would be the phase-interleaved schedule of the CDNA guide.
-__global__ __launch_bounds__(512) void gemm_bf16_kk256_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
-                                                              int c_vec) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 32 KB | B 32 KB)
-  constexpr int STAGE = 65536, A_BYTES = 32768;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int ntiles = tiles_m * tiles_n;
-  const int nkt = p.K / BK;
-  const int G = gridDim.x;
-  const int xq = blockIdx.x >> 3, xx = blockIdx.x & 7, per_xcd = G >> 3;
-  auto tile_of = [&](int step) { return per_xcd * (8 * step + xx) + xq; };   // G % 8 == 0 (launcher)
-  const __bf16* A = reinterpret_cast<const __bf16*>(p.A);
-  const __bf16* B = reinterpret_cast<const __bf16*>(p.B);
-  const int lrow = lane >> 3, lpos = lane & 7;
-  const int fr = lane & 15, fg = lane >> 4;
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  // per-lane DMA sources of the CURRENT load tile: wave w, instruction i covers tile rows (w*4+i)*8 .. +7
-  const __bf16* asrc[4];
-  const __bf16* bsrc[4];
-  auto set_src = [&](int tile) {
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave * 4 + i) * 8 + lrow;
-      const int sw = (lpos ^ (row & 7)) * 8;
-      asrc[i] = A + (long long)min(tm * 256 + row, p.M - 1) * p.a_rs + sw;
-      bsrc[i] = B + (long long)min(tn * 256 + row, p.N - 1) * p.b_ns + sw;
-    }
-  };
-  auto issue = [&](int stage, int kt) {
-    unsigned char* sa = ring + stage * STAGE;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void*)(asrc[i] + k0), (lds_void*)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + k0), (lds_void*)(sa + A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
-    }
-  };
-  int step = 0;
-  int tile = tile_of(0);
-  if (tile >= ntiles) return;
-  set_src(tile);
-  issue(0, 0);
-  int seq = 0;                       // k-tiles consumed so far by this workgroup (ring position)
-  while (tile < ntiles) {
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int next_tile = tile_of(step + 1);
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nkt; ++kt, ++seq) {
-      const int st = seq & 1;
-      // this wave's loads of k-tile `seq` have landed; after the barrier everybody's have, and every
-      // wave has finished reading stage st^1 (k-tile seq-1 / the previous tile's epilogue staging)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 1 < nkt) {
-        issue(st ^ 1, kt + 1);
-      } else if (next_tile < ntiles) {
-        set_src(next_tile);          // the ring keeps running across the tile boundary
-        issue(st ^ 1, 0);
-      }
-      const unsigned char* smA = ring + st * STAGE;
-      const unsigned char* smB = smA + A_BYTES;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 af[8], bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int rb = wn * 64 + i * 16 + fr;
-          bf[i] = *reinterpret_cast<const bf16x8*>(smB + rb * 128 + (((s * 4 + fg) ^ (rb & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int ra = wm * 128 + i * 16 + fr;
-          af[i] = *reinterpret_cast<const bf16x8*>(smA + ra * 128 + (((s * 4 + fg) ^ (ra & 7)) << 4));
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-      }
-    }
-    // all waves are done with the last stage they multiplied from: it becomes the epilogue's staging
-    // area (the other stage may be receiving the next tile's first k-tile right now)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // two 64-row halves through the MI = 4 epilogue (an 8-fragment instantiation is not fully unrolled by
-    // hipcc: the accumulators would round-trip through scratch); row = m0 + wm*128 + half*64 + ...
-    unsigned char* stg = ring + ((seq - 1) & 1) * STAGE;
-    gemm_epilogue<4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stg, m0 + wm * 64, n0, wm, wn, lane, wave, 0, c_vec);
-    gemm_epilogue<4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stg, m0 + wm * 64 + 64, n0, wm, wn, lane, wave, 0, c_vec);
-    ++step;
-    tile = next_tile;
-  }
-}
-
 // ---- DIRECT epilogue (round 4): no LDS.  The MFMA leaves lane (fr, fg) with C[row fr][4 consecutive columns] of every
 // 16 x 16 fragment; a store instruction of one fragment therefore covers 16 rows x 64 B (fp32) / 32 B (bf16).  The staged
 // epilogue above exists to turn that into full 256-B row segments -- at the price of a ds_write / ds_read round trip and a
@@ -1651,16 +1245,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     coff = p.c_ss ? (long long)tc.split * p.c_ss : 0;
   }
   const int xq = blockIdx.x >> 3, xx = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-  if constexpr (!RR) {
-    // STAGGER (c_vec >> 8, NSP_GEMM_8P_STAGGER): the 32 workgroups of an XCD start in four groups ~3.9 us x the factor
-    // apart.  All 256 persistent workgroups otherwise start together and do identical work: main loops and epilogues
-    // of the whole chip coincide, the epilogues' stores arrive at HBM in bursts (measured below).
-    const int sg = c_vec >> 8;
-    if (sg > 0) {
-      const int grp = xq & 3;
-      for (int i = 0; i < grp * sg; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
+  // (a staggered start of the XCDs' workgroups -- NSP_GEMM_8P_STAGGER, round 4 -- measured nothing and was removed:
+  // profiles/r04v_gemm_8p_stagger_negative.log)
   // Tile order (KK).  Narrow outputs (< 16 tile columns: every GEMM of the training step): the 32 workgroups of an XCD
   // take 32 CONSECUTIVE tiles of the n-fastest list -- a few A panels x all their column tiles, so every A panel crosses
   // the fabric once and the whole weight matrix stays in the XCD's L2.  Wide outputs (N >= 4096: the 8192^3 square the
@@ -1932,10 +1518,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
 #ifndef NSP_HOST_EMULATION
     asm volatile("" : "+v"(elane));
 #endif
-    if constexpr (S::kRnnt) {
-      rnnt_epilogue_core<4, S::LSE, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol, elane);
-      rnnt_epilogue_core<4, S::LSE, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol, elane);
-    } else if constexpr (!S::kStatic || (VAR & 4)) {
+    if constexpr (!S::kStatic || (VAR & 4)) {
       gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol + (elane & 15) * 4, elane, coff);
       gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol + (elane & 15) * 4, elane, coff);
     } else {
@@ -2067,199 +1650,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_rr_ring_kernel(const nsp_g
   gemm_epilogue<4>(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);
 }
 
-// ---- the same RC x RC tile with ONE LDS stage and four workgroups per CU (the weight-gradient analogue of
-// gemm_bf16_kk_glds_kernel): load -> wait -> barrier -> 32 MFMAs -> barrier per k-tile, the DMA latency of one
-// workgroup hidden by the three others instead of by a second stage.  NSP_GEMM_RR_RING=1 selects it.
-__global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_rr_glds_kernel(const nsp_gemm_params p, int tiles_m,
-                                                                        int tiles_n, int c_vec) {
-  __shared__ __attribute__((aligned(16))) unsigned char ring[32768];   // A image 16 KB | B image 16 KB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const TileCoord tc = tile_coord(p, tiles_m * tiles_n);
-  const int tile = tc.tile, split = tc.split, z1 = tc.z1, z2 = tc.z2;
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const __bf16* A = reinterpret_cast<const __bf16*>(p.A) + z1 * p.a_b1 + z2 * p.a_b2;
-  const __bf16* B = reinterpret_cast<const __bf16*>(p.B) + z1 * p.b_b1 + z2 * p.b_b2;
-  const long long coff = z1 * p.c_b1 + z2 * p.c_b2 + (p.c_ss ? (long long)split * p.c_ss : 0);
-  const long long lda = p.a_cs, ldb = p.b_ks;
-  int kbeg = 0, kend = p.K;
-  if (p.splitk > 1) {
-    int nkt_all = p.K / BK;
-    int per = (nkt_all + p.splitk - 1) / p.splitk;
-    kbeg = split * per * BK;
-    kend = min(p.K, (split + 1) * per * BK);
-    if (kbeg >= kend) {
-      if (!p.c_ss) return;
-      kend = kbeg;
-    }
-  }
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int lk = lane >> 4, lp = lane & 15;
-  // one base pointer per operand; DMA instruction i adds 4 k-rows (the swizzle of row 16w + 4i + lk depends
-  // on i only through bit 3 of the row: two variants per operand)
-  const int krow0 = wave * 16 + lk;
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  const int nkt = (kend - kbeg) / BK;
-  const int fr = lane & 15, fg = lane >> 4;
-  for (int kt = 0; kt < nkt; ++kt) {
-    unsigned char* sa = ring + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int krow = krow0 + i * 4;
-      const int csrc = lp ^ rr_swz(krow);
-      const int ma = (m0 + csrc * 8 < p.M) ? m0 + csrc * 8 : m0;
-      const int nb = (n0 + csrc * 8 < p.N) ? n0 + csrc * 8 : n0;
-      const long long kr = (long long)(kbeg + kt * BK + krow);
-      __builtin_amdgcn_global_load_lds((glb_void*)(A + kr * lda + ma), (lds_void*)(sa + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void*)(B + kr * ldb + nb), (lds_void*)(sa + 16384 + i * 1024), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const unsigned char* smA = ring;
-    const unsigned char* smB = ring + 16384;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = rr_frag(smA, wm * 64 + i * 16, s, fr, fg);
-        bf[i] = rr_frag(smB, wn * 64 + i * 16, s, fr, fg);
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // every wave has read the stage: it may be re-armed
-    asm volatile("" ::: "memory");
-  }
-  gemm_epilogue<4, false>(p, acc, ring, m0, n0, wm, wn, lane, wave, coff, c_vec);   // fast path only (launcher: fast_epi)
-}
-
-// ---- RC x RC on 256 x 256 tiles: the weight gradients dW[N, K'] = dY[M, N]^T X[M, K'] of the training step
-// (reduction over M = 25..100 k rows; outputs 512 x 512 .. 2048 x 512, the RNN-T output layer 1000 x 512 over
-// ~3.6 M lattice nodes).  Why a second tile size: at 128 x 128 with 64 x 64 wave tiles a k-tile costs 32 KB
-// of L2 -> LDS fill and 16 KB of LDS fragment reads per wave for 32 MFMAs -- at MFMA rate that is the whole
-// LDS read bandwidth (8 waves x 16 KB per 544 MFMA cycles = 235 of 256 B/clk) and ~16 TB/s of L2 fill per
-// PFLOP/s.  Here: 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 (24 KB of fragment reads per 64 MFMAs: 0.75x),
-// 64 KB of fill per 8.4 MFLOP (0.5x), one workgroup per CU, two waves per SIMD covering each other's LDS
-// reads and waits.  Images as in the ring kernel above, per operand two half-images [64 k][128 cols]
-// (unpadded 256-B rows, LDS-DMA, source-side XOR swizzle, transposed reads); two stages of 64 KB; the DMA
-// of k-tile t+1 is in flight while tile t is multiplied.
-// Split-K over a FLAT grid (tile_coord): the launcher sizes splitk so that tiles x splitk ~ 256 = one
-// workgroup per CU, and an XCD's 32 workgroups are whole splits: each operand panel crosses the fabric once.
-// Ragged reduction length (K % 64 != 0: the compacted RNN-T lattice): rows >= K of the LAST k-tile are read
-// from row K - 1 (finite) for A and from a zero line for B, so their products vanish.
-
-__global__ __launch_bounds__(512) void gemm_bf16_rr256_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
-                                                              int c_vec) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A lo | A hi | B lo | B hi), 16 KB each
-  constexpr int STAGE = 65536, HALF = 16384;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const TileCoord tc = tile_coord(p, tiles_m * tiles_n);
-  const int tm = tc.tile / tiles_n, tn = tc.tile % tiles_n;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int split = tc.split;
-  const __bf16* A = reinterpret_cast<const __bf16*>(p.A);
-  const __bf16* B = reinterpret_cast<const __bf16*>(p.B);
-  const long long coff = p.c_ss ? (long long)split * p.c_ss : 0;
-  const long long lda = p.a_cs, ldb = p.b_ks;   // row pitch of the k-major operands
-  const int nkt_all = (p.K + BK - 1) / BK;
-  int ktbeg = 0, ktend = nkt_all;
-  if (p.splitk > 1) {
-    const int per = (nkt_all + p.splitk - 1) / p.splitk;
-    ktbeg = min(split * per, nkt_all);
-    ktend = min((split + 1) * per, nkt_all);
-    if (ktbeg >= ktend && !p.c_ss) return;   // atomic accumulation: nothing to add (slab mode writes its zeros)
-  }
-  const int nkt = ktend - ktbeg;
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // DMA piece pi = 4 * wave + i (0..31) of an operand: half-image pi >> 4, k-rows 4 * (pi & 15) .. + 3;
-  // lane = (k-row & 3, 16-B chunk).  Per-lane element offsets of k-tile 0 of this split:
-  const int lk = lane >> 4, lp = lane & 15;
-  long long aoff[4], boff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pi = wave * 4 + i, half = pi >> 4, krow = (pi & 15) * 4 + lk;
-    const int csrc = lp ^ rr_swz(krow);
-    // chunks beyond M / N re-read the tile's first chunk: they only feed outputs that are never stored
-    const int ma = (m0 + half * 128 + csrc * 8 < p.M) ? m0 + half * 128 + csrc * 8 : m0;
-    const int nb = (n0 + half * 128 + csrc * 8 < p.N) ? n0 + half * 128 + csrc * 8 : n0;
-    aoff[i] = (long long)(ktbeg * BK + krow) * lda + ma;
-    boff[i] = (long long)(ktbeg * BK + krow) * ldb + nb;
-  }
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  const bool ragged = (p.K % BK) != 0;
-  auto issue = [&](int kt) {
-    unsigned char* st = ring + (kt & 1) * STAGE;
-    const long long ka = (long long)kt * BK * lda, kb = (long long)kt * BK * ldb;
-    const bool tail = ragged && (ktbeg + kt == nkt_all - 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pi = wave * 4 + i;
-      const __bf16* sa = A + aoff[i] + ka;
-      const __bf16* sb = B + boff[i] + kb;
-      if (tail) {
-        const int krow = (pi & 15) * 4 + lk;
-        const int kg = (ktbeg + kt) * BK + krow;
-        if (kg >= p.K) {
-          sa -= (long long)(kg - (p.K - 1)) * lda;
-          sb = reinterpret_cast<const __bf16*>(nsp_zero_line) + ((lp ^ rr_swz(krow)) & 15) * 8;
-        }
-      }
-      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(st + (pi >> 4) * HALF + (pi & 15) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(st + 2 * HALF + (pi >> 4) * HALF + (pi & 15) * 1024), 16, 0, 0);
-    }
-  };
-  const int fr = lane & 15, fg = lane >> 4;
-  if (nkt > 0) issue(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    // this wave's pieces of k-tile kt have landed; behind the barrier everybody's have, and every wave has
-    // finished reading the other stage (k-tile kt - 1), which is re-armed right away
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 1 < nkt) issue(kt + 1);
-    const unsigned char* smA = ring + (kt & 1) * STAGE + wm * HALF;
-    const unsigned char* smB = ring + (kt & 1) * STAGE + 2 * HALF + (wn >> 1) * HALF;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[8], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bf[i] = rr_frag(smB, (wn & 1) * 64 + i * 16, s, fr, fg);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) af[i] = rr_frag(smA, i * 16, s, fr, fg);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  }
-  __syncthreads();  // the epilogue stages through the ring
-  // two 64-row halves through the MI = 4 epilogue (as gemm_bf16_kk256_kernel): rows m0 + wm*128 (+ 64) ..
-  gemm_epilogue<4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), ring, m0 + wm * 64, n0, wm, wn, lane, wave, coff, c_vec);
-  gemm_epilogue<4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), ring, m0 + wm * 64 + 64, n0, wm, wn, lane, wave, coff, c_vec);
-}
-
-// fp32 [rows, cols] (row stride ld_in) -> bf16 [rows, ld_out] with zero fill; 8 elements per lane
 __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long long rows,
                                  int cols, long long ld_in, long long ld_out, int vec_in) {
   const long long chunks_per_row = (cols + 7) >> 3;  // pad only inside the last 8-wide chunk
@@ -2286,32 +1676,9 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, __bf16* __restrict
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// NSP_GEMM_RR_RING = 2 / 3 selects the LDS-DMA weight-gradient kernel with that many ring stages
-// (default 2 stages; 0 = register-staged kernel; read on every call so that tests can switch it)
-inline int rr_ring_stages() {
-  const char* e = getenv("NSP_GEMM_RR_RING");
-  return e ? atoi(e) : 2;   // round 2: -0.35 ms/step in an A/B inside the step (was +1 % in round 1)
-}
-
-inline int rr_ring_min_tiles() {
-  const char* e = getenv("NSP_GEMM_RR_RING_MIN_TILES");
-  return e ? atoi(e) : 24;
-}
-
-// 256 x 256 weight-gradient kernel.  MEASURED (round 3, interleaved A/B, profiles/r03b_wgrad_ab.log): with its
-// one-barrier-per-k-tile loop it is 0.6-0.9x the 128 x 128 kernels (which gained 10-35 % from the flat grid
-// alone: 700-840 TFLOP/s) at the encoder's shapes (25-100 k rows, 256 workgroups of 25-100 k-tiles each: the
-// single workgroup per CU has nothing to hide its prologue / slab epilogue behind), and 1.10x on the RNN-T
-// output layer (3.6 M rows: 829 vs 751 TFLOP/s).  So by default it takes the long reductions only
-// (>= 2^19 rows); NSP_GEMM_RR256 = 1 forces it for every eligible shape, 0 switches it off (read on every call
-// so that tests can flip it).
-inline bool rr256_shape_ok(long long M, long long N, long long K) {
-  if (!(M % 8 == 0 && N % 8 == 0 && M > 128 && N > 128 && K >= 2 * BK)) return false;
-  const char* e = getenv("NSP_GEMM_RR256");
-  if (e) return atoi(e) != 0;
-  return K >= (1ll << 19);
-}
-inline bool rr256_enabled() { return true; }
+// weight gradients the 8-phase kernel does not take (M or N <= 128, short reductions) run on the 2-stage LDS-DMA ring from
+// this many output tiles on, below it on the register-staged kernel
+constexpr int RR_RING_MIN_TILES = 24;
 
 // 8-phase weight-gradient kernel (gemm_bf16_kk8p_kernel<.., RR = true>): NSP_GEMM_RR8P = 0 switches it off (read on every call)
 inline bool rr8p_shape_ok(long long M, long long N, long long K, long long lda, long long ldb, int splitk) {
@@ -2372,46 +1739,16 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   const bool fast_epi = c_vec && p.N % 4 == 0 && !(p.splitk > 1 && p.c_ss == 0) && !(p.res && p.dact_src);
   if (a_kc && b_kc && p.K % BK == 0 && p.K >= BK) {
     // how many workgroups would share a CU decides how the load latency gets hidden
-    static int ring_env = -1;
-    static long long ring2_max = 640;
-    if (ring_env < 0) {
-      const char* e = getenv("NSP_GEMM_RING");
-      ring_env = e ? atoi(e) : 1;
-      const char* e2 = getenv("NSP_GEMM_RING2_MAX");
-      if (e2) ring2_max = atoll(e2);
+    constexpr long long ring2_max = 640;
+    static bool ring_attr = false;
+    if (!ring_attr) {
+      ring_attr = true;
       (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_kk_ring_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
     }
     const long long wgs = (long long)grid.x * grid.z;
     const int nkt = p.K / BK / p.splitk;
-    // 256 x 256 persistent kernel: one problem, enough 256-tiles to keep 256 CUs busy for >= 2 rounds
-    // (or an exact multiple of a round), and at least 4 k-tiles per output tile
-    static int k256_env = -1, k256_min = 448;
-    if (k256_env < 0) {
-      const char* e = getenv("NSP_GEMM_256");
-      k256_env = e ? atoi(e) : 0;
-      const char* e2 = getenv("NSP_GEMM_256_MIN_TILES");
-      if (e2) k256_min = atoi(e2);
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_kk256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    }
-    // persistent 128 x 128 kernel with the deferred epilogue: single problem, >= 3 tiles per workgroup slot
-    // (the two switches are read on every call so that tests can flip them inside one process)
-    static bool kkp_attr = false;
-    if (!kkp_attr) {
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_kkp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768 + 8192);
-      kkp_attr = true;
-    }
-    const char* kkp_e = getenv("NSP_GEMM_PERSIST");
-    const char* kkp_e2 = getenv("NSP_GEMM_PERSIST_MIN_TILES");
-    const int kkp_env = kkp_e ? atoi(kkp_e) : 0;   // OPT-IN: measured slower than the classic kernels (below)
-    const long long kkp_min = kkp_e2 ? atoll(kkp_e2) : 1536;
-    if (kkp_env && p.epi_mode == NSP_EPI_NONE && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 2 && wgs >= kkp_min &&
-        !(p.epi_mode == NSP_EPI_NONE && p.epi_f3)) {   // (its standard epilogue has no column-sum slabs)
-      hipLaunchKernelGGL(gemm_bf16_kkp_kernel, dim3(512), block, 2 * 32768 + 8192, st, p, tiles_m, tiles_n, c_vec);
-      NSP_LAUNCH_CHECK();
-      return NSP_OK;
-    }
     const long long t256 = (long long)nsp_cdiv(p.M, 256) * nsp_cdiv(p.N, 256);
     // 256 x 256 phase-interleaved persistent kernel (round 4): the default for one problem with the fast epilogue
     // and enough 256-tiles (NSP_GEMM_8P=0 switches it off, NSP_GEMM_8P_MIN_TILES moves the threshold; both read on
@@ -2430,28 +1767,6 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
       const long long rounds8 = (t256 + 255) / 256;
       const bool fills = t256 * 10 >= rounds8 * 256 * 9;
       const bool want8 = on8 >= 2 || p.K >= 1024 || (fills && !p.pre_out && p.N >= 1536);
-      if (on8 && p.epi_mode != NSP_EPI_NONE && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 && p.N % 64 == 0 &&
-          t256 >= min8 && 256ll * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31) &&
-          getenv("NSP_GEMM_8P_RNNT") && atoi(getenv("NSP_GEMM_8P_RNNT")) != 0) {
-        // the RNN-T joint's logit GEMMs (M = lattice nodes, N = padded vocabulary, K = joint width): 200+ rounds of tiles.
-        // OPT-IN (NSP_GEMM_8P_RNNT=1): measured inside the step (4 alternating runs, profiles/r04q_rnnt_8p_ab.log) the
-        // forward logit GEMM is 0.95 ms SLOWER here than on the 128 x 128 kernel (loss forward 8.4 -> 9.4 ms) and the
-        // backward one equal -- K = 512 and an epilogue of ~12 VALU per logit: one workgroup per CU cannot hide it.
-        const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
-        const int g8 = (int)(t256 >= 256 ? 256 : (t256 + 7) / 8 * 8);
-        static bool attr = false;
-        if (!attr) {
-          (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<EpiRnnt<true>, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-          (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<EpiRnnt<false>, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-          attr = true;
-        }
-        if (p.epi_mode == NSP_EPI_RNNT_LSE)
-          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<EpiRnnt<true>, 0>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
-        else
-          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<EpiRnnt<false>, 0>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec);
-        NSP_LAUNCH_CHECK();
-        return NSP_OK;
-      }
       if (on8 && want8 && p.epi_mode == NSP_EPI_NONE && fast_epi && p.batch1 * p.batch2 == 1 && p.splitk == 1 && p.K % 128 == 0 &&
           t256 >= min8 && 256ll * p.a_rs + p.K < (1ll << 31) && (long long)p.N * p.b_ns + p.K < (1ll << 31)) {
         const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
@@ -2460,8 +1775,6 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         if (e8g && atoi(e8g) >= 8 && atoi(e8g) < g8) g8 = atoi(e8g) / 8 * 8;
         const char* e8v = getenv("NSP_GEMM_8P_VAR");
         const int var8 = e8v ? atoi(e8v) : 4;   // default: the staged epilogue (the direct one measured 0.4-0.9x, see gemm_epilogue_direct)
-        const char* e8s = getenv("NSP_GEMM_8P_STAGGER");
-        const int stagger8 = e8s ? atoi(e8s) & 15 : 0;
         auto launch8 = [&](auto spec, auto var) {
           using S8 = decltype(spec);
           constexpr int V8 = decltype(var)::value;
@@ -2470,7 +1783,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<S8, V8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             attr = true;
           }
-          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<S8, V8>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, (c_vec & 255) | (stagger8 << 8));
+          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<S8, V8>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec & 255);
         };
         // the direct epilogue's own conditions (32-bit byte offsets into C; column-sum slabs only with an act' source)
         const bool direct_ok = (long long)p.M * p.ldc < (1ll << 29) && !(p.epi_f3 && !p.dact_src) && !(p.bias && p.dact_src);
@@ -2496,19 +1809,13 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         return NSP_OK;
       }
     }
-    if (k256_env && p.batch1 * p.batch2 == 1 && p.splitk == 1 && nkt >= 4 && t256 >= k256_min && p.N >= 256) {
-      const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
-      hipLaunchKernelGGL(gemm_bf16_kk256_kernel, dim3(256), dim3(512), 131072, st, p, tm256, tn256, c_vec);
-      NSP_LAUNCH_CHECK();
-      return NSP_OK;
-    }
-    if (ring_env && wgs < 192 && p.M > 64 && nkt >= 4 && p.epi_mode == NSP_EPI_NONE) {
+    if (wgs < 192 && p.M > 64 && nkt >= 4 && p.epi_mode == NSP_EPI_NONE) {
       tiles_m = nsp_cdiv(p.M, 64);
       grid.x = tiles_m * tiles_n * flat;
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 2>), grid, block, 4 * 24576, st, p, tiles_m, tiles_n, c_vec);
-    } else if (ring_env && wgs <= 288 && nkt >= 4)
+    } else if (wgs <= 288 && nkt >= 4)
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<4, 4>), grid, block, 4 * 32768, st, p, tiles_m, tiles_n, c_vec);
-    else if (ring_env && wgs <= ring2_max && nkt >= 2)
+    else if (wgs <= ring2_max && nkt >= 2)
       hipLaunchKernelGGL((gemm_bf16_kk_ring_kernel<2, 4>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
     else if (p.epi_mode == NSP_EPI_RNNT_LSE)
       hipLaunchKernelGGL(gemm_bf16_kk_glds_kernel<1>, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
@@ -2534,32 +1841,17 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     if (plain) hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<EpiSpec<0, 0, false, false, false, false>, 4, true>), g, dim3(512), 163840, st, p, tm256, tn256, c_vec);
     else hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<EpiRuntime, 0, true>), g, dim3(512), 163840, st, p, tm256, tn256, c_vec);
   }
-  else if (!a_kc && !b_kc && p.batch1 * p.batch2 == 1 && rr256_enabled() && rr256_shape_ok(p.M, p.N, p.K)) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_rr256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      attr = true;
-    }
-    const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
-    hipLaunchKernelGGL(gemm_bf16_rr256_kernel, dim3(tm256 * tn256 * p.splitk), dim3(512), 131072, st, p, tm256, tn256, c_vec);
-  }
   else if (!a_kc && !b_kc && p.K % BK == 0 && p.K >= 2 * BK && p.M % 8 == 0 && p.N % 8 == 0 &&
-           tiles_m * tiles_n >= rr_ring_min_tiles() && rr_ring_stages() > 0) {
-    // weight gradients on the LDS-DMA ring with swizzled transposed reads (default: 2 stages, two workgroups
-    // per CU).  History: back to back it beat the register-staged kernel from the start (545 -> 660 TFLOP/s on
-    // dW[2048,512] over 51200 rows; 3 stages = 1 workgroup per CU is slower); inside the training step it was
-    // 1 % slower in round 1 and 0.35 ms/step faster in round 2's A/B, hence the default.  NSP_GEMM_RR_RING=1
-    // selects the single-stage / four-workgroup variant: measured equal or 3-6 % slower at the step's shapes
-    // with the current split-K factors (512 workgroups fill only half of its slots).
-    if (rr_ring_stages() == 1 && fast_epi) {
-      hipLaunchKernelGGL(gemm_bf16_rr_glds_kernel, grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
-    } else if (rr_ring_stages() >= 3) {
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_rr_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
-      hipLaunchKernelGGL((gemm_bf16_rr_ring_kernel<3>), grid, block, 3 * 32768, st, p, tiles_m, tiles_n, c_vec);
-    } else {
+           tiles_m * tiles_n >= RR_RING_MIN_TILES) {
+    // the weight gradients the 8-phase kernel does not take: LDS-DMA ring with swizzled transposed reads, 2 stages, two
+    // workgroups per CU (the 1-stage / 3-stage variants and the 256 x 256 one-barrier kernel of rounds 1-3 measured equal
+    // or slower at every shape of the step and were removed in round 5)
+    static bool rr_attr = false;
+    if (!rr_attr) {
       (void)hipFuncSetAttribute((const void*)gemm_bf16_rr_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
-      hipLaunchKernelGGL((gemm_bf16_rr_ring_kernel<2>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
+      rr_attr = true;
     }
+    hipLaunchKernelGGL((gemm_bf16_rr_ring_kernel<2>), grid, block, 2 * 32768, st, p, tiles_m, tiles_n, c_vec);
   }
   else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
   else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, p, tiles_m, tiles_n, c_vec);
@@ -2583,14 +1875,7 @@ extern "C" int nsp_wgrad_splitk(long long N, long long K, long long rows) {
     const int plan = (int)((nkt_pad + per - 1) / per);      // no empty splits
     if (rr8p_shape_ok(N, K, rows, N, K, plan)) return plan;
   }
-  if (!rr256_enabled() || !rr256_shape_ok(N, K, rows)) return 0;
-  const long long tiles = (long long)nsp_cdiv((int)N, 256) * nsp_cdiv((int)K, 256);
-  const long long nkt = (rows + BK - 1) / BK;
-  long long sk = 256 / tiles;
-  if (sk < 1) sk = 1;
-  if (sk > nkt / 2) sk = nkt / 2 > 0 ? nkt / 2 : 1;
-  const long long per = (nkt + sk - 1) / sk;      // no empty splits
-  return (int)((nkt + per - 1) / per);
+  return 0;
 }
 
 extern "C" int nsp_cast_bf16(const float* x, void* out, long long rows, int cols, long long ld_in,

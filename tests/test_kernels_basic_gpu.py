@@ -225,60 +225,22 @@ def test_splitk_slabs_with_an_empty_split_are_fully_written(mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('stages', ['2', '3'])
-def test_weight_gradient_gemm_on_the_lds_dma_ring(stages, monkeypatch, shapes=((2048, 640, 512), (1280, 1000, 264), (4096, 512, 2048))):
-    """Opt-in RC x RC kernel (NSP_GEMM_RR_RING): unpadded k-major LDS images written by LDS-DMA,
-    operands formed by swizzled transposed reads; split-K slabs; ragged M/N edges."""
+def test_weight_gradient_gemm_on_the_lds_dma_ring(monkeypatch, shapes=((2048, 640, 512), (1280, 1000, 264), (4096, 512, 2048), (512, 128, 384))):
+    """gemm_bf16_rr_ring_kernel<2> -- what a weight gradient runs on when the 8-phase kernel does not take it (forced here by
+    NSP_GEMM_RR8P=0; by default: an output extent <= 128): unpadded k-major LDS images written by LDS-DMA, operands formed by
+    swizzled transposed reads; split-K slabs; ragged M/N edges.  The last shape (3 output tiles < 24) stays on the
+    register-staged kernel.  (The 1- / 3-stage and 256 x 256 variants of rounds 1-3 were removed in round 5.)"""
     from neural_sp_amd import ops
     torch.manual_seed(1)
     dev = _dev()
+    monkeypatch.setenv('NSP_GEMM_RR8P', '0')
     for rows, N, K in shapes:
         dy = torch.randn(rows, N, device=dev).bfloat16()
         x = torch.randn(rows, K, device=dev).bfloat16()
         ref = dy.float().t() @ x.float()
-        monkeypatch.setenv('NSP_GEMM_RR256', '0')     # (the 256 x 256 kernels have their own tests below)
-        monkeypatch.setenv('NSP_GEMM_RR8P', '0')
         with ops.compute_mode('bf16'):
-            monkeypatch.setenv('NSP_GEMM_RR_RING', '0')
-            base = ops.linear_wgrad(dy, x)
-            monkeypatch.setenv('NSP_GEMM_RR_RING', stages)
             dw = ops.linear_wgrad(dy, x)
-        scale = ref.abs().max()
-        assert ((base - ref).abs().max() / scale).item() < 1e-4
-        assert ((dw - ref).abs().max() / scale).item() < 1e-4
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('rows,N,K', [(2048, 640, 512), (1291, 1000, 264), (4096, 512, 2048), (333, 136, 1280), (130, 256, 256)])
-def test_weight_gradient_gemm_on_256_tiles(rows, N, K, monkeypatch):
-    """gemm_bf16_rr256_kernel (default for weight gradients with both output extents > 128): flat split-K grid with
-    whole splits per XCD, split count from nsp_wgrad_splitk, ragged output edges (1000, 264, 136), a reduction
-    length that is not a multiple of the 64-row k-tile (1291, 333, 130: the tail rows must contribute exactly
-    nothing -- the B operand reads a zero line there), and the single-k-tile / two-k-tile corner (130 rows)."""
-    from neural_sp_amd import ops, _lib
-    torch.manual_seed(rows)
-    dev = _dev()
-    dy = torch.randn(rows, N, device=dev).bfloat16()
-    x = torch.randn(rows, K, device=dev).bfloat16()
-    ref = dy.float().t() @ x.float()
-    monkeypatch.setenv('NSP_GEMM_RR8P', '0')      # (the 8-phase kernel, which takes these shapes by default, has its own test)
-    monkeypatch.setenv('NSP_GEMM_RR256', '1')     # (default: reductions of >= 2^19 rows only)
-    assert _lib.lib().nsp_wgrad_splitk(N, K, rows) > 0
-    with ops.compute_mode('bf16'):
-        dw = ops.linear_wgrad(dy, x)
-        monkeypatch.setenv('NSP_GEMM_RR256', '0')
-        assert _lib.lib().nsp_wgrad_splitk(N, K, rows) == 0
-        base = ops.linear_wgrad(dy, x)
-    scale = ref.abs().max()
-    assert ((base - ref).abs().max() / scale).item() < 1e-4
-    assert ((dw - ref).abs().max() / scale).item() < 1e-4
-    # explicit split counts, incl. more splits than k-tiles need (empty splits write zero slabs)
-    with ops.compute_mode('bf16'):
-        monkeypatch.setenv('NSP_GEMM_RR256', '1')
-        for sk in (1, 3, 8):
-            part = torch.full((sk, N, K), float('nan'), device=dev)
-            ops.gemm_raw(N, K, rows, dy, 1, N, x, K, 1, part, K, splitk=sk, c_ss=N * K)
-            assert ((part.sum(0) - ref).abs().max() / scale).item() < 1e-4, sk
+        assert ((dw - ref).abs().max() / ref.abs().max()).item() < 1e-4, (rows, N, K)
 
 
 @pytest.mark.gpu
@@ -300,7 +262,6 @@ def test_weight_gradient_gemm_on_the_phase_interleaved_kernel(rows, N, K, monkey
     with ops.compute_mode('bf16'):
         dw = ops.linear_wgrad(dy, x)
         monkeypatch.setenv('NSP_GEMM_RR8P', '0')
-        monkeypatch.setenv('NSP_GEMM_RR256', '0')
         base = ops.linear_wgrad(dy, x)
     scale = ref.abs().max()
     assert ((base - ref).abs().max() / scale).item() < 1e-4
@@ -519,46 +480,6 @@ def test_phase_interleaved_gemm_with_an_operand_beyond_4_gb(monkeypatch):
         want = (a[rows].float() @ w.float().t()) * (1 - h[rows].float() ** 2)
         assert _rel(out[rows].float(), want) < 1e-2, r0
     assert torch.isfinite(out.float()).all()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('M,N,K', [(1000, 384, 128), (2051, 1000, 512), (4096, 512, 2048), (700, 2048, 64)])
-def test_persistent_gemm_with_deferred_epilogue(M, N, K, monkeypatch):
-    """gemm_bf16_kkp_kernel (persistent tiles, the epilogue of tile i sliced into the k-loop of tile i+1)
-    forced onto small problems: every epilogue feature against torch, ragged M / N, nkt < 8 and > 8,
-    workgroups with 0, 1 and several tiles."""
-    from neural_sp_amd import ops
-    monkeypatch.setenv('NSP_GEMM_PERSIST', '1')
-    monkeypatch.setenv('NSP_GEMM_PERSIST_MIN_TILES', '1')
-    torch.manual_seed(M + N)
-    dev = _dev()
-    a = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
-    w = (torch.randn(N, K, device=dev) * 0.5).bfloat16()
-    bias = torch.randn(N, device=dev)
-    res = torch.randn(M, N, device=dev)
-    src = torch.randn(M, N, device=dev)
-    ref = a.float() @ w.float().t()
-    with ops.compute_mode('bf16'):
-        c = torch.empty(M, N, device=dev)
-        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N)
-        assert _rel(c, ref) < 1e-5
-        c16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c16, N, bias=bias, act=2, pre_out=pre)
-        z = ref + bias
-        assert _rel(pre.float(), z) < 1e-2 and _rel(c16.float(), z * torch.sigmoid(z)) < 1e-2
-        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, bias=bias, res=res, alpha=0.5)
-        assert _rel(c, 0.5 * (ref + bias) + res) < 1e-5
-        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, dact_src=src, dact=2)
-        s = torch.sigmoid(src)
-        assert _rel(c, ref * (s * (1 + src * (1 - s)))) < 1e-4
-        # dropout: same mask as the non-persistent kernel (pure function of seed / element offset)
-        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, dropout_p=0.3, seed=11, offset=0)
-        monkeypatch.setenv('NSP_GEMM_PERSIST', '0')
-        c2 = torch.empty(M, N, device=dev)
-        ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c2, N, dropout_p=0.3, seed=11, offset=0)
-        assert torch.equal(c == 0, c2 == 0) and _rel(c, c2) < 1e-6
-        assert 0.2 < (c == 0).float().mean().item() < 0.4
 
 
 @pytest.mark.gpu

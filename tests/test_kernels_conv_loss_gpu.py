@@ -406,10 +406,6 @@ def test_rnnt_joint_loss_fused_compact_no_logit_tensor(B, T, U, J, V, rows, monk
     the padded [B,T,U+1] grid."""
     from oracle.rnnt_ref import rnnt_loss_ref_diag
     from neural_sp_amd import ops
-    # J % 128 == 0: the logit GEMMs (LSE / DLOGITS epilogues) take the phase-interleaved 256 x 256 kernel, here also on
-    # grids far below its usual threshold (one to a few tiles per workgroup, ragged M and N edges)
-    monkeypatch.setenv('NSP_GEMM_8P_MIN_TILES', '1')
-    monkeypatch.setenv('NSP_GEMM_8P_RNNT', '1')       # (opt-in: measured slower than the 128 x 128 kernel inside the step)
     # rows = '1': J = 128 / 256 / 512 take the node-stationary kernel (nsp_rnnt_joint_rows: whole vocabulary per workgroup,
     # no partials / merge / packed records); '0' keeps every width on the tiled GEMM epilogues
     monkeypatch.setenv('NSP_RNNT_ROWS', rows)
