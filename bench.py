@@ -486,6 +486,8 @@ def main():
                     ent.update(bound='hbm', achieved=round(tb, 2), unit='TB/s', peak=8.0, frac=round(tb / 8.0, 4))
                 if cname.endswith('@side'):
                     ent['note'] = 'side stream: the event pairs include co-scheduling with main-stream kernels'
+                if c['unit'] != 'flop':
+                    ent['algorithmic_bytes_per_step'] = round(c['work'] / steps_sampled)
                 cls.append(ent)
             roof['classes'] = cls
             # HBM bytes per GEMM launch cannot be counted from inside the process: it is the committed result of
@@ -502,6 +504,17 @@ def main():
                     roof['traffic_algorithmic'] = round(tjd['algorithmic_bytes_per_launch'])
                     roof['traffic_over_algorithmic'] = round(tjd['hbm_bytes_per_launch'] / tjd['algorithmic_bytes_per_launch'], 3)
                 roof['traffic_source'] = 'profiles/pmc_gemm_traffic.json (rocprofv3 PMC passes at %s, bytes per launch; NOT measured in this run)' % tjd.get('revision', 'unknown revision')
+                # counter bytes of the other classes (same PMC passes): wasted-traffic ratio where the class has algorithmic bytes
+                for ent in roof.get('classes', []):
+                    pc = tjd.get('classes', {}).get(ent['class'])
+                    if pc is None and ent['class'] == 'conv_frontend_fwd':
+                        pc = None      # (the counters cannot separate the forward from the data gradient: see classes_pmc)
+                    if pc:
+                        ent['traffic_per_step'] = round(pc['hbm_bytes_per_step'])
+                        if ent.get('algorithmic_bytes_per_step'):
+                            ent['traffic_over_algorithmic'] = round(pc['hbm_bytes_per_step'] / ent['algorithmic_bytes_per_step'], 3)
+                if tjd.get('classes'):
+                    roof['classes_pmc'] = {k: {kk: vv for kk, vv in v.items() if kk != 'kernels'} for k, v in tjd['classes'].items()}
         out = {
             'encoder_mfu': None,     # (the north-star figure leads the line; filled below)
             'metric': 'speech-frames/sec/node (Conformer-L + CTC+RNN-T, 80-d fbank)',

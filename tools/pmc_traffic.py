@@ -58,7 +58,26 @@ if __name__ == '__main__':
             # NSP_GEMM_DEBUG=1 dump of the SAME command: one line per bf16 GEMM launch with its algorithmic HBM bytes
             vals = [int(l.rsplit('algbytes', 1)[1]) for l in open(sys.argv[6]) if 'algbytes' in l]
             alg = {'launches': len(vals), 'bytes_per_launch': sum(vals) / max(1, len(vals))}
-        json.dump({'algorithmic_bytes_per_launch': alg['bytes_per_launch'] if alg else None,
+        # the other kernel classes bench.py times (roofline.classes): counter bytes per STEP (the trace holds `steps` steps)
+        steps = 2
+        CLASSES = {'flash_fwd': ('flash_fwd_kernel',), 'flash_bwd': ('flash_bwd_dq_kernel', 'flash_bwd_dkv_kernel'),
+                   'layernorm_fwd': ('ln_fwd_kernel',), 'layernorm_bwd': ('ln_bwd_kernel',),
+                   'conv_frontend_fwd+dgrad': ('conv3x3_c1_kernel', 'conv3x3_c32_b16_kernel', 'conv3x3_c32_kernel')}
+        classes = {}
+        for cname, pats in CLASSES.items():
+            sel = [r for r in rows if any(r[1].startswith(pt) for pt in pats)]
+            if not sel:
+                continue
+            nl = sum(r[2] for r in sel)
+            by = sum((r[3] + r[4]) * r[2] for r in sel)
+            us = sum(r[5] * r[2] for r in sel)
+            classes[cname] = {'launches_per_step': nl / steps, 'hbm_bytes_per_step': by / steps, 'kernel_us_per_step': round(us / steps, 1),
+                              'hbm_tb_per_s_while_running': round(by / us / 1e6, 3) if us > 0 else None,
+                              'kernels': sorted(set(r[1] for r in sel))}
+        json.dump({'classes': classes,
+                   'classes_note': 'counter bytes (FETCH_SIZE x2 + WRITE_SIZE) of every launch of the named kernels in the traced steps / steps; '
+                                   'conv3x3 kernels serve the forward AND the data gradient, bench.py times only the forward calls',
+                   'algorithmic_bytes_per_launch': alg['bytes_per_launch'] if alg else None,
                    'algorithmic_launches': alg['launches'] if alg else None,
                    'algorithmic_definition': 'both operands once + every output image (split-K slabs included) + every side operand once, '
                                              'summed over all bf16 GEMM launches of the traced steps (NSP_GEMM_DEBUG=1 pass of the same command) / launches',
