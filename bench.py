@@ -534,6 +534,12 @@ def main():
             roof['peaks_measured'] = peaks
             if 'library_gemm_bf16_8192_tflops' in peaks:
                 roof['frac_of_measured_library_gemm'] = round(roof['achieved'] / peaks['library_gemm_bf16_8192_tflops'], 4)
+            if peaks.get('stream_copy_tb_per_s'):
+                # streaming classes beside what a plain device-to-device copy reaches on THIS box (the vendor 8 TB/s is not
+                # reachable by any kernel here: the copy measures ~5 TB/s)
+                for ent in roof.get('classes', []):
+                    if ent.get('bound') == 'hbm':
+                        ent['frac_of_measured_copy'] = round(ent['achieved'] / peaks['stream_copy_tb_per_s'], 3)
         if phases is not None and 'encoder_mfu' in phases:
             out['encoder_mfu'] = phases['encoder_mfu']['valid_frames']     # the north-star figure (target 0.40)
         if distributed and comm_log:
