@@ -335,15 +335,15 @@ def refresh_weight_shadows(force=False):
         if now is None:
             dead.append(k)
         elif ent[0] != now[0]:
-            stale.setdefault(dst.device, []).append((rec, dst, srcs))
+            stale.setdefault(dst.device, []).append((rec, dst, srcs, owner, now))
     for k in dead:
         del _SHADOWS[k]
     for dev, recs in stale.items():
-        key = tuple((id(rec), dst.data_ptr()) + tuple(w.data_ptr() for w in srcs) for rec, dst, srcs in recs)
+        key = tuple((id(rec), dst.data_ptr()) + tuple(w.data_ptr() for w in srcs) for rec, dst, srcs, _, _ in recs)
         tab = _SHADOW_TABLE.get(dev)
         if tab is None or tab['key'] != key:
             rows_, tiles = [], 0
-            for rec, dst, srcs in recs:
+            for rec, dst, srcs, _, _ in recs:
                 for (sp, r0, c0, rows, cols, tr), w in zip(rec['parts'], srcs):
                     K = w[0].numel()
                     rows_.append([w.data_ptr(), dst.data_ptr() + 2 * (r0 * dst.stride(0) + c0), rows, cols, K, dst.stride(0),
@@ -355,9 +355,9 @@ def refresh_weight_shadows(force=False):
                 _check(_lib.lib().nsp_shadow_refresh(_p(tab['table']), tab['n'], tab['tiles'], _stream()), 'nsp_shadow_refresh')
         else:
             _check(_lib.lib().nsp_shadow_refresh(_p(tab['table']), tab['n'], tab['tiles'], _stream()), 'nsp_shadow_refresh')
-        for rec, dst, srcs in recs:
+        for rec, dst, srcs, owner, now in recs:
             try:
-                setattr(rec['owner'](), rec['attr'], _shadow_entry(rec))
+                setattr(owner, rec['attr'], now)      # (the entry computed above: versions and epoch cannot have moved since)
             except Exception:
                 pass
 
