@@ -16,9 +16,9 @@ grep nsp_gemm_bf16 /tmp/gemm_debug_$tag.err > /tmp/gemm_shapes_$tag.txt
 f=$(find $root/gpurun_out/pmc_${tag}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 w=$(find $root/gpurun_out/pmc_${tag}_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 {
-  echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-b16  (per-GPU batch 128; 2 steps) at revision $(cat $root/.git_rev 2>/dev/null)"
+  echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-b16  (per-GPU batch 128; 2 steps) at revision ${NSP_REV:-$(cat $root/.git_rev 2>/dev/null)}"
   echo "# aggregated by tools/pmc_traffic.py: FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md, HBM section); bytes per launch"
-  python $root/tools/pmc_traffic.py $f $w $root/gpurun_out/${tag}_pmc_gemm_traffic.json "$(cat $root/.git_rev 2>/dev/null)" 128 /tmp/gemm_shapes_$tag.txt
+  python $root/tools/pmc_traffic.py $f $w $root/gpurun_out/${tag}_pmc_gemm_traffic.json "${NSP_REV:-$(cat $root/.git_rev 2>/dev/null)}" 128 /tmp/gemm_shapes_$tag.txt
 } > $root/gpurun_out/${tag}_pmc_hbm_traffic.txt 2>&1
 rm -rf $root/gpurun_out/pmc_${tag}_FETCH_SIZE $root/gpurun_out/pmc_${tag}_WRITE_SIZE
 head -14 $root/gpurun_out/${tag}_pmc_hbm_traffic.txt | cut -c1-140

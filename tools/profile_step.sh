@@ -9,7 +9,7 @@ rm -rf $out; mkdir -p $out
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $out -- python $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-b16 --no-kernel-events "$@" > $out/bench.out 2> $out/bench.err)
 db=$(find $out -name '*.db' | head -1)
 {
-  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-b16 --no-kernel-events $@   (6 steps in the trace) at revision $(cat $root/.git_rev 2>/dev/null)"
+  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-b16 --no-kernel-events $@   (6 steps in the trace) at revision ${NSP_REV:-$(cat $root/.git_rev 2>/dev/null)}"
   echo "# per-kernel durations from the rocpd database (tools/rocpd_stats.py); divide totals by 6 for one step"
   python $root/tools/rocpd_stats.py $db 70
 } > $root/gpurun_out/${tag}_kernel_stats.txt
