@@ -65,7 +65,7 @@ if __name__ == '__main__':
                    'conv_frontend_fwd+dgrad': ('conv3x3_c1_kernel', 'conv3x3_c32_b16_kernel', 'conv3x3_c32_kernel')}
         classes = {}
         for cname, pats in CLASSES.items():
-            sel = [r for r in rows if any(r[1].startswith(pt) for pt in pats)]
+            sel = [r for r in rows if any(pt in r[1] for pt in pats)]      # (substring: anonymous-namespace kernels come back mangled)
             if not sel:
                 continue
             nl = sum(r[2] for r in sel)
