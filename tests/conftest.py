@@ -20,7 +20,7 @@ def pytest_configure(config):
 # must not hide the kernel and parity results (round 4: the suite stopped in the 2nd of 11 files, 274 tests never ran).
 GPU_FILE_ORDER = ['test_kernels_basic_gpu.py', 'test_kernels_conv_loss_gpu.py', 'test_flash_attn_gpu.py', 'test_golden_gpu.py',
                   'test_fullsize_parity_gpu.py', 'test_variants_gpu.py', 'test_dropin_gpu.py', 'test_alignment_e2e_gpu.py',
-                  'test_train_script_gpu.py', 'test_hostile_neighbour_gpu.py', 'test_ddp_hip_gpu.py']
+                  'test_memory_hygiene_gpu.py', 'test_hostile_neighbour_gpu.py', 'test_ddp_hip_gpu.py']
 
 
 def pytest_collection_modifyitems(config, items):
