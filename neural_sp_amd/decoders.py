@@ -352,7 +352,9 @@ class RNNTransducer(DecoderBase):
         else:
             dec_proj = self._prediction_network(ys, dev, defer_tail=True)       # `[B,L+1,J]`
             if isinstance(dec_proj, tuple):
-                ops.lstm_forward_resolve()
+                # (inline on the step's stream: no host wait for a launch that was enqueued a moment ago -- except under the
+                # test hook, which has nothing to wait for)
+                ops.lstm_forward_resolve(block=os.environ.get('NSP_LSTM_TEST_FAKE_TIMEOUT', '0') == '1')
                 dec_proj = self._prediction_network_tail(dec_proj[1])
         enc_proj = ops.linear(eouts, self.w_enc.weight, self.w_enc.bias)       # `[B,T,J]`
         loss, _ = ops.rnnt_joint_loss(enc_proj, dec_proj, self.output.weight, self.output.bias,

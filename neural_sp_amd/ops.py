@@ -2661,8 +2661,10 @@ _LSTM_FWD_RESCUE = []
 _LSTM_RESCUES = [0]          # (how many forwards have been re-run in this process: tests, logs)
 
 
-def lstm_forward_resolve():
-    """-> number of forward launches that had to be re-run"""
+def lstm_forward_resolve(block=True):
+    """-> number of forward launches that had to be re-run.  block=False (the prediction network ran INLINE on the step's only
+    stream -- stock DistributedDataParallel): waiting for the launch would drain the whole queue the host has built up, so a
+    launch that has not finished yet is left to the one-step-late check (ops.lstm_check / the next launch), as before"""
     if not _LSTM_FWD_RESCUE:
         return 0
     pending = list(_LSTM_FWD_RESCUE)
@@ -2670,6 +2672,8 @@ def lstm_forward_resolve():
     n = 0
     for P, keep, checks, stream in pending:
         dead = False
+        if not block and any(not ev.query() for _, ev in checks):
+            continue
         for flag, ev in checks:
             ev.synchronize()
             dead = dead or int(flag[0]) != 0
