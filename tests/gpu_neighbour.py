@@ -11,7 +11,9 @@ import time
 import torch
 
 
-def main(seconds):
+def main(seconds, kind='all'):
+    """kind: 'all' (the tests), or one of 'gemm' / 'elementwise' / 'softmax' (tools/r05_neighbour_kinds.sh: which tenant
+    triggers the packed-fp32 failure)"""
     dev = torch.device('cuda', 0)
     a = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
     b = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
@@ -19,15 +21,17 @@ def main(seconds):
     t0, said = time.time(), False
     while time.time() - t0 < seconds:
         for _ in range(20):
-            d = a @ b
-            e = torch.relu(c * 1.0001 + 0.5)
-            f = torch.softmax(d.float(), dim=-1)
+            if kind in ('all', 'gemm'):
+                d = a @ b
+            if kind in ('all', 'elementwise'):
+                e = torch.relu(c * 1.0001 + 0.5)
+            if kind in ('all', 'softmax'):
+                f = torch.softmax((d if kind == 'all' else a).float(), dim=-1)
         torch.cuda.synchronize()
         if not said:
             print('READY', flush=True)
             said = True
-    del d, e, f
 
 
 if __name__ == '__main__':
-    main(float(sys.argv[1]) if len(sys.argv) > 1 else 30.0)
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 30.0, sys.argv[2] if len(sys.argv) > 2 else 'all')
