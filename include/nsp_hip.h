@@ -294,14 +294,20 @@ int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
  *        reproduced bit for bit by backward (softmax shift invariance of dS, see   *
  *        flash_attn.hip)                                                           *
  *   LSE  fp32 [2,B,H,T]: ceil(row max) (log2 domain) and 1/row-sum of exp2(. - it) *
+ *   keepbits (required iff dropout_p > 0; nsp_flash_attn_keepbits_bytes(B,H,T)     *
+ *        bytes): the dropout decisions the forward drew (the reference's            *
+ *        nn.Dropout on the attention weights, relative_multihead_attention.py:206), *
+ *        one bit per (query, key) pair in the forward's register layout; backward   *
+ *        reads them instead of drawing them again                                   *
  * Backward: dqkv bf16 [B*T,3d] receives dK (block d) and dV (block 2d);      *
  * dq32 fp32 [B*T,d] and dQP [B,T,H,r_pitch] are written (no zero-init);      *
  * D is scratch [B,H,T].  Masks / dropout as in nsp_attn_softmax_*.          *
  * ------------------------------------------------------------------------ */
-int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* O32, float* LSE,
+long long nsp_flash_attn_keepbits_bytes(int B, int H, int T);
+int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* O32, float* LSE, void* keepbits,
                        const nsp_attn_mask_params* p, void* stream);
 int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const float* O32,
-                       const float* LSE, float* D, void* dqkv, float* dq32, float* dQP,
+                       const float* LSE, const void* keepbits, float* D, void* dqkv, float* dq32, float* dQP,
                        const nsp_attn_mask_params* p, void* stream);
 
 /* ------------------------------------------------------------------------ *

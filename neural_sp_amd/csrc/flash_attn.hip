@@ -68,6 +68,17 @@ __device__ __forceinline__ bool fa_visible(const nsp_attn_mask_params& p, int kl
   return ok;
 }
 
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+__device__ __forceinline__ void fa_lds_read2(u32x2& dst, const void* p) {
+#ifdef NSP_HOST_EMULATION
+  dst = *reinterpret_cast<const u32x2*>(p);
+#else
+  typedef __attribute__((address_space(3))) unsigned char lds_uchar;
+  const unsigned a = (unsigned)(uintptr_t)((lds_uchar*)const_cast<void*>(p));
+  asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(a) : "memory");
+#endif
+}
+
 // ---- per-element work of a (query tile, key tile) pair.  With d_k = 64 the softmax arithmetic,
 // not the MFMA, bounds these kernels (16 logits per lane per tile against 16 MFMAs per wave), so
 // everything that is uniform over a tile is decided once per tile:
@@ -165,11 +176,27 @@ __device__ __forceinline__ int fa_key_tiles(const nsp_attn_mask_params& p, int T
   return min(nkt, (min(klen, T) + 63) / 64);
 }
 
-__device__ __forceinline__ void fa_keep(float (&kp)[4][4], unsigned rowhash, int k0, int g, unsigned thr16, float inv_keep) {
-  // one 32-bit value per PAIR of adjacent keys (16 bits per decision), from full-rate integer ops only:
-  // a 24-bit multiply-add of the pair index folded into the per-row hash, one xorshift round and a
-  // second 24-bit multiply-add (v_mul_lo_u32 is quarter rate; two of them per pair were ~40 % of this
-  // kernel's VALU cycles with dropout on).  Forward and both backward kernels call this same function.
+// Dropout decisions.  Round 6: the FORWARD draws them and stores them, one 16-bit word per lane and (16-query block, 64-key
+// tile) pair -- bit 15 - (4 kf + e) = keep (query 16 qblk + r, key k0 + 16 kf + 4 g + e), lane = r + 16 g, i.e. exactly the
+// forward's / dQ kernel's score registers; keepbits is u16 [B][H][key tile][16-query block][64 lanes] (128 B per pair, 89 MB
+// at B = 128, H = 8, T = 800) -- and both backward kernels READ them (2 VALU per score: sign-extended bit field + AND) instead
+// of re-drawing them (~14 VALU per score in each of the two kernels: the hash was more than half of their vector
+// instructions).  The draw itself is unchanged: one 32-bit value per PAIR of adjacent keys (16 bits per decision) from
+// full-rate integer ops only -- a 24-bit multiply-add of the pair index folded into the per-row hash, one xorshift round and a
+// second 24-bit multiply-add -- so the decisions (and therefore every result) equal those of the rounds before bit for bit.
+// bits = 2 bits + c in ONE instruction: the compare's lane mask is the carry-in of v_addc_co_u32 (written as
+// `bits + bits + (c ? 1 : 0)` hipcc built the word with a v_cndmask and 16-bit shift / or per decision: + 2 VALU per score)
+__device__ __forceinline__ void fa_shift_in(unsigned& bits, bool c) {
+#ifdef NSP_HOST_EMULATION
+  bits = bits + bits + (c ? 1u : 0u);
+#else
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+  asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(m) : "vcc");
+#endif
+}
+// kp = inv_keep or 0 per score (what the forward multiplies with), return = the 16 decisions as a word
+__device__ __forceinline__ unsigned fa_keep_bits(float (&kp)[4][4], unsigned rowhash, int k0, int g, unsigned thr16, float inv_keep) {
+  unsigned bits = 0u;
 #pragma unroll
   for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
@@ -178,9 +205,23 @@ __device__ __forceinline__ void fa_keep(float (&kp)[4][4], unsigned rowhash, int
       unsigned y = rowhash + __umul24(pair, 0x9E3779u) + (pair << 11);
       y ^= y << 13; y ^= y >> 17; y ^= y << 5;
       y = __umul24(y >> 8, 0x85EBCBu) ^ y;
-      kp[kf][2 * pr] = (y & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
-      kp[kf][2 * pr + 1] = (y >> 16) >= thr16 ? inv_keep : 0.f;
+      const bool c0 = (y & 0xFFFFu) >= thr16, c1 = (y >> 16) >= thr16;
+      kp[kf][2 * pr] = c0 ? inv_keep : 0.f;
+      kp[kf][2 * pr + 1] = c1 ? inv_keep : 0.f;
+      fa_shift_in(bits, c0);
+      fa_shift_in(bits, c1);
     }
+  return bits;
+}
+// v if the decision with index idx (= 4 kf + e) of `bits` says keep, else +0
+__device__ __forceinline__ float fa_keep_apply(float v, unsigned bits, int idx) {
+  const int m = ((int)(bits << (16 + idx))) >> 31;
+  return __uint_as_float(__float_as_uint(v) & (unsigned)m);
+}
+// the word of (key tile kt, 16-query block qblk) of head (b, h) starts at this u16 index (+ lane)
+__device__ __forceinline__ long long fa_keep_index(const nsp_attn_mask_params& p, int b, int h, int kt, int qblk) {
+  const int nkt = (p.Tq + 63) >> 6;
+  return ((((long long)b * p.H + h) * nkt + kt) * (4 * nkt) + qblk) * 64;
 }
 __device__ __forceinline__ unsigned fa_rowhash(const nsp_attn_mask_params& p, int b, int h, int T, int qi) {
   return nsp_hash_u32(p.seed, p.offset + (unsigned long long)(((long long)b * p.H + h) * T + qi));
@@ -272,10 +313,11 @@ __device__ __forceinline__ void fa_tr_wait(FaTr (&t)[8], int half) {
 // grid.x = 8-way interleave of heads and query tiles (id % H = head): with H = 8 every head lives on one
 // XCD, so the q-tiles of one (utterance, head) re-read its K / V from that XCD's L2.
 template <int NQ>   // 16-query fragments per wave: workgroup tile = 64 * NQ queries
-__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restrict__ qkv, int d,
+__global__ __launch_bounds__(256, 4) void flash_fwd_kernel(const __bf16* __restrict__ qkv, int d,
                                                         const float* __restrict__ QP,
                                                         __bf16* __restrict__ O, float* __restrict__ O32,
                                                         float* __restrict__ LSE,
+                                                        unsigned short* __restrict__ keepbits,
                                                         const nsp_attn_mask_params p) {
   __shared__ __attribute__((aligned(16))) unsigned char KV[4 * 64 * KD + 64 * NQ * 17 * 4];   // ONE LDS object (a second one makes
   unsigned char (*Ks)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV);             //  hipcc wait vmcnt(0) per LDS read
@@ -409,7 +451,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const __bf16* __restr
       auto probs = [&](auto uni_, auto drop_) {
         constexpr bool UNI = decltype(uni_)::value, DROP = decltype(drop_)::value;
         float kp[4][4];
-        if (DROP) fa_keep(kp, rowhash[f], kt * 64, g, thr16, inv_keep);
+        if constexpr (DROP) {
+          const unsigned kb = fa_keep_bits(kp, rowhash[f], kt * 64, g, thr16, inv_keep);
+          keepbits[fa_keep_index(p, b, h, kt, (q0 >> 4) + wave * NQ + f) + lane] = (unsigned short)kb;   // for backward
+        }
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
@@ -511,9 +556,9 @@ template <bool H2>
 __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Drow, __bf16* __restrict__ dqkv,
-    const nsp_attn_mask_params p) {
-  // one LDS object (see the forward kernel): Q | dO tiles (DMA images), position rows, per-query statistics
-  __shared__ __attribute__((aligned(16))) unsigned char SM[4 * 64 * KD + 2 * 64 * 16 * 4 + 5 * 2 * 64 * 4];
+    const unsigned short* __restrict__ keepbits, const nsp_attn_mask_params p) {
+  // one LDS object (see the forward kernel): Q | dO tiles (DMA images), position rows, per-query statistics, dropout words
+  __shared__ __attribute__((aligned(16))) unsigned char SM[4 * 64 * KD + 2 * 64 * 16 * 4 + 4 * 2 * 64 * 4 + 2 * 128 * 4];
   unsigned char (*Qs)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(SM);
   unsigned char (*dOs)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(SM + 2 * 64 * KD);
   float (*QPs)[64][16] = reinterpret_cast<float (*)[64][16]>(SM + 4 * 64 * KD);
@@ -521,7 +566,8 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
   float (*st_max)[64] = st_c0 + 2;       // row max (log2 domain)
   float (*st_inv)[64] = st_c0 + 4;       // 1 / row sum (0 for rows >= T)
   float (*st_d)[64] = st_c0 + 6;         // D_i = dO_i . O_i
-  unsigned (*st_hash)[64] = reinterpret_cast<unsigned (*)[64]>(st_c0 + 8);
+  // the forward's dropout decisions of the current 64-query tile against this workgroup's key tile: 4 blocks x 64 lanes x u16
+  unsigned (*st_keep)[128] = reinterpret_cast<unsigned (*)[128]>(st_c0 + 8);
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -532,7 +578,6 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
   const int klen = p.klens ? p.klens[b] : T;
   const float sl2 = p.scale * LOG2E;
   const bool drop = p.dropout_p > 0.f;
-  const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
   const int rp = p.r_pitch;
   if (!p.causal && p.chunk_nc == 0 && klen >= 1 && k0 >= klen) {
@@ -571,21 +616,26 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
   // statistics of query q0 + tid
   // RAW loaded values only: every use of them (scaling, selects) happens in *_store at the END of the iteration, so the
   // loads -- issued BEFORE the next tile's DMA -- are not waited for until then
-  struct Stat { float mx, inv, dd, farv; unsigned hash; int qi; };
+  struct Stat { float mx, inv, dd, farv; unsigned keep; int qi; };
   // STRAIGHT-LINE loads (round 4, ISA audit): with the loads inside conditional expressions (`qi < T ? LSE[..] : 0`,
   // `c < rp ? src[c] * sl2 : 0`) hipcc put every one of them into its own branch with an s_waitcnt vmcnt(0) behind it --
   // up to eight SERIALISED global round trips at the top of every query-tile iteration of this kernel.  All addresses
   // are clamped to valid ones and everything is requested back to back.
   const bool has_far = QP && p.clamp > 0;
+  // dropout words of (key tile k0 / 64, query blocks q0 / 16 .. + 3): 512 contiguous bytes, one dword per thread 0..127
+  // (see fa_keep_bits; a valid address also without dropout: straight-line load)
+  const unsigned* kb32 = drop ? reinterpret_cast<const unsigned*>(keepbits + fa_keep_index(p, b, h, k0 >> 6, 0)) + (threadIdx.x & 127)
+                              : reinterpret_cast<const unsigned*>(LSE);
+  const int kb_step = drop ? 32 : 0;             // dwords per 16-query block
   auto stat_load = [&](int q0) {
     Stat s_;
-    s_.mx = 0.f; s_.inv = 0.f; s_.dd = 0.f; s_.farv = 0.f; s_.hash = 0u; s_.qi = q0 + (int)threadIdx.x;
+    s_.mx = 0.f; s_.inv = 0.f; s_.dd = 0.f; s_.farv = 0.f; s_.qi = q0 + (int)threadIdx.x;
+    s_.keep = kb32[(q0 >> 4) * kb_step];
     if (threadIdx.x < 64) {
       const int qc = min(s_.qi, T - 1);
       const long long ri = ((long long)b * p.H + h) * T + qc;
       const float* farp = has_far ? QP + ((brow0 + qc) * p.H + h) * rp + p.clamp : LSE + ri;   // (any readable word)
       s_.mx = LSE[ri]; s_.inv = LSE[nrow + ri]; s_.dd = Drow[ri]; s_.farv = *farp;
-      s_.hash = drop ? fa_rowhash(p, b, h, T, s_.qi) : 0u;
     }
     return s_;
   };
@@ -594,8 +644,9 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
       st_c0[buf][threadIdx.x] = (has_far ? s_.farv * sl2 : 0.f) - s_.mx;
       st_max[buf][threadIdx.x] = s_.mx;
       st_inv[buf][threadIdx.x] = s_.qi < T ? s_.inv : 0.f;      // rows beyond T contribute nothing
-      st_d[buf][threadIdx.x] = s_.dd; st_hash[buf][threadIdx.x] = s_.hash;
+      st_d[buf][threadIdx.x] = s_.dd;
     }
+    if (threadIdx.x < 128) st_keep[buf][threadIdx.x] = s_.keep;
   };
   auto qp_load = [&](int q0) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -628,10 +679,11 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
   stat_store(0, str);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // dropout: the pair-of-keys part of the hash is constant for the lane (its key is fixed)
-  const unsigned pair = (unsigned)key >> 1;
-  const unsigned pair_mix = __umul24(pair, 0x9E3779u) + (pair << 11);
-  const int half_shift = (key & 1) * 16;
+  // dropout: lane (key r, queries 4 g + e of block qq) finds its decision in the forward's lane (query 4 g + e, key group
+  // r >> 2) word, bit 15 - (4 wave + (r & 3)): the four words e = 0..3 are 8 contiguous bytes of the block's 128; shift that
+  // moves the bit of the even (low half-word) / odd (high) query to bit 31
+  const int keep_off = 8 * g + 32 * (r >> 2);                   // byte offset inside a 16-query block's words
+  const int keep_sh_odd = wave * 4 + (r & 3), keep_sh_even = 16 + keep_sh_odd;
   const int nqt = (T + 63) / 64;
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 64;
@@ -676,18 +728,17 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
         // instructions earlier, was drained right here, before the soft-max arithmetic it is supposed to hide behind.
         // (The compiler does not count asm loads: the destinations are named in the wait statement, CDNA guide 5.7.)
         f32x4 c0v, mxv, inv, ddv;
-        u32x4 hv = {0u, 0u, 0u, 0u};
+        u32x2 kw = {0u, 0u};
         fa_lds_read4(c0v, &st_c0[cur][qq * 16 + 4 * g]);
         fa_lds_read4(mxv, &st_max[cur][qq * 16 + 4 * g]);
         fa_lds_read4(inv, &st_inv[cur][qq * 16 + 4 * g]);
         fa_lds_read4(ddv, &st_d[cur][qq * 16 + 4 * g]);
-        if (DROP) fa_lds_read4(hv, &st_hash[cur][qq * 16 + 4 * g]);
+        if (DROP) fa_lds_read2(kw, reinterpret_cast<const unsigned char*>(&st_keep[cur][qq * 32]) + keep_off);
 #ifndef NSP_HOST_EMULATION
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0v), "+v"(mxv), "+v"(inv), "+v"(ddv), "+v"(hv));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0v), "+v"(mxv), "+v"(inv), "+v"(ddv), "+v"(kw));
 #endif
         const float c0a[4] = {c0v[0], c0v[1], c0v[2], c0v[3]}, mxa[4] = {mxv[0], mxv[1], mxv[2], mxv[3]};
         const float ina[4] = {inv[0], inv[1], inv[2], inv[3]}, dda[4] = {ddv[0], ddv[1], ddv[2], ddv[3]};
-        const unsigned ha[4] = {hv[0], hv[1], hv[2], hv[3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int ql = qq * 16 + 4 * g + e;
@@ -712,17 +763,15 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
             ex = __builtin_amdgcn_exp2f(v - mxa[e]);
             if (key >= T) ex = 0.f;                          // tile padding: not in the softmax
           }
-          float keep = 1.f;
+          float exk = ex;
           if constexpr (DROP) {
-            unsigned y = ha[e] + pair_mix;
-            y ^= y << 13; y ^= y >> 17; y ^= y << 5;
-            y = __umul24(y >> 8, 0x85EBCBu) ^ y;
-            keep = ((y >> half_shift) & 0xFFFFu) >= thr16 ? inv_keep : 0.f;
+            const int m = ((int)(kw[e >> 1] << ((e & 1) ? keep_sh_odd : keep_sh_even))) >> 31;
+            exk = __uint_as_float(__float_as_uint(ex * inv_keep) & (unsigned)m);
           }
           // pdr = the value forward fed into P V, bit for bit (integer row max: see the forward kernel); the first
           // term pairs it with dP so that sum_j of it equals D_i = dO_i . O_i, the second uses the fp32
           // probability that sums to one with the saved 1 / l
-          const float pdr = (float)(__bf16)(ex * keep);
+          const float pdr = (float)(__bf16)exk;
           float ds = ina[e] * p.scale * fmaf(pdr, dp_acc[qb][e], -ex * dda[e]);
           if (KIND == 2 && !vis) ds = 0.f;
           Pt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)(pdr * ina[e]);
@@ -742,12 +791,23 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
 #pragma unroll
     for (int sl = 0; sl < NQB / 2; ++sl) {
       const int s2 = hq * (NQB / 2) + sl;      // 32-query k-step inside the tile
+      // all eight transposed fragments of the 32-query k-step requested back to back through inline asm (the builtin
+      // drew an s_waitcnt vmcnt(0) -- the NEXT tile's Q / dO DMA drained in the middle of this tile -- and hipcc
+      // serialised read -> wait -> MFMA per fragment), then two counted waits
+      FaTr tf[8];                                     // [df * 2 + {dO, Q}]
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        const bf16x8 doT = frag_tr_dma(dOs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
-        const bf16x8 qT = frag_tr_dma(Qs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
-        dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pt[sl], doT, dv_acc[df], 0, 0, 0);
-        dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dSt[sl], qT, dk_acc[df], 0, 0, 0);
+        fa_tr_issue(tf[df * 2], dOs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
+        fa_tr_issue(tf[df * 2 + 1], Qs[cur], df * 16, 32 * s2 + 4 * g, 32 * s2 + 16 + 4 * g, r);
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        fa_tr_wait(tf, hf);
+#pragma unroll
+        for (int df = hf * 2; df < hf * 2 + 2; ++df) {
+          dv_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pt[sl], fa_tr_join(tf[df * 2]), dv_acc[df], 0, 0, 0);
+          dk_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dSt[sl], fa_tr_join(tf[df * 2 + 1]), dk_acc[df], 0, 0, 0);
+        }
       }
     }
     };
@@ -786,7 +846,7 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
 __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ O32, const float* __restrict__ LSE, float* __restrict__ Drow, float* __restrict__ dq32,
-    float* __restrict__ dQP, const nsp_attn_mask_params p) {
+    float* __restrict__ dQP, const unsigned short* __restrict__ keepbits, const nsp_attn_mask_params p) {
   __shared__ __attribute__((aligned(16))) unsigned char KV[4 * 64 * KD + 2 * 64 * 17 * 4];   // one LDS object (see the forward kernel)
   unsigned char (*Ks)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV);
   unsigned char (*Vs)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV + 2 * 64 * KD);
@@ -844,9 +904,15 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     if (g == 0 && qi < T) Drow[ri] = dsum;
   }
   const bool drop = p.dropout_p > 0.f;
-  const unsigned thr16 = (unsigned)(p.dropout_p * 65536.f);
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
-  const unsigned rowhash = drop ? fa_rowhash(p, b, h, T, qi) : 0u;
+  // the forward's dropout decisions of this wave's 16 queries (see fa_keep_bits): one 16-bit word per lane and key tile,
+  // requested one tile ahead -- and BEFORE that tile's DMA, so that the wait for it never has to cover the DMA
+  // (straight-line load from a valid address whether or not there is dropout: a conditional load becomes a branch with
+  // its own s_waitcnt vmcnt(0))
+  const unsigned short* kbp = drop ? keepbits + fa_keep_index(p, b, h, 0, (q0 >> 4) + wave) + lane
+                                   : reinterpret_cast<const unsigned short*>(LSE);
+  const long long kb_stride = drop ? 4LL * ((T + 63) >> 6) * 64 : 0;      // u16 elements between consecutive key tiles
+  unsigned kb_next = *kbp;
   const __bf16* kbase = qkv + d + h * DK;
   const __bf16* vbase = qkv + 2 * d + h * DK;
   tile_dma(Ks[0], kbase, ld3, brow0, 0, T, wave, lane);
@@ -861,7 +927,9 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
   for (int kt = 0; kt < nkt; ++kt) {
     const unsigned char* Kc = Ks[kt & 1];
     const unsigned char* Vc = Vs[kt & 1];
+    const unsigned kb = kb_next;
     if (kt + 1 < nkt) {
+      kb_next = kbp[(long long)(kt + 1) * kb_stride];
       tile_dma(Ks[(kt + 1) & 1], kbase, ld3, brow0, (kt + 1) * 64, T, wave, lane);
       tile_dma(Vs[(kt + 1) & 1], vbase, ld3, brow0, (kt + 1) * 64, T, wave, lane);
     }
@@ -888,11 +956,10 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     auto tile_scores = [&](auto kind_, auto drop_) {
       constexpr int KIND = decltype(kind_)::value;
       constexpr bool DROP = decltype(drop_)::value;
-      float ev[4][4], kp[4][4];
+      float ev[4][4];
       unsigned vis = 0xFFFFu;
       if constexpr (KIND == 1) fa_logits_near(s_acc, ev, qrow, sl2, qi, kt * 64, g, p.clamp);
       if constexpr (KIND == 2) vis = fa_logits(s_acc, ev, p, qrow, sl2, qi, kt * 64, g, klen, tl);
-      if constexpr (DROP) fa_keep(kp, rowhash, kt * 64, g, thr16, inv_keep);
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
@@ -902,8 +969,8 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
           if constexpr (KIND == 0) ex = __builtin_amdgcn_exp2f(fmaf(s_acc[kf][e], sl2, c0));
           else ex = __builtin_amdgcn_exp2f(ev[kf][e] - rmax);
           if (KIND == 2 && !tl.plain && key >= T) ex = 0.f;
-          const float keep = DROP ? kp[kf][e] : 1.f;
-          const float pdr = (float)(__bf16)(ex * keep);       // forward's P V operand, bit for bit (see flash_bwd_dkv_kernel)
+          // forward's P V operand, bit for bit (see flash_bwd_dkv_kernel)
+          const float pdr = (float)(__bf16)(DROP ? fa_keep_apply(ex * inv_keep, kb, kf * 4 + e) : ex);
           float ds = rs_ * fmaf(pdr, dp_acc[kf][e], -ex * dsum);
           if (KIND == 2 && !tl.plain && !((vis >> (kf * 4 + e)) & 1u)) ds = 0.f;
           dSf[kf >> 1][(kf & 1) * 4 + e] = (__bf16)ds;
@@ -970,10 +1037,16 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
 
 }  // namespace
 
-extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* O32, float* LSE,
+extern "C" long long nsp_flash_attn_keepbits_bytes(int B, int H, int T) {
+  const long long nkt = (T + 63) / 64;
+  return (long long)B * H * nkt * (4 * nkt) * 128;
+}
+
+extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* O32, float* LSE, void* keepbits,
                                   const nsp_attn_mask_params* pp, void* stream) {
   if (!pp || !qkv || !O || !LSE) return NSP_EINVAL;
   nsp_attn_mask_params p = *pp;
+  if (p.dropout_p > 0.f && !keepbits) return NSP_EINVAL;
   if (p.Tq != p.Tk || d != p.H * DK) return NSP_EUNSUPPORTED;
   if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16 && p.R >= (p.clamp + 1 < p.Tk ? p.clamp + 1 : p.Tk)))
     return NSP_EUNSUPPORTED;
@@ -984,19 +1057,22 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
   {
     dim3 grid(((p.Tq + 63) / 64) * p.H, p.B);
     hipLaunchKernelGGL(flash_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE, p);
+                       reinterpret_cast<const __bf16*>(qkv), d, QP, reinterpret_cast<__bf16*>(O), O32, LSE,
+                       reinterpret_cast<unsigned short*>(keepbits), p);
   }
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }
 
 // dq32 [B*T, d] fp32 and dQP are plainly written (no zero-init needed); dqkv receives dK at
-// column block d and dV at 2d (bf16); D is scratch [B,H,T].
+// column block d and dV at 2d (bf16); D is scratch [B,H,T]; keepbits = what the forward call with the same parameters wrote
+// (required iff dropout_p > 0).
 extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const float* O32,
-                                  const float* LSE, float* D, void* dqkv, float* dq32, float* dQP,
+                                  const float* LSE, const void* keepbits, float* D, void* dqkv, float* dq32, float* dQP,
                                   const nsp_attn_mask_params* pp, void* stream) {
   if (!pp || !qkv || !dO || !O32 || !LSE || !D || !dqkv || !dq32) return NSP_EINVAL;
   nsp_attn_mask_params p = *pp;
+  if (p.dropout_p > 0.f && !keepbits) return NSP_EINVAL;
   if (p.Tq != p.Tk || d != p.H * DK) return NSP_EUNSUPPORTED;
   if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16)) return NSP_EUNSUPPORTED;
   if (QP && !dQP) return NSP_EINVAL;
@@ -1005,11 +1081,13 @@ extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const
   dim3 grid(((p.Tq + 63) / 64) * p.H, p.B);
   // the dQ kernel first: it forms D = dO . O for its queries and leaves it in D for the dK/dV kernel
   hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
-                     reinterpret_cast<const __bf16*>(dO), O32, LSE, D, dq32, dQP, p);
+                     reinterpret_cast<const __bf16*>(dO), O32, LSE, D, dq32, dQP,
+                     reinterpret_cast<const unsigned short*>(keepbits), p);
   // the 64-query tile as two halves of 32 (168 VGPRs, a third wave per SIMD; the whole-tile form -- 255 VGPRs -- and its
   // switch were removed in round 5: bit-identical results, 3-7 % slower, profiles/r04zn_flash_dkv_two_halves_ab.log)
   hipLaunchKernelGGL(flash_bwd_dkv_kernel<true>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,
-                     QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv), p);
+                     QP, reinterpret_cast<const __bf16*>(dO), LSE, D, reinterpret_cast<__bf16*>(dqkv),
+                     reinterpret_cast<const unsigned short*>(keepbits), p);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

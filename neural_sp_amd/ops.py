@@ -3115,10 +3115,10 @@ class SelfAttnFn(torch.autograd.Function):
                      cfg.get('chunk_nc', 0), p_att, seed, offset)
         scale = 1.0 / math.sqrt(dk)
         mp = _mask_params(B, H, T, T, R, clamp, scale, klens, *mask_args, p_bf16=1, tk_pitch=Tkp, r_pitch=Rp)
-        P16 = Pd16 = LSE = cv32 = None
+        P16 = Pd16 = LSE = cv32 = keepbits = None
         if fused:
             # flash-style kernel: scores / probabilities never leave the CU
-            cv16, cv32, LSE = flash_attn_fwd_raw(qkv, d, QP, mp, want_o32=any(ctx.needs_input_grad))
+            cv16, cv32, LSE, keepbits = flash_attn_fwd_raw(qkv, d, QP, mp, want_o32=any(ctx.needs_input_grad))
             aw = None
         else:
             S = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)
@@ -3136,7 +3136,7 @@ class SelfAttnFn(torch.autograd.Function):
         s_o = next_dropout_seed() if p_o > 0 else (0, 0)
         res2d = _f32c(res).reshape(M, d) if res is not None else None
         out = linear_fwd(cv16, wo, bo, 0, res2d, 1.0, dropout_p=p_o, seed=s_o[0], offset=s_o[1])
-        ctx.save_for_backward(x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens, QP, LSE, cv32)
+        ctx.save_for_backward(x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens, QP, LSE, cv32, keepbits)
         ctx.cfg = (B, T, d, H, dk, R, Rp, Tkp, clamp, scale, mask_args, p_o, s_o, res is not None,
                    bq is not None, bo is not None)
         ctx.prep_token = _prep_offer(res is not None, 1.0, p_o, s_o[0], s_o[1], d)
@@ -3147,7 +3147,7 @@ class SelfAttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _unused):
-        x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens, QP, LSE, cv32 = ctx.saved_tensors
+        x16, wq, wk, wv, wo, w_pos, qkv, pos16, pe16, P16, Pd16, cv16, klens, QP, LSE, cv32, keepbits = ctx.saved_tensors
         (B, T, d, H, dk, R, Rp, Tkp, clamp, scale, mask_args, p_o, s_o, has_res, has_qkv_bias,
          has_o_bias) = ctx.cfg
         has_pos = pos16 is not None
@@ -3170,7 +3170,7 @@ class SelfAttnFn(torch.autograd.Function):
         dqkv = torch.empty((M, d3), device=dev, dtype=torch.bfloat16)
         mp = _mask_params(B, H, T, T, R, clamp, scale, klens, *mask_args, p_bf16=1, tk_pitch=Tkp, r_pitch=Rp)
         if fused:
-            dq_acc, dQP = flash_attn_bwd_raw(qkv, d, QP, dO, cv32, LSE, mp, dqkv)
+            dq_acc, dQP = flash_attn_bwd_raw(qkv, d, QP, dO, cv32, LSE, keepbits, mp, dqkv)
         else:
             dP = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)       # dP = dO v^T
             gemm_raw(T, T, dk, dO, d, 1, qkv, 1, d3, dP, T, batch=(B, H), a_b=(T * d, dk),
@@ -3229,18 +3229,23 @@ class SelfAttnFn(torch.autograd.Function):
 # fused (flash-style) attention core, d_k = 64
 # --------------------------------------------------------------------------
 def flash_attn_fwd_raw(qkv16, d, QP, mp, want_o32=True):
-    """-> (O bf16, O32 fp32 or None, LSE).  O32 is what backward's D = dO . O is formed from."""
+    """-> (O bf16, O32 fp32 or None, LSE, keepbits or None).  O32 is what backward's D = dO . O is formed from; keepbits
+    (only with dropout) = the dropout decisions the forward drew, which backward reads instead of drawing them again."""
     M = qkv16.shape[0]
     O = torch.empty((M, d), device=qkv16.device, dtype=torch.bfloat16)
     O32 = torch.empty((M, d), device=qkv16.device, dtype=torch.float32) if want_o32 else None
     LSE = torch.empty((2, mp.B, mp.H, mp.Tq), device=qkv16.device, dtype=torch.float32)  # max, 1/sum
+    keep = None
+    if mp.dropout_p > 0:
+        keep = torch.empty((_lib.lib().nsp_flash_attn_keepbits_bytes(mp.B, mp.H, mp.Tq),), device=qkv16.device,
+                           dtype=torch.uint8)
     with _kev_class('flash_fwd', 4.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop'):
-        _check(_lib.lib().nsp_flash_attn_fwd(_p(qkv16), d, _p(QP), _p(O), _p(O32), _p(LSE), ctypes.byref(mp), _stream()),
-               'nsp_flash_attn_fwd')
-    return O, O32, LSE
+        _check(_lib.lib().nsp_flash_attn_fwd(_p(qkv16), d, _p(QP), _p(O), _p(O32), _p(LSE), _p(keep), ctypes.byref(mp),
+                                             _stream()), 'nsp_flash_attn_fwd')
+    return O, O32, LSE, keep
 
 
-def flash_attn_bwd_raw(qkv16, d, QP, dO16, O32, LSE, mp, dqkv16):
+def flash_attn_bwd_raw(qkv16, d, QP, dO16, O32, LSE, keep, mp, dqkv16):
     """-> (dq32 [M,d] fp32, dQP or None); dK / dV are written into dqkv16 column blocks d / 2d."""
     M = qkv16.shape[0]
     dev = qkv16.device
@@ -3248,6 +3253,6 @@ def flash_attn_bwd_raw(qkv16, d, QP, dO16, O32, LSE, mp, dqkv16):
     dQP = torch.empty_like(QP) if QP is not None else None
     D = torch.empty((mp.B, mp.H, mp.Tq), device=dev, dtype=torch.float32)
     with _kev_class('flash_bwd', 10.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop'):
-        _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O32), _p(LSE), _p(D), _p(dqkv16),
+        _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O32), _p(LSE), _p(keep), _p(D), _p(dqkv16),
                                              _p(dq32), _p(dQP), ctypes.byref(mp), _stream()), 'nsp_flash_attn_bwd')
     return dq32, dQP

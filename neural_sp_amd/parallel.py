@@ -103,6 +103,7 @@ class CommStats(object):
 
     def reset(self):
         self.buckets, self.bytes, self.last_ready, self.waited_side = 0, 0, None, 0
+        self.wire_bytes = 0          # what the collective moves per rank incl. rs_ag padding and bf16 compression
 
     def exposed_ms(self, after):
         return None if self.last_ready is None else self.last_ready.elapsed_time(after)
@@ -146,6 +147,15 @@ def _reduce_scatter_all_gather(buf, group, world, on_device):
         fut = dist.all_gather_into_tensor(src, shard, group=group, async_op=True).get_future()
 
     def done(f):
+        # The callback of a device future runs on a stream of torch's callback pool, not on the gather stream the
+        # temporaries were allocated on: without record_stream the caching allocator may hand `src` / `shard` to the next
+        # bucket's torch.cat on the gather stream while this copy is still in flight.
+        if on_device:
+            cb = torch.cuda.current_stream(buf.device)
+            shard.record_stream(cb)
+            if pad:
+                src.record_stream(cb)
+            buf.record_stream(cb)
         if pad:
             buf.copy_(src[:n])
         return buf
@@ -195,6 +205,8 @@ def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_strea
         if stats is not None:
             stats.buckets += 1
             stats.bytes += buf.numel() * buf.element_size()
+            n_pad = buf.numel() + ((-buf.numel()) % world if algorithm == 'rs_ag' else 0)
+            stats.wire_bytes += n_pad * (2 if compress == 'bf16' else buf.element_size())
             stats.waited_side += len(need)
             if bucket.is_last():
                 stats.last_ready = torch.cuda.Event(enable_timing=True)
@@ -209,7 +221,13 @@ def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_strea
                     fut = dist.all_reduce(send, group=group, async_op=True).get_future().then(lambda f: f.value()[0])
 
                 def decompress(f):
-                    buf.copy_(f.value())
+                    v = f.value()
+                    v = v[0] if isinstance(v, (list, tuple)) else v
+                    cb = torch.cuda.current_stream(dev)          # (callback stream: see _reduce_scatter_all_gather)
+                    v.record_stream(cb)
+                    send.record_stream(cb)
+                    buf.record_stream(cb)
+                    buf.copy_(v)
                     return buf
                 return fut.then(decompress)
             buf.div_(world)

@@ -64,14 +64,14 @@ def test_flash_attention_matches_reference(T, with_pos, causal, nc):
     mp = ops._mask_params(B, H, T, T, R if with_pos else 0, clamp if with_pos else -1, scale, klens, causal, 1,
                           nl, nc, r_pitch=Rp if with_pos else 0)
     qkv2 = qkv.view(B * T, 3 * d)
-    O, O32, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP if with_pos else None, mp)
+    O, O32, LSE, keep = ops.flash_attn_fwd_raw(qkv2, d, QP if with_pos else None, mp)
     assert _rel(O32.view(B, T, d), Oref.detach()) < 4e-3      # one bf16 probability operand (integer row max: backward reproduces it bit for bit)
     assert _rel(O.float().view(B, T, d), Oref.detach()) < 1.5e-2
     lse = LSE[0] * math.log(2.0) - torch.log(LSE[1])   # LSE[0]: row max in the log2 domain
     ok = LSEref.detach() > -1e30  # fully masked rows: max + log(sum) is not representable in fp32
     assert _rel(lse[ok], LSEref.detach()[ok]) < 1e-3
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
-    dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP if with_pos else None, dO.view(B * T, d), O32, LSE, mp, dqkv)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP if with_pos else None, dO.view(B * T, d), O32, LSE, keep, mp, dqkv)
     g = grads[0].view(B * T, 3 * d)
     assert _rel(dq32, g[:, :d]) < 2e-2, 'dq'
     assert _rel(dqkv[:, d:2 * d].float(), g[:, d:2 * d]) < 2e-2, 'dk'
@@ -103,7 +103,7 @@ def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward
                           offset=5 << 40, r_pitch=Rp)
     eye = torch.eye(T, dk, device=dev).repeat(1, H)[None].expand(B, T, d)            # V[j] = e_j per head
     qkv_eye = torch.cat([qk, eye.bfloat16()], dim=-1).contiguous().view(B * T, 3 * d)
-    Pd, _, _ = ops.flash_attn_fwd_raw(qkv_eye, d, QP, mp)                               # [B*T, d]: Pdrop[b,i,h,j]
+    Pd, _, _, _ = ops.flash_attn_fwd_raw(qkv_eye, d, QP, mp)                               # [B*T, d]: Pdrop[b,i,h,j]
     Pd = Pd.float().view(B, T, H, T).permute(0, 2, 1, 3)                             # [B,H,i,j]
     q32 = qk.float()
     e = torch.einsum('bihd,bjhd->bhij', q32[..., :d].reshape(B, T, H, dk), q32[..., d:].reshape(B, T, H, dk))
@@ -130,10 +130,10 @@ def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward
     Oref = torch.einsum('bhij,bjhd->bihd', P2, vv).reshape(B, T, d)
     dO = torch.randn_like(Oref).bfloat16()
     gx, gqp = torch.autograd.grad(Oref, [x32, QPr], dO.float())
-    O, O32, LSE = ops.flash_attn_fwd_raw(qkv.view(B * T, 3 * d), d, QP, mp)
+    O, O32, LSE, keep = ops.flash_attn_fwd_raw(qkv.view(B * T, 3 * d), d, QP, mp)
     assert _rel(O.float().view(B, T, d), Oref.detach()) < 2e-2
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
-    dq32, dQP = ops.flash_attn_bwd_raw(qkv.view(B * T, 3 * d), d, QP, dO.view(B * T, d), O32, LSE, mp, dqkv)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv.view(B * T, 3 * d), d, QP, dO.view(B * T, d), O32, LSE, keep, mp, dqkv)
     g = gx.view(B * T, 3 * d)
     assert _rel(dq32, g[:, :d]) < 3e-2, 'dq'
     assert _rel(dqkv[:, d:2 * d].float(), g[:, d:2 * d]) < 3e-2, 'dk'
@@ -148,14 +148,14 @@ def test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward
     mp = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, dropout_p=pdrop, seed=99,
                           offset=7 << 40, r_pitch=Rp)
     mp0 = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, r_pitch=Rp)
-    O1, O1_32, LSE1 = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
-    O2, _, _ = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
-    O0, _, _ = ops.flash_attn_fwd_raw(qkv, d, QP, mp0)
-    assert torch.equal(O1, O2)
+    O1, O1_32, LSE1, keep1 = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
+    O2, _, _, keep2 = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
+    O0, _, _, keep0 = ops.flash_attn_fwd_raw(qkv, d, QP, mp0)
+    assert torch.equal(O1, O2) and keep0 is None      # (keep1 / keep2: words of skipped key tiles are never written)
     assert _rel(O1.float(), O0.float()) > 0.05          # dropout does something
     dO = torch.randn(B * T, d, device=dev).bfloat16()
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
-    ops.flash_attn_bwd_raw(qkv, d, QP, dO, O1_32, LSE1, mp, dqkv)
+    ops.flash_attn_bwd_raw(qkv, d, QP, dO, O1_32, LSE1, keep1, mp, dqkv)
     lhs = (dO.float() * O1.float()).sum().item()
     rhs = (dqkv[:, 2 * d:].float() * qkv[:, 2 * d:].float()).sum().item()
     # <dO, O> is a sum of random-sign terms: normalise by the norms, not by the (possibly tiny) sum
@@ -194,9 +194,9 @@ def test_flash_attention_backward_keeps_softmax_shift_invariance(T, H, B):
     g = g.view(B * T, 3 * d)
     mp = ops._mask_params(B, H, T, T, R, clamp, scale, klens, False, 0, 0, 0, r_pitch=Rp)
     qkv2 = qkv.view(B * T, 3 * d)
-    O, O32, LSE = ops.flash_attn_fwd_raw(qkv2, d, QP, mp)
+    O, O32, LSE, keep = ops.flash_attn_fwd_raw(qkv2, d, QP, mp)
     dqkv = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
-    dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP, dO.view(B * T, d), O32, LSE, mp, dqkv)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv2, d, QP, dO.view(B * T, d), O32, LSE, keep, mp, dqkv)
 
     def cos(a, b):
         return torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()

@@ -29,7 +29,7 @@ for T in Ts:
         dqkv = torch.empty(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
         fwd_out = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
         def fwd(): ops.flash_attn_fwd_raw(qkv, d, QP, mp)
-        def bwd(): ops.flash_attn_bwd_raw(qkv, d, QP, dO, *fwd_out[1:], mp, dqkv)
+        def bwd(): ops.flash_attn_bwd_raw(qkv, d, QP, dO, fwd_out[1], fwd_out[2], fwd_out[3], mp, dqkv)
         res = []
         for fn in (fwd, bwd):
             for _ in range(2): fn()
