@@ -306,9 +306,12 @@ int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
 long long nsp_flash_attn_keepbits_bytes(int B, int H, int T);
 int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* O32, float* LSE, void* keepbits,
                        const nsp_attn_mask_params* p, void* stream);
+/* query gradient: dq32 fp32 [B*T,d] (position term's share dQP . pos NOT included; pos16 NULL), or with dq32 == NULL     *
+ * finished and rounded, in column block 0 of dqkv: dS k + dQP . pos16 (pos16 = projected position table [>=R, d] bf16, or *
+ * NULL for plain MHA)                                                                                                    */
 int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const float* O32,
                        const float* LSE, const void* keepbits, float* D, void* dqkv, float* dq32, float* dQP,
-                       const nsp_attn_mask_params* p, void* stream);
+                       const void* pos16, const nsp_attn_mask_params* p, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Conformer convolution module core: depthwise Conv1d over time on         *

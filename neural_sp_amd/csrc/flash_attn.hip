@@ -643,8 +643,12 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
     if (threadIdx.x < 64) {
       st_c0[buf][threadIdx.x] = (has_far ? s_.farv * sl2 : 0.f) - s_.mx;
       st_max[buf][threadIdx.x] = s_.mx;
-      st_inv[buf][threadIdx.x] = s_.qi < T ? s_.inv : 0.f;      // rows beyond T contribute nothing
-      st_d[buf][threadIdx.x] = s_.dd;
+      // A = scale / l (0 for rows beyond T: they contribute nothing) and A D: dS = A Pd dP - (A D) p~, and the dV operand is
+      // bf16(A Pd) -- the same mantissa as bf16(Pd / l) for the power-of-two scale of d_k = 64; dV is multiplied by 1 / scale
+      // once at the end (round 6: two multiplies per score fewer)
+      const float a_ = s_.qi < T ? s_.inv * p.scale : 0.f;
+      st_inv[buf][threadIdx.x] = a_;
+      st_d[buf][threadIdx.x] = a_ * s_.dd;
     }
     if (threadIdx.x < 128) st_keep[buf][threadIdx.x] = s_.keep;
   };
@@ -653,9 +657,9 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
     if (QP) {
       const int ql = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
       const int q = min(q0 + ql, T - 1);
+      // one 16-B load (r_pitch is a multiple of 4: rows are 16-B aligned; columns >= r_pitch are zeroed in qp_store)
       const float* src = QP + ((brow0 + q) * p.H + h) * rp;
-      v.x = src[min(c4 + 0, rp - 1)]; v.y = src[min(c4 + 1, rp - 1)];
-      v.z = src[min(c4 + 2, rp - 1)]; v.w = src[min(c4 + 3, rp - 1)];
+      v = *reinterpret_cast<const float4*>(src + min(c4, rp - 4));
     }
     return v;
   };
@@ -772,9 +776,10 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
           // term pairs it with dP so that sum_j of it equals D_i = dO_i . O_i, the second uses the fp32
           // probability that sums to one with the saved 1 / l
           const float pdr = (float)(__bf16)exk;
-          float ds = ina[e] * p.scale * fmaf(pdr, dp_acc[qb][e], -ex * dda[e]);
+          const float pa = pdr * ina[e];                  // (ina = scale / l, dda = D scale / l: see stat_store)
+          float ds = fmaf(pa, dp_acc[qb][e], -ex * dda[e]);
           if (KIND == 2 && !vis) ds = 0.f;
-          Pt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)(pdr * ina[e]);
+          Pt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)pa;
           dSt[qb >> 1][(qb & 1) * 4 + e] = (__bf16)ds;
         }
       }
@@ -825,6 +830,7 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
     __syncthreads();  // next tile's buffers visible; this tile's free
   }
   // D[i = key (4g+e)][j = lane&15 = channel within fragment df]
+  const float inv_scale = 1.f / p.scale;         // the dV operand carried the factor `scale` (see stat_store)
 #pragma unroll
   for (int df = 0; df < 4; ++df)
 #pragma unroll
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
       if (ko < T) {
         const long long rowoff = (brow0 + ko) * ld3 + h * DK + df * 16 + r;
         dqkv[rowoff + d] = (__bf16)dk_acc[df][e];
-        dqkv[rowoff + 2 * d] = (__bf16)dv_acc[df][e];
+        dqkv[rowoff + 2 * d] = (__bf16)(dv_acc[df][e] * inv_scale);
       }
     }
 }
@@ -846,12 +852,14 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
 __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     const __bf16* __restrict__ qkv, int d, const float* __restrict__ QP, const __bf16* __restrict__ dO,
     const float* __restrict__ O32, const float* __restrict__ LSE, float* __restrict__ Drow, float* __restrict__ dq32,
-    float* __restrict__ dQP, const unsigned short* __restrict__ keepbits, const nsp_attn_mask_params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char KV[4 * 64 * KD + 2 * 64 * 17 * 4];   // one LDS object (see the forward kernel)
+    float* __restrict__ dQP, const unsigned short* __restrict__ keepbits, const __bf16* __restrict__ pos16,
+    __bf16* __restrict__ dq16, const nsp_attn_mask_params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char KV[4 * 64 * KD + 2 * 64 * 17 * 4 + 16 * 64 * 4];   // one LDS object (see the forward kernel)
   unsigned char (*Ks)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV);
   unsigned char (*Vs)[64 * KD] = reinterpret_cast<unsigned char (*)[64 * KD]>(KV + 2 * 64 * KD);
   float (*QPs)[17] = reinterpret_cast<float (*)[17]>(KV + 4 * 64 * KD);
   float (*dQPs)[17] = reinterpret_cast<float (*)[17]>(KV + 4 * 64 * KD + 64 * 17 * 4);
+  float (*POSs)[64] = reinterpret_cast<float (*)[64]>(KV + 4 * 64 * KD + 2 * 64 * 17 * 4);   // this head's projected position table
   const int T = p.Tq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -861,6 +869,12 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
   const long long nrow = (long long)p.B * p.H * T;
   const int klen = p.klens ? p.klens[b] : T;
   const int ql = wave * 16 + r;
+  if (pos16) {      // rows rel < R of pos16[R.., d] (bf16), columns of head h; read after the k-loop's barriers
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+      const int rr = idx >> 6, c = idx & 63;
+      POSs[rr][c] = rr < p.R ? (float)pos16[(long long)rr * d + h * DK + c] : 0.f;
+    }
+  }
   const int qi = q0 + ql;
   const int qc = min(qi, T - 1);
   // everything the loop reads from global memory besides the K / V tiles is fetched BEFORE tile 0
@@ -1014,7 +1028,7 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (qi < T) {
+  if (dq32 && qi < T) {
     float* dqp = dq32 + (brow0 + qi) * d + h * DK;
 #pragma unroll
     for (int df = 0; df < 4; ++df)
@@ -1031,6 +1045,33 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
     for (int idx = threadIdx.x; idx < 64 * p.r_pitch; idx += 256) {
       const int l2 = idx / p.r_pitch, rr = idx % p.r_pitch;
       if (q0 + l2 < T) dQP[((brow0 + q0 + l2) * p.H + h) * p.r_pitch + rr] = dQPs[l2][rr];
+    }
+  }
+  if (dq16) {
+    // Round 6: the query gradient leaves this kernel FINISHED -- the position term's share dQP . pos (the reference's
+    // BD = q pos^T, relative_multihead_attention.py:188-193; was a K = 16 GEMM that read the fp32 dQ back, accumulated
+    // into it, and a cast pass: 18 bytes per element of fp32 hand-overs) is 11 multiply-adds per output here, on the table
+    // gradient this workgroup has just finished in LDS -- and as the bf16 operand of the QKV gradient GEMMs, in column
+    // block 0 of dqkv.
+    if (pos16 && QP) {
+      for (int rr = 0; rr < p.R; ++rr) {
+        const float w = dQPs[ql][rr];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+          const float4 pv = *reinterpret_cast<const float4*>(&POSs[rr][df * 16 + 4 * g]);
+          dq_acc[df][0] = fmaf(w, pv.x, dq_acc[df][0]); dq_acc[df][1] = fmaf(w, pv.y, dq_acc[df][1]);
+          dq_acc[df][2] = fmaf(w, pv.z, dq_acc[df][2]); dq_acc[df][3] = fmaf(w, pv.w, dq_acc[df][3]);
+        }
+      }
+    }
+    if (qi < T) {
+      __bf16* dqp = dq16 + (brow0 + qi) * ld3 + h * DK;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        bf16x4 o4;
+        o4[0] = (__bf16)dq_acc[df][0]; o4[1] = (__bf16)dq_acc[df][1]; o4[2] = (__bf16)dq_acc[df][2]; o4[3] = (__bf16)dq_acc[df][3];
+        *reinterpret_cast<bf16x4*>(dqp + df * 16 + 4 * g) = o4;
+      }
     }
   }
 }
@@ -1064,25 +1105,30 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
   return NSP_OK;
 }
 
-// dq32 [B*T, d] fp32 and dQP are plainly written (no zero-init needed); dqkv receives dK at
-// column block d and dV at 2d (bf16); D is scratch [B,H,T]; keepbits = what the forward call with the same parameters wrote
+// dqkv receives dK at column block d and dV at 2d (bf16); dQP is plainly written (no zero-init needed); the query gradient
+// either as dq32 [B*T, d] fp32 WITHOUT the position term's share (pos16 must be NULL), or -- dq32 == NULL -- finished, as
+// bf16 in column block 0 of dqkv: dS K plus, when pos16 (the projected position table [>= R, d] bf16) is given, dQP . pos16.
+// D is scratch [B,H,T]; keepbits = what the forward call with the same parameters wrote
 // (required iff dropout_p > 0).
 extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const float* O32,
                                   const float* LSE, const void* keepbits, float* D, void* dqkv, float* dq32, float* dQP,
-                                  const nsp_attn_mask_params* pp, void* stream) {
-  if (!pp || !qkv || !dO || !O32 || !LSE || !D || !dqkv || !dq32) return NSP_EINVAL;
+                                  const void* pos16, const nsp_attn_mask_params* pp, void* stream) {
+  if (!pp || !qkv || !dO || !O32 || !LSE || !D || !dqkv) return NSP_EINVAL;
   nsp_attn_mask_params p = *pp;
   if (p.dropout_p > 0.f && !keepbits) return NSP_EINVAL;
+  if (dq32 && pos16) return NSP_EINVAL;          // the position term is only folded into the finished (bf16) query gradient
   if (p.Tq != p.Tk || d != p.H * DK) return NSP_EUNSUPPORTED;
   if (QP && !(p.clamp > 0 && p.R <= 16 && p.r_pitch <= 16)) return NSP_EUNSUPPORTED;
   if (QP && !dQP) return NSP_EINVAL;
   if (p.r_pitch < p.R) p.r_pitch = p.R;
+  if (QP && (p.r_pitch % 4 != 0 || p.r_pitch < 4)) return NSP_EUNSUPPORTED;     // (the dK/dV kernel loads table rows as float4)
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(((p.Tq + 63) / 64) * p.H, p.B);
   // the dQ kernel first: it forms D = dO . O for its queries and leaves it in D for the dK/dV kernel
   hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d, QP,
                      reinterpret_cast<const __bf16*>(dO), O32, LSE, D, dq32, dQP,
-                     reinterpret_cast<const unsigned short*>(keepbits), p);
+                     reinterpret_cast<const unsigned short*>(keepbits), reinterpret_cast<const __bf16*>(pos16),
+                     dq32 ? nullptr : reinterpret_cast<__bf16*>(dqkv), p);
   // the 64-query tile as two halves of 32 (168 VGPRs, a third wave per SIMD; the whole-tile form -- 255 VGPRs -- and its
   // switch were removed in round 5: bit-identical results, 3-7 % slower, profiles/r04zn_flash_dkv_two_halves_ab.log)
   hipLaunchKernelGGL(flash_bwd_dkv_kernel<true>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(qkv), d,

@@ -3170,7 +3170,8 @@ class SelfAttnFn(torch.autograd.Function):
         dqkv = torch.empty((M, d3), device=dev, dtype=torch.bfloat16)
         mp = _mask_params(B, H, T, T, R, clamp, scale, klens, *mask_args, p_bf16=1, tk_pitch=Tkp, r_pitch=Rp)
         if fused:
-            dq_acc, dQP = flash_attn_bwd_raw(qkv, d, QP, dO, cv32, LSE, keepbits, mp, dqkv)
+            # the kernel leaves the finished query gradient (dS k + dQP . pos) as bf16 in dqkv[:, :d]
+            dq_acc, dQP = flash_attn_bwd_raw(qkv, d, QP, dO, cv32, LSE, keepbits, mp, dqkv, pos16=pos16, dq_in_dqkv=True)
         else:
             dP = torch.empty((B, H, T, T), device=dev, dtype=torch.float32)       # dP = dO v^T
             gemm_raw(T, T, dk, dO, d, 1, qkv, 1, d3, dP, T, batch=(B, H), a_b=(T * d, dk),
@@ -3186,10 +3187,11 @@ class SelfAttnFn(torch.autograd.Function):
         dq_pos = dw_pos = None
         if has_pos:
             dQP16 = to_bf16(dQP.view(M * H, Rp)).view(M, H * Rp)
-            # dq (position term) = dQP pos, accumulated on top of the fused kernel's dq when present
-            dq_pos = dq_acc if dq_acc is not None else torch.empty((M, d), device=dev, dtype=torch.float32)
-            gemm_raw(M, dk, Rp, dQP16, H * Rp, 1, pos16, d, 1, dq_pos, d, batch=(H, 1), a_b=(Rp, 0),
-                     b_b=(dk, 0), c_b=(dk, 0), res=dq_acc)
+            if not fused:
+                # dq (position term) = dQP pos (the fused kernel adds it itself)
+                dq_pos = torch.empty((M, d), device=dev, dtype=torch.float32)
+                gemm_raw(M, dk, Rp, dQP16, H * Rp, 1, pos16, d, 1, dq_pos, d, batch=(H, 1), a_b=(Rp, 0),
+                         b_b=(dk, 0), c_b=(dk, 0))
             if ctx.needs_input_grad[10]:
                 dpos = zeros_small((Rp, d), dev)                                      # dQP^T q
                 gemm_raw(Rp, dk, M, dQP16, 1, H * Rp, qkv, d3, 1, dpos, d, batch=(H, 1), a_b=(Rp, 0),
@@ -3198,10 +3200,7 @@ class SelfAttnFn(torch.autograd.Function):
                 dw_pos = torch.empty((d, d), device=dev, dtype=torch.float32)        # dpos^T pe
                 gemm_raw(d, d, Rp, dpos16, 1, d, pe16, d, 1, dw_pos, d)
                 dw_pos = dw_pos.view(w_pos.shape)
-        if fused:
-            dq_fin = dq_pos if has_pos else dq_acc
-            _check(_lib.lib().nsp_cast_bf16(_p(dq_fin), _p(dqkv), M, d, d, d3, _stream()), 'nsp_cast_bf16')
-        else:
+        if not fused:
             if has_pos:
                 # dq = dS k accumulated in fp32 on top of the position-term gradient, then cast
                 gemm_raw(T, dk, T, dS16, Tkp, 1, qkv, d3, 1, dq_pos, d, batch=(B, H),
@@ -3245,14 +3244,17 @@ def flash_attn_fwd_raw(qkv16, d, QP, mp, want_o32=True):
     return O, O32, LSE, keep
 
 
-def flash_attn_bwd_raw(qkv16, d, QP, dO16, O32, LSE, keep, mp, dqkv16):
-    """-> (dq32 [M,d] fp32, dQP or None); dK / dV are written into dqkv16 column blocks d / 2d."""
+def flash_attn_bwd_raw(qkv16, d, QP, dO16, O32, LSE, keep, mp, dqkv16, pos16=None, dq_in_dqkv=False):
+    """-> (dq32 [M,d] fp32 or None, dQP or None); dK / dV are written into dqkv16 column blocks d / 2d.
+    dq_in_dqkv: the query gradient is written FINISHED (incl. the position term's share dQP . pos16 when pos16 is given)
+    as bf16 into column block 0 of dqkv16 and no fp32 dq exists; otherwise dq32 = dS k only (pos16 must be None)."""
     M = qkv16.shape[0]
     dev = qkv16.device
-    dq32 = torch.empty((M, d), device=dev, dtype=torch.float32)
+    dq32 = None if dq_in_dqkv else torch.empty((M, d), device=dev, dtype=torch.float32)
     dQP = torch.empty_like(QP) if QP is not None else None
     D = torch.empty((mp.B, mp.H, mp.Tq), device=dev, dtype=torch.float32)
     with _kev_class('flash_bwd', 10.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop'):
         _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O32), _p(LSE), _p(keep), _p(D), _p(dqkv16),
-                                             _p(dq32), _p(dQP), ctypes.byref(mp), _stream()), 'nsp_flash_attn_bwd')
+                                             _p(dq32), _p(dQP), _p(pos16 if dq_in_dqkv else None), ctypes.byref(mp),
+                                             _stream()), 'nsp_flash_attn_bwd')
     return dq32, dQP

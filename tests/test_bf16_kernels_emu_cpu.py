@@ -116,6 +116,11 @@ def test_flash_attention_dropout_mask(flash):
     flash.test_flash_attention_dropout_mask_is_consistent_between_forward_and_backward()
 
 
+@pytest.mark.parametrize('T,with_pos,pdrop', [(130, True, 0.1), (96, False, 0.0)])
+def test_flash_backward_finishes_the_query_gradient(flash, T, with_pos, pdrop):
+    flash.test_flash_backward_finishes_the_query_gradient(T, with_pos, pdrop)
+
+
 @pytest.mark.parametrize('mode', ['bf16', 'bf16maps'])
 @pytest.mark.parametrize('Ci', [1, 32])
 def test_conv3x3_bf16(convloss, mode, Ci, monkeypatch):

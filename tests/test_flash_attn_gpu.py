@@ -208,3 +208,43 @@ def test_flash_attention_backward_keeps_softmax_shift_invariance(T, H, B):
     c['x^T dk'] = cos(x.t() @ dqkv[:, d:2 * d].float(), x.t() @ g[:, d:2 * d])
     print('[flash shift-invariance T=%d H=%d] cosines %s' % (T, H, {k: round(v, 5) for k, v in c.items()}))
     assert min(c.values()) > 0.999, c
+
+
+@pytest.mark.parametrize('T,with_pos,pdrop', [(130, True, 0.0), (200, True, 0.1), (96, False, 0.0)])
+def test_flash_backward_finishes_the_query_gradient(T, with_pos, pdrop):
+    """Round 6: with dq32 == NULL the dQ kernel writes the FINISHED query gradient -- dS k plus the position term's share
+    dQP . pos (relative_multihead_attention.py:188-193) -- as bf16 into column block 0 of dqkv.  It must equal what the
+    fp32 hand-over path gives (dq32 from the same kernel + the position product in torch), rounded once."""
+    from neural_sp_amd import ops
+    torch.manual_seed(T + 7)
+    dev = _dev()
+    B, H, dk, clamp = 2, 2, 64, 10
+    d = H * dk
+    R, Rp = clamp + 1, 16
+    qkv = (torch.randn(B * T, 3 * d, device=dev) * 0.5).bfloat16()
+    QP = None
+    pos16 = None
+    if with_pos:
+        QP = torch.zeros(B, T, H, Rp, device=dev)
+        QP[..., :R] = torch.randn(B, T, H, R, device=dev)
+        pos16 = torch.zeros(Rp, d, device=dev)
+        pos16[:R] = torch.randn(R, d, device=dev) * 0.3
+        pos16 = pos16.bfloat16()
+    klens = torch.tensor([T, max(1, T - 29)], device=dev, dtype=torch.int32)
+    mp = ops._mask_params(B, H, T, T, R if with_pos else 0, clamp if with_pos else -1, 1.0 / math.sqrt(dk), klens, False, 0, 0, 0,
+                          dropout_p=pdrop, seed=11, offset=3 << 40, r_pitch=Rp if with_pos else 0)
+    O, O32, LSE, keep = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
+    dO = torch.randn(B * T, d, device=dev).bfloat16()
+    dqkv_a = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+    dq32, dQP = ops.flash_attn_bwd_raw(qkv, d, QP, dO, O32, LSE, keep, mp, dqkv_a)
+    want = dq32.clone()
+    if with_pos:
+        want += torch.einsum('mhr,rhc->mhc', dQP.view(B * T, H, Rp)[..., :R], pos16[:R].float().view(R, H, dk)).reshape(B * T, d)
+    dqkv_b = torch.zeros(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+    none32, dQP_b = ops.flash_attn_bwd_raw(qkv, d, QP, dO, O32, LSE, keep, mp, dqkv_b, pos16=pos16, dq_in_dqkv=True)
+    assert none32 is None
+    got = dqkv_b[:, :d].float()
+    assert _rel(got, want) < 6e-3, _rel(got, want)                 # one bf16 rounding of the fp32 result
+    assert torch.equal(dqkv_a[:, d:], dqkv_b[:, d:])               # dK / dV untouched by the output form
+    if with_pos:
+        assert torch.equal(dQP, dQP_b)
