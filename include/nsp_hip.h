@@ -332,6 +332,17 @@ int nsp_dwconv1d_wgrad(const float* x, const float* dy, float* dwt, float* dbias
  * nsp_splitk_reduce. */
 int nsp_dwconv1d_wgrad_slabs(const float* x, const float* dy, float* part, int tsplit,
                              int B, int T, int C, int k, int pad, void* stream);
+/* GLU folded into the depthwise conv (conformer_convolution.py:110-113) for the bf16 image h2 [B*T, 2C] that the first
+ * pointwise conv's GEMM wrote: y = dwconv(glu(h2)); backward writes d h2 as bf16 (operand of the pointwise conv's gradient
+ * GEMMs) and its column sums as slabs [nsp_dwconv1d_glu_bwd_slabs(B,T,C), 2C] fp32 (every row written); the weight gradient
+ * as nsp_dwconv1d_wgrad_slabs with x = glu(h2).  k in {7, 15}, pad = (k-1)/2, C/4 a divisor of 256 (else NSP_EUNSUPPORTED). */
+int nsp_dwconv1d_glu_bwd_slabs(int B, int T, int C);
+int nsp_dwconv1d_glu_fwd(const void* h2, const float* wt, const float* bias, float* y, int B, int T, int C,
+                         int k, int pad, void* stream);
+int nsp_dwconv1d_glu_bwd(const void* h2, const float* dy, const float* wt, void* g16, float* colsum_slabs,
+                         int B, int T, int C, int k, int pad, void* stream);
+int nsp_dwconv1d_glu_wgrad_slabs(const void* h2, const float* dy, float* part, int tsplit,
+                                 int B, int T, int C, int k, int pad, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * VGG-style Conv2d frontend on channels-last [B,T,F,C] (conv.py:289-396).  *

@@ -82,6 +82,137 @@ __global__ __launch_bounds__(256) void dwconv_fwd_sw_kernel(const float* __restr
   }
 }
 
+// ---- Round 6: GLU folded into the depthwise conv (conformer_convolution.py:110-113: glu -> depthwise_conv).  In
+// throughput mode the first pointwise conv leaves its [rows, 2C] output as a bf16 image (nsp_glu_fwd_b16's input).  The
+// GLU used to turn it into a fp32 [rows, C] tensor that the depthwise conv read back (and kept for its weight gradient),
+// and backward moved the fp32 gradient of that tensor from the conv's data-gradient pass to the GLU's backward pass: 16
+// bytes per element of fp32 hand-overs and two launches per direction.  Here the conv kernels apply the GLU to the bf16
+// image as they load it (same arithmetic: (float)a * sigmoid((float)b)), and the data-gradient kernel finishes with the
+// GLU's backward: it writes d(image) as the bf16 operand of the pointwise conv's gradient GEMMs and the column sums of it
+// (that conv's bias gradient) as slabs, exactly what nsp_glu_bwd_b16 produced.
+__device__ __forceinline__ float4 glu_load4(const __bf16* __restrict__ row, int C, int tc) {
+  const bf16x4 a = reinterpret_cast<const bf16x4*>(row)[tc];
+  const bf16x4 b = reinterpret_cast<const bf16x4*>(row + C)[tc];
+  return make_float4((float)a[0] * nsp_sigmoid((float)b[0]), (float)a[1] * nsp_sigmoid((float)b[1]),
+                     (float)a[2] * nsp_sigmoid((float)b[2]), (float)a[3] * nsp_sigmoid((float)b[3]));
+}
+
+// forward: y = bias + sum_j w[j] glu(h2)[t + j - PAD]; thread = 4 channels x TT frames (the sliding window of
+// dwconv_fwd_sw_kernel, its rows made from the bf16 image)
+template <int K, int TT>
+__global__ __launch_bounds__(256) void dwconv_glu_fwd_sw_kernel(const __bf16* __restrict__ h2, const float* __restrict__ wt,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                int B, int T, int C) {
+  constexpr int PAD = (K - 1) / 2, W = TT + K - 1;
+  const int C4 = C >> 2;
+  const int truns = (T + TT - 1) / TT;
+  const long long total = (long long)B * truns * C4;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  const int tr = (int)((idx / C4) % truns);
+  const int b = (int)(idx / ((long long)C4 * truns));
+  const int t0 = tr * TT;
+  const __bf16* hb = h2 + (long long)b * T * 2 * C;
+  float4 win[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    const int ts = t0 + i - PAD;
+    // (clamped address + select: the loads stay unconditional)
+    const float4 v = glu_load4(hb + (long long)min(max(ts, 0), T - 1) * 2 * C, C, c4);
+    const bool ok = ts >= 0 && ts < T;
+    win[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  }
+  float4 w[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = reinterpret_cast<const float4*>(wt + (long long)j * C)[c4];
+  const float4 bv = bias ? reinterpret_cast<const float4*>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* yb = reinterpret_cast<float4*>(y + (long long)b * T * C) + c4;
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    if (t0 + i >= T) break;
+    float4 acc = bv;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      acc.x = fmaf(w[j].x, win[i + j].x, acc.x); acc.y = fmaf(w[j].y, win[i + j].y, acc.y);
+      acc.z = fmaf(w[j].z, win[i + j].z, acc.z); acc.w = fmaf(w[j].w, win[i + j].w, acc.w);
+    }
+    yb[(long long)(t0 + i) * C4] = acc;
+  }
+}
+
+// backward (data): d glu = sum_j w[K-1-j] dy[t + j - PAD] (the forward kernel on dy with flipped taps), then the GLU's
+// backward on the bf16 image: g[., c] = d glu * sig(b), g[., C + c] = d glu * a * sig(b) (1 - sig(b)), written as bf16,
+// and their column sums.  Block = (C / 4 channel quads) x (256 / (C / 4) runs of TT frames), `rloop` runs per thread;
+// one slab row [2C] per block, every row written.  grid: (ceil(truns / (nrl * rloop)), B).
+template <int K, int TT>
+__global__ __launch_bounds__(256) void dwconv_glu_bwd_sw_kernel(const __bf16* __restrict__ h2, const float* __restrict__ dy,
+                                                                const float* __restrict__ wt, __bf16* __restrict__ g16,
+                                                                float* __restrict__ colsum, int B, int T, int C, int rloop) {
+  constexpr int PAD = (K - 1) / 2, W = TT + K - 1;
+  __shared__ float red[256][8];
+  const int C4 = C >> 2;
+  const int tc = threadIdx.x % C4, rl = threadIdx.x / C4, nrl = 256 / C4;
+  const int truns = (T + TT - 1) / TT;
+  const int b = blockIdx.y;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float4 w[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = reinterpret_cast<const float4*>(wt + (long long)(K - 1 - j) * C)[tc];
+  const float4* db4 = reinterpret_cast<const float4*>(dy + (long long)b * T * C) + tc;
+  const __bf16* hb = h2 + (long long)b * T * 2 * C;
+  __bf16* gb = g16 + (long long)b * T * 2 * C;
+  for (int it = 0; it < rloop; ++it) {
+    const int tr = (blockIdx.x * rloop + it) * nrl + rl;
+    if (tr >= truns) break;
+    const int t0 = tr * TT;
+    float4 win[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      const int ts = t0 + i - PAD;
+      const float4 v = db4[(long long)min(max(ts, 0), T - 1) * C4];
+      const bool ok = ts >= 0 && ts < T;
+      win[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      if (t0 + i >= T) break;
+      float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        dg.x = fmaf(w[j].x, win[i + j].x, dg.x); dg.y = fmaf(w[j].y, win[i + j].y, dg.y);
+        dg.z = fmaf(w[j].z, win[i + j].z, dg.z); dg.w = fmaf(w[j].w, win[i + j].w, dg.w);
+      }
+      const long long rb = (long long)(t0 + i) * 2 * C;
+      const bf16x4 a = reinterpret_cast<const bf16x4*>(hb + rb)[tc];
+      const bf16x4 bb = reinterpret_cast<const bf16x4*>(hb + rb + C)[tc];
+      const float g[4] = {dg.x, dg.y, dg.z, dg.w};
+      bf16x4 da, dbv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sg = nsp_sigmoid((float)bb[e]);
+        const float va = g[e] * sg, vb = g[e] * (float)a[e] * sg * (1.f - sg);
+        da[e] = (__bf16)va; dbv[e] = (__bf16)vb;
+        acc[e] += va; acc[4 + e] += vb;
+      }
+      reinterpret_cast<bf16x4*>(gb + rb)[tc] = da;
+      reinterpret_cast<bf16x4*>(gb + rb + C)[tc] = dbv;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  if (rl == 0) {
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nrl; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum[e] += red[j * C4 + tc][e];
+    float* cs = colsum + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+    *reinterpret_cast<float4*>(cs + tc * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    *reinterpret_cast<float4*>(cs + C + tc * 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
+  }
+}
+
 // dwt[j][c] += sum_{b,t} dy[b,t,c] * x[b, t + j - pad, c] ; dbias[c] += sum dy
 // grid: (ceil(C4/64), nchunks); block 256 = 4 waves striding over the rows of a chunk
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x,
@@ -209,6 +340,7 @@ inline int ew_grid(long long n) {
 // rows are staged once; every (row, tap) product then reads LDS only.  (The register version
 // issues 1 + k global loads per row and is TA-bound: 80 us for 52 MB.)
 constexpr int DW_RC = 24;
+template <bool GLU>      // GLU: x is the bf16 [rows, 2C] image of the first pointwise conv and the conv's input is glu(x) (round 6)
 __global__ __launch_bounds__(256) void dwconv_wgrad_lds_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ dy,
                                                                float* __restrict__ part, int B, int T, int C,
@@ -224,6 +356,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_lds_kernel(const float* __re
   const int ts = blockIdx.y * rows_per_wg;
   const int te = min(T, ts + rows_per_wg);
   const float4* x4 = reinterpret_cast<const float4*>(x) + b * T * C4;
+  const __bf16* h2 = reinterpret_cast<const __bf16*>(x) + b * T * 2 * C;
   const float4* d4 = reinterpret_cast<const float4*>(dy) + b * T * C4;
   float4 acc[4];
 #pragma unroll
@@ -242,7 +375,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_lds_kernel(const float* __re
 #pragma unroll
       for (int q = 0; q < NX; ++q) {
         const int tt = min(max(tf - pad + jg + 4 * q, 0), T - 1);
-        px[q] = x4[(long long)tt * C4 + c4c];
+        if constexpr (GLU) px[q] = glu_load4(h2 + (long long)tt * 2 * C, C, c4c);
+        else px[q] = x4[(long long)tt * C4 + c4c];
       }
 #pragma unroll
       for (int q = 0; q < ND; ++q) pd[q] = d4[(long long)min(tf + jg + 4 * q, T - 1) * C4 + c4c];
@@ -299,8 +433,61 @@ extern "C" int nsp_dwconv1d_wgrad_slabs(const float* x, const float* dy, float* 
   if (C % 4 || k < 1 || k > 15 || tsplit < 1) return NSP_EUNSUPPORTED;
   const int rows_per_wg = nsp_cdiv(T, tsplit);
   const size_t shmem = sizeof(float4) * 64 * (size_t)(2 * DW_RC + k - 1);
-  hipLaunchKernelGGL(dwconv_wgrad_lds_kernel, dim3(nsp_cdiv(C / 4, 64), tsplit, B), dim3(256), shmem,
+  hipLaunchKernelGGL(dwconv_wgrad_lds_kernel<false>, dim3(nsp_cdiv(C / 4, 64), tsplit, B), dim3(256), shmem,
                      (hipStream_t)stream, x, dy, part, B, T, C, k, pad, rows_per_wg);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+
+// ---- GLU folded into the depthwise conv (bf16 image h2 [B*T, 2C] of the first pointwise conv): see the kernels
+static bool dwglu_ok(const void* h2, int C, int k, int pad) {
+  return C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 && (k == 15 || k == 7) && pad == (k - 1) / 2 &&
+         (reinterpret_cast<uintptr_t>(h2) & 7) == 0;
+}
+static int dwglu_rloop(int B, int T, int C) {
+  const int nrl = 256 / (C / 4), truns = (T + 7) / 8;
+  int r = nsp_cdiv((long long)B * truns, (long long)nrl * 3072);
+  return r < 1 ? 1 : (r > 8 ? 8 : r);
+}
+extern "C" int nsp_dwconv1d_glu_bwd_slabs(int B, int T, int C) {
+  if (C % 4 || C / 4 > 256 || 256 % (C / 4)) return 0;
+  const int nrl = 256 / (C / 4), truns = (T + 7) / 8;
+  return B * nsp_cdiv(truns, nrl * dwglu_rloop(B, T, C));
+}
+extern "C" int nsp_dwconv1d_glu_fwd(const void* h2, const float* wt, const float* bias, float* y, int B, int T, int C,
+                                    int k, int pad, void* stream) {
+  if (!dwglu_ok(h2, C, k, pad)) return NSP_EUNSUPPORTED;
+  const long long threads = (long long)B * ((T + 7) / 8) * (C / 4);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  const __bf16* h = reinterpret_cast<const __bf16*>(h2);
+  if (k == 15)
+    hipLaunchKernelGGL((dwconv_glu_fwd_sw_kernel<15, 8>), grid, dim3(256), 0, (hipStream_t)stream, h, wt, bias, y, B, T, C);
+  else
+    hipLaunchKernelGGL((dwconv_glu_fwd_sw_kernel<7, 8>), grid, dim3(256), 0, (hipStream_t)stream, h, wt, bias, y, B, T, C);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+extern "C" int nsp_dwconv1d_glu_bwd(const void* h2, const float* dy, const float* wt, void* g16, float* colsum_slabs,
+                                    int B, int T, int C, int k, int pad, void* stream) {
+  if (!dwglu_ok(h2, C, k, pad) || !colsum_slabs || (reinterpret_cast<uintptr_t>(g16) & 7)) return NSP_EUNSUPPORTED;
+  const int nrl = 256 / (C / 4), truns = (T + 7) / 8, rloop = dwglu_rloop(B, T, C);
+  const dim3 grid(nsp_cdiv(truns, nrl * rloop), B);
+  const __bf16* h = reinterpret_cast<const __bf16*>(h2);
+  __bf16* g = reinterpret_cast<__bf16*>(g16);
+  if (k == 15)
+    hipLaunchKernelGGL((dwconv_glu_bwd_sw_kernel<15, 8>), grid, dim3(256), 0, (hipStream_t)stream, h, dy, wt, g, colsum_slabs, B, T, C, rloop);
+  else
+    hipLaunchKernelGGL((dwconv_glu_bwd_sw_kernel<7, 8>), grid, dim3(256), 0, (hipStream_t)stream, h, dy, wt, g, colsum_slabs, B, T, C, rloop);
+  NSP_LAUNCH_CHECK();
+  return NSP_OK;
+}
+extern "C" int nsp_dwconv1d_glu_wgrad_slabs(const void* h2, const float* dy, float* part, int tsplit, int B,
+                                            int T, int C, int k, int pad, void* stream) {
+  if (C % 4 || k < 1 || k > 15 || tsplit < 1 || (reinterpret_cast<uintptr_t>(h2) & 7)) return NSP_EUNSUPPORTED;
+  const int rows_per_wg = nsp_cdiv(T, tsplit);
+  const size_t shmem = sizeof(float4) * 64 * (size_t)(2 * DW_RC + k - 1);
+  hipLaunchKernelGGL(dwconv_wgrad_lds_kernel<true>, dim3(nsp_cdiv(C / 4, 64), tsplit, B), dim3(256), shmem,
+                     (hipStream_t)stream, reinterpret_cast<const float*>(h2), dy, part, B, T, C, k, pad, rows_per_wg);
   NSP_LAUNCH_CHECK();
   return NSP_OK;
 }

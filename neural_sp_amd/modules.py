@@ -353,8 +353,8 @@ class ConformerConvBlock(nn.Module):
 
     def forward(self, xs, residual=None, out_dropout=0.0):
         C = xs.shape[-1]
-        h = ops.linear_glu(xs, self.pointwise_conv1.weight, self.pointwise_conv1.bias)  # [2C,C,1] == [2C,C]
-        h = ops.depthwise_conv1d(h, self.depthwise_conv.weight, self.depthwise_conv.bias, self.causal)
+        h = ops.linear_glu_dwconv(xs, self.pointwise_conv1.weight, self.pointwise_conv1.bias,   # [2C,C,1] == [2C,C]
+                                  self.depthwise_conv.weight, self.depthwise_conv.bias, self.causal)
         if isinstance(self.norm, nn.LayerNorm):
             h = ops.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act='swish', gemm_only=True)
         elif isinstance(self.norm, nn.BatchNorm1d):

@@ -1150,6 +1150,85 @@ def depthwise_conv1d(x, weight, bias, causal=False):
     return DepthwiseConv1dFn.apply(x, weight, bias, causal)
 
 
+class LinearGLUDwconvFn(torch.autograd.Function):
+    """depthwise_conv(glu(x W^T + b)) of the Conformer conv module (conformer_convolution.py:107-113) as ONE autograd
+    node in bf16 mode (round 6).  The pointwise conv's GEMM leaves its [M, 2C] output as a bf16 image; the depthwise
+    kernels apply the GLU to it as they load it, and the conv's data-gradient kernel finishes with the GLU's backward
+    (bf16 operand of the pointwise conv's gradient GEMMs + its column sums = that conv's bias gradient).  No fp32 GLU
+    output and no fp32 gradient of it exist: 16 bytes per element of hand-overs and two launches per direction fewer
+    than LinearGLUFn + DepthwiseConv1dFn, same arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dw_weight, dw_bias):
+        K = x.shape[-1]
+        N = weight.shape[0]
+        C = N // 2
+        B, T = x.shape[0], x.shape[1]
+        sh = getattr(x, '_nsp16', None)
+        if sh is not None and sh.shape[-1] == K:
+            xa = sh.reshape(-1, K)
+        else:
+            xa = to_bf16((x if x.dtype == torch.bfloat16 else _f32c(x)).reshape(-1, K))
+        h2 = linear_fwd(xa, weight, bias, out_bf16=True)                        # bf16 [M, 2C]
+        k = dw_weight.shape[-1]
+        wt = dw_weight.reshape(C, k).t().contiguous()                           # tap-major [k, C]
+        pad = (k - 1) // 2
+        y = torch.empty((B, T, C), device=x.device, dtype=torch.float32)
+        _check(_lib.lib().nsp_dwconv1d_glu_fwd(_p(h2), _p(wt), _p(dw_bias), _p(y), B, T, C, k, pad, _stream()),
+               'nsp_dwconv1d_glu_fwd')
+        ctx.save_for_backward(xa, weight, h2, wt)
+        ctx.mode = get_compute_mode()
+        ctx.has_bias, ctx.has_dw_bias = bias is not None, dw_bias is not None
+        ctx.dims = (B, T, C, k, pad)
+        ctx.xshape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, weight, h2, wt = ctx.saved_tensors
+        B, T, C, k, pad = ctx.dims
+        M, N = B * T, 2 * C
+        dev = dy.device
+        dy = _f32c(dy)
+        L = _lib.lib()
+        dx = dw = db = ddw = ddb = None
+        with compute_mode(ctx.mode):
+            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+                tsplit = max(1, min(16, T // 48))
+                part = torch.empty((B * tsplit, (k + 1) * C), device=dev, dtype=torch.float32)
+                _check(L.nsp_dwconv1d_glu_wgrad_slabs(_p(h2), _p(dy), _p(part), tsplit, B, T, C, k, pad, _stream()),
+                       'nsp_dwconv1d_glu_wgrad_slabs')
+                buf = torch.empty((k + 1, C), device=dev, dtype=torch.float32)
+                _check(L.nsp_splitk_reduce(_p(part), _p(buf), B * tsplit, (k + 1) * C, _stream()), 'nsp_splitk_reduce')
+                ddw = buf[:k].t().contiguous().view(C, 1, k)
+                ddb = buf[k] if ctx.has_dw_bias else None
+            if any(ctx.needs_input_grad[:3]):
+                g = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+                slabs = torch.empty((L.nsp_dwconv1d_glu_bwd_slabs(B, T, C), N), device=dev, dtype=torch.float32)
+                _check(L.nsp_dwconv1d_glu_bwd(_p(h2), _p(dy), _p(wt), _p(g), _p(slabs), B, T, C, k, pad, _stream()),
+                       'nsp_dwconv1d_glu_bwd')
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    db = colsum(slabs)
+                if ctx.needs_input_grad[0]:
+                    dx = linear_dgrad(g, weight).reshape(ctx.xshape)
+                if ctx.needs_input_grad[1]:
+                    dw = linear_wgrad(g, xa).view(weight.shape)
+        return dx, dw, db, ddw, ddb
+
+
+def linear_glu_dwconv(x, weight, bias, dw_weight, dw_bias, causal=False):
+    """depthwise_conv1d(glu(linear(x))): fused node in throughput mode where the kernels apply (non-causal, k in {7, 15},
+    the LinearGLUFn shapes); the two-node form otherwise (NSP_GLU_DWCONV=0 forces it)."""
+    N, K = weight.shape[0], x.shape[-1]
+    C = N // 2
+    k = dw_weight.shape[-1]
+    if (bf16_mode() and x.dim() == 3 and not causal and k in (7, 15) and K % 8 == 0 and C % 8 == 0 and C // 4 <= 256
+            and 256 % (C // 4) == 0 and os.environ.get('NSP_LINEAR_GLU', '1') != '0'
+            and os.environ.get('NSP_GLU_DWCONV', '1') != '0'):
+        return LinearGLUDwconvFn.apply(x, weight, bias, dw_weight, dw_bias)
+    return depthwise_conv1d(linear_glu(x, weight, bias), dw_weight, dw_bias, causal)
+
+
 class MaxPool1dFn(torch.autograd.Function):
     """MaxPool1d(kernel=stride=factor, ceil_mode=True) over time of [B,T,C]."""
 

@@ -107,6 +107,11 @@ def test_linear_glu_on_the_bf16_image(basic, M, C, monkeypatch):
     basic.test_linear_glu_on_the_bf16_image(M, C, monkeypatch)
 
 
+@pytest.mark.parametrize('B,T,C,k', [(3, 70, 64, 15), (2, 37, 256, 7)])
+def test_linear_glu_depthwise_conv_as_one_node(basic, B, T, C, k, monkeypatch):
+    basic.test_linear_glu_depthwise_conv_as_one_node(B, T, C, k, monkeypatch)
+
+
 @pytest.mark.parametrize('T,with_pos,causal,nc', [(130, True, False, 0), (64, False, False, 0), (96, True, False, 16)])
 def test_flash_attention_matches_reference(flash, T, with_pos, causal, nc):
     flash.test_flash_attention_matches_reference(T, with_pos, causal, nc)

@@ -457,6 +457,48 @@ def test_linear_glu_on_the_bf16_image(M, C, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,T,C,k', [(3, 70, 64, 15), (2, 37, 256, 7), (2, 130, 512, 15)])
+def test_linear_glu_depthwise_conv_as_one_node(B, T, C, k, monkeypatch):
+    """Round 6: depthwise_conv(glu(pointwise_conv(x))) of the Conformer conv module (conformer_convolution.py:107-113) as
+    one autograd node (LinearGLUDwconvFn: GLU applied by the depthwise kernels to the bf16 image, the GLU's backward inside
+    the conv's data-gradient kernel) against the two-node form it replaces (same arithmetic: the forward is bit-equal) and
+    against torch on the bf16-rounded operands."""
+    from neural_sp_amd import ops
+    torch.manual_seed(B * T + C)
+    dev = _dev()
+    x = (torch.randn(B, T, C, device=dev) * 0.7).requires_grad_()
+    w = torch.nn.Parameter(torch.randn(2 * C, C, 1, device=dev) / C ** 0.5)
+    b = torch.nn.Parameter(torch.randn(2 * C, device=dev) * 0.3)
+    wd = torch.nn.Parameter(torch.randn(C, 1, k, device=dev) / k ** 0.5)
+    bd = torch.nn.Parameter(torch.randn(C, device=dev) * 0.2)
+    dy = torch.randn(B, T, C, device=dev)
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('NSP_GLU_DWCONV', mode)
+        with ops.compute_mode('bf16'):
+            y = ops.linear_glu_dwconv(x, w, b, wd, bd)
+            assert y.grad_fn.__class__.__name__.startswith('LinearGLUDwconvFn' if mode == '1' else 'DepthwiseConv1dFn')
+            outs[mode] = (y.detach(),) + torch.autograd.grad(y, (x, w, b, wd, bd), dy)
+    assert torch.equal(outs['1'][0], outs['0'][0])
+    names = ('y', 'dx', 'dw', 'db', 'dw_dw', 'db_dw')
+    for a, u, name in zip(outs['1'], outs['0'], names):
+        assert a.shape == u.shape, name
+        assert _rel(a, u) < 3e-3, (name, _rel(a, u))
+    xr = x.detach().bfloat16().float().requires_grad_()
+    wr = w.detach().bfloat16().float().requires_grad_()
+    br = b.detach().clone().requires_grad_()
+    wdr = wd.detach().clone().requires_grad_()
+    bdr = bd.detach().clone().requires_grad_()
+    hh = xr @ wr[:, :, 0].t() + br
+    h = hh + (hh.bfloat16().float() - hh).detach()          # the GEMM's bf16 image, straight-through
+    gl = h[..., :C] * torch.sigmoid(h[..., C:])
+    yr = torch.nn.functional.conv1d(gl.transpose(1, 2), wdr, bdr, padding=(k - 1) // 2, groups=C).transpose(1, 2)
+    ref = (yr.detach(),) + torch.autograd.grad(yr, (xr, wr, br, wdr, bdr), dy)
+    for a, r, name in zip(outs['1'], ref, names):
+        assert _rel(a, r) < 2e-2, (name, _rel(a, r))
+
+
+@pytest.mark.gpu
 def test_phase_interleaved_gemm_with_an_operand_beyond_4_gb(monkeypatch):
     """The RNN-T joint's data gradient reads a [3.6 M, 1024] bf16 operand (7.4 GB): the 8-phase kernel addresses A with a
     scalar base per tile + 32-bit lane offsets.  2.2 M x 1024 (4.5 GB) x a [512, 1024] weight with the tanh' epilogue,
