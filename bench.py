@@ -54,6 +54,11 @@ def parse():
     p.add_argument('--cpu-batch', type=int, default=1, help='utterances in the CPU-baseline sample')
     p.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL); 'gloo' only for single-GPU smoke tests of the N>1 code path")
     p.add_argument('--same-device', action='store_true', help='testing only: every rank uses cuda:0')
+    p.add_argument('--layers', type=int, default=12, help='encoder blocks (12 = the workload the metric is quoted on)')
+    p.add_argument('--emulate', action='store_true',
+                   help='testing only (CPU tier, tests/test_bench_emu_cpu.py): CPU tensors and the kernels of libnsp_hip.so on '
+                        'the host emulator of tests/hipemu, gloo between the ranks -- exercises this file\'s launcher, rank '
+                        'binding, step loop, reductions and JSON line without a GPU; its numbers mean nothing and the line says so')
     return p.parse_args()
 
 
@@ -170,7 +175,13 @@ def _spawn_ranks(a):
 _PH = {'on': False}
 
 
+_EMU = [False]
+
+
 def _ev():
+    if _EMU[0]:
+        from neural_sp_amd.parallel import HostEvent
+        return HostEvent().record()
     e = torch.cuda.Event(enable_timing=True)
     e.record()
     return e
@@ -203,10 +214,25 @@ def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(_spawn_ranks(a))
-    assert torch.cuda.is_available(), 'bench.py measures the HIP path; no GPU is visible'
-    world, rank, local_rank, dev_index = rank_binding(a.gpus, a.same_device, os.environ, torch.cuda.device_count())
+    if a.emulate:
+        if a.dist_backend != 'gloo' and a.gpus > 1:
+            raise SystemExit('bench.py: --emulate runs CPU ranks: use --dist-backend gloo')
+        a.no_kernel_events = a.no_b16 = a.no_cpu_baseline = True
+        _EMU[0] = True
+        torch.set_num_threads(2)
+        from tests.cpu_ops_shim import host_logic_on_cpu
+        with host_logic_on_cpu(real_kernels=True, real_conv=False, mode=a.mode):
+            return _main(a)
+    return _main(a)
+
+
+def _main(a):
+    emu = a.emulate
+    assert emu or torch.cuda.is_available(), 'bench.py measures the HIP path; no GPU is visible'
+    world, rank, local_rank, dev_index = rank_binding(a.gpus, a.same_device or emu, os.environ,
+                                                      1 if emu else torch.cuda.device_count())
     distributed = world > 1
-    if a.same_device:
+    if a.same_device and not emu:
         local_rank = dev_index
         # ranks sharing one device cannot guarantee co-residency of each other's grid-barrier kernels (two half-resident
         # persistent grids wait on each other until the barrier times out): rank 0 keeps the persistent LSTM -- so that
@@ -214,8 +240,11 @@ def main():
         # take per-stage launches, which always terminate
         if rank != 0:
             os.environ['NSP_LSTM_PERSISTENT'] = '0'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if emu:
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -231,13 +260,16 @@ def main():
     from neural_sp_amd import parallel
 
     ops.set_compute_mode(a.mode)
-    margs = conformer_rnnt_args(a.size, n_layers=12, vocab=1000, dropout=a.dropout, ctc_weight=0.3)
+    margs = conformer_rnnt_args(a.size, n_layers=a.layers, vocab=1000, dropout=a.dropout, ctc_weight=0.3)
     torch.manual_seed(1)
     model = Speech2Text(margs).to(dev)
     n_params = model.total_parameters
-    train_model = parallel.wrap_ddp(model, local_rank) if distributed else model
+    if distributed:
+        train_model = parallel.wrap_ddp(model, None, cpu_hook=True) if emu else parallel.wrap_ddp(model, local_rank)
+    else:
+        train_model = model
     params = list(model.parameters())
-    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, fused=True)
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, fused=not emu)
     # distinct synthetic batches (different T_max / U_max); at most as many as warm-up steps so
     # that every shape has been through the caching allocator before the timed region
     n_distinct = max(1, min(4, a.warmup))
@@ -300,7 +332,8 @@ def main():
     def sync():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not emu:
+            torch.cuda.synchronize()
 
     for i in range(a.warmup):
         step(i)
@@ -522,9 +555,9 @@ def main():
             'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if a.mode == 'bf16' else 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'Conformer-%s 12L conv-subsample x8 + CTC(0.3)+RNN-T(2x1024 LSTM, joint 512, V=1000), '
+            'config': {'workload': 'Conformer-%s %dL conv-subsample x8 + CTC(0.3)+RNN-T(2x1024 LSTM, joint 512, V=1000), '
                                    'T~U[%d,%d], U~U[%d,%d], dropout %.2f; full train step (fwd+loss+bwd+clip+Adam)'
-                                   % (a.size, a.tmin, a.tmax, a.umin, a.umax, a.dropout),
+                                   % (a.size, a.layers, a.tmin, a.tmax, a.umin, a.umax, a.dropout),
                        'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'params': n_params,
                        'padded_frames_per_s': round(padded_all / dt, 1),
                        'parallelism': 'dp%d' % world, 'phases': phases},
@@ -543,13 +576,19 @@ def main():
         if phases is not None and 'encoder_mfu' in phases:
             out['encoder_mfu'] = phases['encoder_mfu']['valid_frames']     # the north-star figure (target 0.40)
         if distributed and comm_log:
-            torch.cuda.synchronize()
+            if not emu:
+                torch.cuda.synchronize()
             ex = [r.elapsed_time(e) for r, e, _, _, _ in comm_log[a.warmup:]] or [r.elapsed_time(e) for r, e, _, _, _ in comm_log]
-            out['comm'] = {'backend': a.dist_backend, 'buckets_per_step': comm_log[-1][2], 'bytes_per_step': comm_log[-1][3],
+            out['comm'] = {'backend': a.dist_backend, 'algorithm': os.environ.get('NSP_DDP_ALGO') or 'all_reduce',
+                           'compress': os.environ.get('NSP_DDP_COMPRESS') or None,
+                           'buckets_per_step': comm_log[-1][2], 'bytes_per_step': comm_log[-1][3],
+                           'wire_bytes_per_step': getattr(comm, 'wire_bytes', None),
                            'side_stream_waits_per_step': comm_log[-1][4],
                            'exposed_ms_per_step': round(sum(ex) / len(ex), 3),
                            'definition': 'main-stream time from "last bucket ready" (all of backward enqueued) to the point '
                                          'behind DDP\'s wait for every collective, mean over the timed steps, rank 0'}
+        if emu:
+            out['emulated'] = 'CPU tier: kernels on the host emulator (tests/hipemu), gloo ranks -- NOT a measurement'
         if also is not None:
             out['also'] = also
         if not a.no_cpu_baseline and world == 1:

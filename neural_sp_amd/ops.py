@@ -3220,7 +3220,7 @@ class SelfAttnFn(torch.autograd.Function):
                    bq is not None, bo is not None)
         ctx.prep_token = _prep_offer(res is not None, 1.0, p_o, s_o[0], s_o[1], d)
         if aw is None:
-            aw = cv16.new_zeros(1)  # the fused path has no probability tensor to hand out
+            aw = _no_aw(cv16.device).view(1)  # the fused path has no probability tensor to hand out (one cached placeholder per device)
         ctx.mark_non_differentiable(aw)
         return out.view(B, T, d), aw
 
@@ -3306,6 +3306,16 @@ class SelfAttnFn(torch.autograd.Function):
 # --------------------------------------------------------------------------
 # fused (flash-style) attention core, d_k = 64
 # --------------------------------------------------------------------------
+_NO_AW = {}
+
+
+def _no_aw(dev):
+    t = _NO_AW.get(dev)
+    if t is None:
+        t = _NO_AW[dev] = torch.zeros(1, device=dev, dtype=torch.bfloat16)
+    return t
+
+
 def flash_attn_fwd_raw(qkv16, d, QP, mp, want_o32=True):
     """-> (O bf16, O32 fp32 or None, LSE, keepbits or None).  O32 is what backward's D = dO . O is formed from; keepbits
     (only with dropout) = the dropout decisions the forward drew, which backward reads instead of drawing them again."""

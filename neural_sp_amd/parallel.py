@@ -92,6 +92,22 @@ def pin_grad_streams(model):
     return keep
 
 
+class HostEvent(object):
+    """torch.cuda.Event's record / elapsed_time on the host clock: what CommStats and bench.py use where there is no device
+    stream to record on (the CPU tier: gloo ranks on the host-emulated kernels)."""
+
+    def __init__(self):
+        self.t = None
+
+    def record(self, stream=None):
+        import time
+        self.t = time.perf_counter()
+        return self
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
 class CommStats(object):
     """What bench.py reports about the collective under DDP: per backward pass the number of buckets, their bytes,
     and the event recorded on the hook's stream when the LAST bucket became ready (= backward's compute is fully
@@ -138,7 +154,7 @@ def _reduce_scatter_all_gather(buf, group, world, on_device):
     pad = (-n) % world
     src = buf if pad == 0 else torch.cat([buf, buf.new_zeros(pad)])
     shard = torch.empty((src.numel() // world,), device=buf.device, dtype=buf.dtype)
-    if on_device:
+    if on_device and dist.get_backend(group) == 'nccl':
         # same communicator, same (gather) stream: RCCL runs the two collectives in issue order
         dist.reduce_scatter_tensor(shard, src, group=group, async_op=True)
         fut = dist.all_gather_into_tensor(src, shard, group=group, async_op=True).get_future()
@@ -181,6 +197,20 @@ def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_strea
         group = state if state is not None else dist.group.WORLD
         world = dist.get_world_size(group)
         if not buf.is_cuda:
+            if stats is not None:
+                stats.buckets += 1
+                stats.bytes += buf.numel() * buf.element_size()
+                stats.wire_bytes += ((buf.numel() + ((-buf.numel()) % world if algorithm == 'rs_ag' else 0))
+                                     * (2 if compress == 'bf16' else buf.element_size()))
+                if bucket.is_last():
+                    stats.last_ready = HostEvent().record()
+            if compress == 'bf16':        # (the CPU tier runs the same algorithm x compression matrix as the device branch)
+                send = buf.to(torch.bfloat16).div_(world)
+                if algorithm == 'rs_ag':
+                    fut = _reduce_scatter_all_gather(send, group, world, False)
+                else:
+                    fut = dist.all_reduce(send, group=group, async_op=True).get_future().then(lambda f: f.value()[0])
+                return fut.then(lambda f: buf.copy_(f.value()))
             if algorithm == 'rs_ag':
                 return _reduce_scatter_all_gather(buf.div_(world), group, world, False)
             return dist.all_reduce(buf.div_(world), group=group, async_op=True).get_future().then(lambda f: f.value()[0])
@@ -238,8 +268,9 @@ def make_comm_hook(streams, compress=None, pstreams=None, stats=None, main_strea
     return hook
 
 
-def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
-    """DDP(model) with the settings above; local_rank=None wraps a CPU module (gloo tests)."""
+def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None, cpu_hook=False):
+    """DDP(model) with the settings above; local_rank=None wraps a CPU module (gloo tests; cpu_hook: with the package's
+    communication hook and its CommStats, as bench.py --emulate wants them)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     # constant tables need no per-forward broadcast; BatchNorm running statistics do (torch DDP's default, which
     # the reference relies on: every rank evaluates / checkpoints rank 0's statistics)
@@ -248,7 +279,12 @@ def wrap_ddp(model, local_rank=None, bucket_cap_mb=48, compress=None):
     kw = dict(broadcast_buffers=has_bn, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
     mark_hooked(model)
     if local_rank is None:
-        return DDP(model, **kw)           # (CPU module: no streams to order)
+        ddp = DDP(model, **kw)            # (CPU module: no streams to order)
+        if cpu_hook:
+            ddp.comm_stats = CommStats()
+            ddp.register_comm_hook(None, make_comm_hook([], compress if compress is not None else
+                                                        (os.environ.get('NSP_DDP_COMPRESS') or None), None, ddp.comm_stats, None))
+        return ddp
     pin_grad_streams(model)
     ddp = DDP(model, device_ids=[local_rank], **kw)
     compress = compress if compress is not None else (os.environ.get('NSP_DDP_COMPRESS') or None)

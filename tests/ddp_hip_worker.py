@@ -102,6 +102,8 @@ def _run(rank, world, port, out_path, compress, device, mode='wrap'):
         ddp = DDP(model, device_ids=[0], bucket_cap_mb=1)
         assert model._nsp_ddp_hooked and len(model._nsp_grad_accumulators) > 0
     elif on_gpu:
+        if mode == 'wrap_rs_ag':          # the hook's reduce-scatter + all-gather form (odd bucket sizes: the padded path)
+            os.environ['NSP_DDP_ALGO'] = 'rs_ag'
         ddp = parallel.wrap_ddp(model, 0, bucket_cap_mb=1, compress=compress)   # 1 MB: several buckets even at XS size
         assert len(model._nsp_grad_accumulators) > 0
     else:

@@ -19,7 +19,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('compress,mode', [(None, 'wrap'), ('bf16', 'wrap'), (None, 'stock'), (None, 'install')])
+@pytest.mark.parametrize('compress,mode', [(None, 'wrap'), ('bf16', 'wrap'), (None, 'stock'), (None, 'install'),
+                                           (None, 'wrap_rs_ag'), ('bf16', 'wrap_rs_ag')])
 def test_two_rank_ddp_gradients_equal_single_process(compress, mode):
     """mode 'stock': the reference's own line (train.py:263), `DistributedDataParallel(model, device_ids=[0])` of an
     unpatched torch around the transducer model -- Speech2Text's guard keeps the step on one stream, so the reducer's
