@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, 4) void flash_fwd_kernel(const __bf16* __restr
 // query tile and 36 KB of LDS).  The wave's K / V fragments are 16 registers; Q / dO tiles and the
 // per-query statistics (row max, 1/sum, D, dropout row hash, far-diagonal position score) of the NEXT
 // query tile are fetched while the current one is processed: one barrier per query tile.
-// H2 (the default; NSP_FLASH_DKV_HALVES=0 selects the one-pass form): the 64-query tile is processed as two halves of
+// H2 (what is launched; the one-pass form <false> has no switch any more): the 64-query tile is processed as two halves of
 // 32 queries (S / dP / P / dS of one half live at a time) under __launch_bounds__(256, 3), i.e. 168 VGPRs (24 B of
 // scratch) and a third wave per SIMD for a kernel that at 255 VGPRs waits more than it issues.  Same
 // arithmetic in the same order per accumulator: dK / dV are BIT-identical to the one-pass form (checked on the

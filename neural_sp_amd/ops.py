@@ -2831,7 +2831,8 @@ class LSTMStackFn(torch.autograd.Function):
         checks = _lstm_stack_launch('fwd', P, dev)
         del xchg
         if checks or os.environ.get('NSP_LSTM_TEST_FAKE_TIMEOUT', '0') == '1':
-            del _LSTM_FWD_RESCUE[:-3]          # (launches nobody resolved -- ops.lstm_stack driven directly -- do not pile up)
+            del _LSTM_FWD_RESCUE[:-1]          # (launches nobody resolved -- ops.lstm_stack driven directly -- do not pile up: at most
+                                               #  two forwards' activations are ever pinned here: main + one auxiliary decoder)
             _LSTM_FWD_RESCUE.append((P, keep + [y_top] + hp16 + yd16 + c_all + gates, checks or [], _stream()))
         ctx.save_for_backward(xa, *ws, *hp16, *yd16, *c_all, *gates)
         ctx.cfg = (nl, B, L, I, H, float(p_drop), seeds)

@@ -239,9 +239,10 @@ class Speech2Text(nn.Module):
         # out of stock DistributedDataParallel's per-forward buffer broadcast (train.py:263 leaves broadcast_buffers=True) --
         # one collective, and one cross-rank synchronisation at the top of every step, saved.  BatchNorm statistics are
         # state, not tables: they stay in.  (They remain in state_dict either way.)
+        # An ALLOW-list of known constant tables: any other buffer -- BatchNorm statistics today, whatever
+        # stateful buffer a later change adds -- keeps torch's default and is synchronised.
         self._ddp_params_and_buffers_to_ignore = [
-            n for n, _ in self.named_buffers()
-            if n.rsplit('.', 1)[-1] not in ('running_mean', 'running_var', 'num_batches_tracked')]
+            n for n, _ in self.named_buffers() if n.rsplit('.', 1)[-1] in ('inv_freq', 'pe')]
 
     # ---- bookkeeping members touched by neural_sp/bin/asr/train.py (speech2text.py:206-237, base.py)
     @property
@@ -376,15 +377,17 @@ class Speech2Text(nn.Module):
         if teacher is not None or teacher_lm is not None:
             raise NotImplementedError('knowledge distillation')
         # (speech2text.py:253-262 calls self.eval() / self.train() on every forward: a walk over ~400 modules, 1.2 ms of
-        # host time per step at 16 utterances per GPU -- only when the mode actually changes)
+        # host time per step at 16 utterances per GPU -- only when the mode actually changes.  The reference's call also
+        # RE-PROPAGATES the mode, i.e. resets a sub-module someone put into the other mode on its own (a frozen encoder
+        # in eval, say): the cheap check over the direct children keeps that behaviour for the top-level sub-modules;
+        # a flag flipped deeper than that survives until the next mode change -- documented divergence)
+        want = not is_eval
+        if self.training != want or any(m.training != want for m in self.children()):
+            self.train(want)
         if is_eval:
-            if self.training:
-                self.eval()
             with torch.no_grad():
                 loss, observation = self._forward(batch, task)
         else:
-            if not self.training:
-                self.train()
             loss, observation = self._forward(batch, task)
         return loss, observation
 

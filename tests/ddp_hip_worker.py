@@ -111,7 +111,7 @@ def _run(rank, world, port, out_path, compress, device, mode='wrap'):
         ddp.register_comm_hook(None, parallel.make_comm_hook(parallel.step_streams(model), compress))
     local = sub_batch(full, list(range(rank, 4, world)))
     losses = []
-    # NSP_DDP_ITERS / NSP_DDP_DIAG (tools/r05_ddp_loop.sh): more iterations per process, and a checksum of every
+    # NSP_DDP_ITERS / NSP_DDP_DIAG (round 5's loop script, profiles/r05_ddp_loop_variants*.log): more iterations per process, and a checksum of every
     # sub-module's output per iteration (device scalars, read after the loop: no extra synchronisation inside a step) --
     # the first module whose checksum differs from iteration 0 is where a nondeterministic forward starts
     n_iters = int(os.environ.get('NSP_DDP_ITERS', '2'))

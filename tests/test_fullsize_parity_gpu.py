@@ -283,7 +283,7 @@ def test_prediction_network_forward_is_rerun_in_step_after_a_grid_barrier_timeou
             rerun = (g2b[n] - g2[n]).abs().max().item()
             assert (g1[n] - g2[n]).abs().max().item() <= max(4 * rerun, 2e-6 * g2[n].abs().max().item()), n
         # against the persistent launch: the two recurrences agree to the last fp32 bits, not bit for bit -- a handful of
-        # bf16 roundings of the joint's operands flip (tools/r05_lstm_diag2.py: gradient into the encoder 3.6e-4 of its
+        # bf16 roundings of the joint's operands flip (round 5, DESIGN 12.4: gradient into the encoder 3.6e-4 of its
         # maximum, parameters up to 6e-3) -- so the gate here is the bf16 mode's own (loss 1e-6, per-tensor cosine)
         assert l0 == l0b and abs(l1 - l0) <= 1e-6 * abs(l0), (l0, l0b, l1)
         for n in g0:

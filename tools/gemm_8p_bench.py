@@ -10,8 +10,7 @@ from neural_sp_amd import ops
 
 ops.set_compute_mode('bf16')
 dev = torch.device('cuda:0')
-ARMS = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p (rule)', {'NSP_GEMM_8P': '1'}), ('8p forced', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '4'}),
-        ('8p stagger1', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_STAGGER': '1'}), ('8p stagger2', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_STAGGER': '2'})]
+ARMS = [('128x128', {'NSP_GEMM_8P': '0'}), ('8p (rule)', {'NSP_GEMM_8P': '1'}), ('8p forced', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '4'})]
 if os.environ.get('NSP_8P_AB_BUILD'):      # a -DNSP_GEMM_8P_AB=1 build: the direct-epilogue twins
     ARMS += [('8p-direct', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '0'}), ('8p-direct-l2', {'NSP_GEMM_8P': '2', 'NSP_GEMM_8P_VAR': '8'})]
 if os.environ.get('ARMS'):
@@ -19,7 +18,7 @@ if os.environ.get('ARMS'):
 
 
 def setarm(env):
-    for k in ('NSP_GEMM_8P', 'NSP_GEMM_8P_VAR', 'NSP_GEMM_8P_STAGGER'):
+    for k in ('NSP_GEMM_8P', 'NSP_GEMM_8P_VAR'):
         os.environ.pop(k, None)
     os.environ.update(env)
 

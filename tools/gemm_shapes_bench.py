@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel-only timing + correctness of the bf16 KCxKC GEMM (y = x W^T) at the step's shapes (batch 64).
-usage: NSP_GEMM_256=0|1 python tools/gemm_shapes_bench.py [quick]"""
+usage: python tools/gemm_shapes_bench.py [quick]      (arms: NSP_GEMM_8P = 0 -> 128 x 128 kernels, 1 -> the launcher's rule)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,6 @@ shapes = [(51200, 2048, 512), (51200, 512, 2048), (51200, 1536, 512), (51200, 51
           (1843200, 1024, 512), (1843200, 512, 1024)]
 if len(sys.argv) > 1 and sys.argv[1] == 'quick':
     shapes = shapes[:6]
-print('NSP_GEMM_256=%s' % os.environ.get('NSP_GEMM_256', '(default 1)'))
 for M, N, K in shapes:
     big = M > 1000000
     a = (torch.randn(M, K, device='cuda') * 0.5).bfloat16()
@@ -22,8 +21,8 @@ for M, N, K in shapes:
     def run():
         ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N, bias=bias)
     out = []
-    for persist in ('0', '1'):
-        os.environ['NSP_GEMM_PERSIST'] = persist
+    for arm in ('0', '1'):
+        os.environ['NSP_GEMM_8P'] = arm
         for _ in range(3): run()
         torch.cuda.synchronize()
         iters = 5 if big else 30
@@ -36,4 +35,4 @@ for M, N, K in shapes:
         ref = a[rows].float() @ w.float().t() + bias
         err = ((c[rows].float() - ref).abs().max() / ref.abs().max()).item()
         out.append('%9.1f us %7.1f TFLOP/s err %.0e' % (us, 2.0 * M * N * K / us / 1e6, err))
-    print('M %8d N %5d K %5d | classic %s | persistent %s' % (M, N, K, out[0], out[1]), flush=True)
+    print('M %8d N %5d K %5d | 128 x 128 %s | launcher's rule %s' % (M, N, K, out[0], out[1]), flush=True)
