@@ -692,9 +692,15 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 64;
     const int cur = qt & 1;
+    // the position rows of the next query tile are read only by the 1-3 tiles around the diagonal and by masked tiles: a
+    // uniform tile (the other ~10 of 13) takes its one value per query from the statistics (round 6: the table rows were
+    // fetched and staged for every tile -- 0.7 GB of L2 reads per call at T = 800, B = 128)
+    bool qp_next = false;
     if (qt + 1 < nqt) {
+      const FaTile tn = fa_tile(p, QP != nullptr, q0 + 64, k0, T, klen);
+      qp_next = QP != nullptr && !(tn.plain && tn.far);
       // (the register loads first: a wait for them then does not have to cover the DMA issued after them)
-      qpr = qp_load(q0 + 64);
+      if (qp_next) qpr = qp_load(q0 + 64);
       str = stat_load(q0 + 64);
       tile_dma(Qs[cur ^ 1], qbase, ld3, brow0, q0 + 64, T, wave, lane);
       tile_dma(dOs[cur ^ 1], dobase, d, brow0, q0 + 64, T, wave, lane);
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
       half_tile(0);
     }
     if (qt + 1 < nqt) {
-      qp_store(cur ^ 1, qpr);
+      if (qp_next) qp_store(cur ^ 1, qpr);
       stat_store(cur ^ 1, str);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
