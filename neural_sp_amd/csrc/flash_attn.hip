@@ -242,15 +242,21 @@ __device__ __forceinline__ unsigned fa_rowhash(const nsp_attn_mask_params& p, in
 constexpr int KD = 128;   // DMA tile row pitch (bytes)
 typedef __attribute__((address_space(3))) void fa_lds_void;
 typedef const __attribute__((address_space(1))) void fa_glb_void;
+// Addresses (round 6): a workgroup-uniform 64-bit base (the utterance's first row: src + brow0 * ld, formed once) plus a
+// 32-bit byte offset per lane -- one 24-bit multiply-add per piece.  (As `src + (brow0 + row) * ld` per lane hipcc issued a
+// 64-bit multiply -- two v_mul_lo_u32 and a v_mad_u64_u32 -- per piece and tile: 12 of the ~25 slow-rate integer
+// instructions of every iteration of the three kernels.)  An utterance's rows span < 2^31 bytes: T * ld * 2.
 __device__ __forceinline__ void tile_dma(unsigned char* tile, const __bf16* __restrict__ src, long long ld, long long brow0,
                                          int row0, int T, int wave, int lane) {
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(src + brow0 * ld);     // uniform
+  const unsigned ldb = (unsigned)ld * 2u;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ii = wave * 2 + i;                    // 1-KB piece: rows 8 ii .. 8 ii + 7
     const int row = ii * 8 + (lane >> 3), c = lane & 7;
     const int sc = c ^ (row & 7);
-    const __bf16* g = src + (brow0 + min(row0 + row, T - 1)) * ld + sc * 8;
-    __builtin_amdgcn_global_load_lds((fa_glb_void*)g, (fa_lds_void*)(tile + ii * 1024), 16, 0, 0);
+    const unsigned off = __umul24((unsigned)min(row0 + row, T - 1), ldb) + (unsigned)(sc * 16);
+    __builtin_amdgcn_global_load_lds((fa_glb_void*)(base + off), (fa_lds_void*)(tile + ii * 1024), 16, 0, 0);
   }
 }
 __device__ __forceinline__ bf16x8 frag_kc_dma(const unsigned char* tile, int rbase, int s, int r, int g) {
