@@ -183,6 +183,18 @@ int nsp_layernorm_bwd_prep(const float* dy, const float* x, const float* gamma, 
                            const float* dres, float* dx, float* dgamma, float* dbeta, void* g16, float* gsum,
                            float g_alpha, float g_p, unsigned long long g_seed, unsigned long long g_offset,
                            int rows, int d, void* stream);
+/* LayerNorm pair at a Conformer block boundary (conformer_block.py:176-180 + :132-133 of the next block): y = LN_a(x)
+ * (fp32: the residual stream) and z16 = bf16(LN_b(y)) (the operand of the next block's first feed-forward GEMM) in one
+ * pass; backward: dx = LN_a'(LN_b'(dz) + dres) with y recomputed from x; the four parameter gradients and gsum are
+ * ACCUMULATED into caller-zeroed buffers; g16 / gsum as in nsp_layernorm_bwd_prep (both or neither). */
+int nsp_layernorm_pair_fwd(const float* x, const float* gamma_a, const float* beta_a, float eps_a,
+                           const float* gamma_b, const float* beta_b, float eps_b, float* y, void* z16,
+                           float* mean_a, float* rstd_a, float* mean_b, float* rstd_b, int rows, int d, void* stream);
+int nsp_layernorm_pair_bwd(const float* dz, const float* dres, const float* x, const float* gamma_a,
+                           const float* beta_a, const float* mean_a, const float* rstd_a, const float* gamma_b,
+                           const float* mean_b, const float* rstd_b, float* dx, float* dgamma_a, float* dbeta_a,
+                           float* dgamma_b, float* dbeta_b, void* g16, float* gsum, float g_alpha, float g_p,
+                           unsigned long long g_seed, unsigned long long g_offset, int rows, int d, void* stream);
 int nsp_layernorm_bwd_recompute(const float* dy, const float* x, const float* gamma, const float* beta,
                                 const float* mean, const float* rstd, const float* dres, float* dx,
                                 float* dgamma, float* dbeta, int rows, int d, int act, void* stream);

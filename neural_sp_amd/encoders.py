@@ -413,18 +413,26 @@ class ConformerEncoderBlock(nn.Module):
     def xx_aws(self):
         return self._xx_aws
 
-    def forward(self, xs, xx_mask=None, cache=None, pos_embs=None, rel_bias=(None, None)):
+    def forward(self, xs, xx_mask=None, cache=None, pos_embs=None, rel_bias=(None, None), next_norm=None):
+        """next_norm (round 6): the first LayerNorm of the block that will consume this block's output UNCHANGED (no
+        subsampling, no layer dropout in between): its normalisation is then produced together with this block's last one
+        (ops.layer_norm_pair) and travels on the output as `_nsp_prenorm` = (that LayerNorm module, its output)."""
         if cache is not None:
             raise NotImplementedError('streaming cache')
         self._xx_aws = None
         u_bias, v_bias = rel_bias
+        pre = getattr(xs, '_nsp_prenorm', None)
         if self.dropout_layer > 0:
             if self.training and random.random() < self.dropout_layer:
                 return xs, {}
             else:
                 xs = ops.scale(xs, 1.0 / (1 - self.dropout_layer))
+                pre = None
         p = self.dropout_p
-        xn, xs = ops.layer_norm_split(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        if pre is not None and pre[0] is self.norm1:
+            xn = pre[1]                        # LN_1(xs), made by the previous block's last kernel; xs is its residual output
+        else:
+            xn, xs = ops.layer_norm_split(xs, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         xs = self.feed_forward_macaron(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
         xn, xs = ops.layer_norm_split(xs, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         xs, self._xx_aws = self.self_attn(xn, xn, pos_embs, xx_mask, u_bias, v_bias,
@@ -433,7 +441,12 @@ class ConformerEncoderBlock(nn.Module):
         xs = self.conv(xn, residual=xs, out_dropout=p)
         xn, xs = ops.layer_norm_split(xs, self.norm4.weight, self.norm4.bias, self.norm4.eps)
         xs = self.feed_forward(xn, residual=xs, alpha=self.fc_factor, out_dropout=p)
-        xs = ops.layer_norm(xs, self.norm5.weight, self.norm5.bias, self.norm5.eps)
+        if next_norm is not None and ops.layer_norm_pair_ok(xs, xs.shape[-1]):
+            xn, xs = ops.layer_norm_pair(xs, self.norm5.weight, self.norm5.bias, self.norm5.eps,
+                                         next_norm.weight, next_norm.bias, next_norm.eps)
+            xs._nsp_prenorm = (next_norm, xn)
+        else:
+            xs = ops.layer_norm(xs, self.norm5.weight, self.norm5.bias, self.norm5.eps)
         return xs, {}
 
 
@@ -737,7 +750,19 @@ class TransformerEncoder(EncoderBase):
         else:
             xx_mask = self._mask(xlens, self.lookaheads[0])
             for lth, layer in enumerate(self.layers):
-                xs, _ = layer(xs, xx_mask, cache=None, pos_embs=rel_pos_embs, rel_bias=rel_bias)
+                # the next block's first LayerNorm rides in this block's last kernel when the block output reaches it
+                # unchanged: same time resolution (no subsampling layer in between), no layer dropout, training mode only
+                # (evaluation keeps per-layer outputs for plotting and takes the plain path)
+                nxt = None
+                if (self.training and isinstance(layer, ConformerEncoderBlock) and lth < len(self.layers) - 1
+                        and self.subsample_factors[lth] == 1 and isinstance(self.layers[lth + 1], ConformerEncoderBlock)
+                        and self.layers[lth + 1].dropout_layer == 0 and lth != self.n_layers_sub1 - 1
+                        and lth != self.n_layers_sub2 - 1):
+                    nxt = self.layers[lth + 1].norm1
+                if nxt is not None:
+                    xs, _ = layer(xs, xx_mask, cache=None, pos_embs=rel_pos_embs, rel_bias=rel_bias, next_norm=nxt)
+                else:
+                    xs, _ = layer(xs, xx_mask, cache=None, pos_embs=rel_pos_embs, rel_bias=rel_bias)
                 if not self.training:
                     self.aws_dict['xx_aws_layer%d' % lth] = layer.xx_aws  # device tensor (plot on demand)
                     self.data_dict['elens%d' % lth] = xlens.numpy()

@@ -802,6 +802,72 @@ class LayerNormSplitFn(torch.autograd.Function):
         return dx.view(dy.shape), dg, db, None
 
 
+class LayerNormPairFn(torch.autograd.Function):
+    """(LN_b(LN_a(x)), LN_a(x)): the last LayerNorm of a Conformer block and the first one of the next block
+    (conformer_block.py:176-180, :132-133) in one kernel per direction (round 6; bf16 mode only).  The first output is the
+    pre-norm input of the next block's feed-forward module -- a stride-0 NaN placeholder carrying the bf16 image `_nsp16`,
+    as LayerNormSplitFn's -- the second is y = LN_a(x), the residual stream.  Backward receives the feed-forward module's
+    data gradient and the residual gradient, recomputes y from x, and leaves dx (plus the prepared image for the linear
+    layer in front of x, if x carries an offer): the gradient of y never exists in memory."""
+
+    @staticmethod
+    def forward(ctx, x, ga, ba, eps_a, gb, bb, eps_b):
+        x2d = _f32c(x).reshape(-1, x.shape[-1])
+        rows, d = x2d.shape
+        dev = x2d.device
+        y = torch.empty_like(x2d)
+        z16 = torch.empty((rows, d), device=dev, dtype=torch.bfloat16)
+        st = torch.empty((4, rows), device=dev, dtype=torch.float32)          # mean_a, rstd_a, mean_b, rstd_b
+        with _kev_class('layernorm_fwd', rows * d * 10, 'byte'):
+            _check(_lib.lib().nsp_layernorm_pair_fwd(_p(x2d), _p(ga), _p(ba), eps_a, _p(gb), _p(bb), eps_b, _p(y), _p(z16),
+                                                     st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                                     rows, d, _stream()), 'nsp_layernorm_pair_fwd')
+        ctx.save_for_backward(x2d, ga, ba, gb, st)
+        ctx.prep = getattr(x, '_nsp_prep', None)
+        ctx.xshape = x.shape
+        zn = _nan_scalar(dev).expand(x.shape).view(x.shape)
+        zn._nsp_placeholder = True
+        zn._nsp16 = z16
+        return zn, y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dz, dres):
+        x2d, ga, ba, gb, st = ctx.saved_tensors
+        rows, d = x2d.shape
+        dev = x2d.device
+        dz2d = _f32c(dz).reshape(rows, d) if dz is not None else torch.zeros_like(x2d)
+        r2d = _f32c(dres).reshape(rows, d) if dres is not None else torch.zeros_like(x2d)
+        dx = torch.empty_like(x2d)
+        dgb = zeros_small((4, d), dev)
+        prep = ctx.prep
+        use_prep = prep is not None and prep[5] == d and d % 8 == 0 and bf16_mode()
+        g16 = gsum = None
+        if use_prep:
+            g16 = torch.empty((rows, d), device=dev, dtype=torch.bfloat16)
+            gsum = zeros_small((d,), dev)
+        with _kev_class('layernorm_bwd', rows * d * (16 + (2 if use_prep else 0)), 'byte'):
+            _check(_lib.lib().nsp_layernorm_pair_bwd(
+                _p(dz2d), _p(r2d), _p(x2d), _p(ga), _p(ba), st[0].data_ptr(), st[1].data_ptr(), _p(gb), st[2].data_ptr(),
+                st[3].data_ptr(), _p(dx), dgb[0].data_ptr(), dgb[1].data_ptr(), dgb[2].data_ptr(), dgb[3].data_ptr(),
+                _p(g16), _p(gsum), prep[1] if use_prep else 1.0, prep[2] if use_prep else 0.0,
+                prep[3] if use_prep else 0, prep[4] if use_prep else 0, rows, d, _stream()), 'nsp_layernorm_pair_bwd')
+        if use_prep:
+            _PREP[prep[0]] = (dx, dx._version, g16, gsum)
+            _PREP_STATS['made'] += 1
+        return dx.view(ctx.xshape), dgb[0], dgb[1], None, dgb[2], dgb[3], None
+
+
+def layer_norm_pair_ok(x, d):
+    """can ops.layer_norm_pair replace layer_norm + the next block's layer_norm_split?  (throughput mode, lean outputs)"""
+    return (bf16_mode() and d % 8 == 0 and d <= 1024 and os.environ.get('NSP_LN_SKIP32', '1') != '0'
+            and os.environ.get('NSP_LN_PAIR', '1') != '0')
+
+
+def layer_norm_pair(x, ga, ba, eps_a, gb, bb, eps_b):
+    """-> (LN_b(LN_a(x)) as a bf16-image placeholder, LN_a(x)); see LayerNormPairFn."""
+    return LayerNormPairFn.apply(x, ga, ba, float(eps_a), gb, bb, float(eps_b))
+
+
 _NAN = {}
 
 

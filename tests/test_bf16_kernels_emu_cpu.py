@@ -107,6 +107,11 @@ def test_linear_glu_on_the_bf16_image(basic, M, C, monkeypatch):
     basic.test_linear_glu_on_the_bf16_image(M, C, monkeypatch)
 
 
+@pytest.mark.parametrize('rows,d,offer', [(70, 256, True), (33, 64, False)])
+def test_layer_norm_pair_at_a_block_boundary(basic, rows, d, offer):
+    basic.test_layer_norm_pair_at_a_block_boundary(rows, d, offer)
+
+
 @pytest.mark.parametrize('B,T,C,k', [(3, 70, 64, 15), (2, 37, 256, 7)])
 def test_linear_glu_depthwise_conv_as_one_node(basic, B, T, C, k, monkeypatch):
     basic.test_linear_glu_depthwise_conv_as_one_node(B, T, C, k, monkeypatch)

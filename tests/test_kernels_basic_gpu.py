@@ -457,6 +457,45 @@ def test_linear_glu_on_the_bf16_image(M, C, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('rows,d,offer', [(70, 256, True), (131, 512, False), (33, 64, True)])
+def test_layer_norm_pair_at_a_block_boundary(rows, d, offer):
+    """Round 6: ops.layer_norm_pair = the last LayerNorm of a Conformer block + the first one of the next block in one
+    kernel per direction, against the two ops it replaces (layer_norm, then layer_norm_split): outputs bit-equal, all five
+    gradients and -- when the input carries a linear layer's offer -- the prepared bf16 image and its column sums."""
+    from neural_sp_amd import ops
+    torch.manual_seed(rows + d)
+    dev = _dev()
+    ga, ba, gb, bb = [torch.nn.Parameter(torch.randn(d, device=dev) * 0.5 + (1.0 if i % 2 == 0 else 0.0)) for i in range(4)]
+    x0 = torch.randn(2, rows, d, device=dev)
+    dz = torch.randn(2, rows, d, device=dev)
+    dres = torch.randn(2, rows, d, device=dev)
+    res = {}
+    with ops.compute_mode('bf16'):
+        for mode in ('pair', 'two'):
+            x = x0.clone().requires_grad_()
+            xin = ops.scale(x, 1.0)                     # (a non-leaf input that can carry an offer)
+            tok = None
+            if offer:
+                tok = ops._prep_offer(True, 0.5, 0.1, 1234, 77, d)
+                ops.tag_prep(xin)
+            if mode == 'pair':
+                zn, y = ops.layer_norm_pair(xin, ga, ba, 1e-12, gb, bb, 1e-12)
+            else:
+                y0 = ops.layer_norm(xin, ga, ba, 1e-12)
+                zn, y = ops.layer_norm_split(y0, gb, bb, 1e-12)
+            z16 = zn._nsp16.clone()
+            grads = torch.autograd.grad([zn, y], [x, ga, ba, gb, bb], [dz, dres])
+            got = ops._PREP.pop(tok, None) if tok is not None else None
+            res[mode] = (y.detach().clone(), z16, grads, got)
+    assert torch.equal(res['pair'][0], res['two'][0]) and torch.equal(res['pair'][1], res['two'][1])
+    for a, b, name in zip(res['pair'][2], res['two'][2], ('dx', 'dga', 'dba', 'dgb', 'dbb')):
+        assert _rel(a, b) < 2e-5, (name, _rel(a, b))
+    if offer:
+        (_, _, g16a, gsa), (_, _, g16b, gsb) = res['pair'][3], res['two'][3]
+        assert _rel(g16a.float(), g16b.float()) < 1e-2 and _rel(gsa, gsb) < 1e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,T,C,k', [(3, 70, 64, 15), (2, 37, 256, 7), (2, 130, 512, 15)])
 def test_linear_glu_depthwise_conv_as_one_node(B, T, C, k, monkeypatch):
     """Round 6: depthwise_conv(glu(pointwise_conv(x))) of the Conformer conv module (conformer_convolution.py:107-113) as
