@@ -426,12 +426,99 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_lds_kernel(const float* __re
   }
 }
 
+// ---- Round 6: streaming weight gradient for K = 15 / 7 (pad = (K-1)/2).  dw[j][c] = sum_t dy[t][c] x[t + j - PAD][c]:
+// a thread owns 4 channels and one time range of one utterance and walks it ONCE with the K input rows around the current
+// frame in registers (a rotating window, unrolled K-fold so that every index is static): per frame one dy row and one new
+// x row are loaded, K fused multiply-adds per channel.  No LDS, no barriers; every element is read exactly once (+ the
+// K - 1 halo rows per range).  The LDS-tiled kernel above stages 24-row chunks between two barriers and reached 40 % of
+// the copy rate at the step's shapes (138 us per call against 54 us of bytes).  x is either fp32 [B*T, C] or -- GLU --
+// the bf16 [B*T, 2C] image of the first pointwise conv, gated as it is loaded.  grid: (C/4/64 channel groups of a wave,
+// tsplit, B) as the tiled kernel; block = 64 threads x up to 4 sub-ranges (threadIdx.y) reduced through LDS at the end.
+template <int K, bool GLU>
+__global__ __launch_bounds__(256) void dwconv_wgrad_stream_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ part, int B, int T, int C, int rows_per_wg) {
+  constexpr int PAD = (K - 1) / 2;
+  __shared__ float4 red[K + 1][64];            // the four waves add their sums into it one after the other (16 KB, not 64)
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  const int c4 = blockIdx.x * 64 + lane;
+  const int c4c = min(c4, C4 - 1);
+  const long long b = blockIdx.z;
+  const int ts = blockIdx.y * rows_per_wg, te = min(T, ts + rows_per_wg);
+  // four sub-ranges of the workgroup's range, one per wave
+  const int span = (te - ts + 3) / 4;
+  const int t0 = ts + sub * span, t1 = min(te, t0 + span);
+  const float4* x4 = reinterpret_cast<const float4*>(x) + b * T * C4 + c4c;
+  const __bf16* h2 = reinterpret_cast<const __bf16*>(x) + b * T * 2 * C;
+  const float4* d4 = reinterpret_cast<const float4*>(dy) + b * T * C4 + c4c;
+  auto xrow = [&](int t) -> float4 {            // input row t of this thread's channels (zero outside the utterance)
+    const int tc = min(max(t, 0), T - 1);
+    float4 v;
+    if constexpr (GLU) v = glu_load4(h2 + (long long)tc * 2 * C, C, c4c);
+    else v = x4[(long long)tc * C4];
+    const bool ok = t >= 0 && t < T;
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+  };
+  float4 acc[K + 1];
+#pragma unroll
+  for (int j = 0; j <= K; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t0 < t1) {
+    // window w[j] = x[t + j - PAD]; slot (j + phase) % K rotates, phase static inside the K-fold unrolled body
+    float4 w[K];
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) w[j + 1] = xrow(t0 + j - PAD);          // rows t0 - PAD .. t0 + PAD - 1 sit in slots 1 .. K-1
+    for (int tb = t0; tb < t1; tb += K) {
+#pragma unroll
+      for (int ph = 0; ph < K; ++ph) {
+        const int t = tb + ph;
+        // entering frame t: the oldest row leaves, row t + PAD enters: slots are indexed (j + ph + 1) % K for tap j
+        w[ph % K] = xrow(t + PAD);
+        const float4 g = d4[(long long)min(t, T - 1) * C4];
+        const bool live = t < t1;
+        const float4 gg = make_float4(live ? g.x : 0.f, live ? g.y : 0.f, live ? g.z : 0.f, live ? g.w : 0.f);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float4 xv = w[(j + ph + 1) % K];
+          acc[j].x = fmaf(gg.x, xv.x, acc[j].x); acc[j].y = fmaf(gg.y, xv.y, acc[j].y);
+          acc[j].z = fmaf(gg.z, xv.z, acc[j].z); acc[j].w = fmaf(gg.w, xv.w, acc[j].w);
+        }
+        acc[K].x += gg.x; acc[K].y += gg.y; acc[K].z += gg.z; acc[K].w += gg.w;
+      }
+    }
+  }
+  for (int q = 0; q < 4; ++q) {
+    if (sub == q) {
+#pragma unroll
+      for (int j = 0; j <= K; ++j) {
+        float4 v = acc[j];
+        if (q > 0) {
+          const float4 o = red[j][lane];
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        red[j][lane] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (c4 < C4) {
+    float* slab = part + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * (long long)(K + 1) * C;
+    for (int j = sub; j <= K; j += 4) *reinterpret_cast<float4*>(slab + (long long)j * C + c4 * 4) = red[j][lane];
+  }
+}
+
 }  // namespace
 
 extern "C" int nsp_dwconv1d_wgrad_slabs(const float* x, const float* dy, float* part, int tsplit, int B,
                                         int T, int C, int k, int pad, void* stream) {
   if (C % 4 || k < 1 || k > 15 || tsplit < 1) return NSP_EUNSUPPORTED;
   const int rows_per_wg = nsp_cdiv(T, tsplit);
+  if ((k == 15 || k == 7) && pad == (k - 1) / 2) {
+    const dim3 grid(nsp_cdiv(C / 4, 64), tsplit, B);
+    if (k == 15) hipLaunchKernelGGL((dwconv_wgrad_stream_kernel<15, false>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, part, B, T, C, rows_per_wg);
+    else hipLaunchKernelGGL((dwconv_wgrad_stream_kernel<7, false>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, part, B, T, C, rows_per_wg);
+    NSP_LAUNCH_CHECK();
+    return NSP_OK;
+  }
   const size_t shmem = sizeof(float4) * 64 * (size_t)(2 * DW_RC + k - 1);
   hipLaunchKernelGGL(dwconv_wgrad_lds_kernel<false>, dim3(nsp_cdiv(C / 4, 64), tsplit, B), dim3(256), shmem,
                      (hipStream_t)stream, x, dy, part, B, T, C, k, pad, rows_per_wg);
@@ -485,6 +572,14 @@ extern "C" int nsp_dwconv1d_glu_wgrad_slabs(const void* h2, const float* dy, flo
                                             int T, int C, int k, int pad, void* stream) {
   if (C % 4 || k < 1 || k > 15 || tsplit < 1 || (reinterpret_cast<uintptr_t>(h2) & 7)) return NSP_EUNSUPPORTED;
   const int rows_per_wg = nsp_cdiv(T, tsplit);
+  if ((k == 15 || k == 7) && pad == (k - 1) / 2) {
+    const dim3 grid(nsp_cdiv(C / 4, 64), tsplit, B);
+    const float* xf = reinterpret_cast<const float*>(h2);
+    if (k == 15) hipLaunchKernelGGL((dwconv_wgrad_stream_kernel<15, true>), grid, dim3(256), 0, (hipStream_t)stream, xf, dy, part, B, T, C, rows_per_wg);
+    else hipLaunchKernelGGL((dwconv_wgrad_stream_kernel<7, true>), grid, dim3(256), 0, (hipStream_t)stream, xf, dy, part, B, T, C, rows_per_wg);
+    NSP_LAUNCH_CHECK();
+    return NSP_OK;
+  }
   const size_t shmem = sizeof(float4) * 64 * (size_t)(2 * DW_RC + k - 1);
   hipLaunchKernelGGL(dwconv_wgrad_lds_kernel<true>, dim3(nsp_cdiv(C / 4, 64), tsplit, B), dim3(256), shmem,
                      (hipStream_t)stream, reinterpret_cast<const float*>(h2), dy, part, B, T, C, k, pad, rows_per_wg);
