@@ -176,12 +176,91 @@ __global__ __launch_bounds__(1024) void rnnt_lattice_compact_kernel(
   }
 }
 
+// One pass over dz (bf16 [M,J], compact rows) for both joint-input gradients.  grid: (J/64, B, nslab);
+// block 256: thread = (8 columns of the workgroup's 64-column slice, one of 32 u-lanes).  A thread meets
+// the same (u, columns) for every t, so sum_t lives in registers; sum_u is reduced across the u-lanes
+// once per t.  Padded positions (t >= T_b, u > U_b) are written as zeros.
+// Round 6: 16-B loads and 128 contiguous bytes per row and workgroup (was 8 B per lane in 64-B segments: half of every
+// line fetched by each of two workgroups), and the cross-wave part of sum_u batched over TB frames per pair of barriers
+// (was two barriers per frame): 1.26 ms per step at 2.9 TB/s before.
+template <int KU>
+__global__ __launch_bounds__(256) void joint_dz_reduce_compact_kernel(
+    const __bf16* __restrict__ dz, const int* __restrict__ elens, const int* __restrict__ ylens,
+    const long long* __restrict__ roff, float* __restrict__ de, float* __restrict__ dg, int B, int T, int U1,
+    int J, int Tc) {
+  constexpr int TB = 8;
+  __shared__ float red[TB][4][64];
+  const int cg = threadIdx.x & 7, ul = threadIdx.x >> 3;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c0 = blockIdx.x * 64 + cg * 8;
+  const long long b = blockIdx.y;
+  const int Ub = min(ylens[b], U1 - 1), U1b = Ub + 1;
+  const int Tb = min(elens[b], T);
+  const long long base = roff[b];
+  float accg[KU][8];
+#pragma unroll
+  for (int k = 0; k < KU; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) accg[k][e] = 0.f;
+  const int t_beg = blockIdx.z * Tc, t_end = min(T, (int)(blockIdx.z + 1) * Tc);
+  dg += (long long)blockIdx.z * B * U1 * J;
+  for (int tb = t_beg; tb < t_end; tb += TB) {
+#pragma unroll 1
+    for (int tt = 0; tt < TB; ++tt) {
+      const int t = tb + tt;
+      float acce[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (t < Tb && t < t_end) {
+        const __bf16* rowp = dz + (base + (long long)t * U1b) * J + c0;
+        bf16x8 v[KU];
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+          const int u = ul + 32 * k;
+          v[k] = *reinterpret_cast<const bf16x8*>(rowp + (long long)min(u, U1b - 1) * J);      // (clamped: unconditional loads)
+        }
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+          const int u = ul + 32 * k;
+          if (u < U1b) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float xv = (float)v[k][e]; accg[k][e] += xv; acce[e] += xv; }
+          }
+        }
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acce[e] += __shfl_xor(acce[e], o, 64);
+      }
+      if (lane < 8) {
+        *reinterpret_cast<float4*>(&red[tt][wave][cg * 8]) = make_float4(acce[0], acce[1], acce[2], acce[3]);
+        *reinterpret_cast<float4*>(&red[tt][wave][cg * 8 + 4]) = make_float4(acce[4], acce[5], acce[6], acce[7]);
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TB * 64; idx += 256) {
+      const int tt = idx >> 6, c = idx & 63;
+      const int t = tb + tt;
+      if (t < t_end) de[(b * T + t) * J + blockIdx.x * 64 + c] = red[tt][0][c] + red[tt][1][c] + red[tt][2][c] + red[tt][3][c];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < KU; ++k) {
+    const int u = ul + 32 * k;
+    if (u < U1) {
+      float* o = dg + (b * U1 + u) * J + c0;
+      *reinterpret_cast<float4*>(o) = make_float4(accg[k][0], accg[k][1], accg[k][2], accg[k][3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(accg[k][4], accg[k][5], accg[k][6], accg[k][7]);
+    }
+  }
+}
+
+// (the 32-column form, kept for joint widths that are not a multiple of 64)
 // One pass over dz (bf16 [M,J], compact rows) for both joint-input gradients.  grid: (J/32, B, nslab);
 // block 256: thread = (4 columns of the workgroup's 32-column slice, one of 32 u-lanes).  A thread meets
 // the same (u, columns) for every t, so sum_t lives in registers; sum_u is reduced across the u-lanes
 // once per t.  Padded positions (t >= T_b, u > U_b) are written as zeros.
 template <int KU>
-__global__ __launch_bounds__(256) void joint_dz_reduce_compact_kernel(
+__global__ __launch_bounds__(256) void joint_dz_reduce_compact32_kernel(
     const __bf16* __restrict__ dz, const int* __restrict__ elens, const int* __restrict__ ylens,
     const long long* __restrict__ roff, float* __restrict__ de, float* __restrict__ dg, int B, int T, int U1,
     int J, int Tc) {
@@ -333,8 +412,19 @@ extern "C" int nsp_rnnt_joint_dz_reduce_compact(const void* dz16, const int* ele
   hipStream_t st = (hipStream_t)stream;
   const __bf16* z = reinterpret_cast<const __bf16*>(dz16);
   const int Tc = nsp_cdiv(T, nslab);
-  dim3 grid(J / 32, B, nslab);
   const int ku = nsp_cdiv(U1, 32);
+  if (J % 64 || (reinterpret_cast<uintptr_t>(dz16) & 15)) {
+    dim3 grid32(J / 32, B, nslab);
+    if (ku <= 4)
+      hipLaunchKernelGGL((joint_dz_reduce_compact32_kernel<4>), grid32, dim3(256), 0, st, z, elens, ylens, roff, de, dg_slabs, B, T, U1, J, Tc);
+    else if (ku <= 8)
+      hipLaunchKernelGGL((joint_dz_reduce_compact32_kernel<8>), grid32, dim3(256), 0, st, z, elens, ylens, roff, de, dg_slabs, B, T, U1, J, Tc);
+    else
+      hipLaunchKernelGGL((joint_dz_reduce_compact32_kernel<16>), grid32, dim3(256), 0, st, z, elens, ylens, roff, de, dg_slabs, B, T, U1, J, Tc);
+    NSP_LAUNCH_CHECK();
+    return NSP_OK;
+  }
+  dim3 grid(J / 64, B, nslab);
   if (ku <= 4)
     hipLaunchKernelGGL((joint_dz_reduce_compact_kernel<4>), grid, dim3(256), 0, st, z, elens, ylens, roff, de, dg_slabs, B, T, U1, J, Tc);
   else if (ku <= 8)
