@@ -313,7 +313,7 @@ int nsp_attn_softmax_bwd(const void* P, const float* dP, void* dS, float* dQP,
  *        reads them instead of drawing them again                                   *
  * Backward: dqkv bf16 [B*T,3d] receives dK (block d) and dV (block 2d);      *
  * dq32 fp32 [B*T,d] and dQP [B,T,H,r_pitch] are written (no zero-init);      *
- * D is scratch [B,H,T].  Masks / dropout as in nsp_attn_softmax_*.          *
+ * D is scratch [B,H,T,4] fp32.  Masks / dropout as in nsp_attn_softmax_*.   *
  * ------------------------------------------------------------------------ */
 long long nsp_flash_attn_keepbits_bytes(int B, int H, int T);
 int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void* O, float* O32, float* LSE, void* keepbits,

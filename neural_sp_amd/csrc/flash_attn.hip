@@ -622,39 +622,34 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
   // statistics of query q0 + tid
   // RAW loaded values only: every use of them (scaling, selects) happens in *_store at the END of the iteration, so the
   // loads -- issued BEFORE the next tile's DMA -- are not waited for until then
-  struct Stat { float mx, inv, dd, farv; unsigned keep; int qi; };
+  struct Stat { float4 s4; unsigned keep; int qi; };
   // STRAIGHT-LINE loads (round 4, ISA audit): with the loads inside conditional expressions (`qi < T ? LSE[..] : 0`,
   // `c < rp ? src[c] * sl2 : 0`) hipcc put every one of them into its own branch with an s_waitcnt vmcnt(0) behind it --
   // up to eight SERIALISED global round trips at the top of every query-tile iteration of this kernel.  All addresses
   // are clamped to valid ones and everything is requested back to back.
-  const bool has_far = QP && p.clamp > 0;
   // dropout words of (key tile k0 / 64, query blocks q0 / 16 .. + 3): 512 contiguous bytes, one dword per thread 0..127
   // (see fa_keep_bits; a valid address also without dropout: straight-line load)
   const unsigned* kb32 = drop ? reinterpret_cast<const unsigned*>(keepbits + fa_keep_index(p, b, h, k0 >> 6, 0)) + (threadIdx.x & 127)
                               : reinterpret_cast<const unsigned*>(LSE);
   const int kb_step = drop ? 32 : 0;             // dwords per 16-query block
+  // per-query statistics: ONE 16-B record {c0, row max, A, A D} written by the dQ kernel (which runs first), a
+  // workgroup-uniform base + a 32-bit lane offset.  A = scale / l and A D: dS = A Pd dP - (A D) p~, and the dV operand is
+  // bf16(A Pd) -- the same mantissa as bf16(Pd / l) for the power-of-two scale of d_k = 64; dV is multiplied by 1 / scale
+  // once at the end (round 6: two multiplies per score fewer).  Rows beyond T contribute nothing: A = A D = 0.
+  const float4* st4 = reinterpret_cast<const float4*>(Drow) + ((long long)b * p.H + h) * T;
   auto stat_load = [&](int q0) {
     Stat s_;
-    s_.mx = 0.f; s_.inv = 0.f; s_.dd = 0.f; s_.farv = 0.f; s_.qi = q0 + (int)threadIdx.x;
+    s_.qi = q0 + (int)(threadIdx.x & 63);
     s_.keep = kb32[(q0 >> 4) * kb_step];
-    if (threadIdx.x < 64) {
-      const int qc = min(s_.qi, T - 1);
-      const long long ri = ((long long)b * p.H + h) * T + qc;
-      const float* farp = has_far ? QP + ((brow0 + qc) * p.H + h) * rp + p.clamp : LSE + ri;   // (any readable word)
-      s_.mx = LSE[ri]; s_.inv = LSE[nrow + ri]; s_.dd = Drow[ri]; s_.farv = *farp;
-    }
+    s_.s4 = st4[min(s_.qi, T - 1)];
     return s_;
   };
   auto stat_store = [&](int buf, const Stat& s_) {
     if (threadIdx.x < 64) {
-      st_c0[buf][threadIdx.x] = (has_far ? s_.farv * sl2 : 0.f) - s_.mx;
-      st_max[buf][threadIdx.x] = s_.mx;
-      // A = scale / l (0 for rows beyond T: they contribute nothing) and A D: dS = A Pd dP - (A D) p~, and the dV operand is
-      // bf16(A Pd) -- the same mantissa as bf16(Pd / l) for the power-of-two scale of d_k = 64; dV is multiplied by 1 / scale
-      // once at the end (round 6: two multiplies per score fewer)
-      const float a_ = s_.qi < T ? s_.inv * p.scale : 0.f;
-      st_inv[buf][threadIdx.x] = a_;
-      st_d[buf][threadIdx.x] = a_ * s_.dd;
+      st_c0[buf][threadIdx.x] = s_.s4.x;
+      st_max[buf][threadIdx.x] = s_.s4.y;
+      st_inv[buf][threadIdx.x] = s_.qi < T ? s_.s4.z : 0.f;
+      st_d[buf][threadIdx.x] = s_.qi < T ? s_.s4.w : 0.f;
     }
     if (threadIdx.x < 128) st_keep[buf][threadIdx.x] = s_.keep;
   };
@@ -663,9 +658,10 @@ __global__ __launch_bounds__(256, H2 ? 3 : 2) void flash_bwd_dkv_kernel(
     if (QP) {
       const int ql = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
       const int q = min(q0 + ql, T - 1);
-      // one 16-B load (r_pitch is a multiple of 4: rows are 16-B aligned; columns >= r_pitch are zeroed in qp_store)
-      const float* src = QP + ((brow0 + q) * p.H + h) * rp;
-      v = *reinterpret_cast<const float4*>(src + min(c4, rp - 4));
+      // one 16-B load (r_pitch is a multiple of 4: rows are 16-B aligned; columns >= r_pitch are zeroed in qp_store);
+      // uniform base + 32-bit lane offset (an utterance's table is T * H * r_pitch floats)
+      const float* src = QP + (brow0 * p.H + h) * rp;
+      v = *reinterpret_cast<const float4*>(src + (__umul24((unsigned)q, (unsigned)(p.H * rp)) + (unsigned)min(c4, rp - 4)));
     }
     return v;
   };
@@ -927,7 +923,14 @@ __global__ __launch_bounds__(256, 3) void flash_bwd_dq_kernel(
       t = fmaf((float)dOf[s2][6], o1.z, t); t = fmaf((float)dOf[s2][7], o1.w, t);
     }
     dsum = fa_xsum4(t);
-    if (g == 0 && qi < T) Drow[ri] = dsum;
+    // Round 6: everything the dK/dV kernel needs per query in ONE 16-B record {c0, row max, A, A D} -- c0 = position score
+    // at the clamp distance (log2 domain) - row max (the uniform tiles' exponent offset), A = scale / l -- instead of four
+    // scalar loads from three arrays per query and tile (that kernel's per-tile prologue was a third of a wave's time)
+    if (g == 0 && qi < T) {
+      const float farv = (QP && p.clamp > 0) ? QP[((brow0 + qc) * p.H + h) * p.r_pitch + p.clamp] * sl2 : 0.f;
+      const float a_ = rinv * p.scale;
+      reinterpret_cast<float4*>(Drow)[ri] = make_float4(farv - rmax, rmax, a_, a_ * dsum);
+    }
   }
   const bool drop = p.dropout_p > 0.f;
   const float inv_keep = drop ? nsp_rcp(1.f - p.dropout_p) : 1.f;
@@ -1120,7 +1123,7 @@ extern "C" int nsp_flash_attn_fwd(const void* qkv, int d, const float* QP, void*
 // dqkv receives dK at column block d and dV at 2d (bf16); dQP is plainly written (no zero-init needed); the query gradient
 // either as dq32 [B*T, d] fp32 WITHOUT the position term's share (pos16 must be NULL), or -- dq32 == NULL -- finished, as
 // bf16 in column block 0 of dqkv: dS K plus, when pos16 (the projected position table [>= R, d] bf16) is given, dQP . pos16.
-// D is scratch [B,H,T]; keepbits = what the forward call with the same parameters wrote
+// D is scratch [B,H,T,4] (the dQ kernel leaves a 16-B record per query for the dK/dV kernel); keepbits = what the forward call with the same parameters wrote
 // (required iff dropout_p > 0).
 extern "C" int nsp_flash_attn_bwd(const void* qkv, int d, const float* QP, const void* dO, const float* O32,
                                   const float* LSE, const void* keepbits, float* D, void* dqkv, float* dq32, float* dQP,

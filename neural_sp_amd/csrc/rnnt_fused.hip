@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void joint_tanh_compact_kernel(
     q[2] = (__bf16)nsp_tanh(e0.z + g0.z); q[3] = (__bf16)nsp_tanh(e0.w + g0.w);
     q[4] = (__bf16)nsp_tanh(e1.x + g1.x); q[5] = (__bf16)nsp_tanh(e1.y + g1.y);
     q[6] = (__bf16)nsp_tanh(e1.z + g1.z); q[7] = (__bf16)nsp_tanh(e1.w + g1.w);
-    *reinterpret_cast<bf16x8*>(h16 + (row0 + u) * J + 8 * c) = q;
+    // (non-temporal: the 3.7-GB image is next read by the joint kernel long after it has left every L2)
+    __builtin_nontemporal_store(q, reinterpret_cast<bf16x8*>(h16 + (row0 + u) * J + 8 * c));
     if (c == 0) lab[row0 + u] = u < Ub ? labels[(long long)b * (U1 - 1) + u] : -1;
   }
 }

@@ -3408,7 +3408,7 @@ def flash_attn_bwd_raw(qkv16, d, QP, dO16, O32, LSE, keep, mp, dqkv16, pos16=Non
     dev = qkv16.device
     dq32 = None if dq_in_dqkv else torch.empty((M, d), device=dev, dtype=torch.float32)
     dQP = torch.empty_like(QP) if QP is not None else None
-    D = torch.empty((mp.B, mp.H, mp.Tq), device=dev, dtype=torch.float32)
+    D = torch.empty((mp.B, mp.H, mp.Tq, 4), device=dev, dtype=torch.float32)      # per-query records dQ kernel -> dK/dV kernel
     with _kev_class('flash_bwd', 10.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop'):
         _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O32), _p(LSE), _p(keep), _p(D), _p(dqkv16),
                                              _p(dq32), _p(dQP), _p(pos16 if dq_in_dqkv else None), ctypes.byref(mp),
