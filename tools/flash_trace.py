@@ -21,15 +21,16 @@ for p_drop in (0.0, 0.1):
     dO = torch.randn(B * T, d, device=dev).bfloat16()
     dqkv = torch.empty(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
     O, O32, LSE, keep = ops.flash_attn_fwd_raw(qkv, d, QP, mp)
-    ops.flash_attn_bwd_raw(qkv, d, QP, dO, O32, LSE, keep, mp, dqkv)
+    run = (lambda: ops.flash_attn_fwd_raw(qkv, d, QP, mp)) if os.environ.get('FA_TRACE_FWD') else (lambda: ops.flash_attn_bwd_raw(qkv, d, QP, dO, O32, LSE, keep, mp, dqkv))
+    run()
     torch.cuda.synchronize()
     L.nsp_debug_flash_trace(None, 1)
-    ops.flash_attn_bwd_raw(qkv, d, QP, dO, O32, LSE, keep, mp, dqkv)
+    run()
     torch.cuda.synchronize()
     out = (ctypes.c_ulonglong * 6)()
     L.nsp_debug_flash_trace(out, 0)
     tot = float(sum(out))
-    names = ['loads + DMA issue', 'S / dP (16 LDS reads + 16 MFMA)', 'soft-max / dS VALU', 'dV / dK (32 tr reads + 16 MFMA)', 'statistics store', 'vmcnt(0) + barrier']
+    names = os.environ.get('FA_TRACE_NAMES', 'loads + DMA issue|S, dP (LDS reads + MFMA)|soft-max, dS VALU|second products (tr reads + MFMA)|statistics store (dkv) or vmcnt(0) (dq)|barrier').split('|')
     print('dropout %.1f: total %.3g ticks over all waves' % (p_drop, tot))
     for n, v in zip(names, out):
         print('   %-34s %5.1f %%' % (n, 100.0 * v / tot))
