@@ -521,6 +521,10 @@ def _main(a):
                     ent['note'] = 'side stream: the event pairs include co-scheduling with main-stream kernels'
                 if c['unit'] != 'flop':
                     ent['algorithmic_bytes_per_step'] = round(c['work'] / steps_sampled)
+                elif c.get('bytes'):
+                    # (MFMA-bound classes also state the bytes their operands weigh, read / written once: the PMC passes'
+                    # counter bytes over this = the re-read factor of a class, e.g. the two-kernel attention backward)
+                    ent['algorithmic_bytes_per_step'] = round(c['bytes'] / steps_sampled)
                 cls.append(ent)
             roof['classes'] = cls
             # HBM bytes per GEMM launch cannot be counted from inside the process: it is the committed result of

@@ -2472,10 +2472,10 @@ _NULL_CTX = _NullCtx()
 
 
 class _KevClassCtx(object):
-    __slots__ = ('name', 'work', 'unit', 'e0')
+    __slots__ = ('name', 'work', 'unit', 'e0', 'nbytes')
 
-    def __init__(self, name, work, unit):
-        self.name, self.work, self.unit = name, work, unit
+    def __init__(self, name, work, unit, nbytes=0.0):
+        self.name, self.work, self.unit, self.nbytes = name, work, unit, nbytes
 
     def __enter__(self):
         if torch.cuda.current_stream() != torch.cuda.default_stream():
@@ -2487,18 +2487,19 @@ class _KevClassCtx(object):
     def __exit__(self, *exc):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        c = _KEV.setdefault('classes', {}).setdefault(self.name, {'events': [], 'work': 0.0, 'unit': self.unit})
+        c = _KEV.setdefault('classes', {}).setdefault(self.name, {'events': [], 'work': 0.0, 'unit': self.unit, 'bytes': 0.0})
         c['events'].append((self.e0, e1))
         c['work'] += float(self.work)
+        c['bytes'] += float(self.nbytes)
         return False
 
 
-def _kev_class(name, work, unit):
+def _kev_class(name, work, unit, nbytes=0.0):
     """bench.py's `roofline.classes`: HIP events around one launch (group) of a NON-GEMM kernel class on sampled steps,
     with its algorithmic work (`unit` = 'flop' or 'byte').  Side-stream launches are recorded under `<name>@side`:
     their event pairs measure co-scheduling with main-stream kernels.  (Off -- every step but bench.py's sampled ones --
     this returns one shared no-op object: a generator-based context manager cost ~2 us at ~200 call sites per step.)"""
-    return _KevClassCtx(name, work, unit) if _KEV['on'] else _NULL_CTX
+    return _KevClassCtx(name, work, unit, nbytes) if _KEV['on'] else _NULL_CTX
 
 
 def kernel_events_start():
@@ -2523,7 +2524,8 @@ def kernel_events_stop():
     out = {'launches': len(_KEV['events']), 'ms': ms, 'flops': _KEV['flops'], 'algo_flops': _KEV.get('algo_flops', 0.0),
            'side': {'launches': len(_KEV['side_events']), 'ms': sms, 'flops': _KEV['side_flops']},
            'classes': {n: {'launches': len(c['events']), 'ms': sum(a.elapsed_time(b) for a, b in c['events']),
-                           'work': c['work'], 'unit': c['unit']} for n, c in _KEV.get('classes', {}).items()}}
+                           'work': c['work'], 'unit': c['unit'], 'bytes': c.get('bytes', 0.0)}
+                       for n, c in _KEV.get('classes', {}).items()}}
     _KEV['events'], _KEV['side_events'], _KEV['classes'] = [], [], {}
     return out
 
@@ -3394,7 +3396,9 @@ def flash_attn_fwd_raw(qkv16, d, QP, mp, want_o32=True):
     if mp.dropout_p > 0:
         keep = torch.empty((_lib.lib().nsp_flash_attn_keepbits_bytes(mp.B, mp.H, mp.Tq),), device=qkv16.device,
                            dtype=torch.uint8)
-    with _kev_class('flash_fwd', 4.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop'):
+    # algorithmic bytes: q, k, v read (bf16), O written as bf16 and fp32, the two statistics, the position scores, the dropout words
+    nb = M * d * (6 + 2 + (4 if want_o32 else 0)) + 8 * mp.B * mp.H * mp.Tq + (QP.numel() * 4 if QP is not None else 0) + (keep.numel() if keep is not None else 0)
+    with _kev_class('flash_fwd', 4.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop', nb):
         _check(_lib.lib().nsp_flash_attn_fwd(_p(qkv16), d, _p(QP), _p(O), _p(O32), _p(LSE), _p(keep), ctypes.byref(mp),
                                              _stream()), 'nsp_flash_attn_fwd')
     return O, O32, LSE, keep
@@ -3409,7 +3413,11 @@ def flash_attn_bwd_raw(qkv16, d, QP, dO16, O32, LSE, keep, mp, dqkv16, pos16=Non
     dq32 = None if dq_in_dqkv else torch.empty((M, d), device=dev, dtype=torch.float32)
     dQP = torch.empty_like(QP) if QP is not None else None
     D = torch.empty((mp.B, mp.H, mp.Tq, 4), device=dev, dtype=torch.float32)      # per-query records dQ kernel -> dK/dV kernel
-    with _kev_class('flash_bwd', 10.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop'):
+    # algorithmic bytes: q, k, v, dO (bf16), O (fp32), statistics, position scores and their gradient, dropout words read ONCE;
+    # dq, dk, dv written (bf16, or dq as fp32)
+    nb = (M * d * (6 + 2 + 4 + 4 + (2 if dq_in_dqkv else 4)) + 8 * mp.B * mp.H * mp.Tq + (QP.numel() * 8 if QP is not None else 0)
+          + (keep.numel() if keep is not None else 0))
+    with _kev_class('flash_bwd', 10.0 * mp.B * mp.H * mp.Tq * mp.Tk * 64, 'flop', nb):
         _check(_lib.lib().nsp_flash_attn_bwd(_p(qkv16), d, _p(QP), _p(dO16), _p(O32), _p(LSE), _p(keep), _p(D), _p(dqkv16),
                                              _p(dq32), _p(dQP), _p(pos16 if dq_in_dqkv else None), ctypes.byref(mp),
                                              _stream()), 'nsp_flash_attn_bwd')

@@ -61,7 +61,7 @@ if __name__ == '__main__':
         # the other kernel classes bench.py times (roofline.classes): counter bytes per STEP (the trace holds `steps` steps)
         steps = 2
         CLASSES = {'flash_fwd': ('flash_fwd_kernel',), 'flash_bwd': ('flash_bwd_dq_kernel', 'flash_bwd_dkv_kernel'),
-                   'layernorm_fwd': ('ln_fwd_kernel',), 'layernorm_bwd': ('ln_bwd_kernel',),
+                   'layernorm_fwd': ('ln_fwd_kernel', 'ln_pair_fwd_kernel'), 'layernorm_bwd': ('ln_bwd_kernel', 'ln_pair_bwd_kernel'),
                    'conv_frontend_fwd+dgrad': ('conv3x3_c1_kernel', 'conv3x3_c32_b16_kernel', 'conv3x3_c32_kernel')}
         classes = {}
         for cname, pats in CLASSES.items():
