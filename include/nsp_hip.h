@@ -145,6 +145,9 @@ int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs, long long 
                   unsigned long long seed, unsigned long long offset, int a_dtype,
                   int b_dtype, int c_dtype, int pre_dtype, int dact_dtype, long long c_ss,
                   float* colsum_slabs, void* stream);
+/* the same call, its 38 arguments (everything but `stream`, in this order) packed into 38 8-byte little-endian slots:
+ * integers and pointers as int64, alpha and dropout_p as double -- one struct.pack on the Python side */
+int nsp_gemm_packed(const void* packed, void* stream);
 /* colsum_slabs (bf16 operands, splitk == 1; may be NULL): fp32 [4 * ceil(M/128), N] (the tile grid overhangs M),
  * ZERO-INITIALISED by the caller.
  * Row (m / R) receives the column sums of the stored values of rows m .. m+R-1 for every R-row block a wave

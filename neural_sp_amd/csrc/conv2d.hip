@@ -344,6 +344,15 @@ __global__ __launch_bounds__(256) void conv3x3_c32_b16_kernel(const __bf16* __re
     const bool ok = tl < ntiles && t < T && f < F;
     return ok ? (unsigned)((((b * T + t) * F + f) * CH + nb * 16 + g * 4) * 2) : OOB;
   };
+  // the same rows as 16-B chunks: lane = (pixel f0 + (lane >> 2), chunk lane & 3) of row t0 + 2 * wave + a
+  auto row_off = [&](long long tl, int a) -> unsigned {
+    const int tf = (int)(tl % tiles_f);
+    const int tt = (int)((tl / tiles_f) % tiles_t);
+    const long long b = tl / ((long long)tiles_f * tiles_t);
+    const int t = tt * TT + wave * 2 + a, f = tf * TF + (lane >> 2);
+    const bool ok = tl < ntiles && t < T && f < F;
+    return ok ? (unsigned)((((b * T + t) * F + f) * CH) * 2 + (lane & 3) * 16) : OOB;
+  };
   auto fetch_mask = [&](long long tl, cu32x2 (&m)[2][2]) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -386,8 +395,13 @@ __global__ __launch_bounds__(256) void conv3x3_c32_b16_kernel(const __bf16* __re
       }
     }
     commit(ch, smem + (cur ^ 1) * (HT * HF * PP));
+    // Round 6: the outputs leave through a per-wave LDS slab so that every store instruction writes ONE row of 16 pixels =
+    // 1 KB contiguous (16 B per lane); the MFMA layout gives a lane 4 channels (8 B) of a pixel, i.e. 32-B pieces at a
+    // 64-B stride per instruction -- partial lines, the same pattern that made the GEMMs' direct epilogue lose to the staged
+    // one.  Slab: [16 pixels][80 B] (pitch 80: 16-B aligned rows, 2-way on the 8-B writes).
+    unsigned char* slab = smem + 2 * (HT * HF * PP) + wave * (16 * 80);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         float v[4] = {acc[a][nb][0] + bb[nb].x, acc[a][nb][1] + bb[nb].y, acc[a][nb][2] + bb[nb].z,
@@ -405,8 +419,14 @@ __global__ __launch_bounds__(256) void conv3x3_c32_b16_kernel(const __bf16* __re
         }
         bf16x4 h;
         h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2, h), ry, out_off(tile, a, nb), 0, 0);
+        *reinterpret_cast<bf16x4*>(slab + r * 80 + nb * 32 + g * 8) = h;
       }
+      // (one wave, in-order LDS queue: the reads below see the writes above; the slab is private to the wave)
+      __builtin_amdgcn_wave_barrier();
+      const cu32x4 o = *reinterpret_cast<const cu32x4*>(slab + (lane >> 2) * 80 + (lane & 3) * 16);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_raw_buffer_store_b128(o, ry, row_off(tile, a), 0, 0);
+    }
     lds_barrier();   // next halo complete in LDS[cur^1], every wave done reading LDS[cur]
     cur ^= 1;
   };
@@ -1180,7 +1200,7 @@ extern "C" int nsp_conv2d3x3_fwd(const void* x, const float* w, const float* bia
     const long long ntiles = (long long)B * tiles_f * tiles_t;
     const int grid = (int)(ntiles < 1024 ? ntiles : 1024);  // 4 persistent workgroups per CU
     if (mode == NSP_COMPUTE_BF16) {
-      const size_t sh = 2 * HT * HF * ConvCfg<0>::PIX_PITCH;   // double-buffered halo
+      const size_t sh = 2 * HT * HF * ConvCfg<0>::PIX_PITCH + 4 * 16 * 80;   // double-buffered halo + the waves' output slabs (bf16-map kernel)
       if (io16) {
         // buffer-addressed kernel: 32-bit byte offsets -> at most 4 GiB of map per launch (cut over the batch)
         const long long per_utt = (long long)T * F * CH * 2;

@@ -22,6 +22,7 @@
 // The MFMA is issued as D^T = B_frag x A_frag so that each lane ends up with 4
 // consecutive n for one m: the epilogue then uses float4 loads/stores.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -392,4 +393,21 @@ extern "C" int nsp_gemm_flat(int M, int N, int K, const void* A, long long a_rs,
   p.epi_f0 = p.epi_f1 = p.epi_f2 = nullptr; p.epi_f3 = colsum_slabs; p.epi_scale_dev = nullptr; p.epi_scale = 1.f;
   if (colsum_slabs && (a_dtype != NSP_DT_BF16 || splitk > 1)) return NSP_EUNSUPPORTED;
   return nsp_gemm(&p, stream);
+}
+
+// The same call with its 38 arguments packed into 38 little-endian 8-byte slots (int64 / pointer / double) in the order of
+// nsp_gemm_flat's parameter list.  Round 6: ctypes converts arguments one by one (~0.2 us each); a training step at 16
+// utterances per GPU makes ~360 GEMM calls and is bound by the host, so the 39-argument call was ~3 ms of every such step --
+// struct.pack + a two-argument call is ~2 us.
+extern "C" int nsp_gemm_packed(const void* packed, void* stream) {
+  if (!packed) return NSP_EINVAL;
+  long long q[38];
+  memcpy(q, packed, sizeof(q));
+  auto ptr = [&](int i) { return reinterpret_cast<void*>(static_cast<uintptr_t>(q[i])); };
+  auto dbl = [&](int i) { double v; memcpy(&v, &q[i], sizeof(v)); return v; };
+  return nsp_gemm_flat((int)q[0], (int)q[1], (int)q[2], ptr(3), q[4], q[5], ptr(6), q[7], q[8], ptr(9), q[10],
+                       (int)q[11], (int)q[12], q[13], q[14], q[15], q[16], q[17], q[18], reinterpret_cast<const float*>(ptr(19)),
+                       (int)q[20], ptr(21), ptr(22), (int)q[23], reinterpret_cast<const float*>(ptr(24)), (float)dbl(25),
+                       (int)q[26], (int)q[27], (float)dbl(28), (unsigned long long)q[29], (unsigned long long)q[30],
+                       (int)q[31], (int)q[32], (int)q[33], (int)q[34], (int)q[35], q[36], reinterpret_cast<float*>(ptr(37)), stream);
 }

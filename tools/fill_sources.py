@@ -13,7 +13,7 @@ margs = conformer_rnnt_args('L', n_layers=12, vocab=1000, dropout=0.1, ctc_weigh
 model = Speech2Text(margs).cuda(0)
 params = list(model.parameters())
 opt = torch.optim.Adam(params, lr=1e-4, fused=True)
-batch = synthetic_batch(B=16, t_range=(1200, 1600), u_range=(120, 200), vocab=1000, seed=0)
+batch = synthetic_batch(B=int(os.environ.get('NSP_B', '16')), t_range=(1200, 1600), u_range=(120, 200), vocab=1000, seed=0)
 def step():
     loss, _ = model(batch, task='all'); loss.backward()
     parallel.clip_grad_norm_(params, 5.0); opt.step(); opt.zero_grad(set_to_none=True)
