@@ -379,6 +379,11 @@ struct EpiSpec {
   static constexpr bool C16 = C16_, PRE16 = PRE16_, RES = RES_, DROP = DROP_;
 };
 
+template <class S>
+__host__ __device__ constexpr bool epi_spec_slabs() {
+  if constexpr (S::kStatic) return S::DACT != NSP_ACT_NONE;
+  else return true;
+}
 template <int MI, class S, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
                                                    int mrow0, int n, int lane, long long coff) {
@@ -399,6 +404,20 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   const char* side = has_res ? reinterpret_cast<const char*>(p.res) : reinterpret_cast<const char*>(p.dact_src);
   const long long off0 = coff + (long long)(mrow0 + er) * p.ldc + n;
   const long long ldc4 = 4ll * p.ldc;
+  // W32 (round 6; the static specialisations, ldc < 2^22 -- epi_spec_visit): every address of the wave's tile is a
+  // SCALAR origin (SGPR pair, SALU arithmetic per row group) + a 32-bit lane offset that is computed once.  The 64-bit
+  // per-lane forms below cost ~12 VALU per row group (v_mad_u64_u32 + two v_mul_lo_u32 for row * ldc alone) and the
+  // dropout counter another ~16 on top of its two hashes; these epilogues are VALU-bound.
+  constexpr bool W32 = S::kStatic;
+  const int mrow_s = W32 ? __builtin_amdgcn_readfirstlane(mrow0) : mrow0;
+  const int nbase_s = W32 ? __builtin_amdgcn_readfirstlane(n - (lane & 15) * 4) : n;
+  const long long sorg = coff + (long long)mrow_s * p.ldc + nbase_s;          // element offset of the tile's origin (uniform)
+  const unsigned loff = (unsigned)__umul24(er, (int)p.ldc) + (unsigned)((lane & 15) * 4);   // this lane inside row group 0
+  // side operand (clamped, never predicated -- see `request`): its own origin, clamped into the matrix, so that the
+  // lane offsets of a wave whose rows / columns lie beyond the edge stay non-negative
+  const int morg = min(mrow_s, p.M - 1), norg = min(nbase_s, p.N - 4);
+  const long long sorg_side = coff + (long long)morg * p.ldc + norg;
+  const int rows_left = p.M - 1 - morg;                                       // last valid row relative to that origin
   float b4[4] = {0.f, 0.f, 0.f, 0.f};
   {
     if (p.bias && colok) {
@@ -427,23 +446,34 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   // that resolves it waits for the load in the row group that issued it)
   const int ncl = min(n, p.N - 4);
   auto request = [&](int mi, int j, uint4& buf) {
-    const int mcl = min(mrow0 + mi * 16 + er + 4 * j, p.M - 1);
-    const long long off = coff + (long long)mcl * p.ldc + ncl;
+    const char* src2;         // the chunk's address for a 2-byte / 4-byte side operand
+    const char* src4;
+    if constexpr (W32) {
+      const unsigned rrel = (unsigned)min(mi * 16 + 4 * j + er, rows_left);
+      const unsigned el = (unsigned)__umul24((int)rrel, (int)p.ldc) + (unsigned)(ncl - norg);
+      src2 = side + sorg_side * 2 + (size_t)(el * 2u);
+      src4 = side + sorg_side * 4 + (size_t)(el * 4u);
+    } else {
+      const int mcl = min(mrow0 + mi * 16 + er + 4 * j, p.M - 1);
+      const long long off = coff + (long long)mcl * p.ldc + ncl;
+      src2 = side + off * 2;
+      src4 = side + off * 4;
+    }
     if (side16) {
 #if NSP_EPI_SIDE_NT
       typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_;
-      const u32x2_ h = __builtin_nontemporal_load(reinterpret_cast<const u32x2_*>(side + off * 2));
+      const u32x2_ h = __builtin_nontemporal_load(reinterpret_cast<const u32x2_*>(src2));
       buf.x = h[0]; buf.y = h[1];
 #else
-      const uint2 h = *reinterpret_cast<const uint2*>(side + off * 2);
+      const uint2 h = *reinterpret_cast<const uint2*>(src2);
       buf.x = h.x; buf.y = h.y;
 #endif
     } else {
 #if NSP_EPI_SIDE_NT
-      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(side + off * 4));
+      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src4));
       buf = make_uint4(q[0], q[1], q[2], q[3]);
 #else
-      buf = *reinterpret_cast<const uint4*>(side + off * 4);
+      buf = *reinterpret_cast<const uint4*>(src4);
 #endif
     }
   };
@@ -451,6 +481,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
 #pragma unroll
     for (int j = 0; j < 4; ++j) request(0, j, raw[j]);
   }
+  // column-sum slabs exist only beside an act' source in the step (the FFN data gradient); the static specialisations
+  // without one do not carry the four accumulations per row group (epi_spec_visit sends such a request to the run-time version)
+  constexpr bool kSlabs = epi_spec_slabs<S>();
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   // one row group (rows er + 4j of block mi, this lane's four columns): staged accumulators -> stores
   auto row_group = [&](int mi, int j) {
@@ -469,7 +502,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
 #endif
     if (has_side && mi + 1 < MI) request(mi + 1, j, raw[j]);
     v[0] = a4.x + b4[0]; v[1] = a4.y + b4[1]; v[2] = a4.z + b4[2]; v[3] = a4.w + b4[3];
-    if (has_pre && ok) store4(p.pre_out, pre_dt, off, v, 4, true);
+    // W32: scalar element offset of this row group's first row + the lane's 32-bit byte offset
+    const long long srg = sorg + (long long)(mi * 16 + 4 * j) * p.ldc;
+    if (has_pre && ok) {
+      if constexpr (W32) store4(reinterpret_cast<char*>(p.pre_out) + srg * 2 + (size_t)(loff * 2u), pre_dt, 0, v, 4, true);
+      else store4(p.pre_out, pre_dt, off, v, 4, true);
+    }
     if (act != NSP_ACT_NONE) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = nsp_act(v[e], act);
@@ -486,19 +524,37 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= nsp_dact(d[e], dact);
     }
+    if (!(W32 && drop)) {       // (W32 with dropout: alpha rides in the keep scale)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    }
     if (drop) {
       float kp[4];
       if constexpr (S::kStatic) {
-        // (p.offset + off) is even here (the dispatcher checks p.offset): the two-mixes-per-four form of
-        // nsp_keep_scale4 without its per-lane parity branch
-        const unsigned long long base = (p.offset + (unsigned long long)off) >> 1;
-        const uint32_t h0 = nsp_hash_u32(p.seed, base), h1 = nsp_hash_u32(p.seed, base + 1ull);
-        kp[0] = (h0 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
-        kp[1] = (h0 >> 16) < keep_thr ? 0.f : keep_inv;
-        kp[2] = (h1 & 0xFFFFu) < keep_thr ? 0.f : keep_inv;
-        kp[3] = (h1 >> 16) < keep_thr ? 0.f : keep_inv;
+        // (p.offset + off) is even here (the dispatcher checks p.offset; ldc % 4 == 0): the two-mixes-per-four form of
+        // nsp_keep_scale4 without its per-lane parity branch.  The counter (p.offset + off) >> 1 = SCALAR part (this row
+        // group's origin) + lane part (loff >> 1), both halves exact because both terms are even; nsp_hash_u32 starts
+        // with x = lo ^ K(hi), K = seed mix ^ ((hi ^ seed_hi) * c1 + c2): K for hi and hi + 1 are scalars, the carry of
+        // the 32-bit add picks one; the second counter is the first + 1 with the first even, i.e. x ^ 1, same hi.
+        // Bit-identical masks to nsp_keep_scale4 (tests/test_gemm_epilogues_gpu.py compares with the oracle's masks).
+        const unsigned long long cnt = (p.offset + (unsigned long long)srg) >> 1;
+        const uint32_t clo = (uint32_t)cnt, chi = (uint32_t)(cnt >> 32);
+        const uint32_t smix = (uint32_t)p.seed * 0x9E3779B9u, shi = (uint32_t)(p.seed >> 32);
+        const uint32_t k0 = smix ^ ((chi ^ shi) * 0x85EBCA6Bu + 0x632BE5ABu);
+        uint32_t k1 = smix ^ (((chi + 1u) ^ shi) * 0x85EBCA6Bu + 0x632BE5ABu);
+#ifndef NSP_HOST_EMULATION
+        asm volatile("" : "+s"(k1));   // (opaque: otherwise the select below is sunk into a per-lane hi word + v_mul_lo_u32 again)
+#endif
+        const uint32_t lo = clo + (loff >> 1);
+        uint32_t h0 = lo ^ (lo < clo ? k1 : k0);
+        uint32_t h1 = h0 ^ 1u;
+        h0 ^= h0 >> 16; h0 *= 0x85EBCA6Bu; h0 ^= h0 >> 13; h0 *= 0xC2B2AE35u; h0 ^= h0 >> 16;
+        h1 ^= h1 >> 16; h1 *= 0x85EBCA6Bu; h1 ^= h1 >> 13; h1 *= 0xC2B2AE35u; h1 ^= h1 >> 16;
+        const float kscale = keep_inv * p.alpha;
+        kp[0] = (h0 & 0xFFFFu) < keep_thr ? 0.f : kscale;
+        kp[1] = (h0 >> 16) < keep_thr ? 0.f : kscale;
+        kp[2] = (h1 & 0xFFFFu) < keep_thr ? 0.f : kscale;
+        kp[3] = (h1 >> 16) < keep_thr ? 0.f : kscale;
       } else {
         nsp_keep_scale4(p.seed, p.offset + (unsigned long long)off, p.dropout_p, kp);
       }
@@ -510,9 +566,16 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
       v[2] += __uint_as_float(sd.z); v[3] += __uint_as_float(sd.w);
     }
     if (ok) {
-      store4(p.C, c_dt, off, v, 4, true);
+      if constexpr (W32) {
+        if (c_dt == NSP_DT_BF16) store4(reinterpret_cast<char*>(p.C) + srg * 2 + (size_t)(loff * 2u), c_dt, 0, v, 4, true);
+        else store4(reinterpret_cast<char*>(p.C) + srg * 4 + (size_t)(loff * 4u), c_dt, 0, v, 4, true);
+      } else {
+        store4(p.C, c_dt, off, v, 4, true);
+      }
+      if constexpr (kSlabs) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) csum[e] += v[e];
+        for (int e = 0; e < 4; ++e) csum[e] += v[e];
+      }
     }
   };
   // MEASURED AND REMOVED (round 3): finishing row groups in pairs with a DPP lane swap so that every bf16 image
@@ -536,7 +599,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (p.epi_f3) {
+  if (kSlabs && p.epi_f3) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       csum[e] += __shfl_xor(csum[e], 16, 64);
@@ -555,6 +618,11 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
 
 // picks the specialisation for the epilogues of the training step (bf16 mode); SPECIALISE = false keeps a
 // kernel on the run-time version only (compile time / code size of the kernels that rarely see big grids)
+// what the static specialisations assume beyond their EpiSpec (gemm_epilogue_fast, W32): 32-bit lane offsets inside a
+// wave's tile (at most 128 rows x ldc elements x 4 B), column-sum slabs only beside an act' source
+__host__ __device__ __forceinline__ bool epi_spec_w32_ok(const nsp_gemm_params& p) {
+  return p.ldc < (1ll << 22) && !(p.epi_f3 && !p.dact_src);
+}
 template <int MI, bool SPECIALISE, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
                                                             int mrow0, int nbase, int lane, long long coff) {
@@ -564,7 +632,7 @@ __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_param
     const bool c16 = p.c_dtype == NSP_DT_BF16;
     const bool drop = p.dropout_p > 0.f;
     const bool even = (p.offset & 1ull) == 0ull;
-    if (even || !drop) {
+    if ((even || !drop) && epi_spec_w32_ok(p)) {
       if (p.pre_out && p.pre_dtype == NSP_DT_BF16 && c16 && !p.res && !p.dact_src) {           // FFN first linear
         if (p.act == NSP_ACT_SWISH) { if (drop) NSP_EPI(NSP_ACT_SWISH, 0, true, true, false, true); NSP_EPI(NSP_ACT_SWISH, 0, true, true, false, false); }
         if (p.act == NSP_ACT_RELU) { if (drop) NSP_EPI(NSP_ACT_RELU, 0, true, true, false, true); NSP_EPI(NSP_ACT_RELU, 0, true, true, false, false); }
@@ -1141,7 +1209,7 @@ __host__ __device__ __forceinline__ bool epi_spec_visit(const nsp_gemm_params& p
   const bool c16 = p.c_dtype == NSP_DT_BF16;
   const bool drop = p.dropout_p > 0.f;
   const bool even = (p.offset & 1ull) == 0ull;
-  if (!(even || !drop)) return false;
+  if (!(even || !drop) || !epi_spec_w32_ok(p)) return false;
 #define NSP_VISIT(...) do { f(EpiSpec<__VA_ARGS__>{}); return true; } while (0)
   if (p.pre_out && p.pre_dtype == NSP_DT_BF16 && c16 && !p.res && !p.dact_src) {           // FFN first linear
     if (p.act == NSP_ACT_SWISH) { if (drop) NSP_VISIT(NSP_ACT_SWISH, 0, true, true, false, true); NSP_VISIT(NSP_ACT_SWISH, 0, true, true, false, false); }
@@ -1831,7 +1899,7 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
     const int tm256 = nsp_cdiv(p.M, 256), tn256 = nsp_cdiv(p.N, 256);
     const dim3 g(tm256 * tn256 * p.splitk);
     const bool plain = !p.bias && !p.res && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE && p.dropout_p == 0.f &&
-                       p.c_dtype == NSP_DT_F32 && !p.epi_f3;
+                       p.c_dtype == NSP_DT_F32 && epi_spec_w32_ok(p);
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<EpiSpec<0, 0, false, false, false, false>, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
