@@ -156,11 +156,18 @@ __device__ __forceinline__ TileCoord tile_coord(const nsp_gemm_params& p, int nt
 #ifndef NSP_EPI_STORE
 #define NSP_EPI_STORE 1
 #endif
+#ifndef NSP_EPI_ABLATE
+#define NSP_EPI_ABLATE 0    // development: bit 0 no stores, bit 1 no epilogue arithmetic, bit 2 no LDS staging (timing only)
+#endif
 #ifndef NSP_EPI_SIDE_NT
 #define NSP_EPI_SIDE_NT 1
 #endif
 __device__ __forceinline__ void store4(void* base, int dtype, long long off, const float* v, int nv,
                                        bool vec) {
+#if NSP_EPI_ABLATE & 1      // (ablation: values computed, nothing stored)
+  asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  return;
+#endif
   if (dtype == NSP_DT_BF16) {
     __bf16* o = reinterpret_cast<__bf16*>(base) + off;
     if (vec) {
@@ -267,10 +274,12 @@ __device__ __forceinline__ void rnnt_epilogue_core(const nsp_gemm_params& p, f32
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
+#if !(NSP_EPI_ABLATE & 4)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
       *reinterpret_cast<float4*>(stage + stage_idx<SWZ>(fr, ni * 4 + fg)) =
           make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+#endif
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -379,6 +388,22 @@ struct EpiSpec {
   static constexpr bool C16 = C16_, PRE16 = PRE16_, RES = RES_, DROP = DROP_;
 };
 
+typedef __attribute__((ext_vector_type(4))) unsigned int cu32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int cu32x2_t;
+#ifndef NSP_EPI_BUF
+#define NSP_EPI_BUF 1         // 0: the static specialisations with predicated global stores / clamped global side loads again
+#endif
+#ifndef NSP_EPI_RG_GROUP_8P
+#define NSP_EPI_RG_GROUP_8P 1   // row groups the scheduler may interleave (8-phase kernel / 128 x 128 kernels)
+#endif
+#ifndef NSP_EPI_RG_GROUP_128
+#define NSP_EPI_RG_GROUP_128 1
+#endif
+template <class S>
+__host__ __device__ constexpr bool epi_spec_has_side() {
+  if constexpr (S::kStatic) return S::DACT != NSP_ACT_NONE || S::RES;
+  else return true;
+}
 template <class S>
 __host__ __device__ constexpr bool epi_spec_slabs() {
   if constexpr (S::kStatic) return S::DACT != NSP_ACT_NONE;
@@ -418,6 +443,26 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   const int morg = min(mrow_s, p.M - 1), norg = min(nbase_s, p.N - 4);
   const long long sorg_side = coff + (long long)morg * p.ldc + norg;
   const int rows_left = p.M - 1 - morg;                                       // last valid row relative to that origin
+  // BUF (static specialisations): stores and side loads are BUFFER instructions whose descriptor starts at the tile's
+  // origin and ends with the matrix -- rows >= M are out of range by construction, lanes with columns >= N carry an
+  // out-of-range offset; the row group's offset rides in the scalar offset field.  No predicated blocks (each was a
+  // basic block of its own: s_and_saveexec + branch, and nothing could be scheduled across it), no address VALU at all.
+  // (the 128 x 128 kernel compiles thirteen specialisations into one kernel at 128 VGPRs: with three descriptors live in
+  // the side-operand variants it spilled 178 registers and the FFN data gradient went from 352 to 488 us -- there the
+  // side-operand variants keep global loads / stores, profiles/r06_gemm_epilogue.log)
+  constexpr bool BUF = W32 && NSP_EPI_BUF && (SWZ || !(S::kStatic && epi_spec_has_side<S>()));
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int AUXS = NSP_EPI_STORE >= 1 ? 2 : 0, AUXL = NSP_EPI_SIDE_NT ? 2 : 0;
+  const long long rem_el = (long long)p.M * p.ldc - ((long long)mrow_s * p.ldc + nbase_s);   // elements from the origin to the end
+  auto mkrsrc = [&](const void* ptr, int esz) {
+    const long long b = rem_el * esz;
+    const unsigned nrec = b <= 0 ? 0u : (b > 0x40000000ll ? 0x40000000u : (unsigned)b);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(ptr)) + sorg * esz, 0, nrec, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rc = mkrsrc(p.C, c_dt == NSP_DT_BF16 ? 2 : 4);
+  const __amdgpu_buffer_rsrc_t rpre = mkrsrc(has_pre ? p.pre_out : p.C, 2);
+  const __amdgpu_buffer_rsrc_t rside = mkrsrc(has_side ? reinterpret_cast<const void*>(side) : reinterpret_cast<const void*>(p.C), side16 ? 2 : 4);
+  const unsigned lo2 = colok ? loff * 2u : OOB, lo4 = colok ? loff * 4u : OOB;
   float b4[4] = {0.f, 0.f, 0.f, 0.f};
   {
     if (p.bias && colok) {
@@ -446,6 +491,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   // that resolves it waits for the load in the row group that issued it)
   const int ncl = min(n, p.N - 4);
   auto request = [&](int mi, int j, uint4& buf) {
+    if constexpr (BUF) {
+      const unsigned srq = (unsigned)(mi * 16 + 4 * j) * (unsigned)p.ldc;
+      if (side16) {
+        const cu32x2_t h = __builtin_amdgcn_raw_buffer_load_b64(rside, lo2, srq * 2u, AUXL);
+        buf.x = h[0]; buf.y = h[1];
+      } else {
+        const cu32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rside, lo4, srq * 4u, AUXL);
+        buf = make_uint4(q[0], q[1], q[2], q[3]);
+      }
+      return;
+    }
     const char* src2;         // the chunk's address for a 2-byte / 4-byte side operand
     const char* src4;
     if constexpr (W32) {
@@ -489,7 +545,11 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   auto row_group = [&](int mi, int j) {
     float v[4];
     const int row = er + 4 * j;
+#if NSP_EPI_ABLATE & 4      // (ablation: no LDS staging -- the lane's own fragment values stand in for the transposed ones)
+    const float4 a4 = make_float4(acc[mi][j][0], acc[mi][j][1], acc[mi][j][2], acc[mi][j][3]);
+#else
     const float4 a4 = *reinterpret_cast<const float4*>(stage + stage_idx<SWZ>(row, lane & 15));
+#endif
     const int m = mrow0 + mi * 16 + row;
     const bool ok = m < p.M && colok;              // only the stores are predicated
     const long long off = off0 + (long long)(mi * 4 + j) * ldc4;
@@ -502,9 +562,23 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
 #endif
     if (has_side && mi + 1 < MI) request(mi + 1, j, raw[j]);
     v[0] = a4.x + b4[0]; v[1] = a4.y + b4[1]; v[2] = a4.z + b4[2]; v[3] = a4.w + b4[3];
+#if NSP_EPI_ABLATE & 2      // (ablation: no activation / act' / dropout arithmetic -- wrong results, timing only)
+    if (ok) {
+      if (has_pre) store4(reinterpret_cast<char*>(p.pre_out) + (sorg + (long long)(mi * 16 + 4 * j) * p.ldc) * 2 + (size_t)(loff * 2u), pre_dt, 0, v, 4, true);
+      store4(reinterpret_cast<char*>(p.C) + (sorg + (long long)(mi * 16 + 4 * j) * p.ldc) * (c_dt == NSP_DT_BF16 ? 2 : 4) + (size_t)(loff * (c_dt == NSP_DT_BF16 ? 2u : 4u)), c_dt, 0, v, 4, true);
+    }
+    return;
+#endif
     // W32: scalar element offset of this row group's first row + the lane's 32-bit byte offset
     const long long srg = sorg + (long long)(mi * 16 + 4 * j) * p.ldc;
-    if (has_pre && ok) {
+    const unsigned srb = (unsigned)(mi * 16 + 4 * j) * (unsigned)p.ldc;     // (BUF) the same relative to the descriptor's base
+    if constexpr (BUF) {
+      if (has_pre) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2_t, h), rpre, lo2, srb * 2u, AUXS);
+      }
+    } else if (has_pre && ok) {
       if constexpr (W32) store4(reinterpret_cast<char*>(p.pre_out) + srg * 2 + (size_t)(loff * 2u), pre_dt, 0, v, 4, true);
       else store4(p.pre_out, pre_dt, off, v, 4, true);
     }
@@ -565,7 +639,20 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
       v[0] += __uint_as_float(sd.x); v[1] += __uint_as_float(sd.y);
       v[2] += __uint_as_float(sd.z); v[3] += __uint_as_float(sd.w);
     }
-    if (ok) {
+    if constexpr (BUF) {
+      if (c_dt == NSP_DT_BF16) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2_t, h), rc, lo2, srb * 2u, AUXS);
+      } else {
+        const f32x4 q = {v[0], v[1], v[2], v[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cu32x4_t, q), rc, lo4, srb * 4u, AUXS);
+      }
+      if constexpr (kSlabs) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] += ok ? v[e] : 0.f;
+      }
+    } else if (ok) {
       if constexpr (W32) {
         if (c_dt == NSP_DT_BF16) store4(reinterpret_cast<char*>(p.C) + srg * 2 + (size_t)(loff * 2u), c_dt, 0, v, 4, true);
         else store4(reinterpret_cast<char*>(p.C) + srg * 4 + (size_t)(loff * 4u), c_dt, 0, v, 4, true);
@@ -594,7 +681,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_sched_barrier(0);   // one row group at a time: interleaving four of them costs ~24 VGPRs
+      // one row group at a time (interleaving four of them costs ~24 VGPRs) unless the build says otherwise
+      if (!BUF || j % (SWZ ? NSP_EPI_RG_GROUP_8P : NSP_EPI_RG_GROUP_128) == 0)
+        __builtin_amdgcn_sched_barrier(0);
       row_group(mi, j);
     }
     __builtin_amdgcn_wave_barrier();
@@ -1053,8 +1142,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kk_ring_kernel(const nsp_g
 // All memory operations are BUFFER instructions with the range check as the predicate (rows >= M, columns >= N get an
 // out-of-range offset: loads return 0, stores are dropped): no branches, so hipcc's counted waits survive.
 // Static specialisations only; requires N % 4 == 0 and M * ldc * 4 < 2^31 (32-bit byte offsets).
-typedef __attribute__((ext_vector_type(4))) unsigned int cu32x4_t;
-typedef __attribute__((ext_vector_type(2))) unsigned int cu32x2_t;
 template <class S, int AUX_NT = 2>               // AUX_NT: gfx940+ cache policy of the stores / side loads (2 = nt, 0 = default)
 __device__ __forceinline__ void gemm_epilogue_direct(const nsp_gemm_params& p, f32x4 (&acc)[4][4], int mrow0, int ncol,
                                                      int lane) {
