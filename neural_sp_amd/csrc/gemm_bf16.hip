@@ -411,7 +411,8 @@ __host__ __device__ constexpr bool epi_spec_slabs() {
 }
 template <int MI, class S, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
-                                                   int mrow0, int n, int lane, long long coff) {
+                                                   int mrow0, int n, int lane, long long coff,
+                                                   const float4* bias_pre = nullptr) {
   const int fr = lane & 15, fg = lane >> 4;
   const int er = lane >> 4, ec = (lane & 15) * 4;
   const bool colok = n < p.N;                       // N % 4 == 0: all four columns or none
@@ -464,20 +465,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   const __amdgpu_buffer_rsrc_t rside = mkrsrc(has_side ? reinterpret_cast<const void*>(side) : reinterpret_cast<const void*>(p.C), side16 ? 2 : 4);
   const unsigned lo2 = colok ? loff * 2u : OOB, lo4 = colok ? loff * 4u : OOB;
   float b4[4] = {0.f, 0.f, 0.f, 0.f};
-  {
-    if (p.bias && colok) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-      b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
-    }
-    // The bias must have LANDED before the row loop, and the compiler must know it.  The row groups below are
-    // predicated blocks (only rows < M store); hipcc's wait insertion does not carry "this load was waited
-    // for" out of a conditional block, so it re-waited for the bias in EVERY row group -- as s_waitcnt
-    // vmcnt(0), which on gfx9 (one in-order counter for loads and stores) also waits for every store of the
-    // previous row groups: 16 store round trips per tile in the epilogues that have a bias but no side
-    // operand (FFN first linear, pointwise conv 1, every plain Linear).  This builtin is a wait the
-    // compiler's scoreboard sees: afterwards only lgkmcnt waits remain inside the loop (round 3, .s audit).
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
-  }
+  const bool bias_here = bias_pre == nullptr && p.bias && colok;
+  float4 bld = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias_pre) bld = *bias_pre;                   // (requested by the kernel in front of its main loop)
+  else if (bias_here) bld = *reinterpret_cast<const float4*>(p.bias + n);
+  // The bias must have LANDED before the row loop, and the compiler must know it.  The row groups below are
+  // predicated blocks (only rows < M store); hipcc's wait insertion does not carry "this load was waited
+  // for" out of a conditional block, so it re-waited for the bias in EVERY row group -- as s_waitcnt
+  // vmcnt(0), which on gfx9 (one in-order counter for loads and stores) also waits for every store of the
+  // previous row groups: 16 store round trips per tile in the epilogues that have a bias but no side
+  // operand (FFN first linear, pointwise conv 1, every plain Linear).  The builtin wait below is a wait the
+  // compiler's scoreboard sees: afterwards only lgkmcnt waits remain inside the loop (round 3, .s audit).
   const uint32_t keep_thr = (uint32_t)(p.dropout_p * 65536.f);
   const float keep_inv = nsp_rcp(1.f - p.dropout_p);
   // side operand of the CURRENT row block, one 16-B (fp32) / 8-B (bf16) chunk per row group; the chunk of
@@ -537,6 +535,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
 #pragma unroll
     for (int j = 0; j < 4; ++j) request(0, j, raw[j]);
   }
+  // ONE wait for everything requested above (round 6): the bias, the side operand of row block 0 and -- in the
+  // persistent 8-phase kernel -- the LDS-DMA units of the next tile that are still in flight (they must have landed
+  // before the first store is issued: the next tile's counted waits then never have a store among the operations they
+  // leave in flight).  Before, these were up to three round trips one after the other in front of every tile's
+  // first row group (drain, then the bias, then the side operand).
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+  b4[0] = bld.x; b4[1] = bld.y; b4[2] = bld.z; b4[3] = bld.w;
   // column-sum slabs exist only beside an act' source in the step (the FFN data gradient); the static specialisations
   // without one do not carry the four accumulations per row group (epi_spec_visit sends such a request to the run-time version)
   constexpr bool kSlabs = epi_spec_slabs<S>();
@@ -687,16 +692,20 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
       row_group(mi, j);
     }
     __builtin_amdgcn_wave_barrier();
-  }
-  if (kSlabs && p.epi_f3) {
+    // column-sum slabs: one slab row per block of FB row blocks (64 rows, or the whole wave tile when it is shorter)
+    constexpr int FB = MI < 4 ? MI : 4;
+    if ((mi % FB) == FB - 1 && kSlabs && p.epi_f3) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      csum[e] += __shfl_xor(csum[e], 16, 64);
-      csum[e] += __shfl_xor(csum[e], 32, 64);
+      for (int e = 0; e < 4; ++e) {
+        csum[e] += __shfl_xor(csum[e], 16, 64);
+        csum[e] += __shfl_xor(csum[e], 32, 64);
+      }
+      if (lane < 16 && colok)
+        *reinterpret_cast<float4*>(p.epi_f3 + (long long)((mrow0 + (mi - (FB - 1)) * 16) / (16 * FB)) * p.N + n) =
+            make_float4(csum[0], csum[1], csum[2], csum[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] = 0.f;
     }
-    if (lane < 16 && colok)
-      *reinterpret_cast<float4*>(p.epi_f3 + (long long)(mrow0 / (16 * MI)) * p.N + n) =
-          make_float4(csum[0], csum[1], csum[2], csum[3]);
   }
   // The run-time version can leave a (conditional, never consumed) side-operand load on the compiler's scoreboard.  In a
   // PERSISTENT caller all epilogue variants merge at the tile loop's back edge, and the merged state made hipcc put an
@@ -714,9 +723,10 @@ __host__ __device__ __forceinline__ bool epi_spec_w32_ok(const nsp_gemm_params& 
 }
 template <int MI, bool SPECIALISE, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_params& p, f32x4 (&acc)[MI][4], float* stage,
-                                                            int mrow0, int nbase, int lane, long long coff) {
+                                                            int mrow0, int nbase, int lane, long long coff,
+                                                            const float4* bias_pre = nullptr) {
   const int n = nbase + (lane & 15) * 4;
-#define NSP_EPI(...) do { gemm_epilogue_fast<MI, EpiSpec<__VA_ARGS__>, SWZ>(p, acc, stage, mrow0, n, lane, coff); return; } while (0)
+#define NSP_EPI(...) do { gemm_epilogue_fast<MI, EpiSpec<__VA_ARGS__>, SWZ>(p, acc, stage, mrow0, n, lane, coff, bias_pre); return; } while (0)
   if constexpr (SPECIALISE) {
     const bool c16 = p.c_dtype == NSP_DT_BF16;
     const bool drop = p.dropout_p > 0.f;
@@ -739,7 +749,7 @@ __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_param
     }
   }
 #undef NSP_EPI
-  gemm_epilogue_fast<MI, EpiRuntime, SWZ>(p, acc, stage, mrow0, n, lane, coff);
+  gemm_epilogue_fast<MI, EpiRuntime, SWZ>(p, acc, stage, mrow0, n, lane, coff, bias_pre);
 }
 
 // ---- shared epilogue (see the comment inside): acc[mi][ni] -> global with full-line accesses
@@ -748,7 +758,8 @@ __device__ __forceinline__ void gemm_epilogue_fast_dispatch(const nsp_gemm_param
 template <int MI, bool GENERIC = true, bool SPEC = !GENERIC>  // MI 16-row fragments per wave along M (wave tile = 16*MI x 64)
 __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&acc)[MI][4],
                                               unsigned char* smem, int m0, int n0, int wm, int wn,
-                                              int lane, int wave, long long coff, int c_vec) {
+                                              int lane, int wave, long long coff, int c_vec,
+                                              const float4* bias_pre = nullptr) {
   if constexpr (GENERIC) {
     if (p.epi_mode != NSP_EPI_NONE) {
       rnnt_epilogue<MI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
@@ -766,7 +777,7 @@ __device__ __forceinline__ void gemm_epilogue(const nsp_gemm_params& p, f32x4 (&
   constexpr int SP = 68;  // floats per staged row (64 + 4 pad)
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * SP);
   if (!GENERIC || (c_vec && (p.N & 3) == 0 && !atomic && !(p.res && p.dact_src))) {
-    gemm_epilogue_fast_dispatch<MI, SPEC>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64, lane, coff);
+    gemm_epilogue_fast_dispatch<MI, SPEC>(p, acc, stage, m0 + wm * (16 * MI), n0 + wn * 64, lane, coff, bias_pre);
     return;
   }
   if constexpr (!GENERIC) return;
@@ -956,6 +967,16 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const ns
       kend = kbeg;           // slab mode: an empty split still has to write its zeros
     }
   }
+#if defined(NSP_GLDS_STAGGER) && !defined(NSP_HOST_EMULATION)
+  // (experiment) the four co-resident workgroups of a CU start together and run their main loops and epilogues in step;
+  // delay the first generation by (wave slot on its SIMD) x NSP_GLDS_STAGGER x 8128 clocks
+  if (blockIdx.x < 1024) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const int slot = hwid & 3;
+    for (int i = 0; i < slot * NSP_GLDS_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -980,6 +1001,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const ns
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
 
+  // the epilogue's bias chunk, requested HERE (round 6): it lands during the first k-tile instead of costing every
+  // workgroup a round trip between its last MFMA and its first store (4 VGPRs through the main loop)
+  float4 bias_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (EPI == 0) {
+    const int nb = n0 + wn * 64 + (lane & 15) * 4;
+    if (p.bias && nb < p.N) bias_pre = *reinterpret_cast<const float4*>(p.bias + nb);
+  }
   if (EPI == 0) NSP_TRACE_MARK(0);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
@@ -1012,7 +1040,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bf16_kk_glds_kernel(const ns
   if (EPI == 0) NSP_TRACE_MARK(2);
   if constexpr (EPI == 1) rnnt_epilogue_mode<4, true>(p, acc, smem, m0, n0, wm, wn, lane, wave);
   else if constexpr (EPI == 2) rnnt_epilogue_mode<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave);
-  else gemm_epilogue<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec);
+  else gemm_epilogue<4, false>(p, acc, smem, m0, n0, wm, wn, lane, wave, coff, c_vec, &bias_pre);
 #if NSP_GEMM_TRACE
   if (EPI == 0) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // the stores have left (vmcnt(0)) before the last mark
@@ -1665,7 +1693,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     }
     // this wave's outstanding DMA (units 3-5 of the next tile) lands before the first store is issued: the counted
     // waits of the next tile then never have a store among the operations they leave in flight
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the wait itself sits inside gemm_epilogue_fast, behind the requests for the bias and the first side-operand chunks)
     const int mrow = tm * 256 + wr * 128, ncol = tn * 256 + wc * 64;
     // everything the epilogue derives from the lane index is derived HERE, behind an opaque copy: otherwise the
     // compiler hoists its address arithmetic out of the tile loop and the main loop spills (ISA audit, round 4)
@@ -1674,9 +1702,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     asm volatile("" : "+v"(elane));
 #endif
     if constexpr (!S::kStatic || (VAR & 4)) {
-      gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol + (elane & 15) * 4, elane, coff);
-      gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol + (elane & 15) * 4, elane, coff);
+      // ONE call over the wave's eight row blocks (round 6; two calls of four re-loaded the bias and started their
+      // side-operand chain behind a vmcnt(0) that also waited for all 32 stores of the first half)
+      if constexpr (S::kStatic) {
+        gemm_epilogue_fast<8, S, true>(p, acc, stage, mrow, ncol + (elane & 15) * 4, elane, coff);
+      } else {   // (the run-time version over eight blocks is not unrolled by hipcc: dynamic accumulator indexing, scratch)
+        gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), stage, mrow, ncol + (elane & 15) * 4, elane, coff);
+        gemm_epilogue_fast<4, S, true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), stage, mrow + 64, ncol + (elane & 15) * 4, elane, coff);
+      }
     } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       gemm_epilogue_direct<S, (VAR & 8) ? 0 : 2>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), mrow, ncol, elane);
       gemm_epilogue_direct<S, (VAR & 8) ? 0 : 2>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), mrow + 64, ncol, elane);
     }
