@@ -451,6 +451,15 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
   // (the 128 x 128 kernel compiles thirteen specialisations into one kernel at 128 VGPRs: with three descriptors live in
   // the side-operand variants it spilled 178 registers and the FFN data gradient went from 352 to 488 us -- there the
   // side-operand variants keep global loads / stores, profiles/r06_gemm_epilogue.log)
+  // STORES: the row group's offset is ADDED TO THE LANE OFFSET, the scalar-offset field stays 0.  With the offset in an SGPR
+  // (first version of this path) some builds of the 8-phase kernel stored a wrong first dword in the last four of every 16
+  // lanes of one row group -- the integer that the NEXT instruction, a VALU write of the store's first data register (the
+  // next row group's LDS address), had just produced: on gfx950 a 128-bit buffer store still reads its data registers in
+  // the cycle after issue, and hipcc's hazard recogniser leaves out the wait state when soffset is a register (its rule:
+  // the hazard exists "only if the instruction is not using a register in the soffset field").  Whether a build showed
+  // it depended on the register allocation, i.e. on unrelated code (found while a stream-K schedule was being added to the
+  // kernel: profiles/r06_gemm_epilogue.log).  An out-of-range lane (OOB = 2^31) stays out of range: the sum is below
+  // 2^32 and the descriptors are at most 2^30 bytes long.  (The side-operand LOADS keep the scalar offset: no such hazard.)
   constexpr bool BUF = W32 && NSP_EPI_BUF && (SWZ || !(S::kStatic && epi_spec_has_side<S>()));
   constexpr unsigned OOB = 0x80000000u;
   constexpr int AUXS = NSP_EPI_STORE >= 1 ? 2 : 0, AUXL = NSP_EPI_SIDE_NT ? 2 : 0;
@@ -581,7 +590,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
       if (has_pre) {
         bf16x4 h;
         h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2_t, h), rpre, lo2, srb * 2u, AUXS);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2_t, h), rpre, lo2 + srb * 2u, 0, AUXS);
       }
     } else if (has_pre && ok) {
       if constexpr (W32) store4(reinterpret_cast<char*>(p.pre_out) + srg * 2 + (size_t)(loff * 2u), pre_dt, 0, v, 4, true);
@@ -648,10 +657,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const nsp_gemm_params& p, f32
       if (c_dt == NSP_DT_BF16) {
         bf16x4 h;
         h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2_t, h), rc, lo2, srb * 2u, AUXS);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cu32x2_t, h), rc, lo2 + srb * 2u, 0, AUXS);
       } else {
         const f32x4 q = {v[0], v[1], v[2], v[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cu32x4_t, q), rc, lo4, srb * 4u, AUXS);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cu32x4_t, q), rc, lo4 + srb * 4u, 0, AUXS);
       }
       if constexpr (kSlabs) {
 #pragma unroll
