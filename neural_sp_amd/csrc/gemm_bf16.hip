@@ -23,7 +23,9 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 #ifndef NSP_GEMM_8P_AB
 #define NSP_GEMM_8P_AB 0   // development (-DNSP_GEMM_8P_AB=1): also compile the direct-epilogue twins (NSP_GEMM_8P_VAR=0 / 8) and the main-loop ablations (20 / 36)
 #endif
@@ -399,6 +401,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int cu32x2_t;
 #ifndef NSP_EPI_RG_GROUP_128
 #define NSP_EPI_RG_GROUP_128 1
 #endif
+// the specialisations that have a stream-K twin of the 8-phase kernel: the fp32-output epilogues of the step's N = 512
+// products (plain data gradients; bias / dropout / residual of the FFN second linear and the attention output)
+template <class S>
+__host__ __device__ constexpr bool epi_spec_streamk_twin() {
+  if constexpr (S::kStatic) return !S::C16 && !S::PRE16 && S::ACT == 0 && S::DACT == 0;
+  else return false;
+}
 template <class S>
 __host__ __device__ constexpr bool epi_spec_has_side() {
   if constexpr (S::kStatic) return S::DACT != NSP_ACT_NONE || S::RES;
@@ -1413,9 +1422,10 @@ __device__ __attribute__((aligned(256))) unsigned int nsp_zero_line[64];   // 25
 // no scratch).  The launcher picks S with the table of epi_spec_visit.
 // VAR (development A/B, NSP_GEMM_8P_VAR): bit 0 = no s_setprio around the MFMA segments, bit 1 = static priority 1 for the
 // second (later dispatched) wave half instead, bit 2 = staged (LDS) epilogue for S instead of the direct one.
-template <class S, int VAR = 0, bool RR = false>
+template <class S, int VAR = 0, bool RR = false, bool SK = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_params p, int tiles_m, int tiles_n,
-                                                                int c_vec) {
+                                                                int c_vec, unsigned char* skws = nullptr,
+                                                                unsigned sk_epoch = 0u) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // 2 x (A 32 KB | B 32 KB) | 8 x 4 KB staging
   constexpr int BUF = 65536, A_BYTES = 32768, STAGING = 131072;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1436,6 +1446,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     nit = (min(ktbeg + per, nkt_pad) - ktbeg) >> 1;
     coff = p.c_ss ? (long long)tc.split * p.c_ss : 0;
   }
+  const int nit_full = nit;                    // iterations of a whole tile (KK) / of this split (RR)
   const int xq = blockIdx.x >> 3, xx = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
   // (a staggered start of the XCDs' workgroups -- NSP_GEMM_8P_STAGGER, round 4 -- measured nothing and was removed:
   // profiles/r04v_gemm_8p_stagger_negative.log)
@@ -1462,6 +1473,46 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
       while (tile_of(st_) < 0) ++st_;
     }
     return st_;
+  };
+  // ---- STREAM-K schedule (round 6, KK, skws != nullptr).  The tile list of a narrow output rarely fills its last
+  // round (M = 102 400, N = 512: 800 tiles on 256 workgroups = 3.125 rounds, the fourth at 12 % occupancy = 22 % of the
+  // launch).  Here an XCD owns ntiles / 8 consecutive tiles and its workgroups equal shares of those tiles' LOOP
+  // ITERATIONS (two k-tiles each): workgroup q takes iterations [q W, (q + 1) W) of the XCD's Tx * U.  With W >= U
+  // (the launcher checks) a tile is shared by at most two neighbours q, q + 1.  A workgroup runs, in this order:
+  //   1. GIVE  -- the head [0, xb) of the tile its range ends in: accumulators stored raw (fragment layout, write-
+  //      through) to its 256-KB workspace slot, then its flag = this launch's epoch;
+  //   2. its whole tiles;
+  //   3. TAKE  -- the tail [ya, U) of the tile its range starts in: accumulators START from the left neighbour's
+  //      partial (produced first thing over there, so the flag is up long before) and end in the normal epilogue.
+  //      (TAKE second instead of last measured 241 vs 217 us on 102 400 x 512 x 2048: the poll waited for the neighbour.)
+  // A producer has the lower blockIdx of the pair (same XCD, q - 1), so it is never dispatched after its consumer.
+  struct Item { int tile, kb, nit, kind; };            // kind 0 whole tile, 1 give, 2 take
+  // (SK is a TEMPLATE parameter: with the schedule behind a run-time flag in the one kernel, builds of it returned wrong
+  // 4 x 4 blocks from the plain tile-list schedule on the device -- a different accumulator allocation each time the dead
+  // code changed, never on the emulator, never with the flag a compile-time false; profiles/r06_gemm_epilogue.log.  The
+  // tile-list kernels are therefore the same code as before, and the stream-K twins exist for the specialisations that
+  // the step's N = 512 products use.)
+  constexpr bool sk = SK && !RR;
+  int sk_ta = 0, sk_tb = 0, sk_ya = 0, sk_xb = 0, sk_n = 0, sk_full0 = 0;
+  const int sk_gidx = xx * per_xcd + xq;
+  if (sk) {
+    const int Tx = ntiles >> 3, U = nit_full;
+    const int total = Tx * U, W = (total + per_xcd - 1) / per_xcd;
+    const int r0 = min(xq * W, total), r1 = min(r0 + W, total);
+    if (r0 >= r1) return;
+    sk_ta = r0 / U; sk_ya = r0 - sk_ta * U;
+    sk_tb = r1 / U; sk_xb = r1 - sk_tb * U;
+    sk_full0 = sk_ta + (sk_ya > 0 ? 1 : 0);
+    sk_n = (sk_xb > 0 ? 1 : 0) + (sk_ya > 0 ? 1 : 0) + max(sk_tb - sk_full0, 0);
+    sk_ta += xx * Tx; sk_tb += xx * Tx; sk_full0 += xx * Tx;
+  }
+  auto item_of = [&](int step) -> Item {
+    if (!sk) return Item{tile_of(step), 0, nit_full, 0};
+    if (step >= sk_n) return Item{ntiles, 0, nit_full, 0};
+    int i = step;
+    if (sk_xb > 0) { if (i == 0) return Item{sk_tb, 0, sk_xb, 1}; --i; }
+    if (sk_ya > 0 && step == sk_n - 1) return Item{sk_ta, sk_ya, nit_full - sk_ya, 2};     // (LAST: the neighbour's partial is long there)
+    return Item{sk_full0 + i, 0, nit_full, 0};
   };
   const char* A = reinterpret_cast<const char*>(p.A);
   const char* B = reinterpret_cast<const char*>(p.B);
@@ -1560,30 +1611,80 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
   const int rr_c = ((fr >> 1) & 1) ^ rr8_swz(rr_k);           // chunk index of columns cbase = 0
   float* stage = reinterpret_cast<float*>(ring + STAGING) + wave * 1024;
 
-  int step = next_step(0);
-  int tile = tile_of(step);
+  int step = sk ? 0 : next_step(0);
+  Item cur = item_of(step);
+  int tile = cur.tile;
   if (tile >= ntiles) return;
   if ((VAR & 2) && wr == 1) __builtin_amdgcn_s_setprio(1);
   set_src(tile);
   // prologue: units 0..5 of the first tile (k-tile 0 -> buffer 0, units 0-1 of k-tile 1 -> buffer 1)
   if (!RR || nit > 0) {                                // (RR: a split without k-tiles only writes its zero slab)
 #pragma unroll
-    for (int u = 0; u < 6; ++u) issue(u & 3, u >> 2, u >> 2);
+    for (int u = 0; u < 6; ++u) issue(u & 3, u >> 2, 2 * cur.kb + (u >> 2));
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // units 0-2: everything phase 0 reads
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   bool first = true;
+  typedef __attribute__((address_space(1))) unsigned int gu32_t;
   while (true) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int step_n = next_step(step + 1);
-    const int next_tile = tile_of(step_n);
+    const int step_n = sk ? step + 1 : next_step(step + 1);
+    const Item nxt = item_of(step_n);
+    const int next_tile = nxt.tile;
     const bool has_next = next_tile < ntiles;
+    if (!RR) nit = cur.nit;
     f32x4 acc[8][4];
+    if (sk && cur.kind == 2) {
+      // TAKE: start from the left neighbour's partial.  Every wave polls for itself (no workgroup barrier: the two wave
+      // halves' barrier phase must not move); the 32 loads are younger than the DMA units in flight, so the first
+      // counted waits of this item over-wait (in-order retirement) -- safe.
+      gu32_t* flag = (gu32_t*)(reinterpret_cast<unsigned int*>(skws) + (sk_gidx - 1));
+      if (lane == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk_epoch) {
+          __builtin_amdgcn_s_sleep(2);
+#ifndef NSP_HOST_EMULATION
+          if (++spins > (1u << 26)) __builtin_trap();     // seconds: the producer never ran -- fail the launch, do not return a wrong tile
+#endif
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const unsigned char* slot = skws + 4096 + (size_t)(sk_gidx - 1) * 262144 + wave * 32768;
+      int tl = lane;                 // (opaque per item: otherwise 16 lane addresses are hoisted in front of the tile loop and spilled)
+#ifndef NSP_HOST_EMULATION
+      asm volatile("" : "+v"(tl));
+#endif
+#ifdef NSP_HOST_EMULATION
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i) {
+        const f32x4* rowp = reinterpret_cast<const f32x4*>(slot + i * 4096);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = rowp[j * 64 + tl];
+      }
+#else
+      // asm loads + one named wait: behind compiler-visible loads hipcc put an s_waitcnt vmcnt(0) in front of EVERY item's
+      // main loop (the accumulators are a phi of "loaded" and "zero"), i.e. every tile waited for the previous epilogue's stores
+      const unsigned toff = (unsigned)tl * 16u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned char* rowbase = slot + i * 4096;
+        // (s_nop 4 first: the scalar base may have just been restored from a spill lane by v_readlane -- VALU writes SGPR ->
+        // VMEM reads it needs 5 wait states, and hipcc cannot see the VMEM instruction inside the asm)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5 nt\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024 nt\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:2048 nt\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072 nt"
+                     : "=&v"(acc[i][0]), "=&v"(acc[i][1]), "=&v"(acc[i][2]), "=&v"(acc[i][3]) : "v"(toff), "s"(rowbase) : "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]) :: "memory");
+#endif
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (wr == 1) {                                     // the second row half runs one barrier behind the first
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -1632,10 +1733,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
           // last iteration on, of the NEXT tile's k-tiles 0 / 1
           const int j = (ph + 6) & 3, ahead = (ph + 6) >> 2, ibuf = ahead & 1;
           if (!last || ph < 2) {
-            issue(j, ibuf, 2 * it + ahead);
+            issue(j, ibuf, 2 * (cur.kb + it) + ahead);
           } else if (has_next) {
             if (ph == 2) set_src(next_tile);
-            issue(j, ibuf, ahead - 2);
+            issue(j, ibuf, 2 * nxt.kb + ahead - 2);
           }
         }
         if (VAR & (16 | 32)) {  // (ablation bit 4: no counted waits -- wrong results, timing only)
@@ -1702,6 +1803,33 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     }
     // this wave's outstanding DMA (units 3-5 of the next tile) lands before the first store is issued: the counted
     // waits of the next tile then never have a store among the operations they leave in flight
+    if (sk && cur.kind == 1) {
+      // GIVE: the raw accumulators to this workgroup's slot (16 B per lane and fragment, write-through), then the flag.
+      // ONE lane-offset register and a scalar base per row of fragments: 32 per-lane 64-bit addresses spilled the kernel.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next item's units have landed: no DMA among the stores
+      unsigned char* slot = skws + 4096 + (size_t)sk_gidx * 262144 + wave * 32768;
+      int gl = lane;
+#ifndef NSP_HOST_EMULATION
+      asm volatile("" : "+v"(gl));
+#endif
+      const unsigned voff = (unsigned)gl * 16u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        unsigned char* rowbase = slot + i * 4096;
+#ifdef NSP_HOST_EMULATION
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(rowbase + j * 1024 + voff) = acc[i][j];
+#else
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %5 sc1\n\tglobal_store_dwordx4 %0, %2, %5 offset:1024 sc1\n\t"
+                     "global_store_dwordx4 %0, %3, %5 offset:2048 sc1\n\tglobal_store_dwordx4 %0, %4, %5 offset:3072 sc1\n\ts_nop 1"
+                     :: "v"(voff), "v"(acc[i][0]), "v"(acc[i][1]), "v"(acc[i][2]), "v"(acc[i][3]), "s"(rowbase) : "memory");
+#endif
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (tid == 0) __hip_atomic_store((gu32_t*)(reinterpret_cast<unsigned int*>(skws) + sk_gidx), sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
     // (the wait itself sits inside gemm_epilogue_fast, behind the requests for the bias and the first side-operand chunks)
     const int mrow = tm * 256 + wr * 128, ncol = tn * 256 + wc * 64;
     // everything the epilogue derives from the lane index is derived HERE, behind an opaque copy: otherwise the
@@ -1724,8 +1852,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
       gemm_epilogue_direct<S, (VAR & 8) ? 0 : 2>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), mrow, ncol, elane);
       gemm_epilogue_direct<S, (VAR & 8) ? 0 : 2>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), mrow + 64, ncol, elane);
     }
+    }
     if (!has_next) break;
     step = step_n;
+    cur = nxt;
     tile = next_tile;
     first = false;
   }
@@ -1892,6 +2022,27 @@ inline bool rr8p_shape_ok(long long M, long long N, long long K, long long lda, 
 }  // namespace
 
 // called from nsp_gemm (gemm.hip) when both operands are bf16
+// Stream-K workspace of the 8-phase kernel: per stream, 4 KB of flags (one per workgroup, compared with the launch's
+// epoch -- never reset) + 256 slots of 256 KB for the raw accumulators of a shared tile's head.  Launches on one stream
+// are ordered, so one workspace per stream is enough; the memory is allocated once and kept.
+static unsigned char* streamk_workspace(hipStream_t st, unsigned* epoch) {
+  struct Ws { hipStream_t st; int dev; unsigned char* p; unsigned epoch; };
+  static std::mutex mu;
+  static std::vector<Ws> all;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& w : all)
+    if (w.st == st && w.dev == dev) { *epoch = ++w.epoch; return w.p; }
+  unsigned char* ptr = nullptr;
+  const size_t bytes = 4096 + 256ull * 262144;
+  if (hipMalloc(reinterpret_cast<void**>(&ptr), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemsetAsync(ptr, 0, 4096, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
+  all.push_back(Ws{st, dev, ptr, 1u});
+  *epoch = 1u;
+  return ptr;
+}
+
 int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
   const bool a_kc = p.a_cs == 1, b_kc = p.b_ks == 1;
   {
@@ -1974,6 +2125,25 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         if (e8g && atoi(e8g) >= 8 && atoi(e8g) < g8) g8 = atoi(e8g) / 8 * 8;
         const char* e8v = getenv("NSP_GEMM_8P_VAR");
         const int var8 = e8v ? atoi(e8v) : 4;   // default: the staged epilogue (the direct one measured 0.4-0.9x, see gemm_epilogue_direct)
+        // stream-K (see the kernel): a full grid whose last round is less than 3/4 full, tile count a multiple of 8 (whole
+        // tiles per XCD), at least one tile of iterations per workgroup and narrow output (the n-fastest tile list).
+        // OFF by default (round 6): alone, back to back, the step's N = 512 products gain 3-8 % (FFN input gradient 217 -> 206 us
+        // at 102 400 rows, 109 -> 101 at 51 200), but inside the step the same library lost 0.6 ms in three same-call A/Bs
+        // (94.0 / 94.1 -> 94.5 / 94.7 / 95.0 ms; profiles/r06_gemm_epilogue.log).  NSP_GEMM_8P_STREAMK = 1 switches it on where
+        // it should pay, 2 wherever it is legal (tests); read on every call.
+        unsigned char* skws = nullptr;
+        unsigned sk_epoch = 0;
+        {
+          const char* esk = getenv("NSP_GEMM_8P_STREAMK");
+          const int sk_on = esk ? atoi(esk) : 0;
+          const long long rem8 = t256 % g8;
+          const bool legal = t256 % 8 == 0 && tn256 < 16 && t256 / 8 >= g8 / 8;   // (>= one tile of iterations per workgroup)
+          const bool pays = g8 == 256 && rem8 != 0 && rem8 * 4 < 3 * g8;
+          const bool twin = p.c_dtype == NSP_DT_F32 && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE;   // epi_spec_streamk_twin
+          if (sk_on && legal && twin && (pays || sk_on >= 2)) {
+            skws = streamk_workspace(st, &sk_epoch);
+          }
+        }
         auto launch8 = [&](auto spec, auto var) {
           using S8 = decltype(spec);
           constexpr int V8 = decltype(var)::value;
@@ -1982,7 +2152,19 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<S8, V8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             attr = true;
           }
-          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<S8, V8>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec & 255);
+          constexpr bool has_twin = S8::kStatic && V8 == 4 && epi_spec_streamk_twin<S8>();
+          if constexpr (has_twin) {
+            if (skws) {
+              static bool attr_sk = false;
+              if (!attr_sk) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_kk8p_kernel<S8, V8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                attr_sk = true;
+              }
+              hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<S8, V8, false, true>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec & 255, skws, sk_epoch);
+              return;
+            }
+          }
+          hipLaunchKernelGGL((gemm_bf16_kk8p_kernel<S8, V8>), dim3(g8), dim3(512), 163840, st, p, tm256, tn256, c_vec & 255, nullptr, 0u);
         };
         // the direct epilogue's own conditions (32-bit byte offsets into C; column-sum slabs only with an act' source)
         const bool direct_ok = (long long)p.M * p.ldc < (1ll << 29) && !(p.epi_f3 && !p.dact_src) && !(p.bias && p.dact_src);

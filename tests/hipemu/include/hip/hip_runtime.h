@@ -72,6 +72,8 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 // occupancy query fails and the launchers refuse the persistent path (callers fall back to per-step kernels)
 enum { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipGetDevice(int*) { return 100; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : 2; }   // (the GEMM's stream-K workspace)
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int*, int, int) { return 100; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int*, K, int, size_t) { return 100; }
 #define __HIP_MEMORY_SCOPE_AGENT 0

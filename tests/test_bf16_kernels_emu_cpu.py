@@ -89,6 +89,11 @@ def test_phase_interleaved_256_tile_gemm(basic, M, N, K, grid, monkeypatch):
     basic.test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch)
 
 
+@pytest.mark.parametrize('M,N,K,grid', [(1536, 1024, 256, 16)])   # 24 tiles, two workgroups per XCD share the middle one of three
+def test_phase_interleaved_gemm_stream_k(basic, M, N, K, grid, monkeypatch):
+    basic.test_phase_interleaved_gemm_stream_k(M, N, K, grid, monkeypatch)
+
+
 def test_layernorm_bf16_only_output_refuses_an_fp32_consumer(basic):
     basic.test_layernorm_bf16_only_output_refuses_an_fp32_consumer()
 

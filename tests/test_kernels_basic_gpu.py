@@ -538,6 +538,53 @@ def test_linear_glu_depthwise_conv_as_one_node(B, T, C, k, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K,grid', [(6144, 256, 512, 16), (5000, 512, 256, 16), (1536, 1024, 256, 16), (102400, 512, 2048, 0), (51200, 512, 1536, 0),
+                                        (40960, 512, 256, 0)])
+def test_phase_interleaved_gemm_stream_k(M, N, K, grid, monkeypatch):
+    """The 8-phase kernel's stream-K schedule (round 6): an XCD's workgroups take equal shares of its tiles' loop
+    iterations, a tile on a share boundary is started by one workgroup (raw accumulators + flag through the workspace) and
+    finished by its right neighbour, which starts from that partial -- the same accumulation order, so every output must
+    be BIT-EQUAL to the tile-list schedule's (NSP_GEMM_8P_STREAMK=0), dropout mask included.  Small problems on 16
+    workgroups (2 per XCD: 3 resp. 5 tiles for two workgroups, ragged M), and the step's N = 512 shapes on the full grid
+    (800 / 400 / 320 tiles on 256 workgroups; 320 tiles x 2 iterations: every workgroup gives and takes)."""
+    from neural_sp_amd import ops
+    monkeypatch.setenv('NSP_GEMM_8P', '2')
+    monkeypatch.setenv('NSP_GEMM_8P_MIN_TILES', '1')
+    if grid:
+        monkeypatch.setenv('NSP_GEMM_8P_GRID', str(grid))
+    torch.manual_seed(M + K)
+    dev = _dev()
+    a = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.5).bfloat16()
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    src = torch.randn(M, N, device=dev).bfloat16()
+    outs = {}
+    with ops.compute_mode('bf16'):
+        for mode in ('0', '2'):
+            monkeypatch.setenv('NSP_GEMM_8P_STREAMK', mode)
+            c = torch.full((M, N), float('nan'), device=dev)
+            ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c, N)
+            cr = torch.full((M, N), float('nan'), device=dev)
+            ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, cr, N, bias=bias, res=res, alpha=0.5)
+            cd = torch.full((M, N), float('nan'), device=dev)
+            ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, cd, N, bias=bias, res=res, alpha=0.5, dropout_p=0.2, seed=5, offset=64)
+            c16 = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)      # (bf16 outputs: no stream-K twin, the same kernel in both modes)
+            slabs = torch.zeros(((M + 127) // 128 * 4, N), device=dev)
+            ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c16, N, dact_src=src, dact=2, colsum_slabs=slabs)
+            for rep in range(3):            # the workspace's flags carry the launch epoch: back-to-back launches must not see stale ones
+                c2 = torch.full((M, N), float('nan'), device=dev)
+                ops.gemm_raw(M, N, K, a, K, 1, w, 1, K, c2, N)
+                assert torch.equal(c2, c), (mode, rep)
+            outs[mode] = (c, cr, cd, c16, slabs.sum(0))
+    ref = a.float() @ w.float().t()
+    assert _rel(outs['2'][0], ref) < 1e-5
+    assert _rel(outs['2'][1], 0.5 * (ref + bias) + res) < 1e-5
+    for x, y, name in zip(outs['0'], outs['2'], ('plain', 'bias + residual', 'bias + dropout + residual', "act' source", 'slabs')):
+        assert torch.equal(x, y), name
+
+
+@pytest.mark.gpu
 def test_phase_interleaved_gemm_with_an_operand_beyond_4_gb(monkeypatch):
     """The RNN-T joint's data gradient reads a [3.6 M, 1024] bf16 operand (7.4 GB): the 8-phase kernel addresses A with a
     scalar base per tile + 32-bit lane offsets.  2.2 M x 1024 (4.5 GB) x a [512, 1024] weight with the tanh' epilogue,
