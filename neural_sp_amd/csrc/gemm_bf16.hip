@@ -1504,15 +1504,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kk8p_kernel(const nsp_gemm_p
     sk_tb = r1 / U; sk_xb = r1 - sk_tb * U;
     sk_full0 = sk_ta + (sk_ya > 0 ? 1 : 0);
     sk_n = (sk_xb > 0 ? 1 : 0) + (sk_ya > 0 ? 1 : 0) + max(sk_tb - sk_full0, 0);
-    sk_ta += xx * Tx; sk_tb += xx * Tx; sk_full0 += xx * Tx;
   }
+  // local tile index of the XCD -> tile: COLUMN-major inside the XCD's row panels (all its tiles of column 0, then column 1, ...),
+  // so that the tiles sharing an A panel are in flight on DIFFERENT workgroups at the same time (one fetch from HBM, the
+  // other hits L2) -- with the n-fastest order both were consecutive items of one workgroup, the panel had left L2 in
+  // between, and inside the step (cold operands) the schedule lost what it gained alone
+  const int sk_rpx = sk ? (ntiles >> 3) / tiles_n : 1;       // row panels per XCD (the launcher: a whole number)
+  auto sk_tile = [&](int l) { const int n_ = l / sk_rpx; return (xx * sk_rpx + (l - n_ * sk_rpx)) * tiles_n + n_; };
   auto item_of = [&](int step) -> Item {
     if (!sk) return Item{tile_of(step), 0, nit_full, 0};
     if (step >= sk_n) return Item{ntiles, 0, nit_full, 0};
     int i = step;
-    if (sk_xb > 0) { if (i == 0) return Item{sk_tb, 0, sk_xb, 1}; --i; }
-    if (sk_ya > 0 && step == sk_n - 1) return Item{sk_ta, sk_ya, nit_full - sk_ya, 2};     // (LAST: the neighbour's partial is long there)
-    return Item{sk_full0 + i, 0, nit_full, 0};
+    if (sk_xb > 0) { if (i == 0) return Item{sk_tile(sk_tb), 0, sk_xb, 1}; --i; }
+    if (sk_ya > 0 && step == sk_n - 1) return Item{sk_tile(sk_ta), sk_ya, nit_full - sk_ya, 2};     // (LAST: the neighbour's partial is long there)
+    return Item{sk_tile(sk_full0 + i), 0, nit_full, 0};
   };
   const char* A = reinterpret_cast<const char*>(p.A);
   const char* B = reinterpret_cast<const char*>(p.B);
@@ -2137,7 +2142,8 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
           const char* esk = getenv("NSP_GEMM_8P_STREAMK");
           const int sk_on = esk ? atoi(esk) : 0;
           const long long rem8 = t256 % g8;
-          const bool legal = t256 % 8 == 0 && tn256 < 16 && t256 / 8 >= g8 / 8;   // (>= one tile of iterations per workgroup)
+          const bool legal = t256 % 8 == 0 && tn256 < 16 && t256 / 8 >= g8 / 8 &&   // (>= one tile of iterations per workgroup)
+                             (t256 / 8) % tn256 == 0;                                  // (whole row panels per XCD)
           const bool pays = g8 == 256 && rem8 != 0 && rem8 * 4 < 3 * g8;
           const bool twin = p.c_dtype == NSP_DT_F32 && !p.pre_out && !p.dact_src && p.act == NSP_ACT_NONE;   // epi_spec_streamk_twin
           if (sk_on && legal && twin && (pays || sk_on >= 2)) {

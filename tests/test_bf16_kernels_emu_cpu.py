@@ -89,7 +89,7 @@ def test_phase_interleaved_256_tile_gemm(basic, M, N, K, grid, monkeypatch):
     basic.test_phase_interleaved_256_tile_gemm(M, N, K, grid, monkeypatch)
 
 
-@pytest.mark.parametrize('M,N,K,grid', [(1536, 1024, 256, 16)])   # 24 tiles, two workgroups per XCD share the middle one of three
+@pytest.mark.parametrize('M,N,K,grid', [(6144, 256, 256, 16)])   # 24 tiles, two workgroups per XCD share the middle one of three
 def test_phase_interleaved_gemm_stream_k(basic, M, N, K, grid, monkeypatch):
     basic.test_phase_interleaved_gemm_stream_k(M, N, K, grid, monkeypatch)
 

@@ -538,14 +538,14 @@ def test_linear_glu_depthwise_conv_as_one_node(B, T, C, k, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('M,N,K,grid', [(6144, 256, 512, 16), (5000, 512, 256, 16), (1536, 1024, 256, 16), (102400, 512, 2048, 0), (51200, 512, 1536, 0),
+@pytest.mark.parametrize('M,N,K,grid', [(6144, 256, 512, 16), (6000, 256, 256, 16), (6144, 512, 256, 32), (102400, 512, 2048, 0), (51200, 512, 1536, 0),
                                         (40960, 512, 256, 0)])
 def test_phase_interleaved_gemm_stream_k(M, N, K, grid, monkeypatch):
     """The 8-phase kernel's stream-K schedule (round 6): an XCD's workgroups take equal shares of its tiles' loop
     iterations, a tile on a share boundary is started by one workgroup (raw accumulators + flag through the workspace) and
     finished by its right neighbour, which starts from that partial -- the same accumulation order, so every output must
-    be BIT-EQUAL to the tile-list schedule's (NSP_GEMM_8P_STREAMK=0), dropout mask included.  Small problems on 16
-    workgroups (2 per XCD: 3 resp. 5 tiles for two workgroups, ragged M), and the step's N = 512 shapes on the full grid
+    be BIT-EQUAL to the tile-list schedule's (NSP_GEMM_8P_STREAMK=0), dropout mask included.  Small problems on 16 / 32
+    workgroups (3 tiles for 2 workgroups per XCD, ragged M; 6 tiles in two columns for 4), and the step's N = 512 shapes on the full grid
     (800 / 400 / 320 tiles on 256 workgroups; 320 tiles x 2 iterations: every workgroup gives and takes)."""
     from neural_sp_amd import ops
     monkeypatch.setenv('NSP_GEMM_8P', '2')
