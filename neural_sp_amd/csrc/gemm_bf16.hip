@@ -2132,15 +2132,17 @@ int nsp_gemm_bf16_launch(const nsp_gemm_params& p, hipStream_t st) {
         const int var8 = e8v ? atoi(e8v) : 4;   // default: the staged epilogue (the direct one measured 0.4-0.9x, see gemm_epilogue_direct)
         // stream-K (see the kernel): a full grid whose last round is less than 3/4 full, tile count a multiple of 8 (whole
         // tiles per XCD), at least one tile of iterations per workgroup and narrow output (the n-fastest tile list).
-        // OFF by default (round 6): alone, back to back, the step's N = 512 products gain 3-8 % (FFN input gradient 217 -> 206 us
-        // at 102 400 rows, 109 -> 101 at 51 200), but inside the step the same library lost 0.6 ms in three same-call A/Bs
-        // (94.0 / 94.1 -> 94.5 / 94.7 / 95.0 ms; profiles/r06_gemm_epilogue.log).  NSP_GEMM_8P_STREAMK = 1 switches it on where
-        // it should pay, 2 wherever it is legal (tests); read on every call.
+        // ON by default where it should pay.  Measured (profiles/r06_gemm_epilogue.log): alone, back to back, the step's N = 512
+        // products gain 3-8 % (FFN input gradient 217 -> 206 us at 102 400 rows, 109 -> 101 at 51 200); inside the step, with the
+        // XCD's tiles in column-major order, five alternating pairs in one call: 93.96 -> 93.59 ms (every pair), kernel time
+        // under rocprofv3 671.6 -> 667.2 ms per 6 steps.  (With the n-fastest order the two tiles sharing an A panel were
+        // consecutive items of one workgroup and the step LOST 0.6 ms.)  NSP_GEMM_8P_STREAMK = 0 switches it off, 2 forces it
+        // wherever it is legal (tests); read on every call.
         unsigned char* skws = nullptr;
         unsigned sk_epoch = 0;
         {
           const char* esk = getenv("NSP_GEMM_8P_STREAMK");
-          const int sk_on = esk ? atoi(esk) : 0;
+          const int sk_on = esk ? atoi(esk) : 1;
           const long long rem8 = t256 % g8;
           const bool legal = t256 % 8 == 0 && tn256 < 16 && t256 / 8 >= g8 / 8 &&   // (>= one tile of iterations per workgroup)
                              (t256 / 8) % tn256 == 0;                                  // (whole row panels per XCD)
