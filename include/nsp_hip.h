@@ -13,7 +13,8 @@
  *     or a negative NSP_E* code for invalid arguments;
  *   - pointers are device pointers unless a comment says "host";
  *   - `stream` is a hipStream_t passed as void*; nothing here synchronises,
- *     allocates or frees: workspaces are passed in by the caller;
+ *     allocates or frees: workspaces are passed in by the caller (one exception, round 6: nsp_gemm* keeps a 64-MB
+ *     stream-K exchange workspace per stream, hipMalloc'ed on the first launch that uses it; NSP_GEMM_8P_STREAMK=0 avoids it);
  *   - tensors are dense fp32 row-major unless stated; lengths are int32;
  *   - `mode`: NSP_COMPUTE_BF16 = bf16 MFMA operands / fp32 accumulate,
  *             NSP_COMPUTE_F32  = exact fp32 MFMA (v_mfma_f32_16x16x4_f32).
